@@ -1,0 +1,141 @@
+"""ctypes binding of libhm_amd.so (the C ABI declared in include/hm_abi.h).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is visible when a
+context is requested, the call raises.  Nothing here imports ``oracle/``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("HM_AMD_LIB", _HERE / "libhm_amd.so"))
+
+
+class HmError(RuntimeError):
+    """Raised when a C-ABI call returns nonzero (message = hm_last_error())."""
+
+
+class hm_stats(C.Structure):
+    _fields_ = [
+        ("ms_total", C.c_double),
+        ("ms_pressure", C.c_double),
+        ("ms_saturation", C.c_double),
+        ("ms_update", C.c_double),
+        ("mean_nts", C.c_double),
+        ("n_pressure_launches", C.c_longlong),
+        ("n_saturation_launches", C.c_longlong),
+        ("member_steps", C.c_longlong),
+    ]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_vp, _ip, _dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol include/hm_abi.h declares
+SIGNATURES = {
+    "hm_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "hm_destroy": (None, [_vp]),
+    "hm_last_error": (C.c_char_p, []),
+    "hm_device_name": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "hm_abi_version": (C.c_int, []),
+    "hm_forward_batched": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _vp, C.c_int, _vp,
+                                     C.c_int, _ip, _dp, C.c_int, C.c_int, _ip, _dp, C.c_int, C.c_double, C.c_int,
+                                     C.c_double, C.c_double, C.c_double, C.c_double, _dp, C.c_int, C.c_int, _vp, _vp,
+                                     _ip, C.POINTER(hm_stats)]),
+    "hm_fwd_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _ip, _dp, C.c_int,
+                                C.c_int, _ip, _dp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
+                                C.c_double, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "hm_fwd_destroy": (None, [_vp]),
+    "hm_fwd_set_inputs": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "hm_fwd_run": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "hm_fwd_sync": (C.c_int, [_vp, C.POINTER(hm_stats)]),
+    "hm_fwd_get_outputs": (C.c_int, [_vp, _vp, _vp, _ip]),
+    "hm_fwd_set_variant": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "hm_fwd_pressure_only": (C.c_int, [_vp, C.c_int]),
+    "hm_fwd_saturation_only": (C.c_int, [_vp, C.c_int]),
+    "hm_fwd_get_field": (C.c_int, [_vp, C.c_char_p, _vp]),
+    "hm_fwd_set_field": (C.c_int, [_vp, C.c_char_p, _vp]),
+    "hm_fwd_device_ptr": (_vp, [_vp, C.c_char_p]),
+    "hm_es_update": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp,
+                               C.POINTER(hm_stats)]),
+    "hm_es_update_loc": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double,
+                                   C.c_int, _vp, C.POINTER(hm_stats)]),
+    "hm_upd_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "hm_upd_destroy": (None, [_vp]),
+    "hm_upd_set_inputs": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double]),
+    "hm_upd_phase": (C.c_int, [_vp, C.c_int]),
+    "hm_upd_reduce_buffer": (_vp, [_vp, C.c_int, C.POINTER(C.c_longlong)]),
+    "hm_upd_sync": (C.c_int, [_vp, C.POINTER(hm_stats)]),
+    "hm_upd_get_output": (C.c_int, [_vp, _vp]),
+    "hm_upd_device_ptr": (_vp, [_vp, C.c_char_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libhm_amd.so and bind every declared symbol.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise HmError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C historymatching_amd/csrc`). There is no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().hm_last_error()
+        raise HmError(f"{what}: {msg.decode() if msg else 'error %d' % rc}")
+
+
+def ptr(a):
+    """void* of a NumPy array (or None)."""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def as_c(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+class Context:
+    """One HIP context (device + stream).  Reused process-wide per device."""
+
+    _cache = {}
+
+    def __init__(self, device=0):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.hm_create(int(device), C.byref(h)), "hm_create")
+        self.handle = h
+        self.device = int(device)
+        self.lib = lib
+
+    @classmethod
+    def get(cls, device=None):
+        if device is None:
+            device = int(os.environ.get("HM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        if device not in cls._cache:
+            cls._cache[device] = cls(device)
+        return cls._cache[device]
+
+    def name(self):
+        buf = C.create_string_buffer(256)
+        check(self.lib.hm_device_name(self.handle, buf, 256), "hm_device_name")
+        return buf.value.decode()

@@ -1,0 +1,61 @@
+// common.h -- context, error handling and small device helpers shared by the HIP sources.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hm_abi.h"
+
+#define HM_ABI_VERSION 1
+
+void hm_set_error(const char* fmt, ...);
+
+#define HM_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            hm_set_error("%s failed at %s:%d: %s", #call, __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+#define HM_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            hm_set_error(__VA_ARGS__); \
+            return 2;                  \
+        }                              \
+    } while (0)
+
+struct hm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    int num_cu = 0;
+};
+
+// RAII-less device buffer bookkeeping (plans free what they allocate).
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+int hm_dev_alloc(DevBuf& b, size_t bytes);
+void hm_dev_free(DevBuf& b);
+
+// Event pair timing accumulated per kernel class.
+struct EvTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    size_t used = 0;
+    int begin(hipStream_t s);
+    int end(hipStream_t s);
+    double total_ms();  // requires stream synchronised
+    void reset() { used = 0; }
+    void destroy();
+};

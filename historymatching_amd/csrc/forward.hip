@@ -1,0 +1,716 @@
+// forward.hip -- ensemble forward model (batched TPFA pressure + explicit upwind saturation):
+// plan management, the C-ABI entry points, and the GENERIC kernels (any Nx, Ny <= 128).
+//
+// Replaces, for all N members at once:  forward_model -> utils.apply(comp1) -> set_perm -> ResSim.sim
+//   notebooks/HistoryMatch.py:383-387, tools/utils.py:155-242, HistoryMatch.py:358-364, 160-164, 362.
+// The arithmetic follows the listings restated in SURVEY.md Appendix A (the simulator package itself,
+// TPFA-ResSim@adc89536, is not vendored in the reference).
+//
+// One workgroup = one ensemble member.  The generic kernels keep the per-member work arrays in HBM/L2
+// scratch and use LDS only for the dense Ny x Ny Schur-complement block; they are the correctness
+// baseline the 128x128 specialisations (press128.hip, sat128.hip) are validated against.
+//
+// This file is compiled with -ffp-contract=off: every product/sum is rounded separately exactly as
+// NumPy does; FMAs appear only where written explicitly (inside the pressure solve, which is not a
+// bit-exact path).
+#include "fwd.h"
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void rel_perm(const FwdParams& p, T s, T& mw, T& mo) {
+    // Listing RelPerm: S* = (s-swc)/(1-swc-sor); Mw = S*^2/vw; Mo = (1-S*)^2/vo
+    if (p.fluid_default) {
+        mw = s * s;
+        T o = T(1) - s;
+        mo = o * o;
+    } else {
+        T den = T((1.0 - p.swc) - p.sor);
+        T S = (s - T(p.swc)) / den;
+        mw = (S * S) / T(p.vw);
+        T o = T(1) - S;
+        mo = (o * o) / T(p.vo);
+    }
+}
+
+__device__ __forceinline__ double block_min(double v, double* red, int tid, int nthreads) {
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 1; s < nthreads; s <<= 1) {
+        // tree over arbitrary thread counts: pairwise with stride doubling
+        int idx = 2 * s * tid;
+        if (idx + s < nthreads) red[idx] = fmin(red[idx], red[idx + s]);
+        __syncthreads();
+    }
+    double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K = 0.1 + exp(5 x)          perm_transf, HistoryMatch.py:137-138
+// ------------------------------------------------------------------------------------------------
+__global__ void k_perm_transform(const double* __restrict__ x, double* __restrict__ K, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) K[i] = 0.1 + exp(5.0 * x[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GENERIC pressure step: assemble TPFA transmissibilities, solve the 5-point SPD system by block
+// elimination along ix (blocks of Ny unknowns; Schur complements inverted by symmetric Gauss-Jordan
+// sweeps in LDS), back-substitute, form face fluxes.      SURVEY.md A.3 (listings TPFA, Pres)
+// blockDim.x = Ny * groups.
+// ------------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ void k_pressure_generic(FwdParams p, const TS* __restrict__ S_base, long long S_stride, int k) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int m = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int T = blockDim.x;
+    const int Nx = p.Nx, Ny = p.Ny, Nxy = p.Nxy;
+    const int LD = Ny | 1;
+    const int groups = T / Ny;
+    const int g = tid / Ny, c = tid % Ny;
+
+    double* A = smem;                 // Ny*LD
+    double* colbuf = A + Ny * LD;     // Ny
+    double* yprev = colbuf + Ny;      // Ny
+    double* ycur = yprev + Ny;        // Ny
+    double* red = ycur + Ny;          // T
+
+    const TS* S = S_base + (long long)m * S_stride;
+    const double* Km = p.K + (long long)m * Nxy;
+    double* TX = p.TX + (long long)m * (Nx + 1) * Ny;
+    double* TY = p.TY + (long long)m * Nx * (Ny + 1);
+    double* G = p.G + (long long)m * Nx * Ny * Ny;
+    double* yv = p.yv + (long long)m * Nxy;
+    double* P = p.P + (long long)m * Nxy;
+    double* Vx = p.Vx + (long long)m * (Nx + 1) * Ny;
+    double* Vy = p.Vy + (long long)m * Nx * (Ny + 1);
+    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+    double* L = P;  // temporarily holds L = 1/(Mt*K)
+
+    // --- mobility-weighted inverse permeability per cell: L = (Mt*K)**(-1)
+    for (int j = tid; j < Nxy; j += T) {
+        double mw, mo;
+        rel_perm<double>(p, (double)S[j], mw, mo);
+        double KM = (mw + mo) * Km[j];
+        L[j] = 1.0 / KM;
+    }
+    __syncthreads();
+    // --- harmonic-mean face transmissibilities, zero on the boundary (no-flow)
+    for (int f = tid; f < (Nx + 1) * Ny; f += T) {
+        int ix = f / Ny, iy = f % Ny;
+        TX[f] = (ix == 0 || ix == Nx) ? 0.0 : p.cx / (L[(ix - 1) * Ny + iy] + L[ix * Ny + iy]);
+    }
+    for (int f = tid; f < Nx * (Ny + 1); f += T) {
+        int ix = f / (Ny + 1), iy = f % (Ny + 1);
+        TY[f] = (iy == 0 || iy == Ny) ? 0.0 : p.cy / (L[ix * Ny + iy - 1] + L[ix * Ny + iy]);
+    }
+    __syncthreads();
+
+    int bad = 0;
+    // --- forward block elimination
+    for (int i = 0; i < Nx; ++i) {
+        const double* e = TX + i * Ny;  // coupling to block i-1: E = -diag(e)
+        if (i > 0) {
+            // t = G_{i-1} y_{i-1}   (A holds G_{i-1}; symmetric, so read columns as rows)
+            double part = 0.0;
+            if (g < groups)
+                for (int r = g; r < Ny; r += groups) part = fma(A[r * LD + c], yprev[r], part);
+            red[tid] = part;
+            __syncthreads();
+            if (tid < Ny) {
+                double t = 0.0;
+                for (int gg = 0; gg < groups; ++gg) t += red[gg * Ny + tid];
+                ycur[tid] = q[i * Ny + tid] + e[tid] * t;
+            }
+            // A <- -(e G e)
+            if (g < groups) {
+                double ec = e[c];
+                for (int r = g; r < Ny; r += groups) A[r * LD + c] = -(e[r] * A[r * LD + c] * ec);
+            }
+        } else {
+            if (g < groups)
+                for (int r = g; r < Ny; r += groups) A[r * LD + c] = 0.0;
+            if (tid < Ny) ycur[tid] = q[tid];
+        }
+        __syncthreads();
+        // add the tridiagonal block D_i
+        if (tid < Ny) {
+            int j = tid;
+            double y1 = TY[i * (Ny + 1) + j], y2 = TY[i * (Ny + 1) + j + 1];
+            double x1 = TX[i * Ny + j], x2 = TX[(i + 1) * Ny + j];
+            double dg = y1 + y2 + x1 + x2;
+            if (i == 0 && j == 0) dg += Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
+            A[j * LD + j] += dg;
+            if (j + 1 < Ny) {
+                A[j * LD + j + 1] -= y2;
+                A[(j + 1) * LD + j] -= y2;
+            }
+        }
+        // symmetric sweeps: A <- -inv(A)
+        for (int kk = 0; kk < Ny; ++kk) {
+            __syncthreads();
+            if (tid < Ny) colbuf[tid] = A[kk * LD + tid];
+            __syncthreads();
+            double d = colbuf[kk];
+            if (!(d > 0.0) || !isfinite(d)) bad = 1;
+            double pinv = 1.0 / d;
+            if (g < groups) {
+                double tc = colbuf[c] * pinv;
+                for (int r = g; r < Ny; r += groups) {
+                    double v;
+                    if (r == kk)
+                        v = (c == kk) ? -pinv : tc;
+                    else if (c == kk)
+                        v = colbuf[r] * pinv;
+                    else
+                        v = fma(-colbuf[r], tc, A[r * LD + c]);
+                    A[r * LD + c] = v;
+                }
+            }
+        }
+        __syncthreads();
+        // A <- -A = G_i ; store G_i and y_i
+        if (g < groups)
+            for (int r = g; r < Ny; r += groups) {
+                double v = -A[r * LD + c];
+                A[r * LD + c] = v;
+                G[((long long)i * Ny + r) * Ny + c] = v;
+            }
+        if (tid < Ny) {
+            yv[i * Ny + tid] = ycur[tid];
+            yprev[tid] = ycur[tid];
+        }
+        __syncthreads();
+    }
+    // --- back substitution: x_i = G_i (y_i + e_{i+1} * x_{i+1}),   e_{i+1} = TX[i+1]
+    for (int i = Nx - 1; i >= 0; --i) {
+        if (tid < Ny) {
+            double v = yv[i * Ny + tid];
+            if (i < Nx - 1) v += TX[(i + 1) * Ny + tid] * ycur[tid];  // ycur holds x_{i+1}
+            yprev[tid] = v;
+        }
+        __syncthreads();
+        double part = 0.0;
+        if (g < groups) {
+            if (i == Nx - 1) {
+                for (int r = g; r < Ny; r += groups) part = fma(A[r * LD + c], yprev[r], part);
+            } else {
+                const double* Gi = G + (long long)i * Ny * Ny;
+                for (int r = g; r < Ny; r += groups) part = fma(Gi[r * Ny + c], yprev[r], part);
+            }
+        }
+        red[tid] = part;
+        __syncthreads();
+        if (tid < Ny) {
+            double t = 0.0;
+            for (int gg = 0; gg < groups; ++gg) t += red[gg * Ny + tid];
+            ycur[tid] = t;
+            P[i * Ny + tid] = t;
+        }
+        __syncthreads();
+    }
+    // --- face fluxes
+    for (int f = tid; f < (Nx + 1) * Ny; f += T) {
+        int ix = f / Ny, iy = f % Ny;
+        Vx[f] = (ix == 0 || ix == Nx) ? 0.0 : (P[(ix - 1) * Ny + iy] - P[ix * Ny + iy]) * TX[f];
+    }
+    for (int f = tid; f < Nx * (Ny + 1); f += T) {
+        int ix = f / (Ny + 1), iy = f % (Ny + 1);
+        Vy[f] = (iy == 0 || iy == Ny) ? 0.0 : (P[ix * Ny + iy - 1] - P[ix * Ny + iy]) * TY[f];
+    }
+    if (bad && tid == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GENERIC saturation step: CFL sub-step count, upwind coefficients, Nts explicit sub-steps, producer
+// gather.   SURVEY.md A.4 (listings GenA, Upstream), obs_model HistoryMatch.py:212-213,363.
+// Summation order of the update = the CSR row order SciPy gives the reference's matrix form
+// (E, N, C, S, W), see oracle/ressim.py saturation_step_stencil.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_saturation_generic(FwdParams p, const T* __restrict__ Sin_base, T* __restrict__ Sout_base,
+                                     long long S_stride, T* __restrict__ prods, int k) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int m = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int NT = blockDim.x;
+    const int Nx = p.Nx, Ny = p.Ny, Nxy = p.Nxy;
+    double* red = smem;  // NT doubles
+
+    const T* Sin = Sin_base + (long long)m * S_stride;
+    T* S = Sout_base + (long long)m * S_stride;
+    const double* Vx = p.Vx + (long long)m * (Nx + 1) * Ny;
+    const double* Vy = p.Vy + (long long)m * Nx * (Ny + 1);
+    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+    T* cE = (T*)p.coef + (long long)m * 6 * Nxy;
+    T *cN = cE + Nxy, *cC = cN + Nxy, *cS = cC + Nxy, *cW = cS + Nxy, *fid = cW + Nxy;
+    T* fw = (T*)p.fw + (long long)m * Nxy;
+
+    // --- CFL: pm = min(pv / (Vi + fi))
+    double lmin = INFINITY;
+    for (int j = tid; j < Nxy; j += NT) {
+        int ix = j / Ny, iy = j % Ny;
+        double xp = fmax(Vx[ix * Ny + iy], 0.0), yp = fmax(Vy[ix * (Ny + 1) + iy], 0.0);
+        double xn = fmin(Vx[(ix + 1) * Ny + iy], 0.0), yn = fmin(Vy[ix * (Ny + 1) + iy + 1], 0.0);
+        double Vi = xp + yp - xn - yn;
+        double fi = fmax(q[j], 0.0);
+        double pv = p.h2 * (p.por ? p.por[j] : 1.0);
+        lmin = fmin(lmin, pv / (Vi + fi));
+    }
+    double pm = block_min(lmin, red, tid, NT);
+    double sat = p.swc + p.sor;
+    double cfl = ((1.0 - sat) / 3.0) * pm;
+    double ntsd = ceil(p.dt / cfl);
+    int bad = !(ntsd >= 1.0 && ntsd <= 1.0e7);
+    int Nts = bad ? 0 : (int)ntsd;
+    if (tid == 0) {
+        p.nts[(long long)m * p.nTime + k] = Nts;
+        if (bad) atomicOr(&p.status[m], HM_MEMBER_BAD_CFL);
+    }
+    // --- upwind coefficients, pre-scaled by dtx = (dt/Nts)/pv
+    for (int j = tid; j < Nxy; j += NT) {
+        int ix = j / Ny, iy = j % Ny;
+        double pv = p.h2 * (p.por ? p.por[j] : 1.0);
+        double d = bad ? 0.0 : (p.dt / (double)Nts) / pv;
+        double vxw = Vx[ix * Ny + iy], vxe = Vx[(ix + 1) * Ny + iy];
+        double vys = Vy[ix * (Ny + 1) + iy], vyn = Vy[ix * (Ny + 1) + iy + 1];
+        double fp = fmin(q[j], 0.0), fi = fmax(q[j], 0.0);
+        double x1 = fmin(vxw, 0.0), x2 = fmax(vxe, 0.0), y1 = fmin(vys, 0.0), y2 = fmax(vyn, 0.0);
+        cC[j] = (T)(d * (fp + x1 - x2 + y1 - y2));
+        cW[j] = (T)(d * fmax(vxw, 0.0));
+        cE[j] = (T)(d * (-fmin(vxe, 0.0)));
+        cS[j] = (T)(d * fmax(vys, 0.0));
+        cN[j] = (T)(d * (-fmin(vyn, 0.0)));
+        fid[j] = (T)(fi * d);
+        S[j] = Sin[j];
+    }
+    __syncthreads();
+    // --- explicit sub-steps
+    for (int it = 0; it < Nts; ++it) {
+        for (int j = tid; j < Nxy; j += NT) {
+            T mw, mo;
+            rel_perm<T>(p, S[j], mw, mo);
+            fw[j] = mw / (mw + mo);
+        }
+        __syncthreads();
+        for (int j = tid; j < Nxy; j += NT) {
+            int ix = j / Ny, iy = j % Ny;
+            T acc = (ix + 1 < Nx) ? cE[j] * fw[j + Ny] : T(0);
+            if (iy + 1 < Ny) acc = acc + cN[j] * fw[j + 1];
+            acc = acc + cC[j] * fw[j];
+            if (iy > 0) acc = acc + cS[j] * fw[j - 1];
+            if (ix > 0) acc = acc + cW[j] * fw[j - Ny];
+            S[j] = S[j] + (acc + fid[j]);
+        }
+        __syncthreads();
+    }
+    // --- checks + producer observations
+    int nonfinite = 0;
+    for (int j = tid; j < Nxy; j += NT)
+        if (!isfinite((double)S[j])) nonfinite = 1;
+    if (nonfinite) atomicOr(&p.status[m], HM_MEMBER_NONFINITE);
+    if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = S[p.prd_ind[tid]];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_fill(T* p, T v, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+template <typename TO>
+__global__ void k_copy_rows(const TO* __restrict__ src, long long src_stride, TO* __restrict__ dst,
+                            long long dst_stride, int rows, long long n) {
+    // dst[r*dst_stride + j] = src[r*src_stride + j]
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < (long long)rows * n; i += stride) {
+        long long r = i / n, j = i % n;
+        dst[r * dst_stride + j] = src[r * src_stride + j];
+    }
+}
+
+static int build_q(hm_fwd* f, int nInj, const int* inj_ind, const double* inj_rates, int inj_cols, int nPrd,
+                   const int* prd_ind, const double* prd_rates, int prd_cols) {
+    const FwdParams& p = f->p;
+    int cols = (inj_cols > 1 || prd_cols > 1) ? p.nTime : 1;
+    HM_REQUIRE(inj_cols == 1 || inj_cols == p.nTime, "inj_rates must have 1 or nTime columns (got %d)", inj_cols);
+    HM_REQUIRE(prd_cols == 1 || prd_cols == p.nTime, "prd_rates must have 1 or nTime columns (got %d)", prd_cols);
+    f->q_host.assign((size_t)cols * p.Nxy, 0.0);
+    for (int k = 0; k < cols; ++k) {
+        double* q = f->q_host.data() + (size_t)k * p.Nxy;
+        double si = 0, sp = 0;
+        for (int w = 0; w < nInj; ++w) {
+            HM_REQUIRE(inj_ind[w] >= 0 && inj_ind[w] < p.Nxy, "injector %d outside the grid", w);
+            double r = inj_rates[(size_t)w * inj_cols + (inj_cols > 1 ? k : 0)];
+            q[inj_ind[w]] += r;
+            si += r;
+        }
+        for (int w = 0; w < nPrd; ++w) {
+            HM_REQUIRE(prd_ind[w] >= 0 && prd_ind[w] < p.Nxy, "producer %d outside the grid", w);
+            double r = prd_rates[(size_t)w * prd_cols + (prd_cols > 1 ? k : 0)];
+            q[prd_ind[w]] -= r;
+            sp += r;
+        }
+        // HistoryMatch.py:182-184: total of the sources must equal that of the sinks
+        HM_REQUIRE(fabs(si - sp) <= 1e-8 + 1e-5 * fabs(sp),
+                   "sum of injection rates (%g) must equal sum of production rates (%g) at step %d", si, sp, k);
+    }
+    f->p.q_cols = cols;
+    return 0;
+}
+
+extern "C" int hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly, int nInj, const int* inj_ind,
+                             const double* inj_rates, int inj_rate_cols, int nPrd, const int* prd_ind,
+                             const double* prd_rates, int prd_rate_cols, double dt, int nTime, double vw, double vo,
+                             double swc, double sor, const double* porosity, int dtype, int keep_history,
+                             hm_fwd** out) {
+    HM_REQUIRE(ctx && out, "hm_fwd_create: NULL argument");
+    HM_REQUIRE(N >= 1 && Nx >= 2 && Ny >= 2, "hm_fwd_create: need N>=1, Nx>=2, Ny>=2 (got %d,%d,%d)", N, Nx, Ny);
+    HM_REQUIRE(Ny <= 128, "hm_fwd_create: Ny=%d > 128 is not supported yet (one workgroup per member)", Ny);
+    HM_REQUIRE(dtype == 64 || dtype == 32, "hm_fwd_create: dtype must be 64 or 32");
+    HM_REQUIRE(nTime >= 1 && dt > 0, "hm_fwd_create: need nTime>=1, dt>0");
+    HM_REQUIRE(nInj >= 1 && nPrd >= 1, "hm_fwd_create: need at least one injector and one producer");
+    HM_REQUIRE(vw > 0 && vo > 0 && swc >= 0 && sor >= 0 && swc + sor < 1, "hm_fwd_create: bad fluid parameters");
+    HM_HIP(hipSetDevice(ctx->device));
+    hm_fwd* f = new hm_fwd();
+    f->ctx = ctx;
+    f->dtype = dtype;
+    f->esz = dtype == 64 ? 8 : 4;
+    f->keep_history = keep_history;
+    FwdParams& p = f->p;
+    p.N = N; p.Nx = Nx; p.Ny = Ny; p.Nxy = Nx * Ny;
+    p.nInj = nInj; p.nPrd = nPrd; p.nTime = nTime;
+    p.hx = Lx / Nx; p.hy = Ly / Ny; p.h2 = p.hx * p.hy;
+    p.cx = 2 * p.hy / p.hx; p.cy = 2 * p.hx / p.hy;
+    p.vw = vw; p.vo = vo; p.swc = swc; p.sor = sor;
+    p.fluid_default = (vw == 1.0 && vo == 1.0 && swc == 0.0 && sor == 0.0);
+    p.dt = dt;
+    int rc = build_q(f, nInj, inj_ind, inj_rates, inj_rate_cols, nPrd, prd_ind, prd_rates, prd_rate_cols);
+    if (rc) { delete f; return rc; }
+    const size_t Nxy = p.Nxy, n = N;
+#define ALLOC(buf, bytes) do { rc = hm_dev_alloc(f->buf, (bytes)); if (rc) { hm_fwd_destroy(f); return rc; } } while (0)
+    ALLOC(K, n * Nxy * 8);
+    ALLOC(perm_in, n * Nxy * 8);
+    ALLOC(q, f->q_host.size() * 8);
+    ALLOC(prd_ind, (size_t)nPrd * 4);
+    ALLOC(TX, n * (Nx + 1) * Ny * 8);
+    ALLOC(TY, n * Nx * (Ny + 1) * 8);
+    ALLOC(G, n * Nxy * Ny * 8);
+    ALLOC(yv, n * Nxy * 8);
+    ALLOC(P, n * Nxy * 8);
+    ALLOC(Vx, n * (Nx + 1) * Ny * 8);
+    ALLOC(Vy, n * Nx * (Ny + 1) * 8);
+    ALLOC(status, n * 4);
+    ALLOC(nts, n * nTime * 4);
+    ALLOC(S, (keep_history ? n * (nTime + 1) : 2 * n) * Nxy * f->esz);
+    ALLOC(prods, n * nTime * nPrd * f->esz);
+    if (porosity) ALLOC(por, Nxy * 8);
+#undef ALLOC
+    p.K = (double*)f->K.p; p.q = (double*)f->q.p; p.prd_ind = (int*)f->prd_ind.p;
+    p.TX = (double*)f->TX.p; p.TY = (double*)f->TY.p; p.G = (double*)f->G.p; p.yv = (double*)f->yv.p;
+    p.P = (double*)f->P.p; p.Vx = (double*)f->Vx.p; p.Vy = (double*)f->Vy.p;
+    p.status = (int*)f->status.p; p.nts = (int*)f->nts.p;
+    p.por = porosity ? (double*)f->por.p : nullptr;
+    p.coef = nullptr; p.fw = nullptr;
+    hipStream_t s = ctx->stream;
+    HM_HIP(hipMemcpyAsync(f->q.p, f->q_host.data(), f->q_host.size() * 8, hipMemcpyHostToDevice, s));
+    HM_HIP(hipMemcpyAsync(f->prd_ind.p, prd_ind, (size_t)nPrd * 4, hipMemcpyHostToDevice, s));
+    if (porosity) HM_HIP(hipMemcpyAsync(f->por.p, porosity, Nxy * 8, hipMemcpyHostToDevice, s));
+    HM_HIP(hipMemsetAsync(f->status.p, 0, n * 4, s));
+    HM_HIP(hipMemsetAsync(f->nts.p, 0, n * nTime * 4, s));
+    HM_HIP(hipMemsetAsync(f->Vx.p, 0, f->Vx.bytes, s));
+    HM_HIP(hipMemsetAsync(f->Vy.p, 0, f->Vy.bytes, s));
+    HM_HIP(hipStreamSynchronize(s));
+    *out = f;
+    return 0;
+}
+
+extern "C" void hm_fwd_destroy(hm_fwd* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->ctx->device);
+    (void)hipStreamSynchronize(f->ctx->stream);
+    DevBuf* bufs[] = {&f->K, &f->por, &f->q, &f->prd_ind, &f->TX, &f->TY, &f->G, &f->yv, &f->P, &f->Vx,
+                      &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods};
+    for (DevBuf* b : bufs) hm_dev_free(*b);
+    f->t_total.destroy(); f->t_press.destroy(); f->t_sat.destroy();
+    delete f;
+}
+
+extern "C" int hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant) {
+    HM_REQUIRE(f, "hm_fwd_set_variant: NULL plan");
+    f->press_variant = pressure_variant;
+    f->sat_variant = saturation_variant;
+    return 0;
+}
+
+extern "C" int hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transformed, const void* wsat0) {
+    HM_REQUIRE(f && perm, "hm_fwd_set_inputs: NULL argument");
+    HM_HIP(hipSetDevice(f->ctx->device));
+    hipStream_t s = f->ctx->stream;
+    const FwdParams& p = f->p;
+    size_t n = (size_t)p.N * p.Nxy;
+    if (perm_is_transformed) {
+        HM_HIP(hipMemcpyAsync(f->K.p, perm, n * 8, hipMemcpyHostToDevice, s));
+    } else {
+        HM_HIP(hipMemcpyAsync(f->perm_in.p, perm, n * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_perm_transform, dim3(2048), dim3(256), 0, s, (const double*)f->perm_in.p, (double*)f->K.p, (long long)n);
+        HM_HIP(hipGetLastError());
+    }
+    long long stride;
+    void* S0 = fwd_S_ptr(f, 0, &stride);
+    if (wsat0) {
+        if (f->keep_history) {
+            HM_HIP(hipMemcpy2DAsync(S0, (size_t)stride * f->esz, wsat0, (size_t)p.Nxy * f->esz, (size_t)p.Nxy * f->esz, p.N, hipMemcpyHostToDevice, s));
+        } else {
+            HM_HIP(hipMemcpyAsync(S0, wsat0, n * f->esz, hipMemcpyHostToDevice, s));
+        }
+    } else {
+        if (f->keep_history) {
+            HM_HIP(hipMemset2DAsync(S0, (size_t)stride * f->esz, 0, (size_t)p.Nxy * f->esz, p.N, s));
+        } else {
+            HM_HIP(hipMemsetAsync(S0, 0, n * f->esz, s));
+        }
+    }
+    HM_HIP(hipMemsetAsync(f->status.p, 0, (size_t)p.N * 4, s));
+    f->cur = 0;
+    HM_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+static int ensure_generic_sat_scratch(hm_fwd* f) {
+    if (f->coef.p) return 0;
+    size_t n = (size_t)f->p.N * f->p.Nxy;
+    int rc = hm_dev_alloc(f->coef, 6 * n * f->esz);
+    if (rc) return rc;
+    rc = hm_dev_alloc(f->fw, n * f->esz);
+    if (rc) return rc;
+    f->p.coef = f->coef.p;
+    f->p.fw = f->fw.p;
+    return 0;
+}
+
+static int generic_threads(int Ny) {
+    int maxT = Ny > 32 ? 1024 : 256;
+    return Ny * (maxT / Ny);
+}
+
+static int launch_pressure(hm_fwd* f, int k) {
+    const FwdParams& p = f->p;
+    hipStream_t s = f->ctx->stream;
+    long long stride;
+    void* S = fwd_S_ptr(f, k, &stride);
+    int rc = f->t_press.begin(s);
+    if (rc) return rc;
+    int done = -1;
+    if (f->press_variant != 1) done = launch_pressure_128(f, S, stride, k);
+    if (done > 0) return done;
+    if (done < 0) {
+        int T = generic_threads(p.Ny);
+        size_t lds = ((size_t)p.Ny * (p.Ny | 1) + 3 * p.Ny + T) * 8;
+        if (f->dtype == 64) {
+            HM_HIP(hipFuncSetAttribute((const void*)k_pressure_generic<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_pressure_generic<double>, dim3(p.N), dim3(T), lds, s, p, (const double*)S, stride, k);
+        } else {
+            HM_HIP(hipFuncSetAttribute((const void*)k_pressure_generic<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_pressure_generic<float>, dim3(p.N), dim3(T), lds, s, p, (const float*)S, stride, k);
+        }
+        HM_HIP(hipGetLastError());
+    }
+    rc = f->t_press.end(s);
+    f->n_press++;
+    return rc;
+}
+
+static int launch_saturation(hm_fwd* f, int k) {
+    const FwdParams& p = f->p;
+    hipStream_t s = f->ctx->stream;
+    long long stride;
+    void* Sin = fwd_S_ptr(f, k, &stride);
+    void* Sout = fwd_S_ptr(f, k + 1, &stride);
+    int rc = f->t_sat.begin(s);
+    if (rc) return rc;
+    int done = -1;
+    if (f->sat_variant != 1) done = launch_saturation_128(f, Sin, Sout, stride, k);
+    if (done > 0) return done;
+    if (done < 0) {
+        rc = ensure_generic_sat_scratch(f);
+        if (rc) return rc;
+        int T = p.Nxy >= 4096 ? 1024 : 256;
+        size_t lds = (size_t)T * 8;
+        if (f->dtype == 64)
+            hipLaunchKernelGGL(k_saturation_generic<double>, dim3(p.N), dim3(T), lds, s, f->p, (const double*)Sin, (double*)Sout, stride, (double*)f->prods.p, k);
+        else
+            hipLaunchKernelGGL(k_saturation_generic<float>, dim3(p.N), dim3(T), lds, s, f->p, (const float*)Sin, (float*)Sout, stride, (float*)f->prods.p, k);
+        HM_HIP(hipGetLastError());
+    }
+    rc = f->t_sat.end(s);
+    f->n_sat++;
+    return rc;
+}
+
+extern "C" int hm_fwd_run(hm_fwd* f, int first_step, int n_steps) {
+    HM_REQUIRE(f, "hm_fwd_run: NULL plan");
+    HM_REQUIRE(first_step >= 0 && n_steps >= 0 && first_step + n_steps <= f->p.nTime,
+               "hm_fwd_run: steps [%d,%d) outside [0,%d)", first_step, first_step + n_steps, f->p.nTime);
+    HM_HIP(hipSetDevice(f->ctx->device));
+    int rc = f->t_total.begin(f->ctx->stream);
+    if (rc) return rc;
+    for (int k = first_step; k < first_step + n_steps; ++k) {
+        if ((rc = launch_pressure(f, k))) return rc;
+        if ((rc = launch_saturation(f, k))) return rc;
+        f->cur = k + 1;
+    }
+    return f->t_total.end(f->ctx->stream);
+}
+
+extern "C" int hm_fwd_pressure_only(hm_fwd* f, int k) {
+    HM_REQUIRE(f && k >= 0 && k < f->p.nTime, "hm_fwd_pressure_only: bad arguments");
+    HM_HIP(hipSetDevice(f->ctx->device));
+    return launch_pressure(f, k);
+}
+
+extern "C" int hm_fwd_saturation_only(hm_fwd* f, int k) {
+    HM_REQUIRE(f && k >= 0 && k < f->p.nTime, "hm_fwd_saturation_only: bad arguments");
+    HM_HIP(hipSetDevice(f->ctx->device));
+    int rc = launch_saturation(f, k);
+    if (!rc) f->cur = k + 1;
+    return rc;
+}
+
+extern "C" int hm_fwd_sync(hm_fwd* f, hm_stats* st) {
+    HM_REQUIRE(f, "hm_fwd_sync: NULL plan");
+    HM_HIP(hipSetDevice(f->ctx->device));
+    HM_HIP(hipStreamSynchronize(f->ctx->stream));
+    if (st) {
+        memset(st, 0, sizeof(*st));
+        st->ms_total = f->t_total.total_ms();
+        st->ms_pressure = f->t_press.total_ms();
+        st->ms_saturation = f->t_sat.total_ms();
+        st->n_pressure_launches = f->n_press;
+        st->n_saturation_launches = f->n_sat;
+        st->member_steps = (long long)f->p.N * f->n_sat;
+        std::vector<int> nts((size_t)f->p.N * f->p.nTime);
+        HM_HIP(hipMemcpy(nts.data(), f->nts.p, nts.size() * 4, hipMemcpyDeviceToHost));
+        double sum = 0; long long cnt = 0;
+        for (int v : nts) if (v > 0) { sum += v; ++cnt; }
+        st->mean_nts = cnt ? sum / cnt : 0.0;
+    }
+    f->t_total.reset(); f->t_press.reset(); f->t_sat.reset();
+    f->n_press = f->n_sat = 0;
+    return 0;
+}
+
+extern "C" int hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status) {
+    HM_REQUIRE(f, "hm_fwd_get_outputs: NULL plan");
+    HM_HIP(hipSetDevice(f->ctx->device));
+    HM_HIP(hipStreamSynchronize(f->ctx->stream));
+    const FwdParams& p = f->p;
+    if (wsats_out) {
+        if (f->keep_history) {
+            HM_HIP(hipMemcpy(wsats_out, f->S.p, (size_t)p.N * (p.nTime + 1) * p.Nxy * f->esz, hipMemcpyDeviceToHost));
+        } else {
+            long long stride;
+            void* S = fwd_S_ptr(f, f->cur, &stride);
+            HM_HIP(hipMemcpy(wsats_out, S, (size_t)p.N * p.Nxy * f->esz, hipMemcpyDeviceToHost));
+        }
+    }
+    if (prods_out) HM_HIP(hipMemcpy(prods_out, f->prods.p, (size_t)p.N * p.nTime * p.nPrd * f->esz, hipMemcpyDeviceToHost));
+    if (status) HM_HIP(hipMemcpy(status, f->status.p, (size_t)p.N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+struct FieldRef { void* p; size_t bytes; bool strided; };
+
+static int field_ref(hm_fwd* f, const char* name, FieldRef& r) {
+    const FwdParams& p = f->p;
+    size_t N = p.N;
+    std::string s(name);
+    r.strided = false;
+    if (s == "P") r = {f->P.p, N * p.Nxy * 8, false};
+    else if (s == "Vx") r = {f->Vx.p, N * (p.Nx + 1) * p.Ny * 8, false};
+    else if (s == "Vy") r = {f->Vy.p, N * p.Nx * (p.Ny + 1) * 8, false};
+    else if (s == "TX") r = {f->TX.p, N * (p.Nx + 1) * p.Ny * 8, false};
+    else if (s == "TY") r = {f->TY.p, N * p.Nx * (p.Ny + 1) * 8, false};
+    else if (s == "K") r = {f->K.p, N * p.Nxy * 8, false};
+    else if (s == "nts") r = {f->nts.p, N * p.nTime * 4, false};
+    else if (s == "G") r = {f->G.p, f->G.bytes, false};
+    else if (s == "S") { r = {nullptr, N * p.Nxy * f->esz, true}; }
+    else { hm_set_error("unknown field '%s'", name); return 2; }
+    return 0;
+}
+
+extern "C" int hm_fwd_get_field(hm_fwd* f, const char* name, void* out) {
+    HM_REQUIRE(f && name && out, "hm_fwd_get_field: NULL argument");
+    HM_HIP(hipSetDevice(f->ctx->device));
+    HM_HIP(hipStreamSynchronize(f->ctx->stream));
+    FieldRef r;
+    int rc = field_ref(f, name, r);
+    if (rc) return rc;
+    if (r.strided) {
+        long long stride;
+        void* S = fwd_S_ptr(f, f->cur, &stride);
+        size_t row = (size_t)f->p.Nxy * f->esz;
+        HM_HIP(hipMemcpy2D(out, row, S, (size_t)stride * f->esz, row, f->p.N, hipMemcpyDeviceToHost));
+    } else {
+        HM_HIP(hipMemcpy(out, r.p, r.bytes, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+extern "C" int hm_fwd_set_field(hm_fwd* f, const char* name, const void* in) {
+    HM_REQUIRE(f && name && in, "hm_fwd_set_field: NULL argument");
+    HM_HIP(hipSetDevice(f->ctx->device));
+    HM_HIP(hipStreamSynchronize(f->ctx->stream));
+    FieldRef r;
+    int rc = field_ref(f, name, r);
+    if (rc) return rc;
+    if (r.strided) {
+        long long stride;
+        void* S = fwd_S_ptr(f, f->cur, &stride);
+        size_t row = (size_t)f->p.Nxy * f->esz;
+        HM_HIP(hipMemcpy2D(S, (size_t)stride * f->esz, in, row, row, f->p.N, hipMemcpyHostToDevice));
+    } else {
+        HM_HIP(hipMemcpy(r.p, in, r.bytes, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" void* hm_fwd_device_ptr(hm_fwd* f, const char* name) {
+    if (!f || !name) return nullptr;
+    std::string s(name);
+    if (s == "S") { long long st; return fwd_S_ptr(f, f->cur, &st); }
+    if (s == "prods") return f->prods.p;
+    if (s == "S_all") return f->S.p;
+    FieldRef r;
+    if (field_ref(f, name, r)) return nullptr;
+    return r.p;
+}
+
+extern "C" int hm_forward_batched(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly, const void* perm,
+                                  int perm_is_transformed, const void* wsat0, int nInj, const int* inj_ind,
+                                  const double* inj_rates, int inj_rate_cols, int nPrd, const int* prd_ind,
+                                  const double* prd_rates, int prd_rate_cols, double dt, int nTime, double vw,
+                                  double vo, double swc, double sor, const double* porosity, int dtype,
+                                  int return_history, void* wsats_out, void* prods_out, int* status_per_member,
+                                  hm_stats* stats) {
+    hm_fwd* f = nullptr;
+    int rc = hm_fwd_create(ctx, N, Nx, Ny, Lx, Ly, nInj, inj_ind, inj_rates, inj_rate_cols, nPrd, prd_ind, prd_rates,
+                           prd_rate_cols, dt, nTime, vw, vo, swc, sor, porosity, dtype, return_history, &f);
+    if (rc) return rc;
+    rc = hm_fwd_set_inputs(f, perm, perm_is_transformed, wsat0);
+    if (!rc) rc = hm_fwd_run(f, 0, nTime);
+    if (!rc) rc = hm_fwd_sync(f, stats);
+    if (!rc) rc = hm_fwd_get_outputs(f, wsats_out, prods_out, status_per_member);
+    hm_fwd_destroy(f);
+    return rc;
+}

@@ -1,0 +1,67 @@
+// fwd.h -- shared definitions of the ensemble forward-model path (plan struct, kernel parameter block).
+#pragma once
+#include "common.h"
+
+// Parameter block passed by value to every forward kernel.  All per-member arrays are laid out
+// member-major: array[m * stride + cell].  Cell index = ix*Ny + iy (C order of shape (Nx,Ny),
+// reference: p.reshape(model.shape) HistoryMatch.py:163).
+struct FwdParams {
+    int N, Nx, Ny, Nxy;
+    int nInj, nPrd, nTime;
+    double hx, hy, h2;        // cell sizes, h2 = hx*hy
+    double cx, cy;            // cx = (2*hy)/hx, cy = (2*hx)/hy   (TPFA harmonic-mean prefactors)
+    double vw, vo, swc, sor;  // fluid
+    int fluid_default;        // 1 when vw=vo=1, swc=sor=0: S*=S, Mw=S^2, Mo=(1-S)^2 exactly
+    double dt;
+    const double* K;          // N*Nxy permeability (isotropic: Kx=Ky, set_perm HistoryMatch.py:164)
+    const double* por;        // Nxy porosity or nullptr (=1)
+    const double* q;          // q_cols*Nxy source field per time column
+    int q_cols;
+    const int* prd_ind;       // nPrd flat cell indices
+    // pressure scratch (fp64 always)
+    double* TX;               // N*(Nx+1)*Ny   x-face transmissibilities
+    double* TY;               // N*Nx*(Ny+1)   y-face transmissibilities
+    double* G;                // N*Nx*Ny*Ny    inverse Schur complements of the block elimination
+    double* yv;               // N*Nxy         forward-eliminated right-hand side
+    double* P;                // N*Nxy         pressure
+    double* Vx;               // N*(Nx+1)*Ny   x-face fluxes
+    double* Vy;               // N*Nx*(Ny+1)   y-face fluxes
+    // generic saturation scratch (dtype of the saturation arithmetic)
+    void* coef;               // 6*N*Nxy : cE,cN,cC,cS,cW,fid
+    void* fw;                 // N*Nxy
+    int* status;              // N
+    int* nts;                 // N*nTime
+};
+
+struct hm_fwd {
+    hm_ctx* ctx = nullptr;
+    FwdParams p{};
+    int dtype = 64;
+    int keep_history = 0;
+    int press_variant = 0, sat_variant = 0;
+    size_t esz = 8;  // bytes per saturation element
+    DevBuf K, por, q, prd_ind, TX, TY, G, yv, P, Vx, Vy, coef, fw, status, nts, perm_in;
+    DevBuf S;      // keep_history ? N*(nTime+1)*Nxy : 2*N*Nxy (ping-pong)
+    DevBuf prods;  // N*nTime*nPrd
+    int cur = 0;   // time index whose saturation is "current" (row in history / ping-pong parity)
+    EvTimer t_total, t_press, t_sat;
+    long long n_press = 0, n_sat = 0;
+    std::vector<double> q_host;
+};
+
+// Pointer to the saturation of (member 0, time index k) and the member stride in elements.
+static inline void* fwd_S_ptr(hm_fwd* f, int k, long long* stride) {
+    char* base = (char*)f->S.p;
+    long long nxy = f->p.Nxy;
+    if (f->keep_history) {
+        *stride = (long long)(f->p.nTime + 1) * nxy;
+        return base + (size_t)k * nxy * f->esz;
+    }
+    *stride = nxy;
+    return base + (size_t)(k & 1) * f->p.N * nxy * f->esz;
+}
+
+// ---- kernels implemented in other translation units ------------------------------------------
+// 128x128 fp64 specialisations (press128.hip / sat128.hip).  Return 0 if launched, -1 if not applicable.
+int launch_pressure_128(hm_fwd* f, const void* S, long long S_stride, int k);
+int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);

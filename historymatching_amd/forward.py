@@ -1,0 +1,148 @@
+"""Ensemble forward model on the GPU: the drop-in for ``forward_model`` / ``utils.apply(comp1, ...)``.
+
+Reference: ``forward_model`` notebooks/HistoryMatch.py:383-387, ``comp1`` :358-364, ``utils.apply``
+notebooks/tools/utils.py:155-242 (process-pool map over members).  Here the whole ensemble is ONE device
+call; multi-GPU runs shard contiguous member blocks over ranks (``historymatching_amd.dist``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .ressim import ResSim
+
+
+def perm_transf(x):
+    """Host version of the reference's transform (HistoryMatch.py:137-138); the device applies the same
+    formula when ``transformed=False``."""
+    return 0.1 + np.exp(5 * x)
+
+
+class ForwardPlan:
+    """Device-resident ensemble forward model (``hm_fwd_*`` in include/hm_abi.h).
+
+    Keeps permeability, saturation history and producer series in HBM so callers (bench.py, ES-MDA,
+    iterative smoothers) can chain forward runs and updates without host round trips.
+    """
+
+    def __init__(self, model: ResSim, N, dt, nTime, keep_history=True, device=None):
+        self.model, self.N, self.dt, self.nTime = model, int(N), float(dt), int(nTime)
+        self.keep_history = bool(keep_history)
+        self.ctx = _lib.Context.get(model.device if device is None else device)
+        self.lib = self.ctx.lib
+        self.ft = np.float64 if model.dtype == 64 else np.float32
+        inj_ind, inj, prd_ind, prd = model._wells(self.nTime)
+        por = None if model.por is None else _lib.as_c(np.asarray(model.por).reshape(-1), np.float64)
+        dp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
+        h = C.c_void_p()
+        _lib.check(self.lib.hm_fwd_create(
+            self.ctx.handle, self.N, model.Nx, model.Ny, model.Lx, model.Ly, model.nInj, ip(inj_ind), dp(inj),
+            inj.shape[1], model.nPrd, ip(prd_ind), dp(prd), prd.shape[1], self.dt, self.nTime, model.vw, model.vo,
+            model.swc, model.sor, dp(por), model.dtype, int(self.keep_history), C.byref(h)), "hm_fwd_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.hm_fwd_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_inputs(self, perms, wsat0s=None, transformed=False):
+        perms = _lib.as_c(perms, np.float64)
+        if perms.shape != (self.N, self.model.Nxy):
+            raise ValueError(f"perms must have shape {(self.N, self.model.Nxy)}, got {perms.shape}")
+        if wsat0s is not None:
+            wsat0s = _lib.as_c(wsat0s, self.ft)
+            if wsat0s.shape != perms.shape:
+                raise ValueError(f"wsat0s must have shape {perms.shape}, got {wsat0s.shape}")
+        _lib.check(self.lib.hm_fwd_set_inputs(self.h, _lib.ptr(perms), int(bool(transformed)), _lib.ptr(wsat0s)),
+                   "hm_fwd_set_inputs")
+
+    def set_variant(self, pressure=0, saturation=0):
+        """0 = fastest applicable kernel, 1 = generic kernels (the in-library correctness baseline)."""
+        _lib.check(self.lib.hm_fwd_set_variant(self.h, int(pressure), int(saturation)), "hm_fwd_set_variant")
+
+    def run(self, first_step=0, n_steps=None):
+        n = self.nTime - first_step if n_steps is None else n_steps
+        _lib.check(self.lib.hm_fwd_run(self.h, int(first_step), int(n)), "hm_fwd_run")
+
+    def pressure_only(self, k=0):
+        _lib.check(self.lib.hm_fwd_pressure_only(self.h, int(k)), "hm_fwd_pressure_only")
+
+    def saturation_only(self, k=0):
+        _lib.check(self.lib.hm_fwd_saturation_only(self.h, int(k)), "hm_fwd_saturation_only")
+
+    def sync(self):
+        st = _lib.hm_stats()
+        _lib.check(self.lib.hm_fwd_sync(self.h, C.byref(st)), "hm_fwd_sync")
+        return st.asdict()
+
+    def outputs(self, want_wsats=True):
+        m = self.model
+        wsats = None
+        if want_wsats:
+            wsats = np.empty((self.N, self.nTime + 1, m.Nxy) if self.keep_history else (self.N, m.Nxy), dtype=self.ft)
+        prods = np.empty((self.N, self.nTime, m.nPrd), dtype=self.ft)
+        status = np.zeros(self.N, dtype=np.int32)
+        _lib.check(self.lib.hm_fwd_get_outputs(self.h, _lib.ptr(wsats), _lib.ptr(prods),
+                                               status.ctypes.data_as(C.POINTER(C.c_int))), "hm_fwd_get_outputs")
+        return wsats, prods, status
+
+    _shapes = {"P": "c", "K": "c", "S": "c", "Vx": "x", "Vy": "y", "TX": "x", "TY": "y", "nts": "t"}
+
+    def _field_array(self, name):
+        m = self.model
+        kind = self._shapes[name]
+        if kind == "c":
+            return np.empty((self.N, m.Nx, m.Ny), dtype=self.ft if name == "S" else np.float64)
+        if kind == "x":
+            return np.empty((self.N, m.Nx + 1, m.Ny))
+        if kind == "y":
+            return np.empty((self.N, m.Nx, m.Ny + 1))
+        return np.empty((self.N, self.nTime), dtype=np.int32)
+
+    def get_field(self, name):
+        out = self._field_array(name)
+        _lib.check(self.lib.hm_fwd_get_field(self.h, name.encode(), _lib.ptr(out)), "hm_fwd_get_field")
+        return out
+
+    def set_field(self, name, arr):
+        ref = self._field_array(name)
+        arr = np.ascontiguousarray(arr, dtype=ref.dtype).reshape(ref.shape)
+        _lib.check(self.lib.hm_fwd_set_field(self.h, name.encode(), _lib.ptr(arr)), "hm_fwd_set_field")
+
+    def device_ptr(self, name):
+        return self.lib.hm_fwd_device_ptr(self.h, name.encode())
+
+
+def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True):
+    """Build the notebook's ``forward_model`` for a given base ``model`` (HistoryMatch.py:358-387).
+
+    The returned function has the reference signature ``forward_model(*args, leave=True, desc="Ens-run",
+    **kwargs)`` -> ``[wsats (N, nTime+1, Nxy), prods (N, nTime, nPrd)]``: the first ensemble argument is the
+    pre-permeability ensemble ``(N, Nxy)``, the optional second (or ``wsat0=`` keyword) the per-member
+    initial saturation ``(N, Nxy)`` (HistoryMatch.py:1224-1227).  ``leave``/``desc`` only drove the
+    reference's progress bar and are accepted and ignored."""
+    default_wsat0 = np.zeros(model.Nxy) if wsat0 is None else np.asarray(wsat0, dtype=float)
+
+    def forward_model(*args, leave=True, desc="Ens-run", **kwargs):
+        args = list(args) + list(kwargs.values())  # utils.py:172-173: kwargs become positional ensembles
+        if not 1 <= len(args) <= 2:
+            raise TypeError(f"comp1() takes 1 or 2 ensemble arguments ({len(args)} given)")
+        perms = np.asarray(args[0])
+        if len(args) == 2:
+            wsat0s = np.asarray(args[1])
+            if len(wsat0s) != len(perms):
+                raise ValueError("zip() arguments have different lengths")  # zip(strict=True), utils.py:175
+        else:
+            wsat0s = np.broadcast_to(default_wsat0, perms.shape)
+        wsats, prods = model.sim_ensemble(perms, wsat0s, dt=dt, nTime=nTime, transformed=False,
+                                          return_history=return_history)
+        return [wsats, prods]
+
+    return forward_model

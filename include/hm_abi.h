@@ -1,0 +1,126 @@
+/* hm_abi.h -- C ABI of libhm_amd.so: the MI355X (gfx950) drop-in for the data-parallel hot path of
+ * patnr/HistoryMatching (reference @ 2024-11-08).
+ *
+ * The reference has no FFI of its own: its boundary is the Python call surface of
+ * notebooks/HistoryMatch.py.  Every entry point below names the reference interface it replaces
+ * (file:line into /root/reference).  Conventions:
+ *   - plain pointers and sizes only; all host arrays are C-contiguous, ensemble axis first;
+ *   - every function returns 0 on success, nonzero on failure; hm_last_error() then describes it;
+ *   - `dtype` is 64 (double) or 32 (float) and is the type of the *saturation* arithmetic and of the
+ *     update arithmetic; the pressure solve is always fp64 (in fp32 the TPFA flux
+ *     T*(p_c-p_nb) has no correct digits at the permeability contrasts of 0.1+exp(5x));
+ *   - host buffers handed in stay owned by the caller; outputs are written into caller buffers;
+ *   - one host thread per context; work inside a context is stream-ordered.
+ */
+#ifndef HM_ABI_H
+#define HM_ABI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hm_ctx hm_ctx;   /* one per process per GPU */
+typedef struct hm_fwd hm_fwd;   /* device-resident ensemble forward-model plan */
+typedef struct hm_upd hm_upd;   /* device-resident ensemble-smoother update plan */
+
+/* Timing/accounting of the last run (all times from HIP events on the context's stream). */
+typedef struct hm_stats {
+    double ms_total;        /* whole call, device side                                         */
+    double ms_pressure;     /* sum over launches of the pressure (assemble+solve+flux) kernel   */
+    double ms_saturation;   /* sum over launches of the saturation sweep kernel                 */
+    double ms_update;       /* ensemble-smoother update kernels                                 */
+    double mean_nts;        /* mean explicit sub-steps per member-step           */
+    long long n_pressure_launches;
+    long long n_saturation_launches;
+    long long member_steps; /* N * nTime processed                                              */
+} hm_stats;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int         hm_create(int device_id, hm_ctx** out);
+void        hm_destroy(hm_ctx* ctx);
+const char* hm_last_error(void);
+int         hm_device_name(hm_ctx* ctx, char* buf, int buflen);   /* e.g. "gfx950:..."           */
+int         hm_abi_version(void);
+
+/* ---- forward model: replaces utils.apply(comp1, ...) = forward_model --------------------------
+ * Reference: forward_model  notebooks/HistoryMatch.py:383-387  (-> utils.apply tools/utils.py:155-242
+ *            -> comp1 HistoryMatch.py:358-364 -> set_perm :160-164 -> model.sim :362 -> obs_model :212-213).
+ * One call runs all N members for nTime steps.
+ *   perm        N*Nxy   pre-permeability x (K = 0.1+exp(5x) applied on device, perm_transf :137-138)
+ *                       when perm_is_transformed==0, else the permeability K itself (Kx=Ky, set_perm :164)
+ *   wsat0       N*Nxy   initial saturation per member, or NULL = zeros (HistoryMatch.py:223, 1224-1227)
+ *   inj_ind/prd_ind     flat cell indices ix*Ny+iy of the wells (model.xy2ind, HistoryMatch.py:209)
+ *   inj_rates   nInj*inj_rate_cols (cols = 1: constant in time; = nTime: per step; HistoryMatch.py:189-193)
+ *   porosity    Nxy or NULL (=1);  vw,vo,swc,sor fluid parameters (upstream defaults 1,1,0,0)
+ *   wsats_out   return_history ? N*(nTime+1)*Nxy (row 0 = wsat0, HistoryMatch.py:224-225) : N*Nxy (final)
+ *   prods_out   N*nTime*nPrd  saturation at producer cells after each step (HistoryMatch.py:363)
+ *   status      N ints, 0 = ok, else HM_MEMBER_* below
+ */
+int hm_forward_batched(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,
+                       const void* perm, int perm_is_transformed, const void* wsat0,
+                       int nInj, const int* inj_ind, const double* inj_rates, int inj_rate_cols,
+                       int nPrd, const int* prd_ind, const double* prd_rates, int prd_rate_cols,
+                       double dt, int nTime, double vw, double vo, double swc, double sor,
+                       const double* porosity, int dtype, int return_history,
+                       void* wsats_out, void* prods_out, int* status_per_member, hm_stats* stats);
+
+#define HM_MEMBER_OK            0
+#define HM_MEMBER_BAD_PIVOT     1   /* non-positive pivot in the pressure factorisation (K<=0, NaN) */
+#define HM_MEMBER_BAD_CFL       2   /* CFL sub-step count not finite / out of range               */
+#define HM_MEMBER_NONFINITE     4   /* NaN/Inf in the saturation                                    */
+
+/* Device-resident form of the same path (what bench.py times; what ES-MDA/IES drivers chain). */
+int  hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,
+                   int nInj, const int* inj_ind, const double* inj_rates, int inj_rate_cols,
+                   int nPrd, const int* prd_ind, const double* prd_rates, int prd_rate_cols,
+                   double dt, int nTime, double vw, double vo, double swc, double sor,
+                   const double* porosity, int dtype, int keep_history, hm_fwd** out);
+void hm_fwd_destroy(hm_fwd* f);
+int  hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transformed, const void* wsat0); /* H2D */
+int  hm_fwd_run(hm_fwd* f, int first_step, int n_steps);           /* async; steps [first, first+n)  */
+int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
+int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member);     /* D2H */
+int  hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant); /* 0=auto, 1=generic */
+/* Component hooks used by the parity tests (each maps to one listing of the cited paper):
+ * run ONLY the pressure step / ONLY the saturation step of time index k on device state, and read
+ * intermediate fields back. */
+int  hm_fwd_pressure_only(hm_fwd* f, int k);
+int  hm_fwd_saturation_only(hm_fwd* f, int k);
+int  hm_fwd_get_field(hm_fwd* f, const char* name /* "S","P","Vx","Vy","TX","TY","K","nts" */, void* out);
+int  hm_fwd_set_field(hm_fwd* f, const char* name /* "S","Vx","Vy" */, const void* in);
+void* hm_fwd_device_ptr(hm_fwd* f, const char* name);   /* raw device pointer of a named buffer */
+
+/* ---- ensemble-smoother update: replaces ens_update0 -------------------------------------------
+ * Reference: ens_update0  notebooks/HistoryMatch.py:578-586  (center: tools/utils.py:10-28).
+ *   E N*M, obs_ens N*n_obs, obs n_obs, perturbs N*n_obs, decorr n_obs*n_obs  ->  E_out N*M
+ * Evaluated in the minimum-flop association  E + (D C^-1)(S^T X)  (SURVEY.md 8a row a8). */
+int hm_es_update(hm_ctx* ctx, int N, int M, int n_obs, const void* E, const void* obs_ens,
+                 const void* obs, const void* perturbs, const void* decorr, int dtype,
+                 void* E_out, hm_stats* stats);
+
+/* Reference: ens_update0_loc  notebooks/HistoryMatch.py:774-797;  taper is M*n_obs (HistoryMatch.py:863),
+ * cutoff is the 1e-2 of HistoryMatch.py:786. */
+int hm_es_update_loc(hm_ctx* ctx, int N, int M, int n_obs, const void* E, const void* obs_ens,
+                     const void* obs, const void* perturbs, const void* decorr, const void* taper,
+                     double cutoff, int dtype, void* E_out, hm_stats* stats);
+
+/* Device-resident / sharded form: rows [row0, row0+N_local) of an N-member ensemble live on this GPU.
+ * The two cross-rank reductions (column sums; Gx = S^T X) are exposed as buffers the host
+ * all-reduces with RCCL between the phases:
+ *   phase 0: local column sums of E and obs_ens            -> hm_upd_reduce_buffer(0) (M+n_obs values)
+ *   phase 1: (after all-reduce) S, D, local S^T S and S^T X -> hm_upd_reduce_buffer(1) (n_obs*(n_obs+M))
+ *   phase 2: (after all-reduce) C^-1, E_out = E + (D C^-1) Gx  (row-local)                              */
+int   hm_upd_create(hm_ctx* ctx, int N_total, int N_local, int M, int n_obs, int dtype, int localized, hm_upd** out);
+void  hm_upd_destroy(hm_upd* u);
+int   hm_upd_set_inputs(hm_upd* u, const void* E_local, const void* obs_ens_local, const void* obs,
+                        const void* perturbs_local, const void* decorr, const void* taper /* or NULL */, double cutoff);
+int   hm_upd_phase(hm_upd* u, int phase);
+void* hm_upd_reduce_buffer(hm_upd* u, int which, long long* n_elems);   /* device pointer, dtype elements */
+int   hm_upd_sync(hm_upd* u, hm_stats* stats);
+int   hm_upd_get_output(hm_upd* u, void* E_out_local);
+void* hm_upd_device_ptr(hm_upd* u, const char* name);   /* "E","E_out","obs_ens","perturbs" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HM_ABI_H */
