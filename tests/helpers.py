@@ -24,3 +24,23 @@ def make_models(Nx, Ny, dtype=64):
 
 def perms(Nx, Ny, N, seed=1, scale=1.0):
     return scale * gaussian_fields_kron(Nx, Ny, 2, 1, N, r=0.8, seed=seed)
+
+
+def oracle_sim_and_noise(om, x, dt, nTime, wsat0=None):
+    """Oracle simulation of one member plus the oracle's OWN numerical noise: the same restatement with
+    SuperLU's column ordering switched from COLAMD to NATURAL.  The TPFA system is ill-conditioned
+    (transmissibilities up to ~1e6: T*eps*|p| ~ 1e-9 flux noise for any fp64 solver), and the saturation
+    front amplifies it, so parity of a different direct solver can only be asked to within this spread."""
+    import oracle.ressim as orc
+    from scipy.sparse.linalg import spsolve
+
+    orc.set_perm(om, x)
+    w0 = np.zeros(om.Nxy) if wsat0 is None else wsat0
+    ref = om.sim(dt, nTime, w0)
+    orig = orc.spsolve
+    orc.spsolve = lambda A, b: spsolve(A.tocsc(), b, permc_spec="NATURAL")
+    try:
+        ref2 = om.sim(dt, nTime, w0)
+    finally:
+        orc.spsolve = orig
+    return ref, float(np.abs(ref2 - ref).max())

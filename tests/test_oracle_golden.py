@@ -1,0 +1,86 @@
+"""Pins oracle/es.py against fixtures captured from the reference's own functions (oracle/make_golden.py)."""
+import numpy as np
+
+from oracle import es
+
+
+def _load(golden, name):
+    return np.load(golden / name)
+
+
+def test_rng_replay_anchor_values(golden):
+    f1 = _load(golden, "f1_rng_replay.npz")
+    # first values of perm.Truth, prior mean/var
+    assert np.allclose(f1["perm_truth"][0, :3], [1.62434536, 1.51231157, 1.35084072])
+    assert abs(f1["perm_prior"].mean() - 0.0607) < 1e-4 and abs(f1["perm_prior"].var() - 1.0118) < 1e-4
+    assert f1["perm_prior"].shape == (40, 400) and f1["hm_perturbs"].shape == (40, 160)
+
+
+def test_obs_error_model(golden):
+    f2 = _load(golden, "f2_obs_error.npz")
+    R, R12, decorr = es.obs_error_model(40, 4)
+    assert np.array_equal(R, f2["R"])
+    assert np.allclose(R12, f2["R12"], rtol=0, atol=1e-15)
+    assert np.allclose(decorr, f2["decorr"], rtol=0, atol=1e-12)
+
+
+def test_ens_update0_gaussian_gaussian_bugcheck(golden):
+    """HistoryMatch.py:594-612: posterior ~ N(y/4 = 1, I) up to sampling error."""
+    f1, f3 = _load(golden, "f1_rng_replay.npz"), _load(golden, "f3_ens_update0.npz")
+    E = f1["gg_E"]
+    post = es.ens_update0(E, E, 4 * np.ones(3), f1["gg_perturbs"], 0.5 * np.eye(3))
+    assert np.abs(post - f3["gg_postr"]).max() < 1e-13
+    assert np.allclose(post.mean(0), [0.98474734, 1.08434752, 1.02224568], atol=1e-8)
+    assert np.abs(np.cov(post.T) - np.eye(3)).max() < 0.15
+
+
+def test_ens_update0_history_matching_shapes(golden):
+    f1, f2, f3 = (_load(golden, n) for n in ("f1_rng_replay.npz", "f2_obs_error.npz", "f3_ens_update0.npz"))
+    kw = dict(obs_ens=f3["obs_ens"], obs=f3["obs"], perturbs=f1["hm_perturbs"], decorr=f2["decorr"])
+    assert np.abs(es.ens_update0(f1["perm_prior"], **kw) - f3["perm_es"]).max() < 1e-12
+    assert np.abs(es.ens_update0(f3["obs_ens"], **kw) - f3["es0"]).max() < 1e-12  # HistoryMatch.py:1156
+
+
+def test_ens_update0_loc(golden):
+    f1, f2, f3, f4 = (_load(golden, n) for n in ("f1_rng_replay.npz", "f2_obs_error.npz", "f3_ens_update0.npz", "f4_ens_update0_loc.npz"))
+    E = f1["gg_E"]
+    gg = es.ens_update0_loc(E, E, 4 * np.ones(3), f1["gg_perturbs"], 0.5 * np.eye(3), np.eye(3))
+    assert np.abs(gg - f4["gg_postr_loc"]).max() < 1e-13
+    kw = dict(obs_ens=f3["obs_ens"], obs=f3["obs"], perturbs=f1["hm_perturbs"], decorr=f2["decorr"])
+    ones = es.ens_update0_loc(f1["perm_prior"], **kw, taper=np.ones((400, 160)))
+    assert np.abs(ones - f4["les_ones"]).max() < 1e-12
+    assert np.allclose(ones, f3["perm_es"])  # "Reproduces global analysis?" HistoryMatch.py:821-822
+    les = es.ens_update0_loc(f1["perm_prior"], **kw, taper=f4["taper"])
+    assert np.abs(les - f4["perm_les"]).max() < 1e-12
+
+
+def test_helpers(golden):
+    f5 = _load(golden, "f5_helpers.npz")
+    X, x = es.center(f5["a"])
+    assert np.array_equal(X, f5["center_X"]) and np.array_equal(x, f5["center_x"])
+    assert np.array_equal(es.center(f5["a"], rescale=True)[0], f5["center_Xr"])
+    assert np.allclose(es.cov(f5["a"], f5["b"]), f5["cov"], rtol=0, atol=1e-15)
+    assert np.allclose(es.corr(f5["a"], f5["b"][:, 0]), f5["corr"], rtol=0, atol=1e-15)
+    for s, ref in zip(f5["bump_sharp"], f5["bumps"]):
+        assert np.array_equal(es.bump(f5["bump_x"], s), ref)
+    assert np.array_equal(es.pairwise_distances(f5["pd_A"]), f5["pd_AA"])
+    assert np.array_equal(es.pairwise_distances(np.arange(4)[:, None], [[2]]), f5["pd_1d"])
+    assert np.array_equal(es.pairwise_distances(np.arange(4)[:, None], domain=(4,)), f5["pd_periodic"])
+    # doctest values of the reference (localization.py:31-60, geostat.py:19-22)
+    assert np.allclose(f5["pd_AA"][0], [0, 1, 1, 2**0.5])
+    assert np.allclose(f5["vg"], [0.0, 0.6689085, 0.98351593])
+
+
+def test_taper_from_restated_grid(golden):
+    """Taper wiring HistoryMatch.py:700-717, 863 on the restated 20x20 grid."""
+    from oracle.ressim import ResSim, default_wells
+
+    f4 = _load(golden, "f4_ens_update0_loc.npz")
+    model = default_wells(ResSim(20, 20, 2, 1))
+    prod_inds = model.xy2ind(*model.prd_xy.T)
+    assert np.array_equal(prod_inds, f4["prod_inds"])
+    xy_obs = np.tile(model.ind2xy(prod_inds), 40)
+    xy_prm = model.ind2xy(np.arange(model.Nxy))
+    d = es.pairwise_distances(xy_prm.T, xy_obs.T)
+    assert np.array_equal(d, f4["distances_to_obs"])
+    assert np.array_equal(es.bump(d / 1.2), f4["taper"])

@@ -1,0 +1,99 @@
+"""The simulator oracle has no upstream golden vectors ("parity unpinned", oracle/ressim.py header).  These tests
+pin what CAN be pinned: internal consistency of the restatement and the physics invariants of SURVEY.md A.6."""
+import numpy as np
+import pytest
+
+from oracle.ressim import ResSim, default_wells, forward_model, set_perm
+from tests.helpers import perms
+
+DT = 0.025
+
+
+@pytest.fixture(scope="module")
+def model():
+    m = default_wells(ResSim(20, 20, 2, 1))
+    set_perm(m, perms(20, 20, 1, seed=1)[0])
+    return m
+
+
+def test_grid_conventions(model):
+    assert model.shape == (20, 20) and model.Nxy == 400
+    X, Y = model.mesh
+    assert X.shape == (20, 20) and np.isclose(X[3, 0], 0.35) and np.isclose(Y[0, 3], 0.175)
+    ind = model.xy2ind(*model.prd_xy.T)
+    assert ind.tolist() == [2 * 20 + 2, 17 * 20 + 2, 2 * 20 + 17, 17 * 20 + 17]
+    assert np.allclose(model.ind2xy(ind).T, model.prd_xy)  # wells collocated to cell centres
+    assert model.xy2ind(2.0, 1.0) == 399  # upper edge clamps into the last cell
+    with pytest.raises(ValueError):
+        model.xy2ind(2.1, 0.5)
+
+
+def test_stencil_form_is_bitexact_with_sparse_form(model):
+    S = np.zeros(400)
+    q, _, _ = model.source_field(0)
+    for _ in range(5):
+        _, Vx, Vy = model.pressure_step(S, q)
+        a = model.saturation_step_upwind(S, q, Vx, Vy, DT)
+        b = model.saturation_step_stencil(S, q, Vx, Vy, DT)
+        assert np.array_equal(a, b)
+        S = a
+
+
+def test_cfl_substeps_default_case(model):
+    q, _, _ = model.source_field(0)
+    _, Vx, Vy = model.pressure_step(np.zeros(400), q)
+    assert model.cfl_substeps(Vx, Vy, q, DT)[0] == 15  # dt/cfl = 14.999999999999998
+
+
+def test_pressure_matrix_and_flux_invariants(model):
+    S = np.linspace(0, 0.6, 400)
+    q, _, _ = model.source_field(0)
+    P, Vx, Vy = model.pressure_step(S, q)
+    div = (Vx[1:] - Vx[:-1]) + (Vy[:, 1:] - Vy[:, :-1])
+    assert np.abs(div.ravel() - q).max() < 1e-9  # discrete divergence = wells
+    assert np.all(Vx[0] == 0) and np.all(Vx[-1] == 0) and np.all(Vy[:, 0] == 0) and np.all(Vy[:, -1] == 0)
+
+
+def test_mass_balance_and_bounds(model):
+    w = model.sim(DT, 40, np.zeros(400))
+    assert w.shape == (41, 400) and np.all(w[0] == 0)
+    assert w.min() >= 0 and w.max() <= 1
+    prod_inds = model.xy2ind(*model.prd_xy.T)
+    # before breakthrough water in place grows by the injected volume (rate 1): sum(pv*S) = t
+    assert np.all(w[10][prod_inds] < 1e-6)
+    assert abs(w[10].sum() * model.h2 - 10 * DT) < 1e-9
+    assert model.actual_rates["inj"].shape == (1, 40)
+
+
+def test_xy_symmetry():
+    """Transposing the (square-celled) problem transposes the solution."""
+    a = ResSim(12, 16, 1.2, 1.6)
+    b = ResSim(16, 12, 1.6, 1.2)
+    k = 0.1 + np.exp(perms(12, 16, 1, seed=4)[0].reshape(12, 16))
+    a.K = np.stack([k, k])
+    b.K = np.stack([k.T, k.T])
+    for m, inj, prd in ((a, [[0.25, 0.35]], [[1.0, 1.3]]), (b, [[0.35, 0.25]], [[1.3, 1.0]])):
+        m.inj_xy, m.prd_xy, m.inj_rates, m.prd_rates = inj, prd, [[1.0]], [[1.0]]
+    wa = a.sim(DT, 5, np.zeros(a.Nxy))[-1].reshape(12, 16)
+    wb = b.sim(DT, 5, np.zeros(b.Nxy))[-1].reshape(16, 12)
+    assert np.abs(wa - wb.T).max() < 1e-9
+
+
+def test_unbalanced_wells_raise(model):
+    import copy
+
+    m = copy.deepcopy(model)
+    m.prd_rates = np.ones((4, 1)) / 3
+    with pytest.raises(ValueError):
+        m.sim(DT, 1, np.zeros(400))
+
+
+def test_forward_model_map_semantics_and_pool():
+    m = default_wells(ResSim(20, 20, 2, 1))
+    x = perms(20, 20, 3, seed=2)
+    w1, p1 = forward_model(m, x, None, DT, 4, nproc=1)
+    w2, p2 = forward_model(m, x, None, DT, 4, nproc=2)
+    assert w1.shape == (3, 5, 400) and p1.shape == (3, 4, 4)
+    assert np.array_equal(w1, w2) and np.array_equal(p1, p2)  # ordered map (utils.py:218 imap)
+    with pytest.raises(ValueError):
+        forward_model(m, x, np.zeros((2, 400)), DT, 4)
