@@ -45,6 +45,8 @@ SIGNATURES = {
     "hm_last_error": (C.c_char_p, []),
     "hm_device_name": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "hm_abi_version": (C.c_int, []),
+    "hm_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_longlong]),
+    "hm_copy_to_device": (C.c_int, [_vp, _vp, _vp, C.c_longlong]),
     "hm_forward_batched": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _vp, C.c_int, _vp,
                                      C.c_int, _ip, _dp, C.c_int, C.c_int, _ip, _dp, C.c_int, C.c_double, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_double, _dp, C.c_int, C.c_int, _vp, _vp,
@@ -65,6 +67,7 @@ SIGNATURES = {
     "hm_fwd_device_ptr": (_vp, [_vp, C.c_char_p]),
     "hm_es_update": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp,
                                C.POINTER(hm_stats)]),
+    "hm_center": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "hm_es_update_loc": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double,
                                    C.c_int, _vp, C.POINTER(hm_stats)]),
     "hm_upd_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),

@@ -91,3 +91,19 @@ void EvTimer::destroy() {
     evs.clear();
     used = 0;
 }
+
+extern "C" int hm_copy_to_host(hm_ctx* ctx, void* dst_host, const void* src_device, long long bytes) {
+    HM_REQUIRE(ctx && dst_host && src_device && bytes >= 0, "hm_copy_to_host: bad arguments");
+    HM_HIP(hipSetDevice(ctx->device));
+    HM_HIP(hipStreamSynchronize(ctx->stream));
+    HM_HIP(hipMemcpy(dst_host, src_device, (size_t)bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int hm_copy_to_device(hm_ctx* ctx, void* dst_device, const void* src_host, long long bytes) {
+    HM_REQUIRE(ctx && dst_device && src_host && bytes >= 0, "hm_copy_to_device: bad arguments");
+    HM_HIP(hipSetDevice(ctx->device));
+    HM_HIP(hipStreamSynchronize(ctx->stream));
+    HM_HIP(hipMemcpy(dst_device, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+    return 0;
+}

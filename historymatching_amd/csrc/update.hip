@@ -1,12 +1,519 @@
-// update.hip -- ensemble-smoother update (placeholder entry points; filled in next)
+// update.hip -- ensemble-smoother (Kalman) update, global and localised.
+//
+// Replaces  ens_update0      notebooks/HistoryMatch.py:578-586   (center: tools/utils.py:10-28)
+//           ens_update0_loc  notebooks/HistoryMatch.py:774-797
+// evaluated in the minimum-flop association:
+//     X, Y anomalies;  S = Y decorr;  D = (obs - obs_ens - perturbs) decorr
+//     G = S^T S ;  Gxt = X^T S  (M x n_obs)         <- the only cross-member contractions
+//     global:     E_out = E + (D (G + (N-1) I)^-1) Gxt^T
+//     localised:  per state element i:  c = sqrt(taper[i]), jj = c > cutoff,
+//                 (c c^T o G[jj,jj] + (N-1) I) w = c o Gxt[i,jj]  (Cholesky in LDS),  Wt[i,jj] = c o w
+//                 E_out = E + D Wt^T
+// Rows (members) may be sharded over GPUs: the column sums and [G | Gxt] are exposed as reduce buffers that
+// the host all-reduces (RCCL) between phases.
+//
+// The GEMMs here are the first correct version: LDS-tiled, 4x4 register micro-tiles, VALU FMAs in the
+// arithmetic dtype.  (An MFMA path for fp32 is the optimisation target named in DESIGN.md.)
 #include "common.h"
-extern "C" int hm_es_update(hm_ctx*, int, int, int, const void*, const void*, const void*, const void*, const void*, int, void*, hm_stats*) { hm_set_error("hm_es_update: not implemented"); return 3; }
-extern "C" int hm_es_update_loc(hm_ctx*, int, int, int, const void*, const void*, const void*, const void*, const void*, const void*, double, int, void*, hm_stats*) { hm_set_error("hm_es_update_loc: not implemented"); return 3; }
-extern "C" int hm_upd_create(hm_ctx*, int, int, int, int, int, int, hm_upd**) { hm_set_error("not implemented"); return 3; }
-extern "C" void hm_upd_destroy(hm_upd*) {}
-extern "C" int hm_upd_set_inputs(hm_upd*, const void*, const void*, const void*, const void*, const void*, const void*, double) { return 3; }
-extern "C" int hm_upd_phase(hm_upd*, int) { return 3; }
-extern "C" void* hm_upd_reduce_buffer(hm_upd*, int, long long*) { return nullptr; }
-extern "C" int hm_upd_sync(hm_upd*, hm_stats*) { return 3; }
-extern "C" int hm_upd_get_output(hm_upd*, void*) { return 3; }
-extern "C" void* hm_upd_device_ptr(hm_upd*, const char*) { return nullptr; }
+
+struct hm_upd {
+    hm_ctx* ctx = nullptr;
+    int N_total = 0, N_local = 0, M = 0, n_obs = 0, dtype = 64, localized = 0;
+    size_t esz = 8;
+    double cutoff = 1e-2;
+    DevBuf E, E_out, obs_ens, perturbs, obs, decorr, taper;
+    DevBuf red0, red1;            // [colsum E (M) | colsum obs_ens (n_obs)],  [G (n_obs^2) | Gxt (M*n_obs)]
+    DevBuf Y, D0, S, D, T1, Cinv, CinvT, Wt, partial, flags;
+    EvTimer t_upd;
+};
+
+// ------------------------------------------------------------------------------------------------
+// column sums (deterministic two-stage)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_colsum_partial(const T* __restrict__ A, int rows, int cols, int rows_per_split, double* __restrict__ partial) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int split = blockIdx.y;
+    if (j >= cols) return;
+    int r0 = split * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+    double s = 0.0;
+    for (int r = r0; r < r1; ++r) s += (double)A[(size_t)r * cols + j];
+    partial[(size_t)split * cols + j] = s;
+}
+
+template <typename T>
+__global__ void k_colsum_final(const double* __restrict__ partial, int splits, int cols, T* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    double s = 0.0;
+    for (int k = 0; k < splits; ++k) s += partial[(size_t)k * cols + j];
+    out[j] = (T)s;
+}
+
+// Y = obs_ens - mean(obs_ens);  D0 = obs - obs_ens - perturbs      (HistoryMatch.py:582, 584)
+template <typename T>
+__global__ void k_prep_obs(const T* __restrict__ obs_ens, const T* __restrict__ perturbs, const T* __restrict__ obs,
+                           const T* __restrict__ colsum_y, double inv_n_total, int rows, int n_obs,
+                           T* __restrict__ Y, T* __restrict__ D0) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * n_obs) return;
+    int j = (int)(i % n_obs);
+    T mean = (T)((double)colsum_y[j] * inv_n_total);
+    T o = obs_ens[i];
+    Y[i] = o - mean;
+    D0[i] = obs[j] - o - perturbs[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic tiled GEMM:  C[i][j] = sum_k (A(i,k) - arow_sub[i]*scale) * B(k,j)  (+ add[i][j])
+//   A(i,k) = A[i*sa_i + k*sa_k],  B(k,j) = B[k*sb_k + j*sb_j]
+// ------------------------------------------------------------------------------------------------
+#define GT 64
+#define GK 16
+template <typename T, bool A_CONTIG_I, bool B_CONTIG_J>
+__global__ __launch_bounds__(256) void k_gemm(int m, int n, int k, const T* __restrict__ A, size_t sa_i, size_t sa_k,
+                                              const T* __restrict__ B, size_t sb_k, size_t sb_j, T* __restrict__ Cm,
+                                              size_t ldc, const T* __restrict__ add, size_t ldadd,
+                                              const T* __restrict__ arow_sub, double sub_scale) {
+    __shared__ T As[GK][GT + 4];
+    __shared__ T Bs[GK][GT + 4];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+    const int ti = tid / 16, tj = tid % 16;  // 16x16 threads, each 4x4 outputs (rows ti+16a, cols tj+16b)
+    T acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = T(0);
+
+    for (int k0 = 0; k0 < k; k0 += GK) {
+        // stage A tile (GT x GK) and B tile (GK x GT); 1024 elements each, 4 per thread
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int idx = tid + 256 * e;
+            int ii, kk;
+            if (A_CONTIG_I) { ii = idx % GT; kk = idx / GT; } else { kk = idx % GK; ii = idx / GK; }
+            int gi = i0 + ii, gk = k0 + kk;
+            T v = T(0);
+            if (gi < m && gk < k) {
+                v = A[gi * sa_i + gk * sa_k];
+                if (arow_sub) v = v - (T)((double)arow_sub[gi] * sub_scale);
+            }
+            As[kk][ii] = v;
+            int jj, kb;
+            if (B_CONTIG_J) { jj = idx % GT; kb = idx / GT; } else { kb = idx % GK; jj = idx / GK; }
+            int gj = j0 + jj, gkb = k0 + kb;
+            Bs[kb][jj] = (gj < n && gkb < k) ? B[gkb * sb_k + gj * sb_j] : T(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; ++kk) {
+            T av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = As[kk][ti + 16 * a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = Bs[kk][tj + 16 * b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        int gi = i0 + ti + 16 * a;
+        if (gi >= m) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int gj = j0 + tj + 16 * b;
+            if (gj >= n) continue;
+            T v = acc[a][b];
+            if (add) v = add[gi * ldadd + gj] + v;
+            Cm[gi * ldc + gj] = v;
+        }
+    }
+}
+
+template <typename T>
+static int gemm(hipStream_t s, int m, int n, int k, const T* A, size_t sa_i, size_t sa_k, const T* B, size_t sb_k,
+                size_t sb_j, T* Cm, size_t ldc, const T* add = nullptr, size_t ldadd = 0, const T* arow_sub = nullptr,
+                double sub_scale = 0.0) {
+    dim3 grid((n + GT - 1) / GT, (m + GT - 1) / GT), block(256);
+    bool ai = (sa_i == 1), bj = (sb_j == 1);
+#define LAUNCH(AI, BJ) hipLaunchKernelGGL((k_gemm<T, AI, BJ>), grid, block, 0, s, m, n, k, A, sa_i, sa_k, B, sb_k, sb_j, Cm, ldc, add, ldadd, arow_sub, sub_scale)
+    if (ai && bj) LAUNCH(true, true);
+    else if (ai && !bj) LAUNCH(true, false);
+    else if (!ai && bj) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cinv = (G + (N-1) I)^-1  by symmetric sweeps, one workgroup, fp64, matrix in global memory.
+// (HistoryMatch.py:585-586: C = S^T S + (N-1) I is SPD with lambda_min >= N-1, so pinv == inv.)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void k_invert_C(const T* __restrict__ G, int n, double ridge, double* __restrict__ W,
+                                                   double* __restrict__ colbuf, T* __restrict__ outT, int* __restrict__ flag) {
+    const int tid = threadIdx.x, NT = blockDim.x;
+    for (int e = tid; e < n * n; e += NT) {
+        int r = e / n, c = e % n;
+        // symmetrise the (all-reduced) Gram matrix: exact in exact arithmetic, removes rounding asymmetry
+        W[e] = 0.5 * ((double)G[r * n + c] + (double)G[c * n + r]) + (r == c ? ridge : 0.0);
+    }
+    int bad = 0;
+    for (int kk = 0; kk < n; ++kk) {
+        __syncthreads();
+        for (int c = tid; c < n; c += NT) colbuf[c] = W[kk * n + c];
+        __syncthreads();
+        double d = colbuf[kk];
+        if (!(d > 0.0)) bad = 1;
+        double pinv = 1.0 / d;
+        for (int e = tid; e < n * n; e += NT) {
+            int r = e / n, c = e % n;
+            double v;
+            if (r == kk) v = (c == kk) ? -pinv : colbuf[c] * pinv;
+            else if (c == kk) v = colbuf[r] * pinv;
+            else v = fma(-colbuf[r], colbuf[c] * pinv, W[e]);
+            W[e] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += NT) {
+        double v = -W[e];
+        W[e] = v;
+        outT[e] = (T)v;
+    }
+    if (bad && tid == 0) *flag = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// localised analysis: one workgroup per state element   (HistoryMatch.py:783-793)
+// LDS: packed lower triangle of Ci (n_loc <= n_obs), rhs, index list.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_local_analysis(int M, int n_obs, int N_total, double cutoff,
+                                                        const T* __restrict__ taper, const T* __restrict__ G,
+                                                        const T* __restrict__ Gxt, T* __restrict__ Wt, int* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) double smem_d[];
+    const int i = blockIdx.x;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    double* L = smem_d;                                    // n_obs*(n_obs+1)/2
+    double* rhs = L + (size_t)n_obs * (n_obs + 1) / 2;     // n_obs
+    double* cvec = rhs + n_obs;                            // n_obs
+    int* jj = (int*)(cvec + n_obs);                        // n_obs
+    int* n_loc_s = jj + n_obs;                             // 1 (all LDS in the one dynamic array, guide G17)
+
+    // ci = sqrt(taper[i]); jj = ci > cutoff   (serial compaction keeps the reference's obs order)
+    for (int j = tid; j < n_obs; j += NT) {
+        cvec[j] = sqrt((double)taper[(size_t)i * n_obs + j]);
+        Wt[(size_t)i * n_obs + j] = T(0);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int cnt = 0;
+        for (int j = 0; j < n_obs; ++j)
+            if (cvec[j] > cutoff) jj[cnt++] = j;
+        *n_loc_s = cnt;
+    }
+    __syncthreads();
+    const int nl = *n_loc_s;
+    if (nl == 0) return;  // no observation in range: element unchanged (HistoryMatch.py:787-788)
+    // Ci = (c c^T) o G[jj,jj] + (N-1) I ;  rhs = c o Gxt[i,jj]
+    for (int e = tid; e < nl * (nl + 1) / 2; e += NT) {
+        int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        while (r * (r + 1) / 2 > e) --r;
+        int c = e - r * (r + 1) / 2;
+        int jr = jj[r], jc = jj[c];
+        double g = 0.5 * ((double)G[jr * n_obs + jc] + (double)G[jc * n_obs + jr]);
+        L[e] = cvec[jr] * g * cvec[jc] + (r == c ? (double)(N_total - 1) : 0.0);
+    }
+    for (int r = tid; r < nl; r += NT) rhs[r] = cvec[jj[r]] * (double)Gxt[(size_t)i * n_obs + jj[r]];
+    __syncthreads();
+    // in-place Cholesky (right-looking) on the packed lower triangle
+    int bad = 0;
+    for (int k = 0; k < nl; ++k) {
+        const int kk = k * (k + 1) / 2;
+        double d = L[kk + k];
+        if (!(d > 0.0)) bad = 1;
+        double dk = sqrt(d), inv = 1.0 / dk;
+        __syncthreads();
+        for (int r = k + 1 + tid; r < nl; r += NT) L[r * (r + 1) / 2 + k] *= inv;
+        if (tid == 0) L[kk + k] = dk;
+        __syncthreads();
+        // trailing update A[r][c] -= L[r][k] L[c][k],  k < c <= r
+        int nt = nl - k - 1;
+        for (int e = tid; e < nt * (nt + 1) / 2; e += NT) {
+            int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            while ((r + 1) * (r + 2) / 2 <= e) ++r;
+            while (r * (r + 1) / 2 > e) --r;
+            int c = e - r * (r + 1) / 2;
+            int R = r + k + 1, Cc = c + k + 1;
+            L[R * (R + 1) / 2 + Cc] = fma(-L[R * (R + 1) / 2 + k], L[Cc * (Cc + 1) / 2 + k], L[R * (R + 1) / 2 + Cc]);
+        }
+        __syncthreads();
+    }
+    // forward substitution L y = rhs (column oriented), then L^T w = y
+    for (int k = 0; k < nl; ++k) {
+        if (tid == 0) rhs[k] = rhs[k] / L[k * (k + 1) / 2 + k];
+        __syncthreads();
+        double yk = rhs[k];
+        for (int r = k + 1 + tid; r < nl; r += NT) rhs[r] = fma(-L[r * (r + 1) / 2 + k], yk, rhs[r]);
+        __syncthreads();
+    }
+    for (int k = nl - 1; k >= 0; --k) {
+        if (tid == 0) rhs[k] = rhs[k] / L[k * (k + 1) / 2 + k];
+        __syncthreads();
+        double wk = rhs[k];
+        for (int r = tid; r < k; r += NT) rhs[r] = fma(-L[k * (k + 1) / 2 + r], wk, rhs[r]);
+        __syncthreads();
+    }
+    for (int r = tid; r < nl; r += NT) Wt[(size_t)i * n_obs + jj[r]] = (T)(cvec[jj[r]] * rhs[r]);
+    if (bad && tid == 0) *flag = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+extern "C" int hm_upd_create(hm_ctx* ctx, int N_total, int N_local, int M, int n_obs, int dtype, int localized, hm_upd** out) {
+    HM_REQUIRE(ctx && out, "hm_upd_create: NULL argument");
+    HM_REQUIRE(N_total >= 2 && N_local >= 1 && N_local <= N_total && M >= 1 && n_obs >= 1, "hm_upd_create: bad sizes");
+    HM_REQUIRE(dtype == 64 || dtype == 32, "hm_upd_create: dtype must be 64 or 32");
+    HM_REQUIRE(!localized || (size_t)n_obs * (n_obs + 1) / 2 * 8 + (size_t)n_obs * 20 <= 160 * 1024 - 64,
+               "hm_upd_create: n_obs=%d too large for the LDS-resident local analysis", n_obs);
+    HM_HIP(hipSetDevice(ctx->device));
+    hm_upd* u = new hm_upd();
+    u->ctx = ctx; u->N_total = N_total; u->N_local = N_local; u->M = M; u->n_obs = n_obs; u->dtype = dtype;
+    u->localized = localized; u->esz = dtype == 64 ? 8 : 4;
+    size_t e = u->esz, nl = N_local, no = n_obs, m = M;
+    int rc = 0;
+#define ALLOC(buf, bytes) do { rc = hm_dev_alloc(u->buf, (bytes)); if (rc) { hm_upd_destroy(u); return rc; } } while (0)
+    ALLOC(E, nl * m * e); ALLOC(E_out, nl * m * e);
+    ALLOC(obs_ens, nl * no * e); ALLOC(perturbs, nl * no * e); ALLOC(obs, no * e); ALLOC(decorr, no * no * e);
+    ALLOC(red0, (m + no) * e); ALLOC(red1, (no * no + m * no) * e);
+    ALLOC(Y, nl * no * e); ALLOC(D0, nl * no * e); ALLOC(S, nl * no * e); ALLOC(D, nl * no * e); ALLOC(T1, nl * no * e);
+    ALLOC(Cinv, (no * no + no) * 8); ALLOC(CinvT, no * no * e);
+    ALLOC(partial, (size_t)64 * (m + no) * 8); ALLOC(flags, 16);
+    if (localized) { ALLOC(taper, m * no * e); ALLOC(Wt, m * no * e); }
+#undef ALLOC
+    HM_HIP(hipMemset(u->flags.p, 0, 16));
+    *out = u;
+    return 0;
+}
+
+extern "C" void hm_upd_destroy(hm_upd* u) {
+    if (!u) return;
+    (void)hipSetDevice(u->ctx->device);
+    (void)hipStreamSynchronize(u->ctx->stream);
+    DevBuf* bufs[] = {&u->E, &u->E_out, &u->obs_ens, &u->perturbs, &u->obs, &u->decorr, &u->taper, &u->red0, &u->red1,
+                      &u->Y, &u->D0, &u->S, &u->D, &u->T1, &u->Cinv, &u->CinvT, &u->Wt, &u->partial, &u->flags};
+    for (DevBuf* b : bufs) hm_dev_free(*b);
+    u->t_upd.destroy();
+    delete u;
+}
+
+extern "C" int hm_upd_set_inputs(hm_upd* u, const void* E, const void* obs_ens, const void* obs, const void* perturbs,
+                                 const void* decorr, const void* taper, double cutoff) {
+    HM_REQUIRE(u, "hm_upd_set_inputs: NULL plan");
+    HM_REQUIRE(!u->localized || taper, "hm_upd_set_inputs: localised plan needs a taper");
+    HM_HIP(hipSetDevice(u->ctx->device));
+    hipStream_t s = u->ctx->stream;
+    size_t e = u->esz, nl = u->N_local, no = u->n_obs, m = u->M;
+    if (E) HM_HIP(hipMemcpyAsync(u->E.p, E, nl * m * e, hipMemcpyHostToDevice, s));
+    if (obs_ens) HM_HIP(hipMemcpyAsync(u->obs_ens.p, obs_ens, nl * no * e, hipMemcpyHostToDevice, s));
+    if (obs) HM_HIP(hipMemcpyAsync(u->obs.p, obs, no * e, hipMemcpyHostToDevice, s));
+    if (perturbs) HM_HIP(hipMemcpyAsync(u->perturbs.p, perturbs, nl * no * e, hipMemcpyHostToDevice, s));
+    if (decorr) HM_HIP(hipMemcpyAsync(u->decorr.p, decorr, no * no * e, hipMemcpyHostToDevice, s));
+    if (taper && u->localized) HM_HIP(hipMemcpyAsync(u->taper.p, taper, m * no * e, hipMemcpyHostToDevice, s));
+    u->cutoff = cutoff;
+    HM_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+template <typename T>
+static int upd_phase(hm_upd* u, int phase) {
+    hipStream_t s = u->ctx->stream;
+    const int nl = u->N_local, no = u->n_obs, M = u->M;
+    T* E = (T*)u->E.p; T* Eo = (T*)u->E_out.p;
+    T* red0 = (T*)u->red0.p; T* red1 = (T*)u->red1.p;
+    T* G = red1; T* Gxt = red1 + (size_t)no * no;
+    T *Y = (T*)u->Y.p, *D0 = (T*)u->D0.p, *S = (T*)u->S.p, *D = (T*)u->D.p, *T1 = (T*)u->T1.p;
+    int rc = u->t_upd.begin(s);
+    if (rc) return rc;
+    if (phase == 0) {
+        const int splits = std::min(64, std::max(1, nl / 16));
+        const int rps = (nl + splits - 1) / splits;
+        double* part = (double*)u->partial.p;
+        hipLaunchKernelGGL(k_colsum_partial<T>, dim3((M + 255) / 256, splits), dim3(256), 0, s, (const T*)E, nl, M, rps, part);
+        hipLaunchKernelGGL(k_colsum_final<T>, dim3((M + 255) / 256), dim3(256), 0, s, (const double*)part, splits, M, red0);
+        double* part2 = part + (size_t)64 * M;
+        hipLaunchKernelGGL(k_colsum_partial<T>, dim3((no + 255) / 256, splits), dim3(256), 0, s, (const T*)u->obs_ens.p, nl, no, rps, part2);
+        hipLaunchKernelGGL(k_colsum_final<T>, dim3((no + 255) / 256), dim3(256), 0, s, (const double*)part2, splits, no, red0 + M);
+        HM_HIP(hipGetLastError());
+    } else if (phase == 1) {
+        const double inv_n = 1.0 / (double)u->N_total;
+        size_t n = (size_t)nl * no;
+        hipLaunchKernelGGL(k_prep_obs<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)u->obs_ens.p,
+                           (const T*)u->perturbs.p, (const T*)u->obs.p, (const T*)(red0 + M), inv_n, nl, no, Y, D0);
+        HM_HIP(hipGetLastError());
+        const T* dec = (const T*)u->decorr.p;
+        // S = Y decorr ; D = D0 decorr                                   (HistoryMatch.py:583-584)
+        if ((rc = gemm<T>(s, nl, no, no, Y, no, 1, dec, no, 1, S, no))) return rc;
+        if ((rc = gemm<T>(s, nl, no, no, D0, no, 1, dec, no, 1, D, no))) return rc;
+        // G = S^T S (local rows)                                         (HistoryMatch.py:585)
+        if ((rc = gemm<T>(s, no, no, nl, S, 1, no, S, no, 1, G, no))) return rc;
+        // Gxt = (E - mean)^T S   (M x n_obs): A(i,k) = E[k][i] - mean[i]   (HistoryMatch.py:581, 586)
+        if ((rc = gemm<T>(s, M, no, nl, E, 1, M, S, no, 1, Gxt, no, nullptr, 0, red0, inv_n))) return rc;
+    } else if (phase == 2) {
+        if (!u->localized) {
+            hipLaunchKernelGGL(k_invert_C<T>, dim3(1), dim3(1024), 0, s, (const T*)G, no, (double)(u->N_total - 1),
+                               (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (T*)u->CinvT.p, (int*)u->flags.p);
+            HM_HIP(hipGetLastError());
+            // T1 = D Cinv ;  E_out = E + T1 Gxt^T                          (HistoryMatch.py:586)
+            if ((rc = gemm<T>(s, nl, no, no, D, no, 1, (const T*)u->CinvT.p, no, 1, T1, no))) return rc;
+            if ((rc = gemm<T>(s, nl, M, no, T1, no, 1, Gxt, 1, no, Eo, M, E, M))) return rc;
+        } else {
+            size_t lds = ((size_t)no * (no + 1) / 2 + 2 * no) * 8 + (size_t)no * 4 + 16;
+            HM_HIP(hipFuncSetAttribute((const void*)k_local_analysis<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_local_analysis<T>, dim3(M), dim3(256), lds, s, M, no, u->N_total, u->cutoff,
+                               (const T*)u->taper.p, (const T*)G, (const T*)Gxt, (T*)u->Wt.p, (int*)u->flags.p);
+            HM_HIP(hipGetLastError());
+            if ((rc = gemm<T>(s, nl, M, no, D, no, 1, (const T*)u->Wt.p, 1, no, Eo, M, E, M))) return rc;
+        }
+    } else {
+        hm_set_error("hm_upd_phase: phase must be 0, 1 or 2");
+        return 2;
+    }
+    return u->t_upd.end(s);
+}
+
+extern "C" int hm_upd_phase(hm_upd* u, int phase) {
+    HM_REQUIRE(u, "hm_upd_phase: NULL plan");
+    HM_HIP(hipSetDevice(u->ctx->device));
+    return u->dtype == 64 ? upd_phase<double>(u, phase) : upd_phase<float>(u, phase);
+}
+
+extern "C" void* hm_upd_reduce_buffer(hm_upd* u, int which, long long* n_elems) {
+    if (!u) return nullptr;
+    if (which == 0) { if (n_elems) *n_elems = (long long)u->M + u->n_obs; return u->red0.p; }
+    if (which == 1) { if (n_elems) *n_elems = (long long)u->n_obs * u->n_obs + (long long)u->M * u->n_obs; return u->red1.p; }
+    return nullptr;
+}
+
+extern "C" int hm_upd_sync(hm_upd* u, hm_stats* st) {
+    HM_REQUIRE(u, "hm_upd_sync: NULL plan");
+    HM_HIP(hipSetDevice(u->ctx->device));
+    HM_HIP(hipStreamSynchronize(u->ctx->stream));
+    int flag = 0;
+    HM_HIP(hipMemcpy(&flag, u->flags.p, 4, hipMemcpyDeviceToHost));
+    if (st) { memset(st, 0, sizeof(*st)); st->ms_update = u->t_upd.total_ms(); st->ms_total = st->ms_update; }
+    u->t_upd.reset();
+    if (flag) {
+        HM_HIP(hipMemset(u->flags.p, 0, 16));
+        hm_set_error("ensemble update: non-positive pivot (C = S^T S + (N-1) I must be SPD; NaN/Inf in inputs?)");
+        return 4;
+    }
+    return 0;
+}
+
+extern "C" int hm_upd_get_output(hm_upd* u, void* E_out) {
+    HM_REQUIRE(u && E_out, "hm_upd_get_output: NULL argument");
+    HM_HIP(hipSetDevice(u->ctx->device));
+    HM_HIP(hipStreamSynchronize(u->ctx->stream));
+    HM_HIP(hipMemcpy(E_out, u->E_out.p, (size_t)u->N_local * u->M * u->esz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" void* hm_upd_device_ptr(hm_upd* u, const char* name) {
+    if (!u || !name) return nullptr;
+    std::string s(name);
+    if (s == "E") return u->E.p;
+    if (s == "E_out") return u->E_out.p;
+    if (s == "obs_ens") return u->obs_ens.p;
+    if (s == "perturbs") return u->perturbs.p;
+    if (s == "obs") return u->obs.p;
+    if (s == "decorr") return u->decorr.p;
+    if (s == "taper") return u->taper.p;
+    return nullptr;
+}
+
+// X = E - mean(E, axis 0) (optionally * sqrt(N/(N-1))), mean          center, tools/utils.py:10-28
+template <typename T>
+__global__ void k_center(const T* __restrict__ E, const T* __restrict__ colsum, double inv_n, double scale, size_t rows,
+                         size_t cols, T* __restrict__ X, T* __restrict__ mean) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < rows * cols; i += stride) {
+        size_t j = i % cols;
+        T mu = (T)((double)colsum[j] * inv_n);
+        T x = E[i] - mu;
+        if (scale != 1.0) x = x * (T)scale;
+        X[i] = x;
+        if (i < cols) mean[j] = mu;
+    }
+}
+
+extern "C" int hm_center(hm_ctx* ctx, int N, int M, const void* E, int dtype, int rescale, void* X_out, void* mean_out) {
+    HM_REQUIRE(ctx && E && X_out && mean_out && N >= 1 && M >= 1, "hm_center: bad arguments");
+    HM_REQUIRE(dtype == 64 || dtype == 32, "hm_center: dtype must be 64 or 32");
+    HM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    size_t e = dtype == 64 ? 8 : 4, n = (size_t)N * M;
+    DevBuf dE, dX, dsum, dmean, part;
+    int rc = hm_dev_alloc(dE, n * e);
+    if (!rc) rc = hm_dev_alloc(dX, n * e);
+    if (!rc) rc = hm_dev_alloc(dsum, (size_t)M * e);
+    if (!rc) rc = hm_dev_alloc(dmean, (size_t)M * e);
+    if (!rc) rc = hm_dev_alloc(part, (size_t)64 * M * 8);
+    if (!rc && hipMemcpyAsync(dE.p, E, n * e, hipMemcpyHostToDevice, s) != hipSuccess) { hm_set_error("hm_center: H2D failed"); rc = 1; }
+    if (!rc) {
+        const int splits = std::min(64, std::max(1, N / 16));
+        const int rps = (N + splits - 1) / splits;
+        const double scale = rescale ? sqrt((double)N / (double)(N - 1)) : 1.0;
+        if (dtype == 64) {
+            hipLaunchKernelGGL(k_colsum_partial<double>, dim3((M + 255) / 256, splits), dim3(256), 0, s, (const double*)dE.p, N, M, rps, (double*)part.p);
+            hipLaunchKernelGGL(k_colsum_final<double>, dim3((M + 255) / 256), dim3(256), 0, s, (const double*)part.p, splits, M, (double*)dsum.p);
+            hipLaunchKernelGGL(k_center<double>, dim3(2048), dim3(256), 0, s, (const double*)dE.p, (const double*)dsum.p, 1.0 / N, scale, (size_t)N, (size_t)M, (double*)dX.p, (double*)dmean.p);
+        } else {
+            hipLaunchKernelGGL(k_colsum_partial<float>, dim3((M + 255) / 256, splits), dim3(256), 0, s, (const float*)dE.p, N, M, rps, (double*)part.p);
+            hipLaunchKernelGGL(k_colsum_final<float>, dim3((M + 255) / 256), dim3(256), 0, s, (const double*)part.p, splits, M, (float*)dsum.p);
+            hipLaunchKernelGGL(k_center<float>, dim3(2048), dim3(256), 0, s, (const float*)dE.p, (const float*)dsum.p, 1.0 / N, scale, (size_t)N, (size_t)M, (float*)dX.p, (float*)dmean.p);
+        }
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(X_out, dX.p, n * e, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(mean_out, dmean.p, (size_t)M * e, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { hm_set_error("hm_center: device error"); rc = 1; }
+    }
+    hm_dev_free(dE); hm_dev_free(dX); hm_dev_free(dsum); hm_dev_free(dmean); hm_dev_free(part);
+    return rc;
+}
+
+static int es_update_host(hm_ctx* ctx, int N, int M, int n_obs, const void* E, const void* obs_ens, const void* obs,
+                          const void* perturbs, const void* decorr, const void* taper, double cutoff, int dtype,
+                          int localized, void* E_out, hm_stats* stats) {
+    HM_REQUIRE(E && obs_ens && obs && perturbs && decorr && E_out, "hm_es_update: NULL array");
+    hm_upd* u = nullptr;
+    int rc = hm_upd_create(ctx, N, N, M, n_obs, dtype, localized, &u);
+    if (rc) return rc;
+    rc = hm_upd_set_inputs(u, E, obs_ens, obs, perturbs, decorr, taper, cutoff);
+    for (int ph = 0; ph < 3 && !rc; ++ph) rc = hm_upd_phase(u, ph);
+    if (!rc) rc = hm_upd_sync(u, stats);
+    if (!rc) rc = hm_upd_get_output(u, E_out);
+    hm_upd_destroy(u);
+    return rc;
+}
+
+extern "C" int hm_es_update(hm_ctx* ctx, int N, int M, int n_obs, const void* E, const void* obs_ens, const void* obs,
+                            const void* perturbs, const void* decorr, int dtype, void* E_out, hm_stats* stats) {
+    return es_update_host(ctx, N, M, n_obs, E, obs_ens, obs, perturbs, decorr, nullptr, 0.0, dtype, 0, E_out, stats);
+}
+
+extern "C" int hm_es_update_loc(hm_ctx* ctx, int N, int M, int n_obs, const void* E, const void* obs_ens, const void* obs,
+                                const void* perturbs, const void* decorr, const void* taper, double cutoff, int dtype,
+                                void* E_out, hm_stats* stats) {
+    HM_REQUIRE(taper, "hm_es_update_loc: taper is NULL");
+    return es_update_host(ctx, N, M, n_obs, E, obs_ens, obs, perturbs, decorr, taper, cutoff, dtype, 1, E_out, stats);
+}

@@ -1,0 +1,94 @@
+"""Multi-GPU layer: one process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm, "gloo" on CPU).
+
+Sharding follows the reference's only parallel axis -- independent ensemble members (``utils.apply`` process
+pool, notebooks/tools/utils.py:201-224; "embarrassingly parallelizable" notebooks/HistoryMatch.py:376-380):
+  * forward model: contiguous member blocks per rank, NO data-path collective;
+  * update: rows of E stay on their rank; two sum-all-reduces per update (column sums: M+n_obs values; the
+    Gram pair [S^T S | X^T S]: n_obs*(n_obs+M) values), SURVEY.md 8e.  Everything else is row-local.
+torch is used only for rendezvous and the collective; compute stays behind the C ABI.
+"""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def shard_bounds(N, world_size, rank):
+    """Contiguous block [lo, hi) of `rank`; the first N % world_size ranks hold one extra member."""
+    base, extra = divmod(int(N), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class Comm:
+    """Thin wrapper over an initialised torch.distributed process group (or a single process)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        try:
+            import torch.distributed as td
+
+            self.td = td if td.is_available() and td.is_initialized() else None
+        except Exception:  # torch absent: single process only
+            self.td = None
+        self.rank = self.td.get_rank(group) if self.td else 0
+        self.world_size = self.td.get_world_size(group) if self.td else 1
+
+    def all_reduce_sum(self, arr):
+        """Sum a host array over ranks (host-staged: works for gloo and, through a device tensor, for nccl)."""
+        if not self.td or self.world_size == 1:
+            return arr
+        import torch
+
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if self.td.get_backend(self.group) == "nccl":
+            dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+            t = t.to(dev)
+            self.td.all_reduce(t, group=self.group)
+            return t.cpu().numpy()
+        self.td.all_reduce(t, group=self.group)
+        return t.numpy()
+
+    def all_gather_rows(self, arr):
+        """Concatenate per-rank row blocks (possibly ragged) in rank order."""
+        if not self.td or self.world_size == 1:
+            return arr
+        out = [None] * self.world_size
+        self.td.all_gather_object(out, np.ascontiguousarray(arr), group=self.group)
+        return np.concatenate(out, axis=0)
+
+    def barrier(self):
+        if self.td and self.world_size > 1:
+            self.td.barrier(group=self.group)
+
+
+def forward_model_sharded(local_forward, perms, wsat0s=None, comm=None, gather=True):
+    """Run ``local_forward(perms_block[, wsat0s_block]) -> [wsats, prods]`` on this rank's member block.
+    With ``gather`` the full ``[wsats, prods]`` (member order preserved, HistoryMatch.py:387) is returned on
+    every rank; otherwise only the local block."""
+    comm = comm or Comm()
+    lo, hi = shard_bounds(len(perms), comm.world_size, comm.rank)
+    args = [np.asarray(perms)[lo:hi]]
+    if wsat0s is not None:
+        if len(wsat0s) != len(perms):
+            raise ValueError("ensemble arguments have different lengths")  # zip(strict=True), utils.py:175
+        args.append(np.asarray(wsat0s)[lo:hi])
+    wsats, prods = local_forward(*args)
+    if gather:
+        return [comm.all_gather_rows(wsats), comm.all_gather_rows(prods)]
+    return [wsats, prods]
+
+
+def sharded_update(plan, comm=None):
+    """Drive a row-sharded update plan (``update.UpdatePlan`` or any object with the same
+    ``phase / get_reduce / set_reduce / sync / output`` methods) through its three phases, summing the two
+    reduce buffers over ranks in between.  Returns this rank's rows of the updated ensemble."""
+    comm = comm or Comm()
+    for ph in range(3):
+        plan.phase(ph)
+        if ph < 2 and comm.world_size > 1:
+            plan.set_reduce(ph, comm.all_reduce_sum(plan.get_reduce(ph)))
+    plan.sync()
+    return plan.output()

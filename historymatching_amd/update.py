@@ -1,0 +1,164 @@
+"""Ensemble-smoother update on the GPU: drop-ins for ``ens_update0`` / ``ens_update0_loc`` / ``center``.
+
+Reference: ``ens_update0`` notebooks/HistoryMatch.py:578-586, ``ens_update0_loc`` :774-797, ``center``
+notebooks/tools/utils.py:10-28.  Same argument names, meaning and return shapes; inputs are not modified.
+ES-MDA is not a reference function: `es_mda` is the loop SURVEY.md section 8f derives from the reference's own
+pieces (`ens_update0` with the observation-error factor inflated by sqrt(alpha)).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _ft(dtype):
+    return np.float64 if int(dtype) == 64 else np.float32
+
+
+def center(E, axis=0, rescale=False, dtype=64, device=None):
+    """``center(E, axis=0, rescale=False)`` -> ``(X, x)`` (utils.py:10-28), computed on the GPU."""
+    E = np.asarray(E)
+    if axis not in (0, -E.ndim):
+        raise NotImplementedError("center: only axis=0 (the ensemble axis) is used on the hot path")
+    shape = E.shape
+    E2 = _lib.as_c(E.reshape(shape[0], -1), _ft(dtype))
+    N, M = E2.shape
+    X = np.empty_like(E2)
+    x = np.empty(M, dtype=E2.dtype)
+    ctx = _lib.Context.get(device)
+    _lib.check(ctx.lib.hm_center(ctx.handle, N, M, _lib.ptr(E2), int(dtype), int(bool(rescale)), _lib.ptr(X),
+                                 _lib.ptr(x)), "hm_center")
+    return X.reshape(shape), x.reshape(shape[1:]).squeeze()
+
+
+def _check_shapes(prior_ens, obs_ens, obs, perturbs, decorr):
+    if prior_ens.ndim != 2:
+        raise ValueError("prior_ens must be (N, M)")
+    N = len(prior_ens)
+    n_obs = len(obs)
+    if obs_ens.shape != (N, n_obs) or perturbs.shape != (N, n_obs) or decorr.shape != (n_obs, n_obs):
+        raise ValueError(f"shape mismatch: prior_ens {prior_ens.shape}, obs_ens {obs_ens.shape}, obs {obs.shape}, "
+                         f"perturbs {perturbs.shape}, decorr {decorr.shape}")
+    if N < 2:
+        raise ValueError("need at least 2 ensemble members")
+    return N, prior_ens.shape[1], n_obs
+
+
+def ens_update0(prior_ens, obs_ens, obs, perturbs, decorr, dtype=64, device=None):
+    """``ens_update0(prior_ens, obs_ens, obs, perturbs, decorr)`` (HistoryMatch.py:578-586) on the GPU."""
+    ft = _ft(dtype)
+    a = [_lib.as_c(v, ft) for v in (prior_ens, obs_ens, obs, perturbs, decorr)]
+    N, M, n_obs = _check_shapes(*a)
+    out = np.empty_like(a[0])
+    st = _lib.hm_stats()
+    ctx = _lib.Context.get(device)
+    _lib.check(ctx.lib.hm_es_update(ctx.handle, N, M, n_obs, *(_lib.ptr(v) for v in a), int(dtype), _lib.ptr(out),
+                                    C.byref(st)), "hm_es_update")
+    ens_update0.last_stats = st.asdict()
+    return out
+
+
+def ens_update0_loc(prior_ens, obs_ens, obs, perturbs, decorr, taper, dtype=64, device=None, cutoff=1e-2):
+    """``ens_update0_loc(..., taper)`` (HistoryMatch.py:774-797) on the GPU; ``taper`` is ``(M, n_obs)``."""
+    ft = _ft(dtype)
+    a = [_lib.as_c(v, ft) for v in (prior_ens, obs_ens, obs, perturbs, decorr)]
+    N, M, n_obs = _check_shapes(*a)
+    taper = _lib.as_c(taper, ft)
+    if taper.shape != (M, n_obs):
+        raise ValueError(f"taper must have shape {(M, n_obs)}, got {taper.shape}")
+    out = np.empty_like(a[0])
+    st = _lib.hm_stats()
+    ctx = _lib.Context.get(device)
+    _lib.check(ctx.lib.hm_es_update_loc(ctx.handle, N, M, n_obs, *(_lib.ptr(v) for v in a), _lib.ptr(taper),
+                                        float(cutoff), int(dtype), _lib.ptr(out), C.byref(st)), "hm_es_update_loc")
+    ens_update0_loc.last_stats = st.asdict()
+    return out
+
+
+class UpdatePlan:
+    """Device-resident, row-sharded update (``hm_upd_*``): rows of this rank's members stay on its GPU; the two
+    reductions of SURVEY.md 8e are done by the caller between phases (see ``historymatching_amd.dist``)."""
+
+    def __init__(self, N_total, N_local, M, n_obs, dtype=64, localized=False, device=None):
+        self.N_total, self.N_local, self.M, self.n_obs = int(N_total), int(N_local), int(M), int(n_obs)
+        self.dtype, self.localized = int(dtype), bool(localized)
+        self.ft = _ft(dtype)
+        self.ctx = _lib.Context.get(device)
+        self.lib = self.ctx.lib
+        h = C.c_void_p()
+        _lib.check(self.lib.hm_upd_create(self.ctx.handle, self.N_total, self.N_local, self.M, self.n_obs, self.dtype,
+                                          int(self.localized), C.byref(h)), "hm_upd_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.hm_upd_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_inputs(self, E=None, obs_ens=None, obs=None, perturbs=None, decorr=None, taper=None, cutoff=1e-2):
+        arrs = [_lib.as_c(v, self.ft) for v in (E, obs_ens, obs, perturbs, decorr, taper)]
+        _lib.check(self.lib.hm_upd_set_inputs(self.h, *(_lib.ptr(v) for v in arrs), float(cutoff)), "hm_upd_set_inputs")
+
+    def phase(self, k):
+        _lib.check(self.lib.hm_upd_phase(self.h, int(k)), "hm_upd_phase")
+
+    def reduce_buffer(self, which):
+        n = C.c_longlong()
+        p = self.lib.hm_upd_reduce_buffer(self.h, int(which), C.byref(n))
+        return p, n.value
+
+    def get_reduce(self, which):
+        """Host copy of reduce buffer `which` (0: column sums, 1: [G | Gxt])."""
+        p, n = self.reduce_buffer(which)
+        out = np.empty(n, dtype=self.ft)
+        _lib.check(self.lib.hm_copy_to_host(self.ctx.handle, _lib.ptr(out), p, out.nbytes), "hm_copy_to_host")
+        return out
+
+    def set_reduce(self, which, arr):
+        p, n = self.reduce_buffer(which)
+        arr = _lib.as_c(arr, self.ft).reshape(-1)
+        if arr.size != n:
+            raise ValueError(f"reduce buffer {which} has {n} elements, got {arr.size}")
+        _lib.check(self.lib.hm_copy_to_device(self.ctx.handle, p, _lib.ptr(arr), arr.nbytes), "hm_copy_to_device")
+
+    def sync(self):
+        st = _lib.hm_stats()
+        _lib.check(self.lib.hm_upd_sync(self.h, C.byref(st)), "hm_upd_sync")
+        return st.asdict()
+
+    def output(self):
+        out = np.empty((self.N_local, self.M), dtype=self.ft)
+        _lib.check(self.lib.hm_upd_get_output(self.h, _lib.ptr(out)), "hm_upd_get_output")
+        return out
+
+    def device_ptr(self, name):
+        return self.lib.hm_upd_device_ptr(self.h, name.encode())
+
+    def run_local(self):
+        """All three phases with no cross-rank reduction (N_local == N_total)."""
+        for k in range(3):
+            self.phase(k)
+        return self.sync()
+
+
+def es_mda(forward, prior_ens, obs, R12, n_iter=4, rng=None, dtype=64, device=None):
+    """ES-MDA: ``n_iter`` passes of `ens_update0` with alpha = n_iter (perturbs * sqrt(alpha), decorr / sqrt(alpha)),
+    a forward run and fresh perturbations per pass (BASELINE.json config 3).
+    ``forward(E) -> obs_ens (N, n_obs)``; ``R12`` is the lower Cholesky factor of R (HistoryMatch.py:259)."""
+    import scipy.linalg as sla
+
+    rng = np.random if rng is None else rng
+    E = np.array(prior_ens, dtype=float)
+    alpha = float(n_iter)
+    decorr = sla.inv(R12.T) / np.sqrt(alpha)
+    for _ in range(n_iter):
+        obs_ens = forward(E)
+        perturbs = np.sqrt(alpha) * (rng.randn(len(E), len(obs)) @ R12.T)
+        E = ens_update0(E, obs_ens, obs, perturbs, decorr, dtype=dtype, device=device).astype(float)
+    return E

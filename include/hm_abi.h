@@ -41,6 +41,10 @@ void        hm_destroy(hm_ctx* ctx);
 const char* hm_last_error(void);
 int         hm_device_name(hm_ctx* ctx, char* buf, int buflen);   /* e.g. "gfx950:..."           */
 int         hm_abi_version(void);
+/* Raw copies between caller host buffers and device pointers handed out by hm_*_device_ptr /
+ * hm_upd_reduce_buffer (used by the host-staged all-reduce of the multi-rank update). Synchronous. */
+int         hm_copy_to_host(hm_ctx* ctx, void* dst_host, const void* src_device, long long bytes);
+int         hm_copy_to_device(hm_ctx* ctx, void* dst_device, const void* src_host, long long bytes);
 
 /* ---- forward model: replaces utils.apply(comp1, ...) = forward_model --------------------------
  * Reference: forward_model  notebooks/HistoryMatch.py:383-387  (-> utils.apply tools/utils.py:155-242
@@ -97,6 +101,10 @@ void* hm_fwd_device_ptr(hm_fwd* f, const char* name);   /* raw device pointer of
 int hm_es_update(hm_ctx* ctx, int N, int M, int n_obs, const void* E, const void* obs_ens,
                  const void* obs, const void* perturbs, const void* decorr, int dtype,
                  void* E_out, hm_stats* stats);
+
+/* Reference: center(E, axis=0, rescale)  notebooks/tools/utils.py:10-28:  X = E - mean (optionally times
+ * sqrt(N/(N-1))), mean (M).  Standalone form; ens_update0* fuse the centring into their contractions. */
+int hm_center(hm_ctx* ctx, int N, int M, const void* E, int dtype, int rescale, void* X_out, void* mean_out);
 
 /* Reference: ens_update0_loc  notebooks/HistoryMatch.py:774-797;  taper is M*n_obs (HistoryMatch.py:863),
  * cutoff is the 1e-2 of HistoryMatch.py:786. */

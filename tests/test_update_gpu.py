@@ -1,0 +1,169 @@
+"""GPU parity tests of the ensemble-smoother update against (a) fixtures captured from the REAL reference
+functions (tests/golden, oracle/make_golden.py) and (b) the oracle restatement on seeded inputs.
+
+Tolerances: fp64 <= 1e-10 abs (min-flop association + sweep/Cholesky inverse instead of the
+reference's left-to-right products + pinv: observed ~1e-13); fp32 <= 1e-4 relative to max |increment|."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _hm(golden):
+    f1, f2, f3, f4 = (np.load(golden / n) for n in ("f1_rng_replay.npz", "f2_obs_error.npz", "f3_ens_update0.npz", "f4_ens_update0_loc.npz"))
+    kw = dict(obs_ens=f3["obs_ens"], obs=f3["obs"], perturbs=f1["hm_perturbs"], decorr=f2["decorr"])
+    return f1, f3, f4, kw
+
+
+def test_center_matches_reference_fixture(golden):
+    from historymatching_amd.update import center
+
+    f5 = np.load(golden / "f5_helpers.npz")
+    X, x = center(f5["a"])
+    assert np.abs(X - f5["center_X"]).max() < 1e-15 and np.abs(x - f5["center_x"]).max() < 1e-15
+    Xr, _ = center(f5["a"], rescale=True)
+    assert np.abs(Xr - f5["center_Xr"]).max() < 1e-15
+
+
+def test_ens_update0_gaussian_gaussian_fixture(golden):
+    """The reference's bug check (HistoryMatch.py:594-612) through the GPU path."""
+    from historymatching_amd.update import ens_update0
+
+    f1, f3, _, _ = _hm(golden)
+    E = f1["gg_E"]
+    E0 = E.copy()
+    post = ens_update0(E, E, 4 * np.ones(3), f1["gg_perturbs"], 0.5 * np.eye(3))
+    assert np.array_equal(E, E0)  # inputs unmodified
+    assert np.abs(post - f3["gg_postr"]).max() < 1e-10
+    assert np.allclose(post.mean(0), [0.98474734, 1.08434752, 1.02224568], atol=1e-8)
+
+
+def test_ens_update0_history_matching_fixture(golden):
+    from historymatching_amd.update import ens_update0
+
+    f1, f3, _, kw = _hm(golden)
+    assert np.abs(ens_update0(f1["perm_prior"], **kw) - f3["perm_es"]).max() < 1e-10
+    assert np.abs(ens_update0(f3["obs_ens"], **kw) - f3["es0"]).max() < 1e-10  # M = n_obs (HistoryMatch.py:1156)
+
+
+def test_ens_update0_fp32_tolerance(golden):
+    from historymatching_amd.update import ens_update0
+
+    f1, f3, _, kw = _hm(golden)
+    out = ens_update0(f1["perm_prior"], **kw, dtype=32)
+    assert out.dtype == np.float32
+    inc = np.abs(f3["perm_es"] - f1["perm_prior"]).max()
+    assert np.abs(out - f3["perm_es"]).max() <= 1e-4 * inc
+
+
+def test_ens_update0_loc_fixtures(golden):
+    from historymatching_amd.update import ens_update0_loc
+
+    f1, f3, f4, kw = _hm(golden)
+    E = f1["gg_E"]
+    gg = ens_update0_loc(E, E, 4 * np.ones(3), f1["gg_perturbs"], 0.5 * np.eye(3), np.eye(3))
+    assert np.abs(gg - f4["gg_postr_loc"]).max() < 1e-10  # HistoryMatch.py:811-815
+    ones = ens_update0_loc(f1["perm_prior"], **kw, taper=np.ones((400, 160)))
+    assert np.abs(ones - f4["les_ones"]).max() < 1e-10
+    assert np.allclose(ones, f3["perm_es"])  # "Reproduces global analysis?" HistoryMatch.py:821-822
+    les = ens_update0_loc(f1["perm_prior"], **kw, taper=f4["taper"])
+    assert np.abs(les - f4["perm_les"]).max() < 1e-10  # HistoryMatch.py:863
+
+
+def test_loc_elements_with_no_obs_in_range_unchanged(golden):
+    from historymatching_amd.update import ens_update0_loc
+
+    f1, _, f4, kw = _hm(golden)
+    taper = f4["taper"].copy()
+    taper[:50] = 0.0
+    taper[50:60] = 5e-5  # sqrt = 7e-3 < 1e-2 cutoff (HistoryMatch.py:786)
+    out = ens_update0_loc(f1["perm_prior"], **kw, taper=taper)
+    assert np.array_equal(out[:, :60], f1["perm_prior"][:, :60])
+    assert np.abs(out[:, 60:] - f1["perm_prior"][:, 60:]).max() > 1e-3
+
+
+def _seeded(N, M, n_obs, seed):
+    from oracle import es
+
+    rng = np.random.RandomState(seed)
+    E = rng.randn(N, M) * 0.7 + rng.randn(M) * 3
+    H = rng.randn(M, n_obs) / np.sqrt(M)
+    obs_ens = E @ H
+    _, R12, decorr = es.obs_error_model(40, 4) if n_obs == 160 else es.obs_error_model(n_obs, 1)
+    obs = obs_ens[0] + R12 @ rng.randn(n_obs)
+    perturbs = rng.randn(N, n_obs) @ R12.T
+    return E, obs_ens, obs, perturbs, decorr
+
+
+@pytest.mark.parametrize("N,M,n_obs", [(100, 400, 160), (37, 1000, 23), (1000, 4099, 160)])
+def test_ens_update0_seeded_vs_oracle(N, M, n_obs):
+    from historymatching_amd.update import ens_update0
+    from oracle import es
+
+    args = _seeded(N, M, n_obs, N + M)
+    ref = es.ens_update0(*args)
+    out = ens_update0(*args)
+    assert np.abs(out - ref).max() < 1e-10
+    out32 = ens_update0(*args, dtype=32)
+    assert np.abs(out32 - ref).max() <= 1e-4 * np.abs(ref - args[0]).max()
+
+
+def test_ens_update0_loc_seeded_vs_oracle():
+    from historymatching_amd.update import ens_update0_loc
+    from oracle import es
+
+    rng = np.random.RandomState(9)
+    N, M, n_obs = 60, 96, 48
+    E = rng.randn(N, M)
+    obs_ens = E @ (rng.randn(M, n_obs) / 10)
+    _, R12, decorr = es.obs_error_model(12, 4)
+    obs = obs_ens[3] + R12 @ rng.randn(n_obs)
+    perturbs = rng.randn(N, n_obs) @ R12.T
+    taper = es.bump(rng.rand(M, n_obs) * 1.3)
+    ref = es.ens_update0_loc(E, obs_ens, obs, perturbs, decorr, taper)
+    out = ens_update0_loc(E, obs_ens, obs, perturbs, decorr, taper)
+    assert np.abs(out - ref).max() < 1e-10
+    out32 = ens_update0_loc(E, obs_ens, obs, perturbs, decorr, taper, dtype=32)
+    assert np.abs(out32 - ref).max() <= 1e-4 * np.abs(ref - E).max()
+
+
+def test_update_properties_at_c3_size():
+    """BASELINE config 3 shape (N=1000, M=128*128, n_obs=160), size-independent properties:
+    (1) a zero-innovation update (D = 0) is the identity; (2) the update is affine-equivariant in the state:
+    update(a*E + b) == a*update(E) + b for a column-wise shift b (anomalies remove it); (3) row-sharded phases
+    with summed reduce buffers reproduce the single-shot update (the multi-GPU path of SURVEY.md 8e)."""
+    from historymatching_amd.dist import sharded_update
+    from historymatching_amd.update import UpdatePlan, ens_update0
+
+    rng = np.random.RandomState(1)
+    N, M, n_obs = 1000, 128 * 128, 160
+    E = rng.randn(N, M)
+    obs_ens = rng.rand(N, n_obs)
+    decorr = np.eye(n_obs) * 3.0
+    obs = rng.rand(n_obs)
+    out = ens_update0(E, obs_ens, obs, obs - obs_ens, decorr)  # obs - obs_ens - perturbs == 0
+    assert np.abs(out - E).max() < 1e-12
+    perturbs = rng.randn(N, n_obs) * 0.1
+    full = ens_update0(E, obs_ens, obs, perturbs, decorr)
+    shift = rng.randn(M)
+    full2 = ens_update0(2.0 * E + shift, obs_ens, obs, perturbs, decorr)
+    assert np.abs(full2 - (2.0 * full + shift)).max() < 1e-9
+    # (3) two uneven shards; the "all-reduce" is a host sum over the two plans
+    plans = []
+    for sl in (slice(0, 600), slice(600, N)):
+        p = UpdatePlan(N, sl.stop - sl.start, M, n_obs)
+        p.set_inputs(E[sl], obs_ens[sl], obs, perturbs[sl], decorr)
+        plans.append(p)
+    for ph in range(3):
+        for p in plans:
+            p.phase(ph)
+        if ph < 2:
+            tot = sum(p.get_reduce(ph) for p in plans)
+            for p in plans:
+                p.set_reduce(ph, tot)
+    outs = np.concatenate([(p.sync(), p.output())[1] for p in plans])
+    assert np.abs(outs - full).max() < 1e-11
+    # single-rank driver path
+    p = UpdatePlan(N, N, M, n_obs)
+    p.set_inputs(E, obs_ens, obs, perturbs, decorr)
+    assert np.abs(sharded_update(p) - full).max() < 1e-12
