@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native ensemble forward model.
+
+Metric (BASELINE.json): ensemble-steps/sec = N_e * nTime / wall(forward_model), workload = config[1]:
+N_e=1000 members, 128x128 grid, forward model only (TPFA pressure solve + explicit upwind saturation sweep per
+member per step), fp64, nTime=40, wells/fluid/dt of notebooks/HistoryMatch.py:97,177-190,219-221.
+
+A "step" (--steps) is ONE pass of the hot path over the whole batch: all N_e members advanced nTime=40 time
+steps, inputs (permeability, initial saturation) already resident in HBM.  Multi-GPU (--gpus N, launched by
+torch.distributed.run): members are independent, so every rank runs its own N_e members with no data-path
+collective ("weak" scaling); value = total member-steps of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the library on the launch
+stream) and `cpu_baseline` (the NumPy/SciPy oracle on the host cores, bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+NX = NY = 128
+N_E = 1000
+NTIME = 40
+DT = 0.025
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def build_model(dtype=64, device=None):
+    from historymatching_amd.ressim import ResSim
+
+    m = ResSim(NX, NY, 2, 1, dtype=dtype, device=device)
+    near01 = np.array([0.12, 0.87])  # HistoryMatch.py:177-190
+    m.prd_xy = [[x, y] for y in m.Ly * near01 for x in m.Lx * near01]
+    m.inj_xy = [[m.Lx / 2, m.Ly / 2]]
+    m.inj_rates = [[1]]
+    m.prd_rates = np.ones((4, 1)) / 4
+    return m
+
+
+def cpu_baseline(members, steps, nproc):
+    """Oracle (oracle/ressim.py, NumPy + SciPy spsolve) on a bounded sample of the same workload, parallelised the
+    way the reference does it (utils.py:201-224: one process per core, BLAS pinned to 1 thread)."""
+    from historymatching_amd.geostat import gaussian_fields_kron
+    from oracle.ressim import ResSim, default_wells, forward_model
+
+    om = default_wells(ResSim(NX, NY, 2, 1))
+    x = gaussian_fields_kron(NX, NY, 2, 1, members, r=0.8, seed=12345)
+    forward_model(om, x[: min(members, nproc)], None, DT, 1, nproc=nproc)  # warm the pool / imports
+    t0 = time.perf_counter()
+    forward_model(om, x, None, DT, steps, nproc=nproc)
+    wall = time.perf_counter() - t0
+    return members * steps / wall, wall
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--members", type=int, default=N_E, help="members per GPU (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--variant", type=int, default=0, help="0 = fastest kernels, 1 = generic kernels")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    td = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as td
+
+        torch.cuda.set_device(local_rank)
+        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    from historymatching_amd import _lib
+    from historymatching_amd.forward import ForwardPlan
+    from historymatching_amd.geostat import gaussian_fields_kron
+
+    ctx = _lib.Context.get(local_rank)
+    model = build_model(64, device=local_rank)
+    n_e = args.members
+    perms = gaussian_fields_kron(NX, NY, 2, 1, n_e, r=0.8, seed=1 + rank)  # synthetic prior, SURVEY.md 8d
+    plan = ForwardPlan(model, n_e, DT, NTIME, keep_history=True, device=local_rank)
+    plan.set_variant(args.variant, args.variant)
+    plan.set_inputs(perms, None, transformed=False)  # inputs resident in HBM before the timed region
+
+    def one_pass():
+        plan.run(0, NTIME)
+
+    for _ in range(args.warmup):
+        one_pass()
+    plan.sync()
+
+    def fence():
+        if td is not None:
+            import torch
+
+            td.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    stats = plan.sync()  # hipStreamSynchronize on the launch stream + event read-out
+    fence()
+    elapsed = time.perf_counter() - t0
+    if td is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    _, prods, status = plan.outputs(want_wsats=False)
+    ok = not status.any() and np.isfinite(prods).all()
+
+    if rank == 0:
+        member_steps = n_e * NTIME * args.steps * world
+        value = member_steps / elapsed
+        # ---- roofline of the dominant kernel (HIP events recorded on the launch stream, inside the library)
+        w = 8
+        nxy = NX * NY
+        nts = stats["mean_nts"]
+        sat_ms = stats["ms_saturation"] / max(1, stats["n_saturation_launches"])
+        prs_ms = stats["ms_pressure"] / max(1, stats["n_pressure_launches"])
+        # algorithmic bytes per member-step: saturation = read S,Vx,Vy + write S per explicit
+        # sub-step; pressure = compulsory (K,S in; P out) + factor write + factor read of the direct block solver
+        sat_bytes = w * nxy * 4 * nts * n_e
+        prs_bytes = w * nxy * (4 + 2 * NY) * n_e
+        dominant = "saturation" if stats["ms_saturation"] >= stats["ms_pressure"] else "pressure"
+        ach = (sat_bytes / (sat_ms * 1e-3) if dominant == "saturation" else prs_bytes / (prs_ms * 1e-3)) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_ms": {"saturation": sat_ms, "pressure": prs_ms},
+            "algorithmic_bytes_per_launch": {"saturation": sat_bytes, "pressure": prs_bytes},
+            "compulsory_floor_bytes_per_member_step": 4 * w * nxy,
+            "mean_nts": nts,
+            "note": "effective GB/s by SURVEY.md 8d accounting; the state is LDS/register-resident so it may exceed HBM peak",
+        }
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            nproc = os.cpu_count() or 1
+            members = max(nproc, 8)
+            v, wall = cpu_baseline(members, args.cpu_steps, nproc)
+            cpu = {"value": v, "unit": "ensemble-steps/s", "cores": nproc, "kind": "port",
+                   "sample": f"{members} members x {args.cpu_steps} steps of the same 128x128 workload, "
+                             f"{nproc} processes x 1 BLAS thread, {wall:.1f} s wall"}
+        out = {
+            "metric": "ensemble-steps/sec", "value": value, "unit": "ensemble-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"N_e={n_e} per GPU, {NX}x{NY} grid, forward model only (nTime={NTIME}, dt={DT}), fp64",
+                       "members_per_gpu": n_e, "grid": [NX, NY], "nTime": NTIME, "device": ctx.name(),
+                       "kernel_variant": args.variant, "results_finite_and_status_ok": bool(ok)},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "device_ms": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
+        }
+        print(json.dumps(out))
+    plan.close()
+    if td is not None:
+        td.barrier()
+        td.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

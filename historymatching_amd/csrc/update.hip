@@ -22,8 +22,12 @@ struct hm_upd {
     size_t esz = 8;
     double cutoff = 1e-2;
     DevBuf E, E_out, obs_ens, perturbs, obs, decorr, taper;
-    DevBuf red0, red1;            // [colsum E (M) | colsum obs_ens (n_obs)],  [G (n_obs^2) | Gxt (M*n_obs)]
-    DevBuf Y, D0, S, D, T1, Cinv, CinvT, Wt, partial, flags;
+    // reduce buffers (summed over ranks by the host): 0: colsum E (M, dtype)   1: colsum obs_ens (n_obs, fp64)
+    //                                                  2: Gxt = X^T S (M*n_obs, dtype)   3: G = S^T S (n_obs^2, fp64)
+    DevBuf red0, red1, red2, red3;
+    // everything of size <= N x n_obs is kept in fp64 whatever the dtype (cond(C) ~ 1e4 makes fp32 Gram matrices
+    // lose 3 digits); only the two contractions over the state dimension M run in `dtype`.
+    DevBuf Y, D0, S, D, T1, decorr64, S_T, A_T, Cinv, Wt, partial, flags;
     EvTimer t_upd;
 };
 
@@ -53,15 +57,22 @@ __global__ void k_colsum_final(const double* __restrict__ partial, int splits, i
 // Y = obs_ens - mean(obs_ens);  D0 = obs - obs_ens - perturbs      (HistoryMatch.py:582, 584)
 template <typename T>
 __global__ void k_prep_obs(const T* __restrict__ obs_ens, const T* __restrict__ perturbs, const T* __restrict__ obs,
-                           const T* __restrict__ colsum_y, double inv_n_total, int rows, int n_obs,
-                           T* __restrict__ Y, T* __restrict__ D0) {
+                           const double* __restrict__ colsum_y, double inv_n_total, int rows, int n_obs,
+                           double* __restrict__ Y, double* __restrict__ D0) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)rows * n_obs) return;
     int j = (int)(i % n_obs);
-    T mean = (T)((double)colsum_y[j] * inv_n_total);
-    T o = obs_ens[i];
+    double mean = colsum_y[j] * inv_n_total;
+    double o = (double)obs_ens[i];
     Y[i] = o - mean;
-    D0[i] = obs[j] - o - perturbs[i];
+    D0[i] = (double)obs[j] - o - (double)perturbs[i];
+}
+
+template <typename TI, typename TO>
+__global__ void k_cast(const TI* __restrict__ in, TO* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (TO)in[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -155,14 +166,13 @@ static int gemm(hipStream_t s, int m, int n, int k, const T* A, size_t sa_i, siz
 // Cinv = (G + (N-1) I)^-1  by symmetric sweeps, one workgroup, fp64, matrix in global memory.
 // (HistoryMatch.py:585-586: C = S^T S + (N-1) I is SPD with lambda_min >= N-1, so pinv == inv.)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(1024) void k_invert_C(const T* __restrict__ G, int n, double ridge, double* __restrict__ W,
-                                                   double* __restrict__ colbuf, T* __restrict__ outT, int* __restrict__ flag) {
+__global__ __launch_bounds__(1024) void k_invert_C(const double* __restrict__ G, int n, double ridge, double* __restrict__ W,
+                                                   double* __restrict__ colbuf, int* __restrict__ flag) {
     const int tid = threadIdx.x, NT = blockDim.x;
     for (int e = tid; e < n * n; e += NT) {
         int r = e / n, c = e % n;
         // symmetrise the (all-reduced) Gram matrix: exact in exact arithmetic, removes rounding asymmetry
-        W[e] = 0.5 * ((double)G[r * n + c] + (double)G[c * n + r]) + (r == c ? ridge : 0.0);
+        W[e] = 0.5 * (G[r * n + c] + G[c * n + r]) + (r == c ? ridge : 0.0);
     }
     int bad = 0;
     for (int kk = 0; kk < n; ++kk) {
@@ -182,11 +192,7 @@ __global__ __launch_bounds__(1024) void k_invert_C(const T* __restrict__ G, int 
         }
     }
     __syncthreads();
-    for (int e = tid; e < n * n; e += NT) {
-        double v = -W[e];
-        W[e] = v;
-        outT[e] = (T)v;
-    }
+    for (int e = tid; e < n * n; e += NT) W[e] = -W[e];
     if (bad && tid == 0) *flag = 1;
 }
 
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(1024) void k_invert_C(const T* __restrict__ G, int 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_local_analysis(int M, int n_obs, int N_total, double cutoff,
-                                                        const T* __restrict__ taper, const T* __restrict__ G,
+                                                        const T* __restrict__ taper, const double* __restrict__ G,
                                                         const T* __restrict__ Gxt, T* __restrict__ Wt, int* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     const int i = blockIdx.x;
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256) void k_local_analysis(int M, int n_obs, int N_
         while (r * (r + 1) / 2 > e) --r;
         int c = e - r * (r + 1) / 2;
         int jr = jj[r], jc = jj[c];
-        double g = 0.5 * ((double)G[jr * n_obs + jc] + (double)G[jc * n_obs + jr]);
+        double g = 0.5 * (G[jr * n_obs + jc] + G[jc * n_obs + jr]);
         L[e] = cvec[jr] * g * cvec[jc] + (r == c ? (double)(N_total - 1) : 0.0);
     }
     for (int r = tid; r < nl; r += NT) rhs[r] = cvec[jj[r]] * (double)Gxt[(size_t)i * n_obs + jj[r]];
@@ -294,9 +300,10 @@ extern "C" int hm_upd_create(hm_ctx* ctx, int N_total, int N_local, int M, int n
 #define ALLOC(buf, bytes) do { rc = hm_dev_alloc(u->buf, (bytes)); if (rc) { hm_upd_destroy(u); return rc; } } while (0)
     ALLOC(E, nl * m * e); ALLOC(E_out, nl * m * e);
     ALLOC(obs_ens, nl * no * e); ALLOC(perturbs, nl * no * e); ALLOC(obs, no * e); ALLOC(decorr, no * no * e);
-    ALLOC(red0, (m + no) * e); ALLOC(red1, (no * no + m * no) * e);
-    ALLOC(Y, nl * no * e); ALLOC(D0, nl * no * e); ALLOC(S, nl * no * e); ALLOC(D, nl * no * e); ALLOC(T1, nl * no * e);
-    ALLOC(Cinv, (no * no + no) * 8); ALLOC(CinvT, no * no * e);
+    ALLOC(red0, m * e); ALLOC(red1, no * 8); ALLOC(red2, m * no * e); ALLOC(red3, no * no * 8);
+    ALLOC(Y, nl * no * 8); ALLOC(D0, nl * no * 8); ALLOC(S, nl * no * 8); ALLOC(D, nl * no * 8); ALLOC(T1, nl * no * 8);
+    ALLOC(decorr64, no * no * 8); ALLOC(S_T, nl * no * e); ALLOC(A_T, nl * no * e);
+    ALLOC(Cinv, (no * no + no) * 8);
     ALLOC(partial, (size_t)64 * (m + no) * 8); ALLOC(flags, 16);
     if (localized) { ALLOC(taper, m * no * e); ALLOC(Wt, m * no * e); }
 #undef ALLOC
@@ -310,7 +317,8 @@ extern "C" void hm_upd_destroy(hm_upd* u) {
     (void)hipSetDevice(u->ctx->device);
     (void)hipStreamSynchronize(u->ctx->stream);
     DevBuf* bufs[] = {&u->E, &u->E_out, &u->obs_ens, &u->perturbs, &u->obs, &u->decorr, &u->taper, &u->red0, &u->red1,
-                      &u->Y, &u->D0, &u->S, &u->D, &u->T1, &u->Cinv, &u->CinvT, &u->Wt, &u->partial, &u->flags};
+                      &u->red2, &u->red3, &u->Y, &u->D0, &u->S, &u->D, &u->T1, &u->decorr64, &u->S_T, &u->A_T, &u->Cinv,
+                      &u->Wt, &u->partial, &u->flags};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     u->t_upd.destroy();
     delete u;
@@ -339,9 +347,13 @@ static int upd_phase(hm_upd* u, int phase) {
     hipStream_t s = u->ctx->stream;
     const int nl = u->N_local, no = u->n_obs, M = u->M;
     T* E = (T*)u->E.p; T* Eo = (T*)u->E_out.p;
-    T* red0 = (T*)u->red0.p; T* red1 = (T*)u->red1.p;
-    T* G = red1; T* Gxt = red1 + (size_t)no * no;
-    T *Y = (T*)u->Y.p, *D0 = (T*)u->D0.p, *S = (T*)u->S.p, *D = (T*)u->D.p, *T1 = (T*)u->T1.p;
+    T* sumE = (T*)u->red0.p; double* sumY = (double*)u->red1.p;
+    T* Gxt = (T*)u->red2.p; double* G = (double*)u->red3.p;
+    double *Y = (double*)u->Y.p, *D0 = (double*)u->D0.p, *S = (double*)u->S.p, *D = (double*)u->D.p, *T1 = (double*)u->T1.p;
+    double* dec = (double*)u->decorr64.p;
+    T *S_T = (T*)u->S_T.p, *A_T = (T*)u->A_T.p;
+    const size_t n_small = (size_t)nl * no;
+    const unsigned gs = (unsigned)std::min<size_t>(2048, (n_small + 255) / 256);
     int rc = u->t_upd.begin(s);
     if (rc) return rc;
     if (phase == 0) {
@@ -349,40 +361,44 @@ static int upd_phase(hm_upd* u, int phase) {
         const int rps = (nl + splits - 1) / splits;
         double* part = (double*)u->partial.p;
         hipLaunchKernelGGL(k_colsum_partial<T>, dim3((M + 255) / 256, splits), dim3(256), 0, s, (const T*)E, nl, M, rps, part);
-        hipLaunchKernelGGL(k_colsum_final<T>, dim3((M + 255) / 256), dim3(256), 0, s, (const double*)part, splits, M, red0);
+        hipLaunchKernelGGL(k_colsum_final<T>, dim3((M + 255) / 256), dim3(256), 0, s, (const double*)part, splits, M, sumE);
         double* part2 = part + (size_t)64 * M;
         hipLaunchKernelGGL(k_colsum_partial<T>, dim3((no + 255) / 256, splits), dim3(256), 0, s, (const T*)u->obs_ens.p, nl, no, rps, part2);
-        hipLaunchKernelGGL(k_colsum_final<T>, dim3((no + 255) / 256), dim3(256), 0, s, (const double*)part2, splits, no, red0 + M);
+        hipLaunchKernelGGL(k_colsum_final<double>, dim3((no + 255) / 256), dim3(256), 0, s, (const double*)part2, splits, no, sumY);
         HM_HIP(hipGetLastError());
     } else if (phase == 1) {
         const double inv_n = 1.0 / (double)u->N_total;
-        size_t n = (size_t)nl * no;
-        hipLaunchKernelGGL(k_prep_obs<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)u->obs_ens.p,
-                           (const T*)u->perturbs.p, (const T*)u->obs.p, (const T*)(red0 + M), inv_n, nl, no, Y, D0);
+        hipLaunchKernelGGL(k_prep_obs<T>, dim3((unsigned)((n_small + 255) / 256)), dim3(256), 0, s, (const T*)u->obs_ens.p,
+                           (const T*)u->perturbs.p, (const T*)u->obs.p, (const double*)sumY, inv_n, nl, no, Y, D0);
+        hipLaunchKernelGGL((k_cast<T, double>), dim3(64), dim3(256), 0, s, (const T*)u->decorr.p, dec, (size_t)no * no);
         HM_HIP(hipGetLastError());
-        const T* dec = (const T*)u->decorr.p;
         // S = Y decorr ; D = D0 decorr                                   (HistoryMatch.py:583-584)
-        if ((rc = gemm<T>(s, nl, no, no, Y, no, 1, dec, no, 1, S, no))) return rc;
-        if ((rc = gemm<T>(s, nl, no, no, D0, no, 1, dec, no, 1, D, no))) return rc;
+        if ((rc = gemm<double>(s, nl, no, no, Y, no, 1, dec, no, 1, S, no))) return rc;
+        if ((rc = gemm<double>(s, nl, no, no, D0, no, 1, dec, no, 1, D, no))) return rc;
         // G = S^T S (local rows)                                         (HistoryMatch.py:585)
-        if ((rc = gemm<T>(s, no, no, nl, S, 1, no, S, no, 1, G, no))) return rc;
+        if ((rc = gemm<double>(s, no, no, nl, S, 1, no, S, no, 1, G, no))) return rc;
         // Gxt = (E - mean)^T S   (M x n_obs): A(i,k) = E[k][i] - mean[i]   (HistoryMatch.py:581, 586)
-        if ((rc = gemm<T>(s, M, no, nl, E, 1, M, S, no, 1, Gxt, no, nullptr, 0, red0, inv_n))) return rc;
+        hipLaunchKernelGGL((k_cast<double, T>), dim3(gs), dim3(256), 0, s, (const double*)S, S_T, n_small);
+        HM_HIP(hipGetLastError());
+        if ((rc = gemm<T>(s, M, no, nl, E, 1, M, S_T, no, 1, Gxt, no, nullptr, 0, sumE, inv_n))) return rc;
     } else if (phase == 2) {
         if (!u->localized) {
-            hipLaunchKernelGGL(k_invert_C<T>, dim3(1), dim3(1024), 0, s, (const T*)G, no, (double)(u->N_total - 1),
-                               (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (T*)u->CinvT.p, (int*)u->flags.p);
+            hipLaunchKernelGGL(k_invert_C, dim3(1), dim3(1024), 0, s, (const double*)G, no, (double)(u->N_total - 1),
+                               (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p);
             HM_HIP(hipGetLastError());
             // T1 = D Cinv ;  E_out = E + T1 Gxt^T                          (HistoryMatch.py:586)
-            if ((rc = gemm<T>(s, nl, no, no, D, no, 1, (const T*)u->CinvT.p, no, 1, T1, no))) return rc;
-            if ((rc = gemm<T>(s, nl, M, no, T1, no, 1, Gxt, 1, no, Eo, M, E, M))) return rc;
+            if ((rc = gemm<double>(s, nl, no, no, D, no, 1, (const double*)u->Cinv.p, no, 1, T1, no))) return rc;
+            hipLaunchKernelGGL((k_cast<double, T>), dim3(gs), dim3(256), 0, s, (const double*)T1, A_T, n_small);
+            HM_HIP(hipGetLastError());
+            if ((rc = gemm<T>(s, nl, M, no, A_T, no, 1, Gxt, 1, no, Eo, M, E, M))) return rc;
         } else {
             size_t lds = ((size_t)no * (no + 1) / 2 + 2 * no) * 8 + (size_t)no * 4 + 16;
             HM_HIP(hipFuncSetAttribute((const void*)k_local_analysis<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k_local_analysis<T>, dim3(M), dim3(256), lds, s, M, no, u->N_total, u->cutoff,
-                               (const T*)u->taper.p, (const T*)G, (const T*)Gxt, (T*)u->Wt.p, (int*)u->flags.p);
+                               (const T*)u->taper.p, (const double*)G, (const T*)Gxt, (T*)u->Wt.p, (int*)u->flags.p);
+            hipLaunchKernelGGL((k_cast<double, T>), dim3(gs), dim3(256), 0, s, (const double*)D, A_T, n_small);
             HM_HIP(hipGetLastError());
-            if ((rc = gemm<T>(s, nl, M, no, D, no, 1, (const T*)u->Wt.p, 1, no, Eo, M, E, M))) return rc;
+            if ((rc = gemm<T>(s, nl, M, no, A_T, no, 1, (const T*)u->Wt.p, 1, no, Eo, M, E, M))) return rc;
         }
     } else {
         hm_set_error("hm_upd_phase: phase must be 0, 1 or 2");
@@ -397,11 +413,19 @@ extern "C" int hm_upd_phase(hm_upd* u, int phase) {
     return u->dtype == 64 ? upd_phase<double>(u, phase) : upd_phase<float>(u, phase);
 }
 
-extern "C" void* hm_upd_reduce_buffer(hm_upd* u, int which, long long* n_elems) {
+extern "C" void* hm_upd_reduce_buffer(hm_upd* u, int which, long long* n_elems, int* elem_bytes) {
     if (!u) return nullptr;
-    if (which == 0) { if (n_elems) *n_elems = (long long)u->M + u->n_obs; return u->red0.p; }
-    if (which == 1) { if (n_elems) *n_elems = (long long)u->n_obs * u->n_obs + (long long)u->M * u->n_obs; return u->red1.p; }
-    return nullptr;
+    long long n = 0; int eb = 8; void* p = nullptr;
+    switch (which) {
+        case 0: n = u->M; eb = (int)u->esz; p = u->red0.p; break;
+        case 1: n = u->n_obs; eb = 8; p = u->red1.p; break;
+        case 2: n = (long long)u->M * u->n_obs; eb = (int)u->esz; p = u->red2.p; break;
+        case 3: n = (long long)u->n_obs * u->n_obs; eb = 8; p = u->red3.p; break;
+        default: return nullptr;
+    }
+    if (n_elems) *n_elems = n;
+    if (elem_bytes) *elem_bytes = eb;
+    return p;
 }
 
 extern "C" int hm_upd_sync(hm_upd* u, hm_stats* st) {

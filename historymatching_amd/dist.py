@@ -3,8 +3,8 @@
 Sharding follows the reference's only parallel axis -- independent ensemble members (``utils.apply`` process
 pool, notebooks/tools/utils.py:201-224; "embarrassingly parallelizable" notebooks/HistoryMatch.py:376-380):
   * forward model: contiguous member blocks per rank, NO data-path collective;
-  * update: rows of E stay on their rank; two sum-all-reduces per update (column sums: M+n_obs values; the
-    Gram pair [S^T S | X^T S]: n_obs*(n_obs+M) values), SURVEY.md 8e.  Everything else is row-local.
+  * update: rows of E stay on their rank; two reduction points per update (column sums: M+n_obs values; the
+    Gram pair S^T S, X^T S: n_obs*(n_obs+M) values), SURVEY.md 8e.  Everything else is row-local.
 torch is used only for rendezvous and the collective; compute stays behind the C ABI.
 """
 
@@ -89,6 +89,7 @@ def sharded_update(plan, comm=None):
     for ph in range(3):
         plan.phase(ph)
         if ph < 2 and comm.world_size > 1:
-            plan.set_reduce(ph, comm.all_reduce_sum(plan.get_reduce(ph)))
+            for which in plan.REDUCE_AFTER_PHASE[ph]:
+                plan.set_reduce(which, comm.all_reduce_sum(plan.get_reduce(which)))
     plan.sync()
     return plan.output()

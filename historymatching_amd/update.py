@@ -108,21 +108,23 @@ class UpdatePlan:
     def phase(self, k):
         _lib.check(self.lib.hm_upd_phase(self.h, int(k)), "hm_upd_phase")
 
+    REDUCE_AFTER_PHASE = {0: (0, 1), 1: (2, 3)}  # which buffers to sum over ranks after each phase
+
     def reduce_buffer(self, which):
-        n = C.c_longlong()
-        p = self.lib.hm_upd_reduce_buffer(self.h, int(which), C.byref(n))
-        return p, n.value
+        n, eb = C.c_longlong(), C.c_int()
+        p = self.lib.hm_upd_reduce_buffer(self.h, int(which), C.byref(n), C.byref(eb))
+        return p, n.value, (np.float64 if eb.value == 8 else np.float32)
 
     def get_reduce(self, which):
-        """Host copy of reduce buffer `which` (0: column sums, 1: [G | Gxt])."""
-        p, n = self.reduce_buffer(which)
-        out = np.empty(n, dtype=self.ft)
+        """Host copy of reduce buffer `which` (0: colsum E, 1: colsum obs_ens, 2: X^T S, 3: S^T S)."""
+        p, n, dt = self.reduce_buffer(which)
+        out = np.empty(n, dtype=dt)
         _lib.check(self.lib.hm_copy_to_host(self.ctx.handle, _lib.ptr(out), p, out.nbytes), "hm_copy_to_host")
         return out
 
     def set_reduce(self, which, arr):
-        p, n = self.reduce_buffer(which)
-        arr = _lib.as_c(arr, self.ft).reshape(-1)
+        p, n, dt = self.reduce_buffer(which)
+        arr = _lib.as_c(arr, dt).reshape(-1)
         if arr.size != n:
             raise ValueError(f"reduce buffer {which} has {n} elements, got {arr.size}")
         _lib.check(self.lib.hm_copy_to_device(self.ctx.handle, p, _lib.ptr(arr), arr.nbytes), "hm_copy_to_device")

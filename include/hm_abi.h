@@ -113,17 +113,19 @@ int hm_es_update_loc(hm_ctx* ctx, int N, int M, int n_obs, const void* E, const 
                      double cutoff, int dtype, void* E_out, hm_stats* stats);
 
 /* Device-resident / sharded form: rows [row0, row0+N_local) of an N-member ensemble live on this GPU.
- * The two cross-rank reductions (column sums; Gx = S^T X) are exposed as buffers the host
- * all-reduces with RCCL between the phases:
- *   phase 0: local column sums of E and obs_ens            -> hm_upd_reduce_buffer(0) (M+n_obs values)
- *   phase 1: (after all-reduce) S, D, local S^T S and S^T X -> hm_upd_reduce_buffer(1) (n_obs*(n_obs+M))
- *   phase 2: (after all-reduce) C^-1, E_out = E + (D C^-1) Gx  (row-local)                              */
+ * The cross-rank reductions are exposed as four sum-reduce buffers the host all-reduces (RCCL)
+ * between the phases:
+ *   phase 0: local column sums                      -> buffers 0 (E: M values, dtype) and 1 (obs_ens: n_obs, fp64)
+ *   phase 1: (after all-reduce of 0,1) S, D, and the local Gram pair
+ *                                                   -> buffers 2 (X^T S: M*n_obs, dtype) and 3 (S^T S: n_obs^2, fp64)
+ *   phase 2: (after all-reduce of 2,3) C^-1 (or the per-element local analyses), E_out = E + (D C^-1) Gx  (row-local)
+ * Everything of size <= N x n_obs is held in fp64 whatever `dtype` is; only the two contractions over M use `dtype`. */
 int   hm_upd_create(hm_ctx* ctx, int N_total, int N_local, int M, int n_obs, int dtype, int localized, hm_upd** out);
 void  hm_upd_destroy(hm_upd* u);
 int   hm_upd_set_inputs(hm_upd* u, const void* E_local, const void* obs_ens_local, const void* obs,
                         const void* perturbs_local, const void* decorr, const void* taper /* or NULL */, double cutoff);
 int   hm_upd_phase(hm_upd* u, int phase);
-void* hm_upd_reduce_buffer(hm_upd* u, int which, long long* n_elems);   /* device pointer, dtype elements */
+void* hm_upd_reduce_buffer(hm_upd* u, int which /*0..3*/, long long* n_elems, int* elem_bytes); /* device pointer */
 int   hm_upd_sync(hm_upd* u, hm_stats* stats);
 int   hm_upd_get_output(hm_upd* u, void* E_out_local);
 void* hm_upd_device_ptr(hm_upd* u, const char* name);   /* "E","E_out","obs_ens","perturbs" */
