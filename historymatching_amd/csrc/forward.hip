@@ -366,6 +366,8 @@ static int build_q(hm_fwd* f, int nInj, const int* inj_ind, const double* inj_ra
                    "sum of injection rates (%g) must equal sum of production rates (%g) at step %d", si, sp, k);
     }
     f->p.q_cols = cols;
+    f->well_cells_host.assign(inj_ind, inj_ind + nInj);
+    f->well_cells_host.insert(f->well_cells_host.end(), prd_ind, prd_ind + nPrd);
     return 0;
 }
 
@@ -403,6 +405,7 @@ extern "C" int hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, doub
     ALLOC(perm_in, n * Nxy * 8);
     ALLOC(q, f->q_host.size() * 8);
     ALLOC(prd_ind, (size_t)nPrd * 4);
+    ALLOC(well_cells, (size_t)(nInj + nPrd) * 4);
     ALLOC(TX, n * (Nx + 1) * Ny * 8);
     ALLOC(TY, n * Nx * (Ny + 1) * 8);
     ALLOC(G, n * Nxy * Ny * 8);
@@ -417,6 +420,7 @@ extern "C" int hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, doub
     if (porosity) ALLOC(por, Nxy * 8);
 #undef ALLOC
     p.K = (double*)f->K.p; p.q = (double*)f->q.p; p.prd_ind = (int*)f->prd_ind.p;
+    p.well_cells = (int*)f->well_cells.p;
     p.TX = (double*)f->TX.p; p.TY = (double*)f->TY.p; p.G = (double*)f->G.p; p.yv = (double*)f->yv.p;
     p.P = (double*)f->P.p; p.Vx = (double*)f->Vx.p; p.Vy = (double*)f->Vy.p;
     p.status = (int*)f->status.p; p.nts = (int*)f->nts.p;
@@ -425,6 +429,7 @@ extern "C" int hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, doub
     hipStream_t s = ctx->stream;
     HM_HIP(hipMemcpyAsync(f->q.p, f->q_host.data(), f->q_host.size() * 8, hipMemcpyHostToDevice, s));
     HM_HIP(hipMemcpyAsync(f->prd_ind.p, prd_ind, (size_t)nPrd * 4, hipMemcpyHostToDevice, s));
+    HM_HIP(hipMemcpyAsync(f->well_cells.p, f->well_cells_host.data(), f->well_cells_host.size() * 4, hipMemcpyHostToDevice, s));
     if (porosity) HM_HIP(hipMemcpyAsync(f->por.p, porosity, Nxy * 8, hipMemcpyHostToDevice, s));
     HM_HIP(hipMemsetAsync(f->status.p, 0, n * 4, s));
     HM_HIP(hipMemsetAsync(f->nts.p, 0, n * nTime * 4, s));
@@ -440,7 +445,7 @@ extern "C" void hm_fwd_destroy(hm_fwd* f) {
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
     DevBuf* bufs[] = {&f->K, &f->por, &f->q, &f->prd_ind, &f->TX, &f->TY, &f->G, &f->yv, &f->P, &f->Vx,
-                      &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods};
+                      &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     f->t_total.destroy(); f->t_press.destroy(); f->t_sat.destroy();
     delete f;

@@ -18,6 +18,7 @@ struct FwdParams {
     const double* q;          // q_cols*Nxy source field per time column
     int q_cols;
     const int* prd_ind;       // nPrd flat cell indices
+    const int* well_cells;    // nInj+nPrd flat cell indices of all wells (injectors first)
     // pressure scratch (fp64 always)
     double* TX;               // N*(Nx+1)*Ny   x-face transmissibilities
     double* TY;               // N*Nx*(Ny+1)   y-face transmissibilities
@@ -47,6 +48,8 @@ struct hm_fwd {
     EvTimer t_total, t_press, t_sat;
     long long n_press = 0, n_sat = 0;
     std::vector<double> q_host;
+    std::vector<int> well_cells_host;
+    DevBuf well_cells;
 };
 
 // Pointer to the saturation of (member 0, time index k) and the member stride in elements.

@@ -1,3 +1,334 @@
-// sat128.hip -- 128x128 fp64 specialisation of the saturation sweep.  (placeholder: not yet applicable)
+// sat128.hip -- 128x128 fp64 specialisation of the explicit upwind saturation sweep.
+//
+// One workgroup (512 threads = 8 waves) = one ensemble member, resident on one CU for all Nts (~615) explicit
+// sub-steps:
+//   * registers: every thread owns an 8 (ix) x 4 (iy) patch of cells: their saturations S and the face fluxes
+//     Vx (9x4) and Vy (8x4 south faces) -- the whole member state S,Vx,Vy = 384 KB lives in the CU's 512 KB
+//     register file; the north face of a patch's last column is the south face of the next lane's first column
+//     and is fetched with a DPP wave shift (lanes = consecutive patches along iy);
+//   * LDS (128 KB): the fractional-flow field fw(S) of the current sub-step, the only thing neighbouring
+//     patches exchange; 16-byte chunks are XOR-swizzled so the b128 row reads are bank-conflict-free;
+//     the iy-halo of a row comes from the neighbouring lane by DPP instead of LDS;
+//   * HBM: S, Vx, Vy are read once and S written once per launch (per member-step).
+// Upwind coefficients are re-derived from the face fluxes every sub-step (there is no register room for a
+// fourth/fifth cell-sized array in fp64), with exactly the reference's operations, so results are bit-identical
+// to the generic kernel and to oracle/ressim.py:saturation_step_upwind:
+//     S_c <- S_c + (((((cE fE + cN fN) + cC fC) + cS fS) + cW fW) + fi_c dtx)      (E,N,C,S,W = CSR order)
+// Wells (cells with q != 0) are handled by the thread that owns the cell in a branch-free side path that keeps the
+// exact state of that cell in a small LDS record and overwrites the LDS fw entry (threads without a well run the
+// same instructions on a dummy record: divergent control flow inside the sub-step loop makes the register
+// allocator spill the whole flux state), so the straight-line code needs no per-cell source terms (x + 0.0 == x).
+// Requires <= 1 well per patch and uniform porosity; otherwise the host falls back to the generic kernel.
+//
+// Compiled with -ffp-contract=off (no FMA contraction: every product and sum is rounded separately, as NumPy does).
 #include "fwd.h"
-int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) { (void)f; (void)S_in; (void)S_out; (void)S_stride; (void)k; return -1; }
+
+namespace {
+
+constexpr int N128 = 128;
+constexpr int PX = 8, PY = 4;
+constexpr int NPY = N128 / PY;            // 32 patches along iy = 32 lanes
+constexpr int NT = (N128 / PX) * NPY;     // 512 threads
+constexpr int FW_BYTES = N128 * N128 * 8; // 128 KB
+constexpr int REC_BYTES = 64;             // well record: S, cE, cN, cC, cS, cW, fid, fw
+constexpr int MAX_WELLS = 16;
+
+__device__ __forceinline__ int lds_off(int ix, int iy) {
+    // byte offset of fw(ix, iy): rows of 1 KB; each thread's 32-byte row segment = two 16-byte chunks whose
+    // order is flipped for every other group of 8 lanes -> ds_read_b128 of a row is conflict-free
+    int py = iy >> 2;
+    int chunk = (iy >> 1) ^ ((py >> 3) & 1);
+    return ix * 1024 + chunk * 16 + (iy & 1) * 8;
+}
+
+// value of lane+1 / lane-1 (whole-wave shift); out-of-wave source reads as 0
+__device__ __forceinline__ double from_next_lane(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);  // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_prev_lane(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);  // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <bool FD>
+__device__ __forceinline__ double frac_flow(const FwdParams& p, double s) {
+    double mw, mo;
+    if (FD) {
+        mw = s * s;
+        double o = 1.0 - s;
+        mo = o * o;
+    } else {
+        double den = (1.0 - p.swc) - p.sor;
+        double S = (s - p.swc) / den;
+        mw = (S * S) / p.vw;
+        double o = 1.0 - S;
+        mo = (o * o) / p.vo;
+    }
+    return mw / (mw + mo);
+}
+
+template <bool FD>
+__global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __restrict__ Sin_base,
+                                               double* __restrict__ Sout_base, long long S_stride,
+                                               double* __restrict__ prods, int k) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // [0,128K) fw field; then well records
+
+    const int tid = threadIdx.x;
+    const int m = blockIdx.x;
+    const int py = tid & (NPY - 1), px = tid >> 5;
+    const int ix0 = px * PX, iy0 = py * PY;
+
+    const double* Sin = Sin_base + (long long)m * S_stride;
+    double* Sout = Sout_base + (long long)m * S_stride;
+    const double* gVx = p.Vx + (long long)m * (N128 + 1) * N128;
+    const double* gVy = p.Vy + (long long)m * N128 * (N128 + 1);
+    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * p.Nxy;
+
+    // ---------------- member state -> registers
+    double S[PX][PY], Vx[PX + 1][PY], Vy[PX][PY];
+#pragma unroll
+    for (int i = 0; i < PX; ++i)
+#pragma unroll
+        for (int j = 0; j < PY; j += 2) {
+            double2 v = *reinterpret_cast<const double2*>(Sin + (ix0 + i) * N128 + iy0 + j);
+            S[i][j] = v.x;
+            S[i][j + 1] = v.y;
+        }
+#pragma unroll
+    for (int i = 0; i <= PX; ++i)
+#pragma unroll
+        for (int j = 0; j < PY; j += 2) {
+            double2 v = *reinterpret_cast<const double2*>(gVx + (ix0 + i) * N128 + iy0 + j);
+            Vx[i][j] = v.x;
+            Vx[i][j + 1] = v.y;
+        }
+#pragma unroll
+    for (int i = 0; i < PX; ++i)
+#pragma unroll
+        for (int j = 0; j < PY; ++j) Vy[i][j] = gVy[(ix0 + i) * (N128 + 1) + iy0 + j];
+
+    // ---------------- the (at most one) well of this patch
+    int wcell = -1, wrec = FW_BYTES + MAX_WELLS * REC_BYTES;  // non-owners work on a shared dummy record
+    double wq = 0.0;
+    const int nW = min(p.nInj + p.nPrd, MAX_WELLS);
+    for (int w = 0; w < nW; ++w) {
+        int cell = p.well_cells[w];
+        if (((cell >> 7) >> 3) == px && ((cell & 127) >> 2) == py && q[cell] != 0.0) {
+            wcell = cell;
+            wq = q[cell];
+            wrec = FW_BYTES + w * REC_BYTES;
+        }
+    }
+    const bool has_well = wcell >= 0;
+
+    // ---------------- CFL: pm = min over cells of pv / (Vi + fi)          
+    const double pv = p.h2 * 1.0;
+    double lmin = INFINITY;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const double vyn3 = from_next_lane(Vy[i][0]);  // north face of column 3 (0 on the domain boundary)
+#pragma unroll
+        for (int j = 0; j < PY; ++j) {
+            const double vyn = j + 1 < PY ? Vy[i][j + 1 < PY ? j + 1 : 0] : vyn3;
+            double xp = fmax(Vx[i][j], 0.0), yp = fmax(Vy[i][j], 0.0);
+            double xn = fmin(Vx[i + 1][j], 0.0), yn = fmin(vyn, 0.0);
+            double Vi = xp + yp - xn - yn;
+            lmin = fmin(lmin, pv / (Vi + 0.0));  // fi = 0 for every cell without an injector
+        }
+    }
+    double wVxW = 0, wVxE = 0, wVyS = 0, wVyN = 0;
+    if (has_well) {
+        const int wix = wcell >> 7, wiy = wcell & 127;
+        wVxW = gVx[wix * N128 + wiy];
+        wVxE = gVx[(wix + 1) * N128 + wiy];
+        wVyS = gVy[wix * (N128 + 1) + wiy];
+        wVyN = gVy[wix * (N128 + 1) + wiy + 1];
+        double Vi = fmax(wVxW, 0.0) + fmax(wVyS, 0.0) - fmin(wVxE, 0.0) - fmin(wVyN, 0.0);
+        lmin = fmin(lmin, pv / (Vi + fmax(wq, 0.0)));
+    }
+    double* red = reinterpret_cast<double*>(lds);
+    red[tid] = lmin;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmin(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    const double pm = red[0];
+    __syncthreads();
+    const double sat = p.swc + p.sor;
+    const double cfl = ((1.0 - sat) / 3.0) * pm;
+    const double ntsd = ceil(p.dt / cfl);
+    const bool bad = !(ntsd >= 1.0 && ntsd <= 1.0e7);
+    const int Nts = bad ? 0 : (int)ntsd;
+    if (tid == 0) {
+        p.nts[(long long)m * p.nTime + k] = Nts;
+        if (bad) atomicOr(&p.status[m], HM_MEMBER_BAD_CFL);
+    }
+    const double d = bad ? 0.0 : (p.dt / (double)Nts) / pv;
+
+    // well record: exact coefficients including the source terms, exact S
+    // (the dummy record is all zeros: S=0 -> fw=0, coefficients 0 -> stays 0; its "cell" slots live behind it)
+    if (tid < 16) reinterpret_cast<double*>(lds + FW_BYTES + MAX_WELLS * REC_BYTES)[tid] = 0.0;
+    __syncthreads();
+    if (has_well) {
+        double* rec = reinterpret_cast<double*>(lds + wrec);
+        double fpq = fmin(wq, 0.0), fiq = fmax(wq, 0.0);
+        double x1 = fmin(wVxW, 0.0), x2 = fmax(wVxE, 0.0), y1 = fmin(wVyS, 0.0), y2 = fmax(wVyN, 0.0);
+        rec[0] = Sin[wcell];
+        rec[1] = d * (-fmin(wVxE, 0.0));             // cE
+        rec[2] = d * (-fmin(wVyN, 0.0));             // cN
+        rec[3] = d * (fpq + x1 - x2 + y1 - y2);      // cC
+        rec[4] = d * fmax(wVyS, 0.0);                // cS
+        rec[5] = d * fmax(wVxW, 0.0);                // cW
+        rec[6] = fiq * d;                            // fid
+    }
+
+    // LDS byte addresses of the well cell and its 4 neighbours (dummy slots for threads without a well)
+    const int dummy = FW_BYTES + MAX_WELLS * REC_BYTES + REC_BYTES;
+    const int wix = wcell >> 7, wiy = wcell & 127;
+    const int waC = has_well ? lds_off(wix, wiy) : dummy;
+    const int waE = has_well ? lds_off(min(wix + 1, N128 - 1), wiy) : dummy;
+    const int waN = has_well ? lds_off(wix, min(wiy + 1, N128 - 1)) : dummy;
+    const int waS = has_well ? lds_off(wix, max(wiy - 1, 0)) : dummy;
+    const int waW = has_well ? lds_off(max(wix - 1, 0), wiy) : dummy;
+    __syncthreads();
+
+    const int swz = (py >> 3) & 1;
+    const int seg = py * 32;                       // byte offset of this thread's segment within a 1 KB row
+    const int ixW = max(ix0 - 1, 0), ixE = min(ix0 + PX, N128 - 1);
+
+    auto load_row = [&](int ix, double (&f)[PY]) {
+        const char* base = lds + ix * 1024 + seg;
+        double2 a = *reinterpret_cast<const double2*>(base + (swz * 16));
+        double2 b = *reinterpret_cast<const double2*>(base + ((1 ^ swz) * 16));
+        f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y;
+    };
+
+    // ---------------- explicit sub-steps
+    for (int it = 0; it < Nts; ++it) {
+        // The upwind coefficients are pure functions of (Vx, Vy, d): left alone, the compiler hoists all of them
+        // (5 extra cell-sized arrays) out of the sub-step loop and spills.  Routing the constants d and 0.0 through
+        // an empty asm makes every coefficient depend on a per-iteration opaque value (no instruction is emitted).
+        double dd = d, z = 0.0;
+        asm volatile("" : "+v"(dd), "+v"(z));
+
+        // phase A: fractional flow of every own cell -> LDS
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            char* base = lds + (ix0 + i) * 1024 + seg;
+            double2 a, b;
+            a.x = frac_flow<FD>(p, S[i][0]);
+            a.y = frac_flow<FD>(p, S[i][1]);
+            b.x = frac_flow<FD>(p, S[i][2]);
+            b.y = frac_flow<FD>(p, S[i][3]);
+            *reinterpret_cast<double2*>(base + (swz * 16)) = a;
+            *reinterpret_cast<double2*>(base + ((1 ^ swz) * 16)) = b;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {   // well side path, branch-free (threads without a well run it on the dummy record)
+            double* rec = reinterpret_cast<double*>(lds + wrec);
+            double wf = frac_flow<FD>(p, rec[0]);
+            rec[7] = wf;
+            *reinterpret_cast<double*>(lds + waC) = wf;  // after this thread's own row write: ordered
+        }
+        __syncthreads();
+
+        // phase B: upwind update row by row
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            const int ix = ix0 + i;
+            double fw_[PY], fc[PY], fe[PY];
+            load_row(i > 0 ? ix - 1 : ixW, fw_);
+            load_row(ix, fc);
+            load_row(i + 1 < PX ? ix + 1 : ixE, fe);
+            const double fS = from_prev_lane(fc[PY - 1]);  // f(ix, iy0-1): its coefficient is 0 on the boundary
+            const double fN = from_next_lane(fc[0]);       // f(ix, iy0+PY)
+            const double vyn3 = from_next_lane(Vy[i][0]);
+#pragma unroll
+            for (int j = 0; j < PY; ++j) {
+                const double vxw = Vx[i][j], vxe = Vx[i + 1][j], vys = Vy[i][j];
+                const double vyn = j + 1 < PY ? Vy[i][j + 1 < PY ? j + 1 : 0] : vyn3;
+                const double x1 = fmin(vxw, z), x2 = fmax(vxe, z), y1 = fmin(vys, z), y2 = fmax(vyn, z);
+                const double cC = dd * (x1 - x2 + y1 - y2);
+                const double cW = dd * fmax(vxw, z);
+                const double cE = dd * (-fmin(vxe, z));
+                const double cS = dd * fmax(vys, z);
+                const double cN = dd * (-fmin(vyn, z));
+                const double fs = j > 0 ? fc[j > 0 ? j - 1 : 0] : fS;
+                const double fn = j + 1 < PY ? fc[j + 1 < PY ? j + 1 : 0] : fN;
+                double acc = cE * fe[j];
+                acc = acc + cN * fn;
+                acc = acc + cC * fc[j];
+                acc = acc + cS * fs;
+                acc = acc + cW * fw_[j];
+                S[i][j] = S[i][j] + acc;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            double* rec = reinterpret_cast<double*>(lds + wrec);
+            double acc = rec[1] * *reinterpret_cast<const double*>(lds + waE);
+            acc = acc + rec[2] * *reinterpret_cast<const double*>(lds + waN);
+            acc = acc + rec[3] * rec[7];
+            acc = acc + rec[4] * *reinterpret_cast<const double*>(lds + waS);
+            acc = acc + rec[5] * *reinterpret_cast<const double*>(lds + waW);
+            rec[0] = rec[0] + (acc + rec[6]);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- write back
+    int nonfinite = 0;
+#pragma unroll
+    for (int i = 0; i < PX; ++i)
+#pragma unroll
+        for (int j = 0; j < PY; j += 2) {
+            double2 v;
+            v.x = S[i][j];
+            v.y = S[i][j + 1];
+            *reinterpret_cast<double2*>(Sout + (ix0 + i) * N128 + iy0 + j) = v;
+            const int c0 = (ix0 + i) * N128 + iy0 + j;
+            nonfinite |= (c0 != wcell && !isfinite(v.x)) || (c0 + 1 != wcell && !isfinite(v.y));
+        }
+    if (has_well) {
+        const double wS = *reinterpret_cast<const double*>(lds + wrec);
+        Sout[wcell] = wS;  // after this thread's own store of the patch: ordered
+        nonfinite |= !isfinite(wS);
+    }
+    if (nonfinite) atomicOr(&p.status[m], HM_MEMBER_NONFINITE);
+    __syncthreads();
+    if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = Sout[p.prd_ind[tid]];
+}
+
+template <bool FD>
+int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
+    const size_t lds = (size_t)FW_BYTES + MAX_WELLS * REC_BYTES + 2 * REC_BYTES;
+    auto kern = k_sat128<FD>;
+    HM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(f->p.N), dim3(NT), lds, f->ctx->stream, f->p, (const double*)S_in, (double*)S_out,
+                       S_stride, (double*)f->prods.p, k);
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
+int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
+    const FwdParams& p = f->p;
+    if (p.Nx != N128 || p.Ny != N128 || f->dtype != 64 || p.por != nullptr) return -1;
+    if ((int)f->well_cells_host.size() > MAX_WELLS) return -1;
+    std::vector<int> seen;  // at most one well per 8x4 patch
+    for (int cell : f->well_cells_host) {
+        int id = ((cell >> 7) >> 3) * 1000 + ((cell & 127) >> 2);
+        for (int s : seen)
+            if (s == id) return -1;
+        seen.push_back(id);
+    }
+    return p.fluid_default ? launch<true>(f, S_in, S_out, S_stride, k) : launch<false>(f, S_in, S_out, S_stride, k);
+}
