@@ -13,27 +13,11 @@
 // This file is compiled with -ffp-contract=off: every product/sum is rounded separately exactly as
 // NumPy does; FMAs appear only where written explicitly (inside the pressure solve, which is not a
 // bit-exact path).
-#include "fwd.h"
+#include "fwd_dev.h"
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void rel_perm(const FwdParams& p, T s, T& mw, T& mo) {
-    // Listing RelPerm: S* = (s-swc)/(1-swc-sor); Mw = S*^2/vw; Mo = (1-S*)^2/vo
-    if (p.fluid_default) {
-        mw = s * s;
-        T o = T(1) - s;
-        mo = o * o;
-    } else {
-        T den = T((1.0 - p.swc) - p.sor);
-        T S = (s - T(p.swc)) / den;
-        mw = (S * S) / T(p.vw);
-        T o = T(1) - S;
-        mo = (o * o) / T(p.vo);
-    }
-}
-
 __device__ __forceinline__ double block_min(double v, double* red, int tid, int nthreads) {
     red[tid] = v;
     __syncthreads();
@@ -92,24 +76,8 @@ __global__ void k_pressure_generic(FwdParams p, const TS* __restrict__ S_base, l
     const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
     double* L = P;  // temporarily holds L = 1/(Mt*K)
 
-    // --- mobility-weighted inverse permeability per cell: L = (Mt*K)**(-1)
-    for (int j = tid; j < Nxy; j += T) {
-        double mw, mo;
-        rel_perm<double>(p, (double)S[j], mw, mo);
-        double KM = (mw + mo) * Km[j];
-        L[j] = 1.0 / KM;
-    }
-    __syncthreads();
-    // --- harmonic-mean face transmissibilities, zero on the boundary (no-flow)
-    for (int f = tid; f < (Nx + 1) * Ny; f += T) {
-        int ix = f / Ny, iy = f % Ny;
-        TX[f] = (ix == 0 || ix == Nx) ? 0.0 : p.cx / (L[(ix - 1) * Ny + iy] + L[ix * Ny + iy]);
-    }
-    for (int f = tid; f < Nx * (Ny + 1); f += T) {
-        int ix = f / (Ny + 1), iy = f % (Ny + 1);
-        TY[f] = (iy == 0 || iy == Ny) ? 0.0 : p.cy / (L[ix * Ny + iy - 1] + L[ix * Ny + iy]);
-    }
-    __syncthreads();
+    // --- mobility-weighted inverse permeability, harmonic-mean face transmissibilities
+    assemble_transmissibilities<TS>(p, S, Km, L, TX, TY, tid, T);
 
     int bad = 0;
     // --- forward block elimination
@@ -215,14 +183,7 @@ __global__ void k_pressure_generic(FwdParams p, const TS* __restrict__ S_base, l
         __syncthreads();
     }
     // --- face fluxes
-    for (int f = tid; f < (Nx + 1) * Ny; f += T) {
-        int ix = f / Ny, iy = f % Ny;
-        Vx[f] = (ix == 0 || ix == Nx) ? 0.0 : (P[(ix - 1) * Ny + iy] - P[ix * Ny + iy]) * TX[f];
-    }
-    for (int f = tid; f < Nx * (Ny + 1); f += T) {
-        int ix = f / (Ny + 1), iy = f % (Ny + 1);
-        Vy[f] = (iy == 0 || iy == Ny) ? 0.0 : (P[ix * Ny + iy - 1] - P[ix * Ny + iy]) * TY[f];
-    }
+    face_fluxes(p, P, TX, TY, Vx, Vy, tid, T);
     if (bad && tid == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
