@@ -478,7 +478,8 @@ static int launch_pressure(hm_fwd* f, int k) {
     int rc = f->t_press.begin(s);
     if (rc) return rc;
     int done = -1;
-    if (f->press_variant != 1) done = launch_pressure_128(f, S, stride, k);
+    if (f->press_variant == 2) done = launch_pressure_128(f, S, stride, k);
+    else if (f->press_variant != 1) done = launch_pressure_128m(f, S, stride, k);
     if (done > 0) return done;
     if (done < 0) {
         int T = generic_threads(p.Ny);

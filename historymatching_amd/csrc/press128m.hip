@@ -1,0 +1,341 @@
+// press128m.hip -- Ny = 128 fp64 pressure step with the Schur-complement inversion on the MATRIX CORES.
+//
+// Same block elimination as press128.hip / the generic kernel, but the symmetric Gauss-Jordan
+// sweep is blocked: 4 pivots at a time.  With U = A[:,K] the 128x4 panel of the 4 pivot columns and
+// P = A[K,K]^-1 (4x4), one block sweep is
+//        A      <- A - (U P) U^T        rank-4 update of the whole 128x128 block  -> v_mfma_f64_16x16x4_f64
+//        A[:,K] <- U P,  A[K,:] <- (U P)^T,  A[K,K] <- -P
+// and after the 32 panels A = -inv(S_i).  The block lives in the MFMA accumulators: 16 waves x (2x2 tiles of
+// 16x16) x 4 fp64 per lane.  Per panel only the panel (128x4 doubles) and P (16 doubles) cross waves, through a
+// double-buffered LDS area; every register index is a compile-time constant (the panel loop is unrolled 8x over
+// the tile parity and the within-tile column group).
+// C/D layout of v_mfma_f64_16x16x4_f64: lane l, reg g -> row (l>>4)+4g, col l&15; A operand: lane l holds
+// A[l&15][l>>4]; B operand: B[l>>4][l&15] (checked on hardware by tests/test_forward_gpu.py::test_mfma_f64_layout).
+#include "fwd_dev.h"
+
+namespace {
+
+constexpr int NB = 128;
+constexpr int NT = 1024;
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct __attribute__((aligned(16))) PressLds {
+    double U[2][NB][4];  // panel columns (current values), double buffered
+    double Pm[2][16];    // inverse of the 4x4 pivot block
+    double ev[NB], dgv[NB], tyv[NB + 8], yprev[NB], ycur[NB];
+    double red[4][NB];
+};
+
+__device__ __forceinline__ double rcp_newton(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
+
+struct Geo {
+    int w, wr, wc, lane, lc, lq;
+};
+
+// t[row] = sum_col acc[row][col] v[col]; result returned to threads tid < 128 (row = tid). Contains barriers.
+__device__ __forceinline__ double matvec_tiles(const d4 (&acc)[2][2], const double* __restrict__ v, PressLds& L,
+                                               const Geo& g, int tid) {
+    const double v0 = v[16 * (2 * g.wc) + g.lc], v1 = v[16 * (2 * g.wc + 1) + g.lc];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double s = fma(acc[ti][1][r], v1, acc[ti][0][r] * v0);
+#pragma unroll
+            for (int msk = 8; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk, 16);
+            if (g.lc == 0) L.red[g.wc][16 * (2 * g.wr + ti) + g.lq + 4 * r] = s;
+        }
+    __syncthreads();
+    double t = 0.0;
+    if (tid < NB) t = (L.red[0][tid] + L.red[1][tid]) + (L.red[2][tid] + L.red[3][tid]);
+    __syncthreads();
+    return t;
+}
+
+// One block-sweep panel: pivot columns k0 .. k0+3, k0 = 16*(2*cp2+TJ) + 4*GQ.
+template <int TJ, int GQ>
+__device__ __forceinline__ void panel(d4 (&acc)[2][2], PressLds& L, int& cur, int cp2, const Geo& g, int& bad) {
+    const int k0 = 16 * (2 * cp2 + TJ) + 4 * GQ;
+    double (*U)[4] = L.U[cur];
+    double* Pm = L.Pm[cur];
+    // A: publish the panel columns (owners: waves of tile-column Cp, lanes holding columns k0..k0+3)
+    if (g.wc == cp2 && (g.lc >> 2) == GQ) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) U[16 * (2 * g.wr + ti) + g.lq + 4 * r][g.lc & 3] = acc[ti][TJ][r];
+    }
+    __syncthreads();
+    // B: P = inverse of the 4x4 pivot block, by one wave (all its lanes redundantly), via 4 rank-1 sweeps
+    if (g.w == cp2 * 5) {
+        double a[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[i][j] = U[k0 + i][j];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double d = a[kk][kk];
+            if (!(d > 0.0)) bad = 1;
+            const double pinv = rcp_newton(d);
+            double col[4], tcl[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                col[r] = a[r][kk];
+                tcl[r] = col[r] * pinv;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    double v = fma(-col[r], tcl[c], a[r][c]);
+                    if (r == kk) v = (c == kk) ? -pinv : tcl[c];
+                    else if (c == kk) v = tcl[r];
+                    a[r][c] = v;
+                }
+        }
+        if (g.lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Pm[4 * i + j] = -a[i][j];
+        }
+    }
+    __syncthreads();
+    // C: rank-4 update on the matrix cores
+    double Prow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Prow[j] = Pm[4 * g.lq + j];  // P symmetric: P[j][lq] = P[lq][j]
+    double wfr[2], ufr[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const double* u = U[16 * (2 * g.wr + ti) + g.lc];
+        double s = u[0] * Prow[0];
+        s = fma(u[1], Prow[1], s);
+        s = fma(u[2], Prow[2], s);
+        s = fma(u[3], Prow[3], s);
+        wfr[ti] = -s;  // (U P)[16R + lc][lq], negated for A - W U^T
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) ufr[tj] = U[16 * (2 * g.wc + tj) + g.lc][g.lq];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(wfr[ti], ufr[tj], acc[ti][tj], 0, 0, 0);
+    // D: rows and columns of the panel take their swept values
+    if (g.wr == cp2) {  // tile row Rp (ti = TJ), register GQ: rows k0+lq, all columns: A[k][c] = (U P)[c][k-k0]
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const double* u = U[16 * (2 * g.wc + tj) + g.lc];
+            double s = u[0] * Prow[0];
+            s = fma(u[1], Prow[1], s);
+            s = fma(u[2], Prow[2], s);
+            s = fma(u[3], Prow[3], s);
+            acc[TJ][tj][GQ] = s;
+        }
+    }
+    if (g.wc == cp2) {  // tile column Cp (tj = TJ), lanes with columns k0..k0+3: A[r][k] = (U P)[r][k-k0]
+        const bool mine = (g.lc >> 2) == GQ;
+        double Pc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Pc[j] = Pm[4 * (g.lc & 3) + j];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double* u = U[16 * (2 * g.wr + ti) + g.lq + 4 * r];
+                double s = u[0] * Pc[0];
+                s = fma(u[1], Pc[1], s);
+                s = fma(u[2], Pc[2], s);
+                s = fma(u[3], Pc[3], s);
+                acc[ti][TJ][r] = mine ? s : acc[ti][TJ][r];
+            }
+        if (g.wr == cp2 && mine) acc[TJ][TJ][GQ] = -Pm[4 * g.lq + (g.lc & 3)];  // pivot block itself: -P
+    }
+    cur ^= 1;
+}
+
+template <typename TS>
+__global__ __launch_bounds__(NT) void k_press128m(FwdParams p, const TS* __restrict__ S_base, long long S_stride, int k) {
+    __shared__ PressLds L;
+    const int m = blockIdx.x;
+    const int tid = threadIdx.x;
+    Geo g;
+    g.lane = tid & 63;
+    g.w = tid >> 6;
+    g.wr = g.w >> 2;
+    g.wc = g.w & 3;
+    g.lc = g.lane & 15;
+    g.lq = g.lane >> 4;
+    const int Nx = p.Nx, Nxy = p.Nxy;
+
+    const TS* S = S_base + (long long)m * S_stride;
+    const double* Km = p.K + (long long)m * Nxy;
+    double* TX = p.TX + (long long)m * (Nx + 1) * NB;
+    double* TY = p.TY + (long long)m * Nx * (NB + 1);
+    double2* G = reinterpret_cast<double2*>(p.G + (long long)m * Nx * NB * NB);
+    double* yv = p.yv + (long long)m * Nxy;
+    double* P = p.P + (long long)m * Nxy;
+    double* Vx = p.Vx + (long long)m * (Nx + 1) * NB;
+    double* Vy = p.Vy + (long long)m * Nx * (NB + 1);
+    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+
+    assemble_transmissibilities<TS>(p, S, Km, P /* scratch for L */, TX, TY, tid, NT);
+
+    d4 acc[2][2];
+    int bad = 0, cur = 0;
+    for (int i = 0; i < Nx; ++i) {
+        if (tid < NB) {
+            const int j = tid;
+            const double y1 = TY[i * (NB + 1) + j], y2 = TY[i * (NB + 1) + j + 1];
+            const double x1 = TX[i * NB + j], x2 = TX[(i + 1) * NB + j];
+            double dg = y1 + y2 + x1 + x2;
+            if (i == 0 && j == 0) dg += Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
+            L.dgv[j] = dg;
+            L.tyv[j] = y1;
+            if (j == NB - 1) L.tyv[NB] = y2;
+            L.ev[j] = x1;
+        }
+        __syncthreads();
+        if (i > 0) {
+            const double t = matvec_tiles(acc, L.yprev, L, g, tid);
+            if (tid < NB) L.ycur[tid] = q[i * NB + tid] + L.ev[tid] * t;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    const double ec = L.ev[16 * (2 * g.wc + tj) + g.lc];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[ti][tj][r] = -(L.ev[16 * (2 * g.wr + ti) + g.lq + 4 * r] * acc[ti][tj][r] * ec);
+                }
+        } else {
+            if (tid < NB) L.ycur[tid] = q[tid];
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+        // add the tridiagonal D_i
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * (2 * g.wr + ti) + g.lq + 4 * r, col = 16 * (2 * g.wc + tj) + g.lc;
+                    if (row == col) acc[ti][tj][r] += L.dgv[row];
+                    else if (col == row + 1) acc[ti][tj][r] -= L.tyv[col];
+                    else if (row == col + 1) acc[ti][tj][r] -= L.tyv[row];
+                }
+        __syncthreads();
+        // 32 block-sweep panels: A <- -inv(A)
+        for (int cp2 = 0; cp2 < 4; ++cp2) {
+            panel<0, 0>(acc, L, cur, cp2, g, bad);
+            panel<0, 1>(acc, L, cur, cp2, g, bad);
+            panel<0, 2>(acc, L, cur, cp2, g, bad);
+            panel<0, 3>(acc, L, cur, cp2, g, bad);
+            panel<1, 0>(acc, L, cur, cp2, g, bad);
+            panel<1, 1>(acc, L, cur, cp2, g, bad);
+            panel<1, 2>(acc, L, cur, cp2, g, bad);
+            panel<1, 3>(acc, L, cur, cp2, g, bad);
+        }
+        // G_i = -A: keep in the accumulators for the next block, stream to HBM (8 x 16-byte chunks, thread-major)
+        double2* Gi = G + (long long)i * (NB * NB / 2);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                acc[ti][tj] = -acc[ti][tj];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double2 v;
+                    v.x = acc[ti][tj][2 * h];
+                    v.y = acc[ti][tj][2 * h + 1];
+                    Gi[(((ti * 2 + tj) * 2) + h) * NT + tid] = v;
+                }
+            }
+        if (tid < NB) {
+            yv[i * NB + tid] = L.ycur[tid];
+            L.yprev[tid] = L.ycur[tid];
+        }
+        __syncthreads();
+    }
+    // back substitution: x_i = G_i (y_i + TX[i+1] * x_{i+1});  ycur holds x_{i+1}
+    for (int i = Nx - 1; i >= 0; --i) {
+        if (i < Nx - 1) {
+            const double2* Gi = G + (long long)i * (NB * NB / 2);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        double2 v = Gi[(((ti * 2 + tj) * 2) + h) * NT + tid];
+                        acc[ti][tj][2 * h] = v.x;
+                        acc[ti][tj][2 * h + 1] = v.y;
+                    }
+        }
+        if (tid < NB) {
+            double v = yv[i * NB + tid];
+            if (i < Nx - 1) v += TX[(i + 1) * NB + tid] * L.ycur[tid];
+            L.yprev[tid] = v;
+        }
+        __syncthreads();
+        const double t = matvec_tiles(acc, L.yprev, L, g, tid);
+        if (tid < NB) {
+            L.ycur[tid] = t;
+            P[i * NB + tid] = t;
+        }
+        __syncthreads();
+    }
+    face_fluxes(p, P, TX, TY, Vx, Vy, tid, NT);
+    if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
+}
+
+__global__ void k_mfma_f64_probe(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ D) {
+    const int l = threadIdx.x;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+
+}  // namespace
+
+// Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
+int launch_pressure_128m(hm_fwd* f, const void* S, long long S_stride, int k) {
+    const FwdParams& p = f->p;
+    if (p.Ny != NB) return -1;
+    if (f->dtype == 64)
+        hipLaunchKernelGGL(k_press128m<double>, dim3(p.N), dim3(NT), 0, f->ctx->stream, p, (const double*)S, S_stride, k);
+    else
+        hipLaunchKernelGGL(k_press128m<float>, dim3(p.N), dim3(NT), 0, f->ctx->stream, p, (const float*)S, S_stride, k);
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+// Self-test hook: D(16x16) = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 with the operand/result lane maps this
+// file assumes.  Host buffers.
+extern "C" int hm_debug_mfma_f64(hm_ctx* ctx, const double* A, const double* B, double* D) {
+    HM_REQUIRE(ctx && A && B && D, "hm_debug_mfma_f64: NULL argument");
+    HM_HIP(hipSetDevice(ctx->device));
+    double *dA, *dB, *dD;
+    HM_HIP(hipMalloc(&dA, 64 * 8));
+    HM_HIP(hipMalloc(&dB, 64 * 8));
+    HM_HIP(hipMalloc(&dD, 256 * 8));
+    HM_HIP(hipMemcpy(dA, A, 64 * 8, hipMemcpyHostToDevice));
+    HM_HIP(hipMemcpy(dB, B, 64 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_mfma_f64_probe, dim3(1), dim3(64), 0, ctx->stream, dA, dB, dD);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipStreamSynchronize(ctx->stream));
+    HM_HIP(hipMemcpy(D, dD, 256 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
+    return 0;
+}

@@ -84,7 +84,7 @@ int  hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transformed, con
 int  hm_fwd_run(hm_fwd* f, int first_step, int n_steps);           /* async; steps [first, first+n)  */
 int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
 int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member);     /* D2H */
-int  hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant); /* 0=auto, 1=generic */
+int  hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant); /* 0=fastest, 1=generic, 2=VALU-register pressure */
 /* Component hooks used by the parity tests (each maps to one listing of the cited paper):
  * run ONLY the pressure step / ONLY the saturation step of time index k on device state, and read
  * intermediate fields back. */
@@ -93,6 +93,10 @@ int  hm_fwd_saturation_only(hm_fwd* f, int k);
 int  hm_fwd_get_field(hm_fwd* f, const char* name /* "S","P","Vx","Vy","TX","TY","K","nts" */, void* out);
 int  hm_fwd_set_field(hm_fwd* f, const char* name /* "S","Vx","Vy" */, const void* in);
 void* hm_fwd_device_ptr(hm_fwd* f, const char* name);   /* raw device pointer of a named buffer */
+
+/* Hardware self-test: D(16x16) = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 with the lane maps the
+ * pressure kernel assumes (host buffers, row-major). */
+int hm_debug_mfma_f64(hm_ctx* ctx, const double* A, const double* B, double* D);
 
 /* ---- ensemble-smoother update: replaces ens_update0 -------------------------------------------
  * Reference: ens_update0  notebooks/HistoryMatch.py:578-586  (center: tools/utils.py:10-28).

@@ -311,24 +311,31 @@ def _comp1_star(args):
     return comp1(*args)
 
 
-def forward_model(model, perms, wsat0s=None, dt=0.025, nTime=40, nproc=1):
+def make_pool(nproc):
+    """Process pool as the reference uses it (utils.py:201-224): one worker per core, BLAS pinned to one thread."""
+    import multiprocessing as mp
+
+    import threadpoolctl
+
+    threadpoolctl.threadpool_limits(1)
+    return mp.get_context("fork").Pool(nproc)
+
+
+def forward_model(model, perms, wsat0s=None, dt=0.025, nTime=40, nproc=1, pool=None):
     """HistoryMatch.py:383-387 + utils.apply (utils.py:155-242): ordered map over members,
     one process per core with BLAS pinned to one thread (utils.py:201-224); stdlib
-    multiprocessing stands in for pathos."""
+    multiprocessing stands in for pathos.  `pool` reuses an existing `make_pool` (benchmarks)."""
     perms = np.asarray(perms)
     if wsat0s is None:
         wsat0s = np.zeros((len(perms), model.Nxy))
     if len(wsat0s) != len(perms):
         raise ValueError("zip() argument 2 is shorter/longer than argument 1")  # utils.py:175 strict zip
     tasks = [(model, p, w, dt, nTime) for p, w in zip(perms, wsat0s)]
-    if nproc > 1:
-        import multiprocessing as mp
-
-        import threadpoolctl
-
-        threadpoolctl.threadpool_limits(1)
-        with mp.get_context("fork").Pool(nproc) as pool:
-            output = pool.map(_comp1_star, tasks, chunksize=1)
+    if pool is not None:
+        output = pool.map(_comp1_star, tasks, chunksize=1)
+    elif nproc > 1:
+        with make_pool(nproc) as own:
+            output = own.map(_comp1_star, tasks, chunksize=1)
     else:
         output = [_comp1_star(t) for t in tasks]
     return [np.asarray(y) for y in zip(*output)]

@@ -44,6 +44,21 @@ def test_device_is_gfx950():
     assert "gfx950" in name, name
 
 
+def test_mfma_f64_layout():
+    """Operand / result lane maps of v_mfma_f64_16x16x4_f64 assumed by press128m.hip (asymmetric integer data)."""
+    import ctypes as C
+
+    from historymatching_amd import _lib
+
+    ctx = _lib.Context.get()
+    A = np.arange(64, dtype=np.float64).reshape(16, 4) + 1
+    B = (np.arange(64, dtype=np.float64).reshape(4, 16) * 3 - 50)
+    D = np.zeros((16, 16))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    _lib.check(ctx.lib.hm_debug_mfma_f64(ctx.handle, dp(A), dp(B), dp(D)), "hm_debug_mfma_f64")
+    assert np.array_equal(D, A @ B)
+
+
 def test_perm_transform_on_device():
     om, gm = make_models(20, 20)
     x = perms(20, 20, 5)
@@ -55,7 +70,7 @@ def test_perm_transform_on_device():
     assert np.max(np.abs(K - ref) / ref) < 4e-16
 
 
-@pytest.mark.parametrize("n,variant", [(20, 1), (20, 0), (128, 1), (128, 0)])
+@pytest.mark.parametrize("n,variant", [(20, 1), (20, 0), (128, 1), (128, 2), (128, 0)])
 def test_assembly_bitexact_and_pressure_within_solver_noise(n, variant):
     from oracle.ressim import perm_transf
     from scipy.sparse.linalg import spsolve
@@ -206,7 +221,7 @@ def test_unbalanced_rates_raise():
         gm.sim(DT, 2, np.zeros(400))
 
 
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [1, 2, 0])
 def test_full_sim_128_within_reference_solver_noise(variant):
     """C2-shaped members (128x128): S after a few steps agrees with the oracle to within the spread the
     oracle itself shows when SuperLU's column ordering is changed (the reference's own numerical noise)."""
