@@ -16,7 +16,6 @@
 namespace {
 
 constexpr int NB = 128;
-constexpr int NT = 1024;
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct __attribute__((aligned(16))) PressLds {
@@ -39,18 +38,30 @@ struct Geo {
     int w, wr, wc, lane, lc, lq;
 };
 
+// Wave grid: NW = 16 waves -> 4 (tile rows) x 4 (tile cols) waves, 2x2 tiles each;
+//            NW =  8 waves -> 2 x 4 waves, 4x2 tiles each (two such workgroups share a CU and hide each other's
+//            per-panel latency chain: pivot-block inverse -> MFMA -> fix-ups -> publish).
+template <int NW>
+struct Cfg {
+    static constexpr int TRW = (NW == 16) ? 2 : 4;  // tile rows per wave
+    static constexpr int TCW = 2;                   // tile cols per wave
+    static constexpr int NT = 64 * NW;
+};
+
 // t[row] = sum_col acc[row][col] v[col]; result returned to threads tid < 128 (row = tid). Contains barriers.
-__device__ __forceinline__ double matvec_tiles(const d4 (&acc)[2][2], const double* __restrict__ v, PressLds& L,
+template <int NW>
+__device__ __forceinline__ double matvec_tiles(const d4 (&acc)[Cfg<NW>::TRW][2], const double* __restrict__ v, PressLds& L,
                                                const Geo& g, int tid) {
+    constexpr int TRW = Cfg<NW>::TRW;
     const double v0 = v[16 * (2 * g.wc) + g.lc], v1 = v[16 * (2 * g.wc + 1) + g.lc];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double s = fma(acc[ti][1][r], v1, acc[ti][0][r] * v0);
 #pragma unroll
             for (int msk = 8; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk, 16);
-            if (g.lc == 0) L.red[g.wc][16 * (2 * g.wr + ti) + g.lq + 4 * r] = s;
+            if (g.lc == 0) L.red[g.wc][16 * (TRW * g.wr + ti) + g.lq + 4 * r] = s;
         }
     __syncthreads();
     double t = 0.0;
@@ -59,22 +70,47 @@ __device__ __forceinline__ double matvec_tiles(const d4 (&acc)[2][2], const doub
     return t;
 }
 
-// One block-sweep panel: pivot columns k0 .. k0+3, k0 = 16*(2*cp2+TJ) + 4*GQ.
-template <int TJ, int GQ>
-__device__ __forceinline__ void panel(d4 (&acc)[2][2], PressLds& L, int& cur, int cp2, const Geo& g, int& bad) {
-    const int k0 = 16 * (2 * cp2 + TJ) + 4 * GQ;
+#ifdef PRESS_STAMPS
+#define STAMP(i) do { long long t_ = clock64(); stamps[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+__device__ __forceinline__ double dot4(const double* __restrict__ u, const double (&p)[4]) {
+    double s = u[0] * p[0];
+    s = fma(u[1], p[1], s);
+    s = fma(u[2], p[2], s);
+    s = fma(u[3], p[3], s);
+    return s;
+}
+
+// One block-sweep panel: pivot columns k0 .. k0+3 of tile column Cp = 4*cq + CP4, k0 = 16*Cp + 4*GQ.
+template <int NW, int CP4, int GQ>
+__device__ __forceinline__ void panel(d4 (&acc)[Cfg<NW>::TRW][2], PressLds& L, int& cur, int cq, const Geo& g, int& bad
+#ifdef PRESS_STAMPS
+                                      , long long (&stamps)[8], long long& tprev
+#endif
+) {
+    constexpr int TRW = Cfg<NW>::TRW;
+    constexpr int TJ = CP4 & 1;                          // tile column inside the owning wave
+    constexpr int TI = (TRW == 2) ? (CP4 & 1) : CP4;     // tile row inside the owning wave
+    const int wc_role = 2 * cq + (CP4 >> 1);             // wave column owning tile column Cp
+    const int wr_role = (TRW == 2) ? wc_role : cq;       // wave row owning tile row Rp = Cp
+    const int k0 = 16 * (4 * cq + CP4) + 4 * GQ;
     double (*U)[4] = L.U[cur];
     double* Pm = L.Pm[cur];
     // A: publish the panel columns (owners: waves of tile-column Cp, lanes holding columns k0..k0+3)
-    if (g.wc == cp2 && (g.lc >> 2) == GQ) {
+    if (g.wc == wc_role && (g.lc >> 2) == GQ) {
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) U[16 * (2 * g.wr + ti) + g.lq + 4 * r][g.lc & 3] = acc[ti][TJ][r];
+            for (int r = 0; r < 4; ++r) U[16 * (TRW * g.wr + ti) + g.lq + 4 * r][g.lc & 3] = acc[ti][TJ][r];
     }
+    STAMP(0);
     __syncthreads();
+    STAMP(1);
     // B: P = inverse of the 4x4 pivot block, by one wave (all its lanes redundantly), via 4 rank-1 sweeps
-    if (g.w == cp2 * 5) {
+    if (g.wr == wr_role && g.wc == wc_role) {
         double a[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -108,62 +144,53 @@ __device__ __forceinline__ void panel(d4 (&acc)[2][2], PressLds& L, int& cur, in
                 for (int j = 0; j < 4; ++j) Pm[4 * i + j] = -a[i][j];
         }
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     // C: rank-4 update on the matrix cores
     double Prow[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) Prow[j] = Pm[4 * g.lq + j];  // P symmetric: P[j][lq] = P[lq][j]
-    double wfr[2], ufr[2];
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const double* u = U[16 * (2 * g.wr + ti) + g.lc];
-        double s = u[0] * Prow[0];
-        s = fma(u[1], Prow[1], s);
-        s = fma(u[2], Prow[2], s);
-        s = fma(u[3], Prow[3], s);
-        wfr[ti] = -s;  // (U P)[16R + lc][lq], negated for A - W U^T
-    }
+    double ufr[2];
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) ufr[tj] = U[16 * (2 * g.wc + tj) + g.lc][g.lq];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TRW; ++ti) {
+        const double wfr = -dot4(U[16 * (TRW * g.wr + ti) + g.lc], Prow);  // -(U P)[16R + lc][lq]
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(wfr[ti], ufr[tj], acc[ti][tj], 0, 0, 0);
-    // D: rows and columns of the panel take their swept values
-    if (g.wr == cp2) {  // tile row Rp (ti = TJ), register GQ: rows k0+lq, all columns: A[k][c] = (U P)[c][k-k0]
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-            const double* u = U[16 * (2 * g.wc + tj) + g.lc];
-            double s = u[0] * Prow[0];
-            s = fma(u[1], Prow[1], s);
-            s = fma(u[2], Prow[2], s);
-            s = fma(u[3], Prow[3], s);
-            acc[TJ][tj][GQ] = s;
-        }
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(wfr, ufr[tj], acc[ti][tj], 0, 0, 0);
     }
-    if (g.wc == cp2) {  // tile column Cp (tj = TJ), lanes with columns k0..k0+3: A[r][k] = (U P)[r][k-k0]
+    STAMP(4);
+    // D: rows and columns of the panel take their swept values
+    if (g.wr == wr_role) {  // tile row Rp (ti = TI), register GQ: rows k0+lq, all columns: A[k][c] = (U P)[c][k-k0]
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[TI][tj][GQ] = dot4(U[16 * (2 * g.wc + tj) + g.lc], Prow);
+    }
+    if (g.wc == wc_role) {  // tile column Cp (tj = TJ), lanes with columns k0..k0+3: A[r][k] = (U P)[r][k-k0]
         const bool mine = (g.lc >> 2) == GQ;
         double Pc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) Pc[j] = Pm[4 * (g.lc & 3) + j];
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double* u = U[16 * (2 * g.wr + ti) + g.lq + 4 * r];
-                double s = u[0] * Pc[0];
-                s = fma(u[1], Pc[1], s);
-                s = fma(u[2], Pc[2], s);
-                s = fma(u[3], Pc[3], s);
+                const double s = dot4(U[16 * (TRW * g.wr + ti) + g.lq + 4 * r], Pc);
                 acc[ti][TJ][r] = mine ? s : acc[ti][TJ][r];
             }
-        if (g.wr == cp2 && mine) acc[TJ][TJ][GQ] = -Pm[4 * g.lq + (g.lc & 3)];  // pivot block itself: -P
+        if (g.wr == wr_role && mine) acc[TI][TJ][GQ] = -Pm[4 * g.lq + (g.lc & 3)];  // pivot block itself: -P
     }
+#ifdef PRESS_STAMPS
+    { long long t_ = clock64(); if (g.wc == wc_role || g.wr == wr_role) stamps[5] += t_ - tprev; else stamps[6] += t_ - tprev; tprev = t_; }
+#endif
     cur ^= 1;
 }
 
-template <typename TS>
-__global__ __launch_bounds__(NT) void k_press128m(FwdParams p, const TS* __restrict__ S_base, long long S_stride, int k) {
+template <typename TS, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_press128m(FwdParams p, const TS* __restrict__ S_base, long long S_stride, int k) {
+    constexpr int TRW = Cfg<NW>::TRW;
+    constexpr int NT = Cfg<NW>::NT;
+    constexpr int NCH = TRW * 2 * 2;  // 16-byte chunks per lane
     __shared__ PressLds L;
     const int m = blockIdx.x;
     const int tid = threadIdx.x;
@@ -189,8 +216,11 @@ __global__ __launch_bounds__(NT) void k_press128m(FwdParams p, const TS* __restr
 
     assemble_transmissibilities<TS>(p, S, Km, P /* scratch for L */, TX, TY, tid, NT);
 
-    d4 acc[2][2];
+    d4 acc[TRW][2];
     int bad = 0, cur = 0;
+#ifdef PRESS_STAMPS
+    long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, tstart = clock64();
+#endif
     for (int i = 0; i < Nx; ++i) {
         if (tid < NB) {
             const int j = tid;
@@ -205,52 +235,54 @@ __global__ __launch_bounds__(NT) void k_press128m(FwdParams p, const TS* __restr
         }
         __syncthreads();
         if (i > 0) {
-            const double t = matvec_tiles(acc, L.yprev, L, g, tid);
+            const double t = matvec_tiles<NW>(acc, L.yprev, L, g, tid);
             if (tid < NB) L.ycur[tid] = q[i * NB + tid] + L.ev[tid] * t;
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
+            for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < 2; ++tj) {
                     const double ec = L.ev[16 * (2 * g.wc + tj) + g.lc];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        acc[ti][tj][r] = -(L.ev[16 * (2 * g.wr + ti) + g.lq + 4 * r] * acc[ti][tj][r] * ec);
+                        acc[ti][tj][r] = -(L.ev[16 * (TRW * g.wr + ti) + g.lq + 4 * r] * acc[ti][tj][r] * ec);
                 }
         } else {
             if (tid < NB) L.ycur[tid] = q[tid];
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
+            for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = d4{0.0, 0.0, 0.0, 0.0};
         }
         // add the tridiagonal D_i
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * (2 * g.wr + ti) + g.lq + 4 * r, col = 16 * (2 * g.wc + tj) + g.lc;
+                    const int row = 16 * (TRW * g.wr + ti) + g.lq + 4 * r, col = 16 * (2 * g.wc + tj) + g.lc;
                     if (row == col) acc[ti][tj][r] += L.dgv[row];
                     else if (col == row + 1) acc[ti][tj][r] -= L.tyv[col];
                     else if (row == col + 1) acc[ti][tj][r] -= L.tyv[row];
                 }
         __syncthreads();
         // 32 block-sweep panels: A <- -inv(A)
-        for (int cp2 = 0; cp2 < 4; ++cp2) {
-            panel<0, 0>(acc, L, cur, cp2, g, bad);
-            panel<0, 1>(acc, L, cur, cp2, g, bad);
-            panel<0, 2>(acc, L, cur, cp2, g, bad);
-            panel<0, 3>(acc, L, cur, cp2, g, bad);
-            panel<1, 0>(acc, L, cur, cp2, g, bad);
-            panel<1, 1>(acc, L, cur, cp2, g, bad);
-            panel<1, 2>(acc, L, cur, cp2, g, bad);
-            panel<1, 3>(acc, L, cur, cp2, g, bad);
+#ifdef PRESS_STAMPS
+#define PANEL(a, b) panel<NW, a, b>(acc, L, cur, cq, g, bad, stamps, tprev)
+        tprev = clock64();
+#else
+#define PANEL(a, b) panel<NW, a, b>(acc, L, cur, cq, g, bad)
+#endif
+        for (int cq = 0; cq < 2; ++cq) {
+            PANEL(0, 0); PANEL(0, 1); PANEL(0, 2); PANEL(0, 3);
+            PANEL(1, 0); PANEL(1, 1); PANEL(1, 2); PANEL(1, 3);
+            PANEL(2, 0); PANEL(2, 1); PANEL(2, 2); PANEL(2, 3);
+            PANEL(3, 0); PANEL(3, 1); PANEL(3, 2); PANEL(3, 3);
         }
-        // G_i = -A: keep in the accumulators for the next block, stream to HBM (8 x 16-byte chunks, thread-major)
+        // G_i = -A: keep in the accumulators for the next block, stream to HBM (16-byte chunks, thread-major)
         double2* Gi = G + (long long)i * (NB * NB / 2);
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj) {
                 acc[ti][tj] = -acc[ti][tj];
@@ -273,15 +305,11 @@ __global__ __launch_bounds__(NT) void k_press128m(FwdParams p, const TS* __restr
         if (i < Nx - 1) {
             const double2* Gi = G + (long long)i * (NB * NB / 2);
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        double2 v = Gi[(((ti * 2 + tj) * 2) + h) * NT + tid];
-                        acc[ti][tj][2 * h] = v.x;
-                        acc[ti][tj][2 * h + 1] = v.y;
-                    }
+            for (int c = 0; c < NCH; ++c) {
+                double2 v = Gi[c * NT + tid];
+                acc[c >> 2][(c >> 1) & 1][2 * (c & 1)] = v.x;
+                acc[c >> 2][(c >> 1) & 1][2 * (c & 1) + 1] = v.y;
+            }
         }
         if (tid < NB) {
             double v = yv[i * NB + tid];
@@ -289,7 +317,7 @@ __global__ __launch_bounds__(NT) void k_press128m(FwdParams p, const TS* __restr
             L.yprev[tid] = v;
         }
         __syncthreads();
-        const double t = matvec_tiles(acc, L.yprev, L, g, tid);
+        const double t = matvec_tiles<NW>(acc, L.yprev, L, g, tid);
         if (tid < NB) {
             L.ycur[tid] = t;
             P[i * NB + tid] = t;
@@ -298,6 +326,14 @@ __global__ __launch_bounds__(NT) void k_press128m(FwdParams p, const TS* __restr
     }
     face_fluxes(p, P, TX, TY, Vx, Vy, tid, NT);
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
+#ifdef PRESS_STAMPS
+    // diagnostic build only: per-phase cycle sums of three waves of member 0 -> tail of the TX scratch
+    if (m == 0 && g.lane == 0 && (g.w == 0 || g.w == 5 || g.w == 3)) {
+        stamps[7] = clock64() - tstart;
+        long long* dbg = reinterpret_cast<long long*>(p.TX + (long long)p.N * (Nx + 1) * NB) - 64 + (g.w == 0 ? 0 : (g.w == 5 ? 8 : 16));
+        for (int s_ = 0; s_ < 8; ++s_) dbg[s_] = stamps[s_];
+    }
+#endif
 }
 
 __global__ void k_mfma_f64_probe(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ D) {
@@ -310,13 +346,19 @@ __global__ void k_mfma_f64_probe(const double* __restrict__ A, const double* __r
 }  // namespace
 
 // Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
+// press_variant 0: 16-wave workgroups (one member per CU);  3: 8-wave workgroups (two per CU; slower today: spills).
 int launch_pressure_128m(hm_fwd* f, const void* S, long long S_stride, int k) {
     const FwdParams& p = f->p;
     if (p.Ny != NB) return -1;
-    if (f->dtype == 64)
-        hipLaunchKernelGGL(k_press128m<double>, dim3(p.N), dim3(NT), 0, f->ctx->stream, p, (const double*)S, S_stride, k);
-    else
-        hipLaunchKernelGGL(k_press128m<float>, dim3(p.N), dim3(NT), 0, f->ctx->stream, p, (const float*)S, S_stride, k);
+    hipStream_t s = f->ctx->stream;
+    const bool w16 = f->press_variant != 3;
+    if (f->dtype == 64) {
+        if (w16) hipLaunchKernelGGL((k_press128m<double, 16>), dim3(p.N), dim3(1024), 0, s, p, (const double*)S, S_stride, k);
+        else hipLaunchKernelGGL((k_press128m<double, 8>), dim3(p.N), dim3(512), 0, s, p, (const double*)S, S_stride, k);
+    } else {
+        if (w16) hipLaunchKernelGGL((k_press128m<float, 16>), dim3(p.N), dim3(1024), 0, s, p, (const float*)S, S_stride, k);
+        else hipLaunchKernelGGL((k_press128m<float, 8>), dim3(p.N), dim3(512), 0, s, p, (const float*)S, S_stride, k);
+    }
     HM_HIP(hipGetLastError());
     return 0;
 }
