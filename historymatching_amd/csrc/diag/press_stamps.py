@@ -15,10 +15,13 @@ plan.pressure_only(0)
 st = plan.sync()
 tx = plan.get_field("TX").ravel()
 dbg = tx.view(np.int64)[-64:]
-names = ["A publish", "barrier1", "B pivot-block inverse", "barrier2", "C frags+MFMA issue", "D fix-ups (role panels)", "D (no role)", "kernel total"]
-for w, off in ((0, 0), (5, 8), (3, 16)):
-    v = dbg[off:off + 8]
-    print("wave", w, {n: int(x) for n, x in zip(names, v)})
-    tot = v[:7].sum()
-    print("   per panel:", {n: int(x / (128 * 32)) for n, x in zip(names[:7], v[:7])}, "sum", int(tot / (128 * 32)), " kernel cycles", int(v[7]))
+names = ["frags", "la: issue LA MFMA", "la: wait+fix LA tiles", "la: publish(+inv4)", "la: rest MFMA+fix", "other: issue MFMA",
+         "other: fix (+MFMA wait)", "la: barrier wait", "other: barrier wait", "n la panels", "n other panels", "kernel total"]
+for w, off in ((0, 0), (5, 16), (3, 32)):
+    v = dbg[off:off + 16]
+    nla, no = max(int(v[9]), 1), max(int(v[10]), 1)
+    print("wave", w, "la panels", nla, "other panels", no, "kernel ticks", int(v[11]))
+    print("   frags/panel", int(v[0] / (nla + no)))
+    print("   la panel:   ", {n: int(v[i] / nla) for i, n in ((1, names[1]), (2, names[2]), (3, names[3]), (4, names[4]), (7, names[7]))})
+    print("   other panel:", {n: int(v[i] / no) for i, n in ((5, names[5]), (6, names[6]), (8, names[8]))})
 print("ms for 2 launches", st["ms_pressure"])
