@@ -144,9 +144,21 @@ def main():
         prs_bytes = w * nxy * (4 + 2 * NY) * n_e
         dominant = "saturation" if stats["ms_saturation"] >= stats["ms_pressure"] else "pressure"
         ach = (sat_bytes / (sat_ms * 1e-3) if dominant == "saturation" else prs_bytes / (prs_ms * 1e-3)) / 1e9
+        # measured HBM traffic of the same kernel: PMC passes are taken separately under rocprofv3 (profiles/),
+        # bench.py only scales the per-member figure to this launch size
+        traffic, traffic_src = None, None
+        try:
+            pmc_file = sorted((ROOT / "profiles").glob("r*/pmc_hbm_traffic.json"))[-1]
+            pmc = json.loads(pmc_file.read_text())
+            key = {"saturation": "sat128", "pressure": "press128m"}[dominant]
+            if args.variant == 0 and key in pmc["kernels"]:
+                traffic = pmc["kernels"][key]["hbm_bytes_per_member_corrected"] * n_e
+                traffic_src = str(pmc_file.relative_to(ROOT))
+        except Exception:
+            pass
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_ms": {"saturation": sat_ms, "pressure": prs_ms},
             "algorithmic_bytes_per_launch": {"saturation": sat_bytes, "pressure": prs_bytes},
             "compulsory_floor_bytes_per_member_step": 4 * w * nxy,
