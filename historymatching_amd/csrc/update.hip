@@ -14,7 +14,15 @@
 //
 // The GEMMs here are the first correct version: LDS-tiled, 4x4 register micro-tiles, VALU FMAs in the
 // arithmetic dtype.  (An MFMA path for fp32 is the optimisation target named in DESIGN.md.)
+#include <type_traits>
+
 #include "common.h"
+
+// fp32 matrix-core paths (update_mfma.hip); return -1 when a shape is not covered
+int mfma_gxt(hipStream_t s, int N, int M, int n_obs, const float* E, const float* colsum, double inv_n, const float* S, float* Gxt);
+int mfma_apply(hipStream_t s, int N, int M, int n_obs, const float* E, const float* At, const float* B, float* Eout);
+int transpose_cast_d2f(hipStream_t s, const double* in, float* out, int rows, int cols);
+int transpose_f2f(hipStream_t s, const float* in, float* out, int rows, int cols);
 
 struct hm_upd {
     hm_ctx* ctx = nullptr;
@@ -27,7 +35,8 @@ struct hm_upd {
     DevBuf red0, red1, red2, red3;
     // everything of size <= N x n_obs is kept in fp64 whatever the dtype (cond(C) ~ 1e4 makes fp32 Gram matrices
     // lose 3 digits); only the two contractions over the state dimension M run in `dtype`.
-    DevBuf Y, D0, S, D, T1, decorr64, S_T, A_T, Cinv, Wt, partial, flags;
+    DevBuf Y, D0, S, D, T1, decorr64, S_T, A_T, Cinv, Wt, Bt, partial, flags;
+    int use_mfma = 1;  // fp32 only: 0 forces the generic VALU GEMMs (tests compare both)
     EvTimer t_upd;
 };
 
@@ -196,6 +205,92 @@ __global__ __launch_bounds__(1024) void k_invert_C(const double* __restrict__ G,
     if (bad && tid == 0) *flag = 1;
 }
 
+// Same inverse with the matrix REGISTER-resident (n <= 32*NS <= 192): 1024 threads, thread (tr, tc) owns rows
+// tr+32a, columns tc+32b (a, b < NS); per pivot only the pivot column goes through a double-buffered LDS line (one
+// barrier per pivot) -- the sweep of press128.hip.  The matrix is padded with the identity up to 32*NS.
+__device__ __forceinline__ double upd_rcp_newton(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
+
+template <int NS, int KB>
+__device__ __forceinline__ void sweep_slab_reg(double (&A)[NS][NS], double* __restrict__ colbuf, int& cur, int tr, int tc, int& bad) {
+    for (int kk = 0; kk < 32; ++kk) {
+        double* cb = colbuf + cur * (32 * NS);
+        if (tc == kk) {
+#pragma unroll
+            for (int a = 0; a < NS; ++a) cb[tr + 32 * a] = A[a][KB];
+        }
+        __syncthreads();
+        double cr[NS], tcv[NS];
+#pragma unroll
+        for (int a = 0; a < NS; ++a) cr[a] = cb[tr + 32 * a];
+        const double d = cb[kk + 32 * KB];
+        if (!(d > 0.0)) bad = 1;
+        const double pinv = upd_rcp_newton(d);
+#pragma unroll
+        for (int b = 0; b < NS; ++b) tcv[b] = cb[tc + 32 * b] * pinv;
+        const bool rp = (tr == kk), cp = (tc == kk);
+#pragma unroll
+        for (int a = 0; a < NS; ++a)
+#pragma unroll
+            for (int b = 0; b < NS; ++b) {
+                double v = fma(-cr[a], tcv[b], A[a][b]);
+                if (a == KB) v = rp ? tcv[b] : v;
+                if (b == KB) v = cp ? cr[a] * pinv : v;
+                if (a == KB && b == KB) v = (rp && cp) ? -pinv : v;
+                A[a][b] = v;
+            }
+        cur ^= 1;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(1024) void k_invert_C_reg(const double* __restrict__ G, int n, double ridge, double* __restrict__ W,
+                                                        int* __restrict__ flag) {
+    __shared__ double colbuf[2 * 32 * NS];
+    const int tid = threadIdx.x, tr = tid >> 5, tc = tid & 31;
+    double A[NS][NS];
+#pragma unroll
+    for (int a = 0; a < NS; ++a)
+#pragma unroll
+        for (int b = 0; b < NS; ++b) {
+            const int r = tr + 32 * a, c = tc + 32 * b;
+            A[a][b] = (r < n && c < n) ? 0.5 * (G[r * n + c] + G[c * n + r]) + (r == c ? ridge : 0.0) : (r == c ? 1.0 : 0.0);
+        }
+    int bad = 0, cur = 0;
+    sweep_slab_reg<NS, 0>(A, colbuf, cur, tr, tc, bad);
+    if (NS > 1) sweep_slab_reg<NS, (NS > 1 ? 1 : 0)>(A, colbuf, cur, tr, tc, bad);
+    if (NS > 2) sweep_slab_reg<NS, (NS > 2 ? 2 : 0)>(A, colbuf, cur, tr, tc, bad);
+    if (NS > 3) sweep_slab_reg<NS, (NS > 3 ? 3 : 0)>(A, colbuf, cur, tr, tc, bad);
+    if (NS > 4) sweep_slab_reg<NS, (NS > 4 ? 4 : 0)>(A, colbuf, cur, tr, tc, bad);
+    if (NS > 5) sweep_slab_reg<NS, (NS > 5 ? 5 : 0)>(A, colbuf, cur, tr, tc, bad);
+#pragma unroll
+    for (int a = 0; a < NS; ++a)
+#pragma unroll
+        for (int b = 0; b < NS; ++b) {
+            const int r = tr + 32 * a, c = tc + 32 * b;
+            if (r < n && c < n) W[r * n + c] = -A[a][b];
+        }
+    if (bad) *flag = 1;
+}
+
+static int invert_C(hipStream_t s, const double* G, int n, double ridge, double* W, double* colbuf, int* flag) {
+    const int ns = (n + 31) / 32;
+#define L(NS) case NS: hipLaunchKernelGGL(k_invert_C_reg<NS>, dim3(1), dim3(1024), 0, s, G, n, ridge, W, flag); break
+    switch (ns) {
+        L(1); L(2); L(3); L(4); L(5); L(6);
+        default: hipLaunchKernelGGL(k_invert_C, dim3(1), dim3(1024), 0, s, G, n, ridge, W, colbuf, flag);
+    }
+#undef L
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // localised analysis: one workgroup per state element   (HistoryMatch.py:783-793)
 // LDS: packed lower triangle of Ci (n_loc <= n_obs), rhs, index list.
@@ -305,6 +400,7 @@ extern "C" int hm_upd_create(hm_ctx* ctx, int N_total, int N_local, int M, int n
     ALLOC(decorr64, no * no * 8); ALLOC(S_T, nl * no * e); ALLOC(A_T, nl * no * e);
     ALLOC(Cinv, (no * no + no) * 8);
     ALLOC(partial, (size_t)64 * (m + no) * 8); ALLOC(flags, 16);
+    if (dtype == 32) ALLOC(Bt, m * no * e);
     if (localized) { ALLOC(taper, m * no * e); ALLOC(Wt, m * no * e); }
 #undef ALLOC
     HM_HIP(hipMemset(u->flags.p, 0, 16));
@@ -318,7 +414,7 @@ extern "C" void hm_upd_destroy(hm_upd* u) {
     (void)hipStreamSynchronize(u->ctx->stream);
     DevBuf* bufs[] = {&u->E, &u->E_out, &u->obs_ens, &u->perturbs, &u->obs, &u->decorr, &u->taper, &u->red0, &u->red1,
                       &u->red2, &u->red3, &u->Y, &u->D0, &u->S, &u->D, &u->T1, &u->decorr64, &u->S_T, &u->A_T, &u->Cinv,
-                      &u->Wt, &u->partial, &u->flags};
+                      &u->Wt, &u->Bt, &u->partial, &u->flags};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     u->t_upd.destroy();
     delete u;
@@ -380,31 +476,63 @@ static int upd_phase(hm_upd* u, int phase) {
         // Gxt = (E - mean)^T S   (M x n_obs): A(i,k) = E[k][i] - mean[i]   (HistoryMatch.py:581, 586)
         hipLaunchKernelGGL((k_cast<double, T>), dim3(gs), dim3(256), 0, s, (const double*)S, S_T, n_small);
         HM_HIP(hipGetLastError());
-        if ((rc = gemm<T>(s, M, no, nl, E, 1, M, S_T, no, 1, Gxt, no, nullptr, 0, sumE, inv_n))) return rc;
+        int done = -1;
+        if constexpr (std::is_same<T, float>::value)
+            if (u->use_mfma) done = mfma_gxt(s, nl, M, no, E, sumE, inv_n, S_T, Gxt);
+        if (done > 0) return done;
+        if (done < 0 && (rc = gemm<T>(s, M, no, nl, E, 1, M, S_T, no, 1, Gxt, no, nullptr, 0, sumE, inv_n))) return rc;
     } else if (phase == 2) {
         if (!u->localized) {
-            hipLaunchKernelGGL(k_invert_C, dim3(1), dim3(1024), 0, s, (const double*)G, no, (double)(u->N_total - 1),
-                               (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p);
-            HM_HIP(hipGetLastError());
+            if ((rc = invert_C(s, G, no, (double)(u->N_total - 1), (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no,
+                               (int*)u->flags.p))) return rc;
             // T1 = D Cinv ;  E_out = E + T1 Gxt^T                          (HistoryMatch.py:586)
             if ((rc = gemm<double>(s, nl, no, no, D, no, 1, (const double*)u->Cinv.p, no, 1, T1, no))) return rc;
-            hipLaunchKernelGGL((k_cast<double, T>), dim3(gs), dim3(256), 0, s, (const double*)T1, A_T, n_small);
-            HM_HIP(hipGetLastError());
-            if ((rc = gemm<T>(s, nl, M, no, A_T, no, 1, Gxt, 1, no, Eo, M, E, M))) return rc;
+            int done = -1;
+            if constexpr (std::is_same<T, float>::value)
+                if (u->use_mfma && M % 4 == 0) {
+                    // matrix-core path: A^T = (D C^-1)^T (n_obs x N_local), B = Gx = Gxt^T (n_obs x M)
+                    if ((rc = transpose_cast_d2f(s, T1, A_T, nl, no))) return rc;
+                    if ((rc = transpose_f2f(s, Gxt, (float*)u->Bt.p, M, no))) return rc;
+                    done = mfma_apply(s, nl, M, no, E, A_T, (const float*)u->Bt.p, Eo);
+                }
+            if (done > 0) return done;
+            if (done < 0) {
+                hipLaunchKernelGGL((k_cast<double, T>), dim3(gs), dim3(256), 0, s, (const double*)T1, A_T, n_small);
+                HM_HIP(hipGetLastError());
+                if ((rc = gemm<T>(s, nl, M, no, A_T, no, 1, Gxt, 1, no, Eo, M, E, M))) return rc;
+            }
         } else {
             size_t lds = ((size_t)no * (no + 1) / 2 + 2 * no) * 8 + (size_t)no * 4 + 16;
             HM_HIP(hipFuncSetAttribute((const void*)k_local_analysis<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k_local_analysis<T>, dim3(M), dim3(256), lds, s, M, no, u->N_total, u->cutoff,
                                (const T*)u->taper.p, (const double*)G, (const T*)Gxt, (T*)u->Wt.p, (int*)u->flags.p);
-            hipLaunchKernelGGL((k_cast<double, T>), dim3(gs), dim3(256), 0, s, (const double*)D, A_T, n_small);
             HM_HIP(hipGetLastError());
-            if ((rc = gemm<T>(s, nl, M, no, A_T, no, 1, (const T*)u->Wt.p, 1, no, Eo, M, E, M))) return rc;
+            int done = -1;
+            if constexpr (std::is_same<T, float>::value)
+                if (u->use_mfma && M % 4 == 0) {
+                    if ((rc = transpose_cast_d2f(s, D, A_T, nl, no))) return rc;
+                    if ((rc = transpose_f2f(s, (const float*)u->Wt.p, (float*)u->Bt.p, M, no))) return rc;
+                    done = mfma_apply(s, nl, M, no, E, A_T, (const float*)u->Bt.p, Eo);
+                }
+            if (done > 0) return done;
+            if (done < 0) {
+                hipLaunchKernelGGL((k_cast<double, T>), dim3(gs), dim3(256), 0, s, (const double*)D, A_T, n_small);
+                HM_HIP(hipGetLastError());
+                if ((rc = gemm<T>(s, nl, M, no, A_T, no, 1, (const T*)u->Wt.p, 1, no, Eo, M, E, M))) return rc;
+            }
         }
     } else {
         hm_set_error("hm_upd_phase: phase must be 0, 1 or 2");
         return 2;
     }
     return u->t_upd.end(s);
+}
+
+extern "C" int hm_upd_set_option(hm_upd* u, const char* name, int value) {
+    HM_REQUIRE(u && name, "hm_upd_set_option: NULL argument");
+    if (std::string(name) == "use_mfma") { u->use_mfma = value; return 0; }
+    hm_set_error("hm_upd_set_option: unknown option '%s'", name);
+    return 2;
 }
 
 extern "C" int hm_upd_phase(hm_upd* u, int phase) {

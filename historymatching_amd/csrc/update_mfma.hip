@@ -1,0 +1,184 @@
+// update_mfma.hip -- fp32 matrix-core (v_mfma_f32_32x32x2_f32) kernels for the two contractions of the
+// ensemble-smoother update that run over the state dimension M (everything else is N x n_obs sized and stays fp64):
+//
+//   k_gxt_mfma    Gxt (M x n_obs) = (E - mean)^T S          reads E exactly once (the HBM stream), K = N members
+//   k_apply_mfma  E_out (N x M)   = E + A^T-operand  * B      A = (D C^-1) or D (n_obs x N, transposed copy),
+//                                                           B = Gx or W (n_obs x M), K = n_obs
+//
+// Reference: the products in ens_update0 / ens_update0_loc, notebooks/HistoryMatch.py:581-586, 789-793, evaluated
+// in the minimum-flop association.  v_mfma_f32_32x32x2_f32 is exact fp32 (k-ordered fmaf chain), so
+// the fp32 error model of the tests (1e-4 of the max increment) is unchanged.
+// Operand maps: A operand lane l holds A[l&31][l>>5], B operand B[l>>5][l&31]; C/D: col = l&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(l>>5)  (cdna_hip_programming.md section 3).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// out[c][r] = (TO) in[r][c]
+template <typename TI, typename TO>
+__global__ void k_transpose(const TI* __restrict__ in, TO* __restrict__ out, int rows, int cols) {
+    __shared__ TO tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+    for (int dy = ty; dy < 32; dy += 8) {
+        int r = r0 + dy, c = c0 + tx;
+        tile[dy][tx] = (r < rows && c < cols) ? (TO)in[(size_t)r * cols + c] : TO(0);
+    }
+    __syncthreads();
+    for (int dy = ty; dy < 32; dy += 8) {
+        int c = c0 + dy, r = r0 + tx;
+        if (c < cols && r < rows) out[(size_t)c * rows + r] = tile[tx][dy];
+    }
+}
+
+// Gxt[i][j] = sum_k (E[k][i] - mean_i) S[k][j].  One workgroup = 32 state elements x all NJ*32 observations; its 4
+// waves split the member dimension K (interleaved pairs), keep 4 pairs of loads in flight each, and reduce their
+// partial accumulators through LDS.  E is read exactly once (the HBM stream); S (N x n_obs) stays L2-resident.
+template <int NJ>
+__global__ __launch_bounds__(256) void k_gxt_mfma(int N, int M, int n_obs, const float* __restrict__ E,
+                                                  const float* __restrict__ colsum, float inv_n,
+                                                  const float* __restrict__ S, float* __restrict__ Gxt) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NJ*16 regs][64 lanes]
+    constexpr int UN = 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 32;
+    const int il = lane & 31, kh = lane >> 5;
+    const int i = min(i0 + il, M - 1);
+    const float mean = colsum[i] * inv_n;
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int npairs = (N + 1) / 2;
+    for (int kp = w; kp < npairs; kp += 4 * UN) {
+        float b[UN], a[UN][NJ];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = 2 * (kp + 4 * u) + kh;
+            const bool ok = k < N;
+            const int kc = ok ? k : N - 1;
+            b[u] = ok ? E[(size_t)kc * M + i] - mean : 0.0f;
+            const float* Srow = S + (size_t)kc * n_obs + il;
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) a[u][t] = ok ? Srow[32 * t] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u], acc[t], 0, 0, 0);
+    }
+    // cross-wave reduction of the K split
+#pragma unroll
+    for (int t = 0; t < NJ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((w * NJ + t) * 16 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+    if (i0 + il < M) {
+        float* out = Gxt + (size_t)(i0 + il) * n_obs;
+        for (int t = w; t < NJ; t += 4) {  // wave w finishes tiles t = w, w+4, ...
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * rq + q;
+                    v[q] = (red[((0 * NJ + t) * 16 + r) * 64 + lane] + red[((1 * NJ + t) * 16 + r) * 64 + lane]) +
+                           (red[((2 * NJ + t) * 16 + r) * 64 + lane] + red[((3 * NJ + t) * 16 + r) * 64 + lane]);
+                }
+                *reinterpret_cast<float4*>(out + 32 * t + 8 * rq + 4 * kh) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+// E_out[n][i] = E[n][i] + sum_j At[j][n] B[j][i];  workgroup = 4 waves = 128 members x 128 state elements,
+// B tile (n_obs x 128) staged once in LDS, every wave 32 members x 128 state elements (4 accumulator tiles).
+__global__ __launch_bounds__(256) void k_apply_mfma(int N, int M, int n_obs, const float* __restrict__ E,
+                                                    const float* __restrict__ At, const float* __restrict__ B,
+                                                    float* __restrict__ Eout) {
+    extern __shared__ __attribute__((aligned(16))) float Bs[];  // n_obs x 128
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 128, n0 = blockIdx.y * 128 + 32 * w;
+    for (int e = threadIdx.x; e < n_obs * 32; e += 256) {  // float4 granules
+        const int j = e >> 5, c4 = (e & 31) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + c4 + 3 < M) v = *reinterpret_cast<const float4*>(B + (size_t)j * M + i0 + c4);
+        else
+            for (int q = 0; q < 4; ++q)
+                if (i0 + c4 + q < M) (&v.x)[q] = B[(size_t)j * M + i0 + c4 + q];
+        *reinterpret_cast<float4*>(Bs + j * 128 + c4) = v;
+    }
+    __syncthreads();
+    const int nl = lane & 31, kh = lane >> 5;
+    const int n = min(n0 + nl, N - 1);
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int npairs = (n_obs + 1) / 2;
+
+    for (int jp = 0; jp < npairs; ++jp) {
+        const int j = 2 * jp + kh;
+        const bool ok = j < n_obs;
+        const int jc = ok ? j : n_obs - 1;
+        const float a = ok ? At[(size_t)jc * N + n] : 0.0f;
+        const float* brow = Bs + jc * 128 + nl;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float b = ok ? brow[32 * t] : 0.0f;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    // C/D: col = lane&31 -> state element, rows -> member
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = i0 + 32 * t + nl;
+        if (i >= M) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (nn < N) Eout[(size_t)nn * M + i] = E[(size_t)nn * M + i] + acc[t][r];
+        }
+    }
+}
+
+// ---- host entry points (return 0 launched, >0 error, -1 not applicable -> caller uses the generic GEMM) ----
+int mfma_gxt(hipStream_t s, int N, int M, int n_obs, const float* E, const float* colsum, double inv_n, const float* S,
+             float* Gxt) {
+    if (n_obs % 32 != 0 || n_obs > 256 || n_obs % 4 != 0) return -1;
+    const int nj = n_obs / 32;
+    dim3 grid((M + 31) / 32), block(256);
+    const size_t lds = (size_t)4 * nj * 16 * 64 * 4;
+#define L(NJ) case NJ: HM_HIP(hipFuncSetAttribute((const void*)k_gxt_mfma<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                       hipLaunchKernelGGL(k_gxt_mfma<NJ>, grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gxt); break
+    switch (nj) { L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); default: return -1; }
+#undef L
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+int mfma_apply(hipStream_t s, int N, int M, int n_obs, const float* E, const float* At, const float* B, float* Eout) {
+    const size_t lds = (size_t)n_obs * 128 * 4;
+    if (lds > 150 * 1024 || M % 4 != 0) return -1;
+    HM_HIP(hipFuncSetAttribute((const void*)k_apply_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((M + 127) / 128, (N + 127) / 128), block(256);
+    hipLaunchKernelGGL(k_apply_mfma, grid, block, lds, s, N, M, n_obs, E, At, B, Eout);
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+int transpose_cast_d2f(hipStream_t s, const double* in, float* out, int rows, int cols) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
+    hipLaunchKernelGGL((k_transpose<double, float>), grid, block, 0, s, in, out, rows, cols);
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+int transpose_f2f(hipStream_t s, const float* in, float* out, int rows, int cols) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
+    hipLaunchKernelGGL((k_transpose<float, float>), grid, block, 0, s, in, out, rows, cols);
+    HM_HIP(hipGetLastError());
+    return 0;
+}

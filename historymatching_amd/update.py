@@ -108,6 +108,10 @@ class UpdatePlan:
     def phase(self, k):
         _lib.check(self.lib.hm_upd_phase(self.h, int(k)), "hm_upd_phase")
 
+    def set_option(self, name, value):
+        """`use_mfma` = 0 forces the generic fp32 GEMMs instead of the matrix-core kernels."""
+        _lib.check(self.lib.hm_upd_set_option(self.h, name.encode(), int(value)), "hm_upd_set_option")
+
     REDUCE_AFTER_PHASE = {0: (0, 1), 1: (2, 3)}  # which buffers to sum over ranks after each phase
 
     def reduce_buffer(self, which):

@@ -129,6 +129,7 @@ void  hm_upd_destroy(hm_upd* u);
 int   hm_upd_set_inputs(hm_upd* u, const void* E_local, const void* obs_ens_local, const void* obs,
                         const void* perturbs_local, const void* decorr, const void* taper /* or NULL */, double cutoff);
 int   hm_upd_phase(hm_upd* u, int phase);
+int   hm_upd_set_option(hm_upd* u, const char* name, int value);  /* "use_mfma": 1 (default) | 0 = generic fp32 GEMMs */
 void* hm_upd_reduce_buffer(hm_upd* u, int which /*0..3*/, long long* n_elems, int* elem_bytes); /* device pointer */
 int   hm_upd_sync(hm_upd* u, hm_stats* stats);
 int   hm_upd_get_output(hm_upd* u, void* E_out_local);

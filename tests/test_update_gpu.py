@@ -169,3 +169,59 @@ def test_update_properties_at_c3_size():
     p = UpdatePlan(N, N, M, n_obs)
     p.set_inputs(E, obs_ens, obs, perturbs, decorr)
     assert np.abs(sharded_update(p) - full).max() < 1e-12
+
+
+def test_es_mda_driver_matches_oracle_loop():
+    """BASELINE config 3 in miniature: ES-MDA (n_iter passes of forward run + ens_update0 with alpha = n_iter,
+    SURVEY.md 8f) through the GPU forward model and the GPU update vs the same loop through the oracle."""
+    from historymatching_amd.forward import make_forward_model
+    from historymatching_amd.update import es_mda
+    from oracle import es
+    from oracle.ressim import forward_model as oracle_forward
+    from tests.helpers import make_models, perms
+
+    nTime, N = 40, 16  # producers see water only late in the 40 steps (HistoryMatch.py:533-535)
+    om, gm = make_models(20, 20)
+    x = perms(20, 20, N + 1, seed=21, scale=0.5)
+    truth, prior = x[0], x[1:]
+    _, R12, _ = es.obs_error_model(nTime, 4)
+    fm = make_forward_model(gm, 0.025, nTime, return_history=False)
+    fwd_gpu = lambda E: es.vect(fm(E)[1], nTime)  # noqa: E731
+    fwd_cpu = lambda E: es.vect(oracle_forward(om, E, None, 0.025, nTime)[1], nTime)  # noqa: E731
+    obs = fwd_cpu(truth[None])[0] + R12 @ np.random.RandomState(5).randn(4 * nTime)
+    post_gpu = es_mda(fwd_gpu, prior, obs, R12, n_iter=2, rng=np.random.RandomState(7))
+    post_cpu = es.es_mda(fwd_cpu, prior, obs, R12, n_iter=2, rng=np.random.RandomState(7))
+    assert post_gpu.shape == prior.shape
+    assert np.abs(post_gpu - post_cpu).max() < 1e-6
+    assert np.abs(post_gpu - prior).max() > 1e-3  # it did update
+
+
+@pytest.mark.parametrize("N,M,n_obs,localized", [(1000, 4096, 160, False), (999, 4100, 160, False), (130, 1024, 64, True),
+                                                  (64, 512, 48, False)])
+def test_fp32_matrix_core_path_matches_generic_and_oracle(N, M, n_obs, localized):
+    """fp32 update: v_mfma_f32_32x32x2 kernels (default) vs the generic VALU GEMMs (use_mfma=0) vs the fp64 oracle.
+    Shapes cover exact tiles, ragged N / M, and an n_obs that is not a multiple of 32 (falls back)."""
+    from historymatching_amd.update import UpdatePlan
+    from oracle import es
+
+    rng = np.random.RandomState(N + M)
+    E = rng.randn(N, M) + rng.randn(M)
+    obs_ens = E[:, :n_obs] * 0.3 + rng.randn(N, n_obs) * 0.1
+    _, R12, decorr = es.obs_error_model(n_obs // 4, 4)
+    obs = obs_ens[0] + R12 @ rng.randn(n_obs)
+    perturbs = rng.randn(N, n_obs) @ R12.T
+    taper = es.bump(rng.rand(M, n_obs) * 1.3) if localized else None
+    ref = (es.ens_update0_loc(E, obs_ens, obs, perturbs, decorr, taper) if localized
+           else es.ens_update0(E, obs_ens, obs, perturbs, decorr))
+    outs = []
+    for use_mfma in (1, 0):
+        p = UpdatePlan(N, N, M, n_obs, dtype=32, localized=localized)
+        p.set_option("use_mfma", use_mfma)
+        p.set_inputs(E, obs_ens, obs, perturbs, decorr, taper)
+        p.run_local()
+        outs.append(p.output())
+        p.close()
+    inc = np.abs(ref - E).max()
+    assert np.abs(outs[0] - ref).max() <= 1e-4 * inc
+    assert np.abs(outs[1] - ref).max() <= 1e-4 * inc
+    assert np.abs(outs[0].astype(np.float64) - outs[1]).max() <= 2e-5 * inc
