@@ -35,7 +35,7 @@ struct hm_upd {
     DevBuf red0, red1, red2, red3;
     // everything of size <= N x n_obs is kept in fp64 whatever the dtype (cond(C) ~ 1e4 makes fp32 Gram matrices
     // lose 3 digits); only the two contractions over the state dimension M run in `dtype`.
-    DevBuf Y, D0, S, D, T1, decorr64, S_T, A_T, Cinv, Wt, Bt, partial, flags;
+    DevBuf Y, D0, S, D, T1, decorr64, S_T, A_T, Cinv, Wt, Bt, partial, gpart, flags;
     int use_mfma = 1;  // fp32 only: 0 forces the generic VALU GEMMs (tests compare both)
     EvTimer t_upd;
 };
@@ -82,6 +82,113 @@ __global__ void k_cast(const TI* __restrict__ in, TO* __restrict__ out, size_t n
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) out[i] = (TO)in[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small fp64 products of the update (everything N x n_obs sized), fused so that each is ONE launch:
+//   k_obs_products : Y = obs_ens - mean, D0 = obs - obs_ens - perturbs, S = Y decorr, D = D0 decorr   (HM.py:582-584)
+//   k_rows_matmul  : T1 = D Cinv (+ transposed fp32 copy for the matrix-core apply)                   (HM.py:586)
+//   k_gram_partial / k_gram_reduce : G = S^T S, deterministic split over row blocks                   (HM.py:585)
+// One workgroup = RB rows; the n_obs x n_obs matrix streams from L2 once per workgroup.
+// ------------------------------------------------------------------------------------------------
+constexpr int RB = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_obs_products(const T* __restrict__ obs_ens, const T* __restrict__ perturbs,
+                                                      const T* __restrict__ obs, const double* __restrict__ colsum_y,
+                                                      double inv_n_total, const T* __restrict__ decorr, int rows, int n_obs,
+                                                      double* __restrict__ S, double* __restrict__ D, T* __restrict__ S_T) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];  // Y[RB][n_obs], D0[RB][n_obs]
+    double* Ys = sm;
+    double* Ds = sm + RB * n_obs;
+    const int r0 = blockIdx.x * RB;
+    for (int e = threadIdx.x; e < RB * n_obs; e += blockDim.x) {
+        const int r = r0 + e / n_obs, j = e % n_obs;
+        double y = 0.0, d0 = 0.0;
+        if (r < rows) {
+            const double o = (double)obs_ens[(size_t)r * n_obs + j];
+            y = o - colsum_y[j] * inv_n_total;
+            d0 = (double)obs[j] - o - (double)perturbs[(size_t)r * n_obs + j];
+        }
+        Ys[e] = y;
+        Ds[e] = d0;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_obs; j += blockDim.x) {
+        double sa[RB], da[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) sa[r] = da[r] = 0.0;
+        for (int k = 0; k < n_obs; ++k) {
+            const double dk = (double)decorr[(size_t)k * n_obs + j];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                sa[r] = fma(Ys[r * n_obs + k], dk, sa[r]);
+                da[r] = fma(Ds[r * n_obs + k], dk, da[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (r0 + r < rows) {
+                S[(size_t)(r0 + r) * n_obs + j] = sa[r];
+                D[(size_t)(r0 + r) * n_obs + j] = da[r];
+                S_T[(size_t)(r0 + r) * n_obs + j] = (T)sa[r];
+            }
+    }
+}
+
+// out = in (rows x n) * Mat (n x n) in fp64; optionally also outT_f32[j][r] = (float) out[r][j]
+__global__ __launch_bounds__(256) void k_rows_matmul(const double* __restrict__ in, const double* __restrict__ Mat, int rows,
+                                                     int n, double* __restrict__ out, float* __restrict__ outT_f32) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];  // in[RB][n]
+    const int r0 = blockIdx.x * RB;
+    for (int e = threadIdx.x; e < RB * n; e += blockDim.x) {
+        const int r = r0 + e / n;
+        sm[e] = r < rows ? in[(size_t)r * n + e % n] : 0.0;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        double acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const double mk = Mat[(size_t)k * n + j];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] = fma(sm[r * n + k], mk, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (r0 + r < rows) {
+                out[(size_t)(r0 + r) * n + j] = acc[r];
+                if (outT_f32) outT_f32[(size_t)j * rows + r0 + r] = (float)acc[r];
+            }
+    }
+}
+
+constexpr int GRB = 16;  // rows per Gram partial
+__global__ __launch_bounds__(256) void k_gram_partial(const double* __restrict__ S, int rows, int n, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];  // S[GRB][n]
+    const int r0 = blockIdx.x * GRB;
+    for (int e = threadIdx.x; e < GRB * n; e += blockDim.x) {
+        const int r = r0 + e / n;
+        sm[e] = r < rows ? S[(size_t)r * n + e % n] : 0.0;
+    }
+    __syncthreads();
+    double* out = part + (size_t)blockIdx.x * n * n;
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+        const int j1 = e / n, j2 = e % n;
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < GRB; ++r) acc = fma(sm[r * n + j1], sm[r * n + j2], acc);
+        out[e] = acc;
+    }
+}
+
+__global__ void k_gram_reduce(const double* __restrict__ part, int nparts, int nn, double* __restrict__ G) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nn) return;
+    double acc = 0.0;
+    for (int p = 0; p < nparts; ++p) acc += part[(size_t)p * nn + e];
+    G[e] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -401,6 +508,7 @@ extern "C" int hm_upd_create(hm_ctx* ctx, int N_total, int N_local, int M, int n
     ALLOC(Cinv, (no * no + no) * 8);
     ALLOC(partial, (size_t)64 * (m + no) * 8); ALLOC(flags, 16);
     if (dtype == 32) ALLOC(Bt, m * no * e);
+    ALLOC(gpart, ((nl + GRB - 1) / GRB) * no * no * 8);
     if (localized) { ALLOC(taper, m * no * e); ALLOC(Wt, m * no * e); }
 #undef ALLOC
     HM_HIP(hipMemset(u->flags.p, 0, 16));
@@ -414,7 +522,7 @@ extern "C" void hm_upd_destroy(hm_upd* u) {
     (void)hipStreamSynchronize(u->ctx->stream);
     DevBuf* bufs[] = {&u->E, &u->E_out, &u->obs_ens, &u->perturbs, &u->obs, &u->decorr, &u->taper, &u->red0, &u->red1,
                       &u->red2, &u->red3, &u->Y, &u->D0, &u->S, &u->D, &u->T1, &u->decorr64, &u->S_T, &u->A_T, &u->Cinv,
-                      &u->Wt, &u->Bt, &u->partial, &u->flags};
+                      &u->Wt, &u->Bt, &u->partial, &u->gpart, &u->flags};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     u->t_upd.destroy();
     delete u;
@@ -445,8 +553,7 @@ static int upd_phase(hm_upd* u, int phase) {
     T* E = (T*)u->E.p; T* Eo = (T*)u->E_out.p;
     T* sumE = (T*)u->red0.p; double* sumY = (double*)u->red1.p;
     T* Gxt = (T*)u->red2.p; double* G = (double*)u->red3.p;
-    double *Y = (double*)u->Y.p, *D0 = (double*)u->D0.p, *S = (double*)u->S.p, *D = (double*)u->D.p, *T1 = (double*)u->T1.p;
-    double* dec = (double*)u->decorr64.p;
+    double *S = (double*)u->S.p, *D = (double*)u->D.p, *T1 = (double*)u->T1.p;
     T *S_T = (T*)u->S_T.p, *A_T = (T*)u->A_T.p;
     const size_t n_small = (size_t)nl * no;
     const unsigned gs = (unsigned)std::min<size_t>(2048, (n_small + 255) / 256);
@@ -464,18 +571,18 @@ static int upd_phase(hm_upd* u, int phase) {
         HM_HIP(hipGetLastError());
     } else if (phase == 1) {
         const double inv_n = 1.0 / (double)u->N_total;
-        hipLaunchKernelGGL(k_prep_obs<T>, dim3((unsigned)((n_small + 255) / 256)), dim3(256), 0, s, (const T*)u->obs_ens.p,
-                           (const T*)u->perturbs.p, (const T*)u->obs.p, (const double*)sumY, inv_n, nl, no, Y, D0);
-        hipLaunchKernelGGL((k_cast<T, double>), dim3(64), dim3(256), 0, s, (const T*)u->decorr.p, dec, (size_t)no * no);
+        // S = Y decorr, D = D0 decorr (fp64) and the dtype copy of S, one launch          (HistoryMatch.py:582-584)
+        hipLaunchKernelGGL(k_obs_products<T>, dim3((nl + RB - 1) / RB), dim3(256), 2 * RB * no * sizeof(double), s,
+                           (const T*)u->obs_ens.p, (const T*)u->perturbs.p, (const T*)u->obs.p, (const double*)sumY, inv_n,
+                           (const T*)u->decorr.p, nl, no, S, D, S_T);
+        // G = S^T S over the local rows: per-16-row partials, then a fixed-order sum      (HistoryMatch.py:585)
+        const int nparts = (nl + GRB - 1) / GRB;
+        hipLaunchKernelGGL(k_gram_partial, dim3(nparts), dim3(256), GRB * no * sizeof(double), s, (const double*)S, nl, no,
+                           (double*)u->gpart.p);
+        hipLaunchKernelGGL(k_gram_reduce, dim3((no * no + 255) / 256), dim3(256), 0, s, (const double*)u->gpart.p, nparts,
+                           no * no, G);
         HM_HIP(hipGetLastError());
-        // S = Y decorr ; D = D0 decorr                                   (HistoryMatch.py:583-584)
-        if ((rc = gemm<double>(s, nl, no, no, Y, no, 1, dec, no, 1, S, no))) return rc;
-        if ((rc = gemm<double>(s, nl, no, no, D0, no, 1, dec, no, 1, D, no))) return rc;
-        // G = S^T S (local rows)                                         (HistoryMatch.py:585)
-        if ((rc = gemm<double>(s, no, no, nl, S, 1, no, S, no, 1, G, no))) return rc;
-        // Gxt = (E - mean)^T S   (M x n_obs): A(i,k) = E[k][i] - mean[i]   (HistoryMatch.py:581, 586)
-        hipLaunchKernelGGL((k_cast<double, T>), dim3(gs), dim3(256), 0, s, (const double*)S, S_T, n_small);
-        HM_HIP(hipGetLastError());
+        // Gxt = (E - mean)^T S   (M x n_obs): A(i,k) = E[k][i] - mean[i]                 (HistoryMatch.py:581, 586)
         int done = -1;
         if constexpr (std::is_same<T, float>::value)
             if (u->use_mfma) done = mfma_gxt(s, nl, M, no, E, sumE, inv_n, S_T, Gxt);
@@ -486,12 +593,14 @@ static int upd_phase(hm_upd* u, int phase) {
             if ((rc = invert_C(s, G, no, (double)(u->N_total - 1), (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no,
                                (int*)u->flags.p))) return rc;
             // T1 = D Cinv ;  E_out = E + T1 Gxt^T                          (HistoryMatch.py:586)
-            if ((rc = gemm<double>(s, nl, no, no, D, no, 1, (const double*)u->Cinv.p, no, 1, T1, no))) return rc;
+            const bool mm = std::is_same<T, float>::value && u->use_mfma && M % 4 == 0;
+            hipLaunchKernelGGL(k_rows_matmul, dim3((nl + RB - 1) / RB), dim3(256), RB * no * sizeof(double), s, (const double*)D,
+                               (const double*)u->Cinv.p, nl, no, T1, mm ? (float*)A_T : nullptr);
+            HM_HIP(hipGetLastError());
             int done = -1;
             if constexpr (std::is_same<T, float>::value)
-                if (u->use_mfma && M % 4 == 0) {
-                    // matrix-core path: A^T = (D C^-1)^T (n_obs x N_local), B = Gx = Gxt^T (n_obs x M)
-                    if ((rc = transpose_cast_d2f(s, T1, A_T, nl, no))) return rc;
+                if (mm) {
+                    // matrix-core path: A^T = (D C^-1)^T (n_obs x N_local, written by k_rows_matmul), B = Gx = Gxt^T
                     if ((rc = transpose_f2f(s, Gxt, (float*)u->Bt.p, M, no))) return rc;
                     done = mfma_apply(s, nl, M, no, E, A_T, (const float*)u->Bt.p, Eo);
                 }
