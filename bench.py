@@ -76,7 +76,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     td = None
-    if world > 1:
+    if world > 1 or os.environ.get("HM_BENCH_FORCE_DIST") == "1":  # the env switch exercises the N>1 code path with 1 rank
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as td

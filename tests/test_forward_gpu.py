@@ -241,3 +241,94 @@ def test_full_sim_128_within_reference_solver_noise(variant):
         assert err <= 10 * noise + 1e-9, (err, noise)
         assert err < 1e-4
     plan.close()
+
+
+@pytest.mark.parametrize("n,variant", [(20, 1), (128, 1), (128, 0)])
+def test_general_fluid_parameters_bitexact(n, variant):
+    """vw, vo, swc, sor away from the upstream defaults exercise the general RelPerm path (three extra divisions):
+    assembly and saturation sweep stay bit-exact, the pressure solve stays within solver noise."""
+    from oracle.ressim import perm_transf, set_perm
+
+    om, gm = make_models(n, n)
+    for mdl in (om, gm):
+        mdl.vw, mdl.vo, mdl.swc, mdl.sor = 0.7, 1.9, 0.05, 0.1
+    N = 2
+    x = perms(n, n, N, seed=23, scale=0.6)
+    plan = _plan(gm, N, nTime=2)
+    plan.set_variant(variant, variant)
+    plan.set_inputs(perm_transf(x), transformed=True)
+    S_in, Vxs, Vys, S_ref = [], [], [], []
+    for m in range(N):
+        set_perm(om, x[m])
+        S = np.full(om.Nxy, om.swc)
+        q, _, _ = om.source_field(0)
+        _, Vx, Vy = om.pressure_step(S, q)
+        S = om.saturation_step_upwind(S, q, Vx, Vy, DT)
+        _, Vx, Vy = om.pressure_step(S, q)
+        S_in.append(S), Vxs.append(Vx), Vys.append(Vy)
+        S_ref.append(om.saturation_step_upwind(S, q, Vx, Vy, DT))
+    plan.set_field("S", np.array(S_in))
+    plan.pressure_only(0)
+    Vx_gpu = plan.get_field("Vx")
+    for m in range(N):
+        assert np.abs(Vx_gpu[m] - Vxs[m]).max() < 1e-7
+    plan.set_field("Vx", np.array(Vxs))
+    plan.set_field("Vy", np.array(Vys))
+    plan.saturation_only(0)
+    S_gpu = plan.get_field("S").reshape(N, -1)
+    for m in range(N):
+        assert np.array_equal(S_gpu[m], S_ref[m])
+    plan.close()
+
+
+def test_time_varying_rates_and_single_member():
+    """inj/prd rates with nTime columns (HistoryMatch.py:189-193, Optimise.py:760-767), N = 1."""
+    from oracle.ressim import set_perm
+
+    om, gm = make_models(20, 20)
+    nT = 6
+    rates = 0.5 + np.arange(nT) / nT
+    for mdl in (om, gm):
+        mdl.inj_rates = rates[None, :]
+        mdl.prd_rates = np.tile(rates / 4, (4, 1))
+    x = perms(20, 20, 1, seed=29)[0]
+    set_perm(om, x)
+    gm.K = om.K
+    ref, noise = oracle_sim_and_noise(om, x, DT, nT)
+    out = gm.sim(DT, nT, np.zeros(400), pbar=False)
+    assert np.abs(out - ref).max() <= 10 * noise + 1e-9
+    assert np.allclose(gm.actual_rates["inj"], rates[None, :])
+    with pytest.raises(ValueError):
+        gm.inj_rates = rates[None, :4]  # wrong number of columns
+        gm.sim(DT, nT, np.zeros(400))
+
+
+def test_nonuniform_porosity_uses_generic_path_and_matches():
+    """Porosity field (upstream Gridded.por): per-cell pore volume enters the CFL count and dtx."""
+    from oracle.ressim import set_perm
+
+    om, gm = make_models(20, 20)
+    por = 0.2 + 0.6 * np.random.RandomState(3).rand(20, 20)
+    om.por = por
+    gm.por = por
+    x = perms(20, 20, 1, seed=31)[0]
+    set_perm(om, x)
+    gm.K = om.K
+    ref = om.sim(DT, 8, np.zeros(400))
+    out = gm.sim(DT, 8, np.zeros(400), pbar=False)
+    assert np.abs(out - ref).max() < 1e-7
+    assert abs(out[-1] @ (por.ravel() * om.h2) - 8 * DT) < 1e-9  # injected volume = water in place
+
+
+def test_fp32_saturation_mode_tolerance():
+    """dtype=32: saturation arithmetic and storage in fp32, pressure and Nts in fp64; <= 1e-3 abs on S."""
+    from oracle.ressim import forward_model as oracle_forward
+
+    om, gm = make_models(20, 20, dtype=32)
+    x = perms(20, 20, 3, seed=37)
+    from historymatching_amd.forward import make_forward_model
+
+    w, p = make_forward_model(gm, DT, 20)(x)
+    assert w.dtype == np.float32 and p.dtype == np.float32
+    wr, pr = oracle_forward(om, x, None, DT, 20)
+    assert np.abs(w - wr).max() < 1e-3 and np.abs(p - pr).max() < 1e-3
