@@ -32,6 +32,8 @@ constexpr int NT = (N128 / PX) * NPY;     // 512 threads
 constexpr int FW_BYTES = N128 * N128 * 8; // 128 KB
 constexpr int REC_BYTES = 64;             // well record: S, cE, cN, cC, cS, cW, fid, fw
 constexpr int MAX_WELLS = 16;
+constexpr int VSP_BYTES = 3 * NT * 16;       // per-thread LDS home of 6 face fluxes (3 x 16 B): Vx[8][0..3], Vy[7][0..1]
+constexpr int VSP_BASE = FW_BYTES + MAX_WELLS * REC_BYTES + 2 * REC_BYTES;
 
 __device__ __forceinline__ int lds_off(int ix, int iy) {
     // byte offset of fw(ix, iy): rows of 1 KB; each thread's 32-byte row segment = two 16-byte chunks whose
@@ -90,7 +92,11 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
     const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * p.Nxy;
 
     // ---------------- member state -> registers
-    double S[PX][PY], Vx[PX + 1][PY], Vy[PX][PY];
+    // Vx row 8 (east boundary faces) and Vy[7][0..1] live in LDS (no register room): VX8(j), VY7(j)
+    double S[PX][PY], Vx[PX][PY], Vy[PX][PY];
+    double2* vsp = reinterpret_cast<double2*>(lds + VSP_BASE) + tid;  // chunk c at vsp[c * NT]
+#define VX8(j) ((j) < 2 ? ((j) == 0 ? vx8a.x : vx8a.y) : ((j) == 2 ? vx8b.x : vx8b.y))
+#define VY7(j) ((j) == 0 ? vy7a.x : vy7a.y)
 #pragma unroll
     for (int i = 0; i < PX; ++i)
 #pragma unroll
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
             S[i][j + 1] = v.y;
         }
 #pragma unroll
-    for (int i = 0; i <= PX; ++i)
+    for (int i = 0; i < PX; ++i)
 #pragma unroll
         for (int j = 0; j < PY; j += 2) {
             double2 v = *reinterpret_cast<const double2*>(gVx + (ix0 + i) * N128 + iy0 + j);
@@ -111,6 +117,11 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
     for (int i = 0; i < PX; ++i)
 #pragma unroll
         for (int j = 0; j < PY; ++j) Vy[i][j] = gVy[(ix0 + i) * (N128 + 1) + iy0 + j];
+    {   // park them in LDS right away (the region behind the fw field is not used by the CFL reduction)
+        vsp[0] = *reinterpret_cast<const double2*>(gVx + (ix0 + PX) * N128 + iy0);
+        vsp[NT] = *reinterpret_cast<const double2*>(gVx + (ix0 + PX) * N128 + iy0 + 2);
+        vsp[2 * NT] = make_double2(Vy[PX - 1][0], Vy[PX - 1][1]);
+    }
 
     // ---------------- the (at most one) well of this patch
     int wcell = -1, wrec = FW_BYTES + MAX_WELLS * REC_BYTES;  // non-owners work on a shared dummy record
@@ -136,7 +147,8 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
         for (int j = 0; j < PY; ++j) {
             const double vyn = j + 1 < PY ? Vy[i][j + 1 < PY ? j + 1 : 0] : vyn3;
             double xp = fmax(Vx[i][j], 0.0), yp = fmax(Vy[i][j], 0.0);
-            double xn = fmin(Vx[i + 1][j], 0.0), yn = fmin(vyn, 0.0);
+            const double vxe = i + 1 < PX ? Vx[i + 1 < PX ? i + 1 : 0][j] : gVx[(ix0 + PX) * N128 + iy0 + j];
+            double xn = fmin(vxe, 0.0), yn = fmin(vyn, 0.0);
             double Vi = xp + yp - xn - yn;
             lmin = fmin(lmin, pv / (Vi + 0.0));  // fi = 0 for every cell without an injector
         }
@@ -188,14 +200,14 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
         rec[6] = fiq * d;                            // fid
     }
 
-    // LDS byte addresses of the well cell and its 4 neighbours (dummy slots for threads without a well)
+    // LDS byte addresses of the well cell and its 4 neighbours are recomputed from `wcell` where they are used
+    // (threads without a well point every one of them at a dummy slot behind the records)
     const int dummy = FW_BYTES + MAX_WELLS * REC_BYTES + REC_BYTES;
-    const int wix = wcell >> 7, wiy = wcell & 127;
-    const int waC = has_well ? lds_off(wix, wiy) : dummy;
-    const int waE = has_well ? lds_off(min(wix + 1, N128 - 1), wiy) : dummy;
-    const int waN = has_well ? lds_off(wix, min(wiy + 1, N128 - 1)) : dummy;
-    const int waS = has_well ? lds_off(wix, max(wiy - 1, 0)) : dummy;
-    const int waW = has_well ? lds_off(max(wix - 1, 0), wiy) : dummy;
+    auto well_addr = [&](int dx, int dy) {
+        const int wix = wcell >> 7, wiy = wcell & 127;
+        const int a = lds_off(min(max(wix + dx, 0), N128 - 1), min(max(wiy + dy, 0), N128 - 1));
+        return has_well ? a : dummy;
+    };
     __syncthreads();
 
     const int swz = (py >> 3) & 1;
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
             double* rec = reinterpret_cast<double*>(lds + wrec);
             double wf = frac_flow<FD>(p, rec[0]);
             rec[7] = wf;
-            *reinterpret_cast<double*>(lds + waC) = wf;  // after this thread's own row write: ordered
+            *reinterpret_cast<double*>(lds + well_addr(0, 0)) = wf;  // after this thread's own row write: ordered
         }
         __syncthreads();
 
@@ -242,41 +254,54 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             const int ix = ix0 + i;
-            double fw_[PY], fc[PY], fe[PY];
-            load_row(i > 0 ? ix - 1 : ixW, fw_);
+            double fc[PY];
             load_row(ix, fc);
-            load_row(i + 1 < PX ? ix + 1 : ixE, fe);
+            const char* rowW = lds + (i > 0 ? ix - 1 : ixW) * 1024 + seg;
+            const char* rowE = lds + (i + 1 < PX ? ix + 1 : ixE) * 1024 + seg;
             const double fS = from_prev_lane(fc[PY - 1]);  // f(ix, iy0-1): its coefficient is 0 on the boundary
             const double fN = from_next_lane(fc[0]);       // f(ix, iy0+PY)
-            const double vyn3 = from_next_lane(Vy[i][0]);
+            double2 vx8a = make_double2(0, 0), vx8b = vx8a, vy7a = vx8a;
+            if (i == PX - 1) {
+                vx8a = vsp[0];
+                vx8b = vsp[NT];
+                vy7a = vsp[2 * NT];
+            }
+            const double vyn3 = i == PX - 1 ? from_next_lane(VY7(0)) : from_next_lane(Vy[i][0]);
 #pragma unroll
-            for (int j = 0; j < PY; ++j) {
-                const double vxw = Vx[i][j], vxe = Vx[i + 1][j], vys = Vy[i][j];
-                const double vyn = j + 1 < PY ? Vy[i][j + 1 < PY ? j + 1 : 0] : vyn3;
-                const double x1 = fmin(vxw, z), x2 = fmax(vxe, z), y1 = fmin(vys, z), y2 = fmax(vyn, z);
-                const double cC = dd * (x1 - x2 + y1 - y2);
-                const double cW = dd * fmax(vxw, z);
-                const double cE = dd * (-fmin(vxe, z));
-                const double cS = dd * fmax(vys, z);
-                const double cN = dd * (-fmin(vyn, z));
-                const double fs = j > 0 ? fc[j > 0 ? j - 1 : 0] : fS;
-                const double fn = j + 1 < PY ? fc[j + 1 < PY ? j + 1 : 0] : fN;
-                double acc = cE * fe[j];
-                acc = acc + cN * fn;
-                acc = acc + cC * fc[j];
-                acc = acc + cS * fs;
-                acc = acc + cW * fw_[j];
-                S[i][j] = S[i][j] + acc;
+            for (int jp = 0; jp < PY; jp += 2) {
+                const double2 fwp = *reinterpret_cast<const double2*>(rowW + (((jp >> 1) ^ swz) * 16));
+                const double2 fep = *reinterpret_cast<const double2*>(rowE + (((jp >> 1) ^ swz) * 16));
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = jp + jj;
+                    const double vxw = Vx[i][j], vxe = (i == PX - 1) ? VX8(j) : Vx[i + 1 < PX ? i + 1 : 0][j];
+                    const double vys = (i == PX - 1 && j < 2) ? VY7(j) : Vy[i][j];
+                    const double vyn = j + 1 < PY ? ((i == PX - 1 && j + 1 < 2) ? VY7(j + 1 < 2 ? j + 1 : 0) : Vy[i][j + 1 < PY ? j + 1 : 0]) : vyn3;
+                    const double x1 = fmin(vxw, z), x2 = fmax(vxe, z), y1 = fmin(vys, z), y2 = fmax(vyn, z);
+                    const double cC = dd * (x1 - x2 + y1 - y2);
+                    const double cW = dd * fmax(vxw, z);
+                    const double cE = dd * (-fmin(vxe, z));
+                    const double cS = dd * fmax(vys, z);
+                    const double cN = dd * (-fmin(vyn, z));
+                    const double fs = j > 0 ? fc[j > 0 ? j - 1 : 0] : fS;
+                    const double fn = j + 1 < PY ? fc[j + 1 < PY ? j + 1 : 0] : fN;
+                    double acc = cE * (jj ? fep.y : fep.x);
+                    acc = acc + cN * fn;
+                    acc = acc + cC * fc[j];
+                    acc = acc + cS * fs;
+                    acc = acc + cW * (jj ? fwp.y : fwp.x);
+                    S[i][j] = S[i][j] + acc;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         {
             double* rec = reinterpret_cast<double*>(lds + wrec);
-            double acc = rec[1] * *reinterpret_cast<const double*>(lds + waE);
-            acc = acc + rec[2] * *reinterpret_cast<const double*>(lds + waN);
+            double acc = rec[1] * *reinterpret_cast<const double*>(lds + well_addr(1, 0));
+            acc = acc + rec[2] * *reinterpret_cast<const double*>(lds + well_addr(0, 1));
             acc = acc + rec[3] * rec[7];
-            acc = acc + rec[4] * *reinterpret_cast<const double*>(lds + waS);
-            acc = acc + rec[5] * *reinterpret_cast<const double*>(lds + waW);
+            acc = acc + rec[4] * *reinterpret_cast<const double*>(lds + well_addr(0, -1));
+            acc = acc + rec[5] * *reinterpret_cast<const double*>(lds + well_addr(-1, 0));
             rec[0] = rec[0] + (acc + rec[6]);
         }
         __syncthreads();
@@ -307,7 +332,7 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
 
 template <bool FD>
 int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
-    const size_t lds = (size_t)FW_BYTES + MAX_WELLS * REC_BYTES + 2 * REC_BYTES;
+    const size_t lds = (size_t)VSP_BASE + VSP_BYTES;
     auto kern = k_sat128<FD>;
     HM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(f->p.N), dim3(NT), lds, f->ctx->stream, f->p, (const double*)S_in, (double*)S_out,
