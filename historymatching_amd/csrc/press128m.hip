@@ -18,6 +18,8 @@
 //
 // C/D layout of v_mfma_f64_16x16x4_f64: lane l, reg g -> row (l>>4)+4g, col l&15; A operand: lane l holds
 // A[l&15][l>>4]; B operand: B[l>>4][l&15] (checked on hardware by tests/test_forward_gpu.py::test_mfma_f64_layout).
+#include <type_traits>
+
 #include "fwd_dev.h"
 
 namespace {
@@ -26,8 +28,22 @@ constexpr int NB = 128;
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct __attribute__((aligned(16))) PressLds {
-    double U[2][NB][4];  // panel columns (current values), double buffered
+    double U[2][NB][4];  // panel columns (current values), double buffered           (rank-4 panels)
     double Pm[2][16];    // inverse of the 4x4 pivot block
+    double ev[NB], dgv[NB], tyv[NB + 8], yprev[NB], ycur[NB];
+    double red[4][NB];
+};
+
+// LDS of the rank-16 pipeline: one panel = one whole tile column (16 pivots)
+struct __attribute__((aligned(16))) PressLds16 {
+    // (static LDS must stay below 64 KB: beyond that the kernel needs the dynamic-LDS opt-in, and out-of-range
+    //  LDS reads silently return 0)
+    // rows padded to 17 doubles: with 16 the 16 lanes of an operand read (row = lane&15) are 8-way bank conflicted
+    double U[2][NB][17];   // the 16 pivot columns (current values); double buffered: panel j+1 publishes while
+                           // slower waves still read panel j's U in their rank-16 update
+    double W[NB][17];      // U P      (written after barrier 1, read after barrier 2: single buffer is safe)
+    double P[16][17];      // inverse of the 16x16 diagonal tile (written before barrier 1, read before barrier 2)
+    double cb[16];         // pivot column of the in-wave 16x16 inversion
     double ev[NB], dgv[NB], tyv[NB + 8], yprev[NB], ycur[NB];
     double red[4][NB];
 };
@@ -63,9 +79,9 @@ __device__ __forceinline__ double dot4(const double* __restrict__ u, const doubl
 }
 
 // t[row] = sum_col acc[row][col] v[col]; result returned to threads tid < 128 (row = tid). Contains barriers.
-template <int NW>
+template <int NW, typename LDS>
 __device__ __forceinline__ double matvec_tiles(const d4 (&acc)[Cfg<NW>::TRW][Cfg<NW>::TCW], const double* __restrict__ v,
-                                               PressLds& L, const Geo& g, int tid) {
+                                               LDS& L, const Geo& g, int tid) {
     constexpr int TRW = Cfg<NW>::TRW, TCW = Cfg<NW>::TCW, WC = Cfg<NW>::WC;
     double vv[TCW];
 #pragma unroll
@@ -192,11 +208,111 @@ __device__ __forceinline__ void panel(d4 (&acc)[Cfg<NW>::TRW][Cfg<NW>::TCW], Pre
     cur ^= 1;
 }
 
-template <typename TS, int NW>
+// ------------------------------------------------------------------------------------------------------------
+// Rank-16 panels (16 waves, 2x2 tiles per wave): one panel = one whole tile column Cp = 2*cp2 + CPP.
+//   1. the 4 waves owning tile column Cp publish U = A[:, 16Cp..16Cp+15]; the wave owning the diagonal tile inverts
+//      it IN-WAVE (16 symmetric sweeps; the pivot column goes through a wave-private LDS line: LDS operations of one
+//      wave are ordered, so no workgroup barrier inside the 16-pivot chain) and publishes P           -> barrier
+//   2. the owners form W = U P with 4 MFMAs per tile (operands re-read from LDS in operand layout), publish W and
+//      keep it as their swept tile column (the diagonal tile becomes -P)                              -> barrier
+//   3. everybody: A <- A - W U^T on the remaining tiles (4 MFMAs per tile); the tile row takes W^T.
+// Two barriers per 16 pivots instead of two per 4: the sequential pivot chain stays inside one wave.
+// ------------------------------------------------------------------------------------------------------------
+template <int CPP>
+__device__ __forceinline__ void panel16(d4 (&acc)[2][2], PressLds16& L, int& cur, int cp2, const Geo& g, int& bad) {
+    constexpr int TJ = CPP, TI = CPP;
+    const int Cp = 2 * cp2 + CPP;
+    const bool col_owner = g.wc == cp2, row_owner = g.wr == cp2;
+    double (*U)[17] = L.U[cur];
+    double (*W)[17] = L.W;
+    double (*P)[17] = L.P;
+    if (col_owner) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) U[16 * (2 * g.wr + ti) + g.lq + 4 * r][g.lc] = acc[ti][TJ][r];
+        if (row_owner) {
+            // in-wave inverse of the diagonal tile: entry (row = lq + 4r, col = lc)
+            d4 t = acc[TI][TJ];
+            for (int k = 0; k < 16; ++k) {
+                if (g.lc == k) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) L.cb[g.lq + 4 * r] = t[r];
+                }
+                // lanes exchange data through LDS inside one wave: the hardware keeps a wave's LDS operations in
+                // order, but the compiler must be told that the other lanes' stores precede these loads (otherwise
+                // it may run the "else" lanes' loads ahead of the "then" lanes' stores)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                double cr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cr[r] = L.cb[g.lq + 4 * r];
+                const double cc = L.cb[g.lc], d = L.cb[k];
+                if (!(d > 0.0)) bad = 1;
+                const double pinv = rcp_newton(d);
+                const double tc = cc * pinv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = g.lq + 4 * r;
+                    double v = fma(-cr[r], tc, t[r]);
+                    if (row == k) v = (g.lc == k) ? -pinv : tc;
+                    else if (g.lc == k) v = cr[r] * pinv;
+                    t[r] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // t = -inv(diagonal tile): publish P = -t and keep -P = t as the swept diagonal tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[g.lq + 4 * r][g.lc] = -t[r];
+            acc[TI][TJ] = t;
+        }
+    }
+    __syncthreads();
+    if (col_owner) {
+        // W tile = U tile * P  (rows 16R.., R = 2*wr + ti);  the diagonal tile's rows are never used
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            if (row_owner && ti == TI) continue;
+            const int R = 2 * g.wr + ti;
+            d4 w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                w = __builtin_amdgcn_mfma_f64_16x16x4f64(U[16 * R + g.lc][4 * kk + g.lq], P[4 * kk + g.lq][g.lc], w, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[16 * R + g.lq + 4 * r][g.lc] = w[r];
+            acc[ti][TJ] = w;  // swept tile column: A[r][K] = (U P)[r]
+        }
+    }
+    __syncthreads();
+    // rank-16 update of every tile outside tile row / tile column Cp; the tile row takes W^T
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int R = 2 * g.wr + ti;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int C = 2 * g.wc + tj;
+            if (C == Cp) continue;  // swept column (done by the owners above)
+            if (R == Cp) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ti][tj][r] = W[16 * C + g.lc][g.lq + 4 * r];
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[16 * R + g.lc][4 * kk + g.lq], U[16 * C + g.lc][4 * kk + g.lq],
+                                                                       acc[ti][tj], 0, 0, 0);
+            }
+        }
+    }
+    cur ^= 1;
+}
+
+template <typename TS, int NW, bool R16>
 __global__ __launch_bounds__(64 * NW) void k_press128m(FwdParams p, const TS* __restrict__ S_base, long long S_stride, int k) {
     constexpr int TRW = Cfg<NW>::TRW, TCW = Cfg<NW>::TCW, WC = Cfg<NW>::WC;
     constexpr int NT = Cfg<NW>::NT;
-    __shared__ PressLds L;
+    __shared__ typename std::conditional<R16, PressLds16, PressLds>::type L;
     const int m = blockIdx.x;
     const int tid = threadIdx.x;
     Geo g;
@@ -268,14 +384,21 @@ __global__ __launch_bounds__(64 * NW) void k_press128m(FwdParams p, const TS* __
                 }
         __syncthreads();
         // 32 block-sweep panels: A <- -inv(A)
+        if constexpr (R16) {
+            for (int cp2 = 0; cp2 < 4; ++cp2) {
+                panel16<0>(acc, L, cur, cp2, g, bad);
+                panel16<1>(acc, L, cur, cp2, g, bad);
+            }
+        } else {
 #define PANEL(a, b) panel<NW, a, b>(acc, L, cur, cq, g, bad)
-        for (int cq = 0; cq < 2; ++cq) {
-            PANEL(0, 0); PANEL(0, 1); PANEL(0, 2); PANEL(0, 3);
-            PANEL(1, 0); PANEL(1, 1); PANEL(1, 2); PANEL(1, 3);
-            PANEL(2, 0); PANEL(2, 1); PANEL(2, 2); PANEL(2, 3);
-            PANEL(3, 0); PANEL(3, 1); PANEL(3, 2); PANEL(3, 3);
-        }
+            for (int cq = 0; cq < 2; ++cq) {
+                PANEL(0, 0); PANEL(0, 1); PANEL(0, 2); PANEL(0, 3);
+                PANEL(1, 0); PANEL(1, 1); PANEL(1, 2); PANEL(1, 3);
+                PANEL(2, 0); PANEL(2, 1); PANEL(2, 2); PANEL(2, 3);
+                PANEL(3, 0); PANEL(3, 1); PANEL(3, 2); PANEL(3, 3);
+            }
 #undef PANEL
+        }
         // G_i = -A: keep in the accumulators for the next block, stream to HBM (16-byte chunks, thread-major)
         double2* Gi = G + (long long)i * (NB * NB / 2);
 #pragma unroll
@@ -339,21 +462,21 @@ __global__ void k_mfma_f64_probe(const double* __restrict__ A, const double* __r
 }  // namespace
 
 // Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
-// press_variant 0 (and any other value): 16 waves per member, one member per CU (fastest measured);  3: 8 waves.
-// (A 4-wave/2-members-per-CU configuration was tried to cheapen the barriers: 16 MFMAs per wave per panel made it
-// MFMA-issue bound and slower, 42 vs 35 ms per launch.)
+// press_variant 0 (and any other value): 16 waves, rank-16 panels;  4: 16 waves, rank-4 panels;  3: 8 waves, rank-4.
 int launch_pressure_128m(hm_fwd* f, const void* S, long long S_stride, int k) {
     const FwdParams& p = f->p;
     if (p.Ny != NB) return -1;
     hipStream_t s = f->ctx->stream;
     const int v = f->press_variant;
-#define LAUNCH(TS, NW) hipLaunchKernelGGL((k_press128m<TS, NW>), dim3(p.N), dim3(64 * NW), 0, s, p, (const TS*)S, S_stride, k)
+#define LAUNCH(TS, NW, R16) hipLaunchKernelGGL((k_press128m<TS, NW, R16>), dim3(p.N), dim3(64 * NW), 0, s, p, (const TS*)S, S_stride, k)
     if (f->dtype == 64) {
-        if (v == 3) LAUNCH(double, 8);
-        else LAUNCH(double, 16);
+        if (v == 3) LAUNCH(double, 8, false);
+        else if (v == 4) LAUNCH(double, 16, false);
+        else LAUNCH(double, 16, true);
     } else {
-        if (v == 3) LAUNCH(float, 8);
-        else LAUNCH(float, 16);
+        if (v == 3) LAUNCH(float, 8, false);
+        else if (v == 4) LAUNCH(float, 16, false);
+        else LAUNCH(float, 16, true);
     }
 #undef LAUNCH
     HM_HIP(hipGetLastError());
