@@ -22,6 +22,20 @@
 
 #include "fwd_dev.h"
 
+#ifdef HM_PRESS_PROF
+// Cycle stamps of workgroup 0 / thread 0 (diag/press_prof.py): built only with -DHM_PRESS_PROF.
+__device__ long long hm_press_prof_buf[16];
+#define PROF_DECL long long prof_t = clock64(), prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(i) do { const long long now_ = clock64(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
+#define PROF_ARGS , long long (&prof_acc)[16], long long& prof_t
+#define PROF_PASS , prof_acc, prof_t
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_ARGS
+#define PROF_PASS
+#endif
+
 namespace {
 
 constexpr int NB = 128;
@@ -31,7 +45,8 @@ struct __attribute__((aligned(16))) PressLds {
     double U[2][NB][4];  // panel columns (current values), double buffered           (rank-4 panels)
     double Pm[2][16];    // inverse of the 4x4 pivot block
     double ev[NB], dgv[NB], tyv[NB + 8], yprev[NB], ycur[NB];
-    double red[4][NB];
+    double red[16][NB];  // mat-vec partial sums
+    __device__ double* redbuf() { return &red[0][0]; }
 };
 
 // LDS of the rank-16 pipeline: one panel = one whole tile column (16 pivots)
@@ -43,9 +58,9 @@ struct __attribute__((aligned(16))) PressLds16 {
                            // slower waves still read panel j's U in their rank-16 update
     double W[NB][17];      // U P      (written after barrier 1, read after barrier 2: single buffer is safe)
     double P[16][17];      // inverse of the 16x16 diagonal tile (written before barrier 1, read before barrier 2)
-    double cb[16];         // pivot column of the in-wave 16x16 inversion
     double ev[NB], dgv[NB], tyv[NB + 8], yprev[NB], ycur[NB];
-    double red[4][NB];
+    // mat-vec partial sums (16 x NB doubles) live in U: the panels are idle during the substitution mat-vecs
+    __device__ double* redbuf() { return &U[0][0][0]; }
 };
 
 template <int NW>
@@ -78,31 +93,39 @@ __device__ __forceinline__ double dot4(const double* __restrict__ u, const doubl
     return s;
 }
 
-// t[row] = sum_col acc[row][col] v[col]; result returned to threads tid < 128 (row = tid). Contains barriers.
+// t = A v for the symmetric block held in the tiles, evaluated column-wise: t[col] = sum_row A[row][col] v[row].
+// In the accumulator layout a lane owns ONE column per tile column and 4*TRW rows of it, so its partial sums need no
+// cross-lane reduction at all: 4*TRW fmas per tile column, one LDS store, and after a barrier thread `col` adds the
+// 4*WR partials (lane-rows x wave-rows) of its column.  (The row-wise form reduced over the 16 lanes of a row with 4
+// shuffle stages per output: 8.2k cycles per mat-vec against ~1k.)  Result returned to threads tid < 128.
 template <int NW, typename LDS>
 __device__ __forceinline__ double matvec_tiles(const d4 (&acc)[Cfg<NW>::TRW][Cfg<NW>::TCW], const double* __restrict__ v,
                                                LDS& L, const Geo& g, int tid) {
-    constexpr int TRW = Cfg<NW>::TRW, TCW = Cfg<NW>::TCW, WC = Cfg<NW>::WC;
-    double vv[TCW];
+    constexpr int TRW = Cfg<NW>::TRW, TCW = Cfg<NW>::TCW, WR = Cfg<NW>::WR;
+    double* red = L.redbuf();  // [WR * 4][NB]
+    double s[TCW];
 #pragma unroll
-    for (int tj = 0; tj < TCW; ++tj) vv[tj] = v[16 * (TCW * g.wc + tj) + g.lc];
+    for (int tj = 0; tj < TCW; ++tj) s[tj] = 0.0;
 #pragma unroll
     for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double s = acc[ti][0][r] * vv[0];
+            const double vr = v[16 * (TRW * g.wr + ti) + g.lq + 4 * r];
 #pragma unroll
-            for (int tj = 1; tj < TCW; ++tj) s = fma(acc[ti][tj][r], vv[tj], s);
-#pragma unroll
-            for (int msk = 8; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk, 16);
-            if (g.lc == 0) L.red[g.wc][16 * (TRW * g.wr + ti) + g.lq + 4 * r] = s;
+            for (int tj = 0; tj < TCW; ++tj) s[tj] = fma(acc[ti][tj][r], vr, s[tj]);
         }
+#pragma unroll
+    for (int tj = 0; tj < TCW; ++tj) red[(4 * g.wr + g.lq) * NB + 16 * (TCW * g.wc + tj) + g.lc] = s[tj];
     __syncthreads();
     double t = 0.0;
     if (tid < NB) {
-        t = L.red[0][tid];
+        double a = red[tid], b = red[NB + tid];
 #pragma unroll
-        for (int c = 1; c < WC; ++c) t += L.red[c][tid];
+        for (int c = 2; c < 4 * WR; c += 2) {
+            a += red[c * NB + tid];
+            b += red[(c + 1) * NB + tid];
+        }
+        t = a + b;
     }
     __syncthreads();
     return t;
@@ -208,74 +231,100 @@ __device__ __forceinline__ void panel(d4 (&acc)[Cfg<NW>::TRW][Cfg<NW>::TCW], Pre
     cur ^= 1;
 }
 
+
 // ------------------------------------------------------------------------------------------------------------
-// Rank-16 panels (16 waves, 2x2 tiles per wave): one panel = one whole tile column Cp = 2*cp2 + CPP.
-//   1. the 4 waves owning tile column Cp publish U = A[:, 16Cp..16Cp+15]; the wave owning the diagonal tile inverts
-//      it IN-WAVE (16 symmetric sweeps; the pivot column goes through a wave-private LDS line: LDS operations of one
-//      wave are ordered, so no workgroup barrier inside the 16-pivot chain) and publishes P           -> barrier
+// In-wave symmetric sweep of one 16x16 tile held in the accumulator layout (lane (lq, lc), reg r <-> entry
+// (lq + 4r, lc)): 16 pivots, on return t = -inv(tile).  One wave is issue bound (~6 cycles per instruction), so the
+// step is written for instruction count (diag/inv16.hip: 156 cycles per pivot against 296 with the pivot column
+// staged through LDS):
+//   * pivot column to the lanes of each row:   v_mov_b64_dpp row_newbcast:K                     (4 instructions)
+//   * pivot row to the 4 lane-rows:            ds_bpermute (the only cross-row move; symmetric tile)
+//   * pivot value:                             v_readlane -> SGPR, reciprocal by rcp + cubic Newton step
+//   * deferred column scaling: the textbook sweep multiplies column K by 1/d_K at pivot K, which costs a select per
+//     entry per pivot.  Every later sweep is linear in that factor, so the lanes of column K simply skip pivot K
+//     (the diagonal entry becomes -1) and the factor is applied once after the last pivot.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_newton3(double d) {
+    const double x = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, x, 1.0);
+    const double e2 = fma(e, e, e);  // x (1 + e + e^2): third-order step, error e^3
+    return fma(x, e2, x);
+}
+
+template <int K>
+__device__ __forceinline__ void sweep16_step(d4& t, double& mypinv, const Geo& g, int& bad) {
+    const double cc = __shfl(t[K >> 2], ((K & 3) << 4) | g.lc);  // a[K][lc]
+    double cr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cr[r] = __builtin_amdgcn_update_dpp(0.0, t[r], 0x150 + K, 0xf, 0xf, true);  // a[lq+4r][K]
+    const int src = ((K & 3) << 4) | K;
+    const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t[K >> 2]), src),
+                                      __builtin_amdgcn_readlane(__double2loint(t[K >> 2]), src));
+    if (!(d > 0.0)) bad = 1;
+    const double pinv = rcp_newton3(d);
+    const double tc = cc * pinv;
+    const bool pc = g.lc == K;
+    if (!pc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = fma(-cr[r], tc, t[r]);
+    }
+    if (g.lq == (K & 3)) t[K >> 2] = pc ? -1.0 : tc;
+    mypinv = pc ? pinv : mypinv;
+}
+
+__device__ __forceinline__ void sweep16_inwave(d4& t, const Geo& g, int& bad) {
+    double mypinv = 0.0;
+#define S(K) sweep16_step<K>(t, mypinv, g, bad);
+    S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
+#undef S
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] *= mypinv;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Rank-16 panels (NW = 16 waves: 2x2 tiles per wave; NW = 8: 4x2 tiles per wave, two workgroups per CU):
+// one panel = one whole tile column Cp = TRW*cpo + CPM.
+//   1. the WR waves owning tile column Cp publish U = A[:, 16Cp..16Cp+15]; the wave owning the diagonal tile inverts
+//      it IN-WAVE (sweep16_inwave: no workgroup barrier inside the 16-pivot chain) and publishes P       -> barrier
 //   2. the owners form W = U P with 4 MFMAs per tile (operands re-read from LDS in operand layout), publish W and
-//      keep it as their swept tile column (the diagonal tile becomes -P)                              -> barrier
+//      keep it as their swept tile column (the diagonal tile becomes -P)                                 -> barrier
 //   3. everybody: A <- A - W U^T on the remaining tiles (4 MFMAs per tile); the tile row takes W^T.
 // Two barriers per 16 pivots instead of two per 4: the sequential pivot chain stays inside one wave.
 // ------------------------------------------------------------------------------------------------------------
-template <int CPP>
-__device__ __forceinline__ void panel16(d4 (&acc)[2][2], PressLds16& L, int& cur, int cp2, const Geo& g, int& bad) {
-    constexpr int TJ = CPP, TI = CPP;
-    const int Cp = 2 * cp2 + CPP;
-    const bool col_owner = g.wc == cp2, row_owner = g.wr == cp2;
+template <int NW, int CPM>
+__device__ __forceinline__ void panel16(d4 (&acc)[Cfg<NW>::TRW][Cfg<NW>::TCW], PressLds16& L, int& cur, int cpo, const Geo& g,
+                                        int& bad PROF_ARGS) {
+    constexpr int TRW = Cfg<NW>::TRW, TCW = Cfg<NW>::TCW;
+    constexpr int TI = CPM % TRW, TJ = CPM % TCW;
+    const int Cp = TRW * cpo + CPM;
+    const bool col_owner = g.wc == Cp / TCW, row_owner = g.wr == cpo;
     double (*U)[17] = L.U[cur];
     double (*W)[17] = L.W;
     double (*P)[17] = L.P;
     if (col_owner) {
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) U[16 * (2 * g.wr + ti) + g.lq + 4 * r][g.lc] = acc[ti][TJ][r];
+            for (int r = 0; r < 4; ++r) U[16 * (TRW * g.wr + ti) + g.lq + 4 * r][g.lc] = acc[ti][TJ][r];
         if (row_owner) {
             // in-wave inverse of the diagonal tile: entry (row = lq + 4r, col = lc)
             d4 t = acc[TI][TJ];
-            for (int k = 0; k < 16; ++k) {
-                if (g.lc == k) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) L.cb[g.lq + 4 * r] = t[r];
-                }
-                // lanes exchange data through LDS inside one wave: the hardware keeps a wave's LDS operations in
-                // order, but the compiler must be told that the other lanes' stores precede these loads (otherwise
-                // it may run the "else" lanes' loads ahead of the "then" lanes' stores)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                double cr[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cr[r] = L.cb[g.lq + 4 * r];
-                const double cc = L.cb[g.lc], d = L.cb[k];
-                if (!(d > 0.0)) bad = 1;
-                const double pinv = rcp_newton(d);
-                const double tc = cc * pinv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = g.lq + 4 * r;
-                    double v = fma(-cr[r], tc, t[r]);
-                    if (row == k) v = (g.lc == k) ? -pinv : tc;
-                    else if (g.lc == k) v = cr[r] * pinv;
-                    t[r] = v;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
+            sweep16_inwave(t, g, bad);
             // t = -inv(diagonal tile): publish P = -t and keep -P = t as the swept diagonal tile
 #pragma unroll
             for (int r = 0; r < 4; ++r) P[g.lq + 4 * r][g.lc] = -t[r];
             acc[TI][TJ] = t;
         }
     }
+    PROF(0);
     __syncthreads();
+    PROF(1);
     if (col_owner) {
-        // W tile = U tile * P  (rows 16R.., R = 2*wr + ti);  the diagonal tile's rows are never used
+        // W tile = U tile * P  (rows 16R.., R = TRW*wr + ti);  the diagonal tile's rows are never used
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
+        for (int ti = 0; ti < TRW; ++ti) {
             if (row_owner && ti == TI) continue;
-            const int R = 2 * g.wr + ti;
+            const int R = TRW * g.wr + ti;
             d4 w = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -285,31 +334,41 @@ __device__ __forceinline__ void panel16(d4 (&acc)[2][2], PressLds16& L, int& cur
             acc[ti][TJ] = w;  // swept tile column: A[r][K] = (U P)[r]
         }
     }
+    PROF(2);
     __syncthreads();
-    // rank-16 update of every tile outside tile row / tile column Cp; the tile row takes W^T
+    PROF(3);
+    // rank-16 update of every tile outside tile row / tile column Cp; the tile row takes W^T.  k-slices outermost:
+    // one slice needs TRW operands of W and TCW of U, each read from LDS once and shared by the wave's tiles.
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const int R = 2 * g.wr + ti;
+    for (int kk = 0; kk < 4; ++kk) {
+        double wv[TRW], uv[TCW];
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-            const int C = 2 * g.wc + tj;
-            if (C == Cp) continue;  // swept column (done by the owners above)
-            if (R == Cp) {
+        for (int ti = 0; ti < TRW; ++ti) wv[ti] = -W[16 * (TRW * g.wr + ti) + g.lc][4 * kk + g.lq];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[ti][tj][r] = W[16 * C + g.lc][g.lq + 4 * r];
-            } else {
+        for (int tj = 0; tj < TCW; ++tj) uv[tj] = U[16 * (TCW * g.wc + tj) + g.lc][4 * kk + g.lq];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[16 * R + g.lc][4 * kk + g.lq], U[16 * C + g.lc][4 * kk + g.lq],
-                                                                       acc[ti][tj], 0, 0, 0);
+        for (int ti = 0; ti < TRW; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TCW; ++tj) {
+                if (TCW * g.wc + tj == Cp || TRW * g.wr + ti == Cp) continue;  // swept column / row (wave-uniform)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[ti], uv[tj], acc[ti][tj], 0, 0, 0);
             }
+    }
+    if (row_owner) {
+#pragma unroll
+        for (int tj = 0; tj < TCW; ++tj) {
+            const int C = TCW * g.wc + tj;
+            if (C == Cp) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[TI][tj][r] = W[16 * C + g.lc][g.lq + 4 * r];
         }
     }
+    PROF(4);
     cur ^= 1;
 }
 
 template <typename TS, int NW, bool R16>
-__global__ __launch_bounds__(64 * NW) void k_press128m(FwdParams p, const TS* __restrict__ S_base, long long S_stride, int k) {
+__global__ __launch_bounds__(64 * NW, (R16 && NW == 8) ? 4 : 1) void k_press128m(FwdParams p, const TS* __restrict__ S_base, long long S_stride, int k) {
     constexpr int TRW = Cfg<NW>::TRW, TCW = Cfg<NW>::TCW, WC = Cfg<NW>::WC;
     constexpr int NT = Cfg<NW>::NT;
     __shared__ typename std::conditional<R16, PressLds16, PressLds>::type L;
@@ -318,8 +377,15 @@ __global__ __launch_bounds__(64 * NW) void k_press128m(FwdParams p, const TS* __
     Geo g;
     g.lane = tid & 63;
     g.w = tid >> 6;
-    g.wr = g.w / WC;
-    g.wc = g.w % WC;
+    if constexpr (R16) {
+        // waves are dealt round-robin to the 4 SIMDs: with wr = w % 4 the four owners of a tile column (equal wc), who
+        // alone run the W = U P MFMAs, sit on four different SIMDs instead of queueing on one
+        g.wr = g.w % (NW / WC);
+        g.wc = g.w / (NW / WC);
+    } else {
+        g.wr = g.w / WC;
+        g.wc = g.w % WC;
+    }
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
     const int Nx = p.Nx, Nxy = p.Nxy;
@@ -335,25 +401,35 @@ __global__ __launch_bounds__(64 * NW) void k_press128m(FwdParams p, const TS* __
     double* Vy = p.Vy + (long long)m * Nx * (NB + 1);
     const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
 
+    PROF_DECL;
     assemble_transmissibilities<TS>(p, S, Km, P /* scratch for L */, TX, TY, tid, NT);
+    PROF(5);
 
     d4 acc[TRW][TCW];
     int bad = 0, cur = 0;
+    // The per-column vectors of block i+1 (transmissibilities, source) are fetched at the END of block i, before the
+    // 128 KB store of G_i is issued: vector-memory operations retire in order, so a load issued after those stores
+    // would stall the next block on the whole store drain (~10k cycles at one CU's share of HBM bandwidth).
+    double pf_y1 = 0.0, pf_y2 = 0.0, pf_x1 = 0.0, pf_x2 = 0.0, pf_q = 0.0, q_cur = 0.0;
+    if (tid < NB) {
+        pf_y1 = TY[tid]; pf_y2 = TY[tid + 1]; pf_x1 = TX[tid]; pf_x2 = TX[NB + tid]; pf_q = q[tid];
+    }
     for (int i = 0; i < Nx; ++i) {
-        for (int j = tid; j < NB; j += NT) {
-            const double y1 = TY[i * (NB + 1) + j], y2 = TY[i * (NB + 1) + j + 1];
-            const double x1 = TX[i * NB + j], x2 = TX[(i + 1) * NB + j];
-            double dg = y1 + y2 + x1 + x2;
-            if (i == 0 && j == 0) dg += Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
-            L.dgv[j] = dg;
-            L.tyv[j] = y1;
-            if (j == NB - 1) L.tyv[NB] = y2;
-            L.ev[j] = x1;
+        if (tid < NB) {
+            double dg = pf_y1 + pf_y2 + pf_x1 + pf_x2;
+            if (i == 0 && tid == 0) dg += Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
+            L.dgv[tid] = dg;
+            L.tyv[tid] = pf_y1;
+            if (tid == NB - 1) L.tyv[NB] = pf_y2;
+            L.ev[tid] = pf_x1;
+            q_cur = pf_q;
         }
         __syncthreads();
+        PROF(10);
         if (i > 0) {
             const double t = matvec_tiles<NW>(acc, L.yprev, L, g, tid);
-            if (tid < NB) L.ycur[tid] = q[i * NB + tid] + L.ev[tid] * t;
+            PROF(11);
+            if (tid < NB) L.ycur[tid] = q_cur + L.ev[tid] * t;
 #pragma unroll
             for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
@@ -364,30 +440,47 @@ __global__ __launch_bounds__(64 * NW) void k_press128m(FwdParams p, const TS* __
                         acc[ti][tj][r] = -(L.ev[16 * (TRW * g.wr + ti) + g.lq + 4 * r] * acc[ti][tj][r] * ec);
                 }
         } else {
-            if (tid < NB) L.ycur[tid] = q[tid];
+            if (tid < NB) L.ycur[tid] = q_cur;
 #pragma unroll
             for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < TCW; ++tj) acc[ti][tj] = d4{0.0, 0.0, 0.0, 0.0};
         }
-        // add the tridiagonal D_i
+        PROF(12);
+        // add the tridiagonal D_i: only diagonal tiles and the corner entries of the two adjacent tile diagonals
+        // are touched; the tile tests are wave-uniform
 #pragma unroll
         for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < TCW; ++tj)
+            for (int tj = 0; tj < TCW; ++tj) {
+                const int R = TRW * g.wr + ti, C = TCW * g.wc + tj;
+                if (R == C) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * (TRW * g.wr + ti) + g.lq + 4 * r, col = 16 * (TCW * g.wc + tj) + g.lc;
-                    if (row == col) acc[ti][tj][r] += L.dgv[row];
-                    else if (col == row + 1) acc[ti][tj][r] -= L.tyv[col];
-                    else if (row == col + 1) acc[ti][tj][r] -= L.tyv[row];
+                    for (int r = 0; r < 4; ++r) {
+                        const int lrow = g.lq + 4 * r, row = 16 * R + lrow, col = 16 * C + g.lc;
+                        double add = 0.0;
+                        if (g.lc == lrow) add = L.dgv[row];
+                        else if (g.lc == lrow + 1) add = -L.tyv[col];
+                        else if (lrow == g.lc + 1) add = -L.tyv[row];
+                        acc[ti][tj][r] += add;
+                    }
+                } else if (C == R + 1) {  // entry (16R+15, 16C): col == row + 1
+                    if (g.lane == 48) acc[ti][tj][3] -= L.tyv[16 * C];
+                } else if (R == C + 1) {  // entry (16R, 16C+15): row == col + 1
+                    if (g.lane == 15) acc[ti][tj][0] -= L.tyv[16 * R];
                 }
+            }
         __syncthreads();
+        PROF(6);
         // 32 block-sweep panels: A <- -inv(A)
         if constexpr (R16) {
-            for (int cp2 = 0; cp2 < 4; ++cp2) {
-                panel16<0>(acc, L, cur, cp2, g, bad);
-                panel16<1>(acc, L, cur, cp2, g, bad);
+            for (int cpo = 0; cpo < 8 / TRW; ++cpo) {
+                panel16<NW, 0>(acc, L, cur, cpo, g, bad PROF_PASS);
+                panel16<NW, 1>(acc, L, cur, cpo, g, bad PROF_PASS);
+                if constexpr (TRW == 4) {
+                    panel16<NW, 2>(acc, L, cur, cpo, g, bad PROF_PASS);
+                    panel16<NW, 3>(acc, L, cur, cpo, g, bad PROF_PASS);
+                }
             }
         } else {
 #define PANEL(a, b) panel<NW, a, b>(acc, L, cur, cq, g, bad)
@@ -398,6 +491,12 @@ __global__ __launch_bounds__(64 * NW) void k_press128m(FwdParams p, const TS* __
                 PANEL(3, 0); PANEL(3, 1); PANEL(3, 2); PANEL(3, 3);
             }
 #undef PANEL
+        }
+        if (i + 1 < Nx && tid < NB) {  // next block's vectors, ahead of the G_i stores (see above)
+            const int in = i + 1;
+            pf_y1 = TY[in * (NB + 1) + tid]; pf_y2 = TY[in * (NB + 1) + tid + 1];
+            pf_x1 = TX[in * NB + tid]; pf_x2 = TX[(in + 1) * NB + tid];
+            pf_q = q[in * NB + tid];
         }
         // G_i = -A: keep in the accumulators for the next block, stream to HBM (16-byte chunks, thread-major)
         double2* Gi = G + (long long)i * (NB * NB / 2);
@@ -419,26 +518,59 @@ __global__ __launch_bounds__(64 * NW) void k_press128m(FwdParams p, const TS* __
             L.yprev[tid] = L.ycur[tid];
         }
         __syncthreads();
+        PROF(7);
     }
-    // back substitution: x_i = G_i (y_i + TX[i+1] * x_{i+1});  ycur holds x_{i+1}
+    // back substitution: x_i = G_i (y_i + TX[i+1] * x_{i+1});  ycur holds x_{i+1}.  G_{Nx-1} is still in the
+    // accumulators; G_{i-1} (128 KB, the HBM stream of this phase) is fetched into a second register set while the
+    // mat-vec of block i runs.
+    constexpr bool PF = NW == 16;  // with 8 waves the second register set does not fit; the co-resident workgroup
+                                   // hides the load latency instead
+    d4 nxt[PF ? TRW : 1][PF ? TCW : 1];
+    double nyv = 0.0, ntx = 0.0;
+    if (PF && tid < NB) nyv = yv[(Nx - 1) * NB + tid];
     for (int i = Nx - 1; i >= 0; --i) {
-        if (i < Nx - 1) {
-            const double2* Gi = G + (long long)i * (NB * NB / 2);
+        if constexpr (!PF) {
+            if (i < Nx - 1) {
+                const double2* Gi = G + (long long)i * (NB * NB / 2);
 #pragma unroll
-            for (int ti = 0; ti < TRW; ++ti)
+                for (int ti = 0; ti < TRW; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < TCW; ++tj)
+                    for (int tj = 0; tj < TCW; ++tj)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        double2 v = Gi[(((ti * TCW + tj) * 2) + h) * NT + tid];
-                        acc[ti][tj][2 * h] = v.x;
-                        acc[ti][tj][2 * h + 1] = v.y;
-                    }
+                        for (int h = 0; h < 2; ++h) {
+                            double2 v = Gi[(((ti * TCW + tj) * 2) + h) * NT + tid];
+                            acc[ti][tj][2 * h] = v.x;
+                            acc[ti][tj][2 * h + 1] = v.y;
+                        }
+            }
+            if (tid < NB) {
+                nyv = yv[i * NB + tid];
+                if (i < Nx - 1) ntx = TX[(i + 1) * NB + tid];
+            }
         }
         if (tid < NB) {
-            double v = yv[i * NB + tid];
-            if (i < Nx - 1) v += TX[(i + 1) * NB + tid] * L.ycur[tid];
+            double v = nyv;
+            if (i < Nx - 1) v += ntx * L.ycur[tid];
             L.yprev[tid] = v;
+        }
+        if constexpr (PF) {
+            if (i > 0) {
+                const double2* Gi = G + (long long)(i - 1) * (NB * NB / 2);
+#pragma unroll
+                for (int ti = 0; ti < TRW; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TCW; ++tj)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            double2 v = Gi[(((ti * TCW + tj) * 2) + h) * NT + tid];
+                            nxt[ti][tj][2 * h] = v.x;
+                            nxt[ti][tj][2 * h + 1] = v.y;
+                        }
+                if (tid < NB) {
+                    nyv = yv[(i - 1) * NB + tid];
+                    ntx = TX[i * NB + tid];
+                }
+            }
         }
         __syncthreads();
         const double t = matvec_tiles<NW>(acc, L.yprev, L, g, tid);
@@ -446,9 +578,23 @@ __global__ __launch_bounds__(64 * NW) void k_press128m(FwdParams p, const TS* __
             L.ycur[tid] = t;
             P[i * NB + tid] = t;
         }
+        if constexpr (PF) {
+            if (i > 0) {
+#pragma unroll
+                for (int ti = 0; ti < TRW; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TCW; ++tj) acc[ti][tj] = nxt[ti][tj];
+            }
+        }
         __syncthreads();
     }
+    PROF(8);
     face_fluxes(p, P, TX, TY, Vx, Vy, tid, NT);
+    PROF(9);
+#ifdef HM_PRESS_PROF
+    if (m == 0 && tid == 0)
+        for (int c = 0; c < 16; ++c) hm_press_prof_buf[c] = prof_acc[c];
+#endif
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
@@ -462,7 +608,8 @@ __global__ void k_mfma_f64_probe(const double* __restrict__ A, const double* __r
 }  // namespace
 
 // Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
-// press_variant 0 (and any other value): 16 waves, rank-16 panels;  4: 16 waves, rank-4 panels;  3: 8 waves, rank-4.
+// press_variant 0 (and any other value): 8 waves x 2 workgroups per CU, rank-16 panels;  5: 16 waves, rank-16 panels;
+// 4: 16 waves, rank-4 panels;  3: 8 waves, rank-4.
 int launch_pressure_128m(hm_fwd* f, const void* S, long long S_stride, int k) {
     const FwdParams& p = f->p;
     if (p.Ny != NB) return -1;
@@ -472,16 +619,24 @@ int launch_pressure_128m(hm_fwd* f, const void* S, long long S_stride, int k) {
     if (f->dtype == 64) {
         if (v == 3) LAUNCH(double, 8, false);
         else if (v == 4) LAUNCH(double, 16, false);
-        else LAUNCH(double, 16, true);
+        else if (v == 5) LAUNCH(double, 16, true);
+        else LAUNCH(double, 8, true);
     } else {
         if (v == 3) LAUNCH(float, 8, false);
         else if (v == 4) LAUNCH(float, 16, false);
-        else LAUNCH(float, 16, true);
+        else if (v == 5) LAUNCH(float, 16, true);
+        else LAUNCH(float, 8, true);
     }
 #undef LAUNCH
     HM_HIP(hipGetLastError());
     return 0;
 }
+
+#ifdef HM_PRESS_PROF
+extern "C" int hm_debug_press_prof(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hm_press_prof_buf), sizeof(long long) * 16);
+}
+#endif
 
 // Self-test hook: D(16x16) = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 with the operand/result lane maps this
 // file assumes.  Host buffers.
