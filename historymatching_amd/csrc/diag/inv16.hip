@@ -219,6 +219,32 @@ void run(const char* name, const std::vector<double>& A, double* dA, double* o, 
     for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double sa = 0; for (int q = 0; q < 16; ++q) sa += A[i * 16 + q] * a[q * 16 + j]; ea = fmax(ea, fabs(sa - (i == j))); }
     printf("%-28s %6.0f ticks per 16x16 inverse (%.0f per pivot), |A inv - I| = %.2e\n", name, c / 9.0, c / 144.0, ea);
 }
+
+// contention test: wave 0 runs the sweep chain; if load != 0 waves 4 (same SIMD as wave 0 under round-robin
+// placement) or 1 (another SIMD) issue back-to-back fp64 MFMAs meanwhile.
+__global__ void k_contend(const double* A, double* out, long long* cyc, int load_wave, int prio) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lc = lane & 15, lq = lane >> 4;
+    if (w == 0) {
+        if (prio) __builtin_amdgcn_s_setprio(3);
+        d4 t;
+        for (int r = 0; r < 4; ++r) t[r] = A[(lq + 4 * r) * 16 + lc];
+        long long t0 = clock64();
+        for (int rep = 0; rep < 9; ++rep) t = invF(t, lane, lc, lq);
+        long long t1 = clock64();
+        for (int r = 0; r < 4; ++r) out[(lq + 4 * r) * 16 + lc] = -t[r];
+        if (lane == 0) cyc[0] = t1 - t0;
+    } else if (w == load_wave) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double a = A[lane], b = A[64 + lane];
+        for (int i = 0; i < 1200; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        if (acc[0] == 123.456) out[0] = acc[1];
+    } else if (w == load_wave + 8) {   // second independent MFMA stream on the same SIMD
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double a = A[lane], b = A[64 + lane];
+        for (int i = 0; i < 1200; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        if (acc[0] == 123.456) out[0] = acc[1];
+    }
+}
 int main() {
     std::vector<double> A(256);
     for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) A[i * 16 + j] = (i == j ? 20.0 + i : 0.0) - 1.0 / (1 + abs(i - j));
@@ -232,5 +258,12 @@ int main() {
     run<4>("dpp64", A, dA, o, dc);
     run<5>("dpp64, deferred col scale", A, dA, o, dc);
     run<6>("same + MFMA row broadcast", A, dA, o, dc);
+    for (int cfg = 0; cfg < 6; ++cfg) {
+        const int lw[6] = {99, 4, 4, 1, 1, 4}, pr[6] = {0, 0, 1, 0, 1, 1};
+        const int nthreads = cfg == 5 ? 64 * 13 : 64 * 5;
+        for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k_contend, dim3(1), dim3(nthreads), 0, 0, dA, o, dc, lw[cfg], pr[cfg]); (void)hipDeviceSynchronize(); }
+        long long c; (void)hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
+        printf("sweep with MFMA load on wave %2d%s, prio %d: %6.0f cycles per 16x16 inverse\n", lw[cfg], cfg == 5 ? "+12" : "", pr[cfg], c / 9.0);
+    }
     return 0;
 }

@@ -1,0 +1,46 @@
+"""Per-kernel HBM bytes from the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; both in KiB on gfx950).
+
+gfx950 correction (MI355X_MICROARCH.md, HBM/rocprofv3 section): FETCH_SIZE counts half of the bytes of wide
+coalesced reads; calibrated on k_perm_transform (reads 128 KiB per member: N * 131072 B expected).  The x2 is applied
+to the kernels whose reads are 16 B/lane streams (perm_transform, press128m); sat128's fetches are dominated by dword
+scratch reloads and are reported uncorrected, with the x2 figure as a bracket."""
+import csv
+import json
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+out_dir, members = Path(sys.argv[1]), int(sys.argv[2])
+KEYS = {"k_perm_transform": "perm_transform", "k_press128m": "press128m", "k_press128<": "press128", "k_sat128": "sat128",
+        "k_pressure_generic": "pressure_generic", "k_saturation_generic": "saturation_generic"}
+
+
+def per_launch(counter):
+    acc = defaultdict(list)
+    with open(out_dir / f"pmc_{counter}_counter_collection.csv") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            for pat, key in KEYS.items():
+                if pat in row["Kernel_Name"]:
+                    acc[key].append(float(row["Counter_Value"]) * 1024.0)
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+fetch, write = per_launch("FETCH_SIZE"), per_launch("WRITE_SIZE")
+kernels = {}
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+    wide = k in ("perm_transform", "press128m")
+    kernels[k] = {
+        "fetch_bytes_raw_per_launch": f, "write_bytes_per_launch": w,
+        "hbm_bytes_per_member_corrected": ((2.0 * f if wide else f) + w) / members,
+        "hbm_bytes_per_member_uncorrected": (f + w) / members,
+        "hbm_bytes_per_member_fetch_x2": (2.0 * f + w) / members,
+    }
+print(json.dumps({
+    "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --members %d --steps 1; gfx950 "
+            "correction: FETCH_SIZE counts 1/2 of the bytes of wide coalesced reads (x2 applied to press128m and "
+            "perm_transform, 16 B/lane streams; calibration: k_perm_transform reads 131072 B per member); sat128 "
+            "uncorrected (dword scratch reloads), x2 figure given as a bracket" % members,
+    "members_per_launch": members, "kernels": kernels}, indent=1))
