@@ -26,7 +26,7 @@ lib = _lib.load()
 buf = (C.c_longlong * 16)()
 lib.hm_debug_press_prof.argtypes = [C.POINTER(C.c_longlong)]
 assert lib.hm_debug_press_prof(buf) == 0
-names = ["B: W = U P", "barrier 1", "C: next column + sweep", "C: other tiles", "barrier 2", "assembly", "per-ix preamble",
+names = ["A: publish+inverse", "barrier 1", "W = U P", "barrier 2", "rank-16 update", "assembly", "per-ix preamble",
          "G store + tail", "back substitution", "face fluxes",
          "  pre: vec->LDS + barrier", "  pre: matvec", "  pre: scale", "-", "-", "-"]
 v = np.array(buf[:16], dtype=np.float64)

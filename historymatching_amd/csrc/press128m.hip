@@ -283,56 +283,42 @@ __device__ __forceinline__ void sweep16_inwave(d4& t, const Geo& g, int& bad) {
 
 // ------------------------------------------------------------------------------------------------------------
 // Rank-16 panels (NW = 16 waves: 2x2 tiles per wave; NW = 8: 4x2 tiles per wave, two workgroups per CU):
-// one panel = one whole tile column Cp = TRW*cpo + CPM.  With U_p = A[:, 16Cp..16Cp+15] (current values) and
-// P_p = inverse of the diagonal tile, already published in LDS by the previous panel (panel16_open for the first):
-//   B. the WR waves owning tile column Cp form W = U_p P_p with 4 MFMAs per tile (operands from LDS in operand
-//      layout), publish W and keep it as their swept tile column (the diagonal tile becomes -P_p)        -> barrier
-//   C. everybody: A <- A - W U_p^T on the remaining tiles (4 MFMAs per tile), the tile row takes W^T.
-//      LOOK-AHEAD: the owners of tile column Cp+1 update that column first and publish it as U_{p+1} (other U
-//      buffer); the owner of the next diagonal tile then inverts it IN-WAVE (sweep16_inwave: no workgroup barrier
-//      inside the 16-pivot chain) and publishes P_{p+1} while the other waves are still in their MFMAs -> barrier
-// Two barriers per 16 pivots, and the sequential pivot chain runs under the other waves' matrix-core work.
+// one panel = one whole tile column Cp = TRW*cpo + CPM.
+//   1. the WR waves owning tile column Cp publish U = A[:, 16Cp..16Cp+15]; the wave owning the diagonal tile inverts
+//      it IN-WAVE (sweep16_inwave: no workgroup barrier inside the 16-pivot chain) and publishes P       -> barrier
+//   2. the owners form W = U P with 4 MFMAs per tile (operands re-read from LDS in operand layout), publish W and
+//      keep it as their swept tile column (the diagonal tile becomes -P)                                 -> barrier
+//   3. everybody: A <- A - W U^T on the remaining tiles (4 MFMAs per tile); the tile row takes W^T.
+// Two barriers per 16 pivots instead of two per 4: the sequential pivot chain stays inside one wave.
 // ------------------------------------------------------------------------------------------------------------
-template <int NW>
-__device__ __forceinline__ void publish_column(const d4 (&acc)[Cfg<NW>::TRW][Cfg<NW>::TCW], int tj, double (*U)[17], const Geo& g) {
-    constexpr int TRW = Cfg<NW>::TRW;
-#pragma unroll
-    for (int ti = 0; ti < TRW; ++ti)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) U[16 * (TRW * g.wr + ti) + g.lq + 4 * r][g.lc] = acc[ti][tj][r];
-}
-
-// in-wave inverse of a diagonal tile (entry (row = lq + 4r, col = lc)): publishes P = inv, keeps -P as the swept tile
-__device__ __forceinline__ void invert_diagonal(d4& tile, double (*P)[17], const Geo& g, int& bad) {
-    d4 t = tile;
-    sweep16_inwave(t, g, bad);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) P[g.lq + 4 * r][g.lc] = -t[r];
-    tile = t;
-}
-
-// first panel of a block: publish U_0 and P_0 (no previous panel to do it)
-template <int NW>
-__device__ __forceinline__ void panel16_open(d4 (&acc)[Cfg<NW>::TRW][Cfg<NW>::TCW], PressLds16& L, int cur, const Geo& g, int& bad) {
-    if (g.wc == 0) {
-        publish_column<NW>(acc, 0, L.U[cur], g);
-        if (g.wr == 0) invert_diagonal(acc[0][0], L.P, g, bad);
-    }
-    __syncthreads();
-}
-
 template <int NW, int CPM>
 __device__ __forceinline__ void panel16(d4 (&acc)[Cfg<NW>::TRW][Cfg<NW>::TCW], PressLds16& L, int& cur, int cpo, const Geo& g,
                                         int& bad PROF_ARGS) {
     constexpr int TRW = Cfg<NW>::TRW, TCW = Cfg<NW>::TCW;
     constexpr int TI = CPM % TRW, TJ = CPM % TCW;
-    constexpr int TIN = (CPM + 1) % TRW, TJN = (CPM + 1) % TCW;  // tile slots of the next panel's diagonal tile
-    const int Cp = TRW * cpo + CPM, Cn = Cp + 1;
-    const bool col_owner = g.wc == Cp / TCW, row_owner = g.wr == Cp / TRW;
-    const bool next_col_owner = Cn < 8 && g.wc == Cn / TCW, next_row_owner = g.wr == Cn / TRW;
+    const int Cp = TRW * cpo + CPM;
+    const bool col_owner = g.wc == Cp / TCW, row_owner = g.wr == cpo;
     double (*U)[17] = L.U[cur];
     double (*W)[17] = L.W;
     double (*P)[17] = L.P;
+    if (col_owner) {
+#pragma unroll
+        for (int ti = 0; ti < TRW; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) U[16 * (TRW * g.wr + ti) + g.lq + 4 * r][g.lc] = acc[ti][TJ][r];
+        if (row_owner) {
+            // in-wave inverse of the diagonal tile: entry (row = lq + 4r, col = lc)
+            d4 t = acc[TI][TJ];
+            sweep16_inwave(t, g, bad);
+            // t = -inv(diagonal tile): publish P = -t and keep -P = t as the swept diagonal tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[g.lq + 4 * r][g.lc] = -t[r];
+            acc[TI][TJ] = t;
+        }
+    }
+    PROF(0);
+    __syncthreads();
+    PROF(1);
     if (col_owner) {
         // W tile = U tile * P  (rows 16R.., R = TRW*wr + ti);  the diagonal tile's rows are never used
 #pragma unroll
@@ -348,39 +334,35 @@ __device__ __forceinline__ void panel16(d4 (&acc)[Cfg<NW>::TRW][Cfg<NW>::TCW], P
             acc[ti][TJ] = w;  // swept tile column: A[r][K] = (U P)[r]
         }
     }
-    PROF(0);
-    __syncthreads();
-    PROF(1);
-    // rank-16 update of one tile outside tile row / tile column Cp; the tile row takes W^T
-    auto update_tile = [&](int ti, int tj) {
-        const int R = TRW * g.wr + ti, C = TCW * g.wc + tj;
-        if (C == Cp) return;  // swept column (done by the owners above)
-        if (R == Cp) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[ti][tj][r] = W[16 * C + g.lc][g.lq + 4 * r];
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[16 * R + g.lc][4 * kk + g.lq], U[16 * C + g.lc][4 * kk + g.lq],
-                                                                   acc[ti][tj], 0, 0, 0);
-        }
-    };
-    if (next_col_owner) {  // look-ahead: next panel's column first
-#pragma unroll
-        for (int ti = 0; ti < TRW; ++ti) update_tile(ti, TJN);
-        publish_column<NW>(acc, TJN, L.U[cur ^ 1], g);
-        if (next_row_owner) invert_diagonal(acc[TIN][TJN], P, g, bad);  // P_p was last read before the barrier above
-    }
     PROF(2);
+    __syncthreads();
+    PROF(3);
+    // rank-16 update of every tile outside tile row / tile column Cp; the tile row takes W^T.  k-slices outermost:
+    // one slice needs TRW operands of W and TCW of U, each read from LDS once and shared by the wave's tiles.
 #pragma unroll
-    for (int ti = 0; ti < TRW; ++ti)
+    for (int kk = 0; kk < 4; ++kk) {
+        double wv[TRW], uv[TCW];
+#pragma unroll
+        for (int ti = 0; ti < TRW; ++ti) wv[ti] = -W[16 * (TRW * g.wr + ti) + g.lc][4 * kk + g.lq];
+#pragma unroll
+        for (int tj = 0; tj < TCW; ++tj) uv[tj] = U[16 * (TCW * g.wc + tj) + g.lc][4 * kk + g.lq];
+#pragma unroll
+        for (int ti = 0; ti < TRW; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TCW; ++tj) {
+                if (TCW * g.wc + tj == Cp || TRW * g.wr + ti == Cp) continue;  // swept column / row (wave-uniform)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[ti], uv[tj], acc[ti][tj], 0, 0, 0);
+            }
+    }
+    if (row_owner) {
 #pragma unroll
         for (int tj = 0; tj < TCW; ++tj) {
-            if (tj == TJN && next_col_owner) continue;
-            update_tile(ti, tj);
+            const int C = TCW * g.wc + tj;
+            if (C == Cp) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[TI][tj][r] = W[16 * C + g.lc][g.lq + 4 * r];
         }
-    PROF(3);
-    __syncthreads();
+    }
     PROF(4);
     cur ^= 1;
 }
@@ -492,7 +474,6 @@ __global__ __launch_bounds__(64 * NW, (R16 && NW == 8) ? 4 : 1) void k_press128m
         PROF(6);
         // 32 block-sweep panels: A <- -inv(A)
         if constexpr (R16) {
-            panel16_open<NW>(acc, L, cur, g, bad);
             for (int cpo = 0; cpo < 8 / TRW; ++cpo) {
                 panel16<NW, 0>(acc, L, cur, cpo, g, bad PROF_PASS);
                 panel16<NW, 1>(acc, L, cur, cpo, g, bad PROF_PASS);
