@@ -478,8 +478,12 @@ static int launch_pressure(hm_fwd* f, int k) {
     int rc = f->t_press.begin(s);
     if (rc) return rc;
     int done = -1;
-    if (f->press_variant == 2) done = launch_pressure_128(f, S, stride, k);
-    else if (f->press_variant != 1) done = launch_pressure_128m(f, S, stride, k);
+    // press_variant: 1 generic, 2 press128 (VALU rank-1), 3/4/5/8 press128m (full tiles: 8w rank-4, 16w rank-4,
+    // 16w rank-16, 8w rank-16 x 2 workgroups/CU), 6/7 and every other value press128s (symmetric tiles, 8/16 waves)
+    const int pv = f->press_variant;
+    if (pv == 2) done = launch_pressure_128(f, S, stride, k);
+    else if (pv == 3 || pv == 4 || pv == 5 || pv == 8) done = launch_pressure_128m(f, S, stride, k);
+    else if (pv != 1) done = launch_pressure_128s(f, S, stride, k);
     if (done > 0) return done;
     if (done < 0) {
         int T = generic_threads(p.Ny);

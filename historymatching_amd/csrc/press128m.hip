@@ -572,7 +572,7 @@ int launch_pressure_128m(hm_fwd* f, const void* S, long long S_stride, int k) {
         if (v == 3) LAUNCH(double, 8, false);
         else if (v == 4) LAUNCH(double, 16, false);
         else if (v == 5) LAUNCH(double, 16, true);
-        else LAUNCH(double, 8, true);
+        else LAUNCH(double, 8, true);  // v == 8
     } else {
         if (v == 3) LAUNCH(float, 8, false);
         else if (v == 4) LAUNCH(float, 16, false);

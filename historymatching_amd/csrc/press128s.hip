@@ -1,0 +1,400 @@
+// press128s.hip -- Ny = 128 fp64 pressure step, SYMMETRIC tile storage + a SIMD reserved for the pivot chain.
+//
+// Same block elimination as press128m.hip (block-Thomas along ix, every 128x128 Schur complement
+// inverted explicitly by blocked symmetric Gauss-Jordan sweeps with rank-16 panels), re-laid-out around two
+// measured facts of gfx950 (diag/inv16.hip):
+//   * fp64 MFMA and the VALU share the SIMD's double-precision lanes: a wave's VALU instruction waits for every
+//     in-flight v_mfma_f64 of the co-resident waves (64 cycles each).  The in-wave 16x16 pivot sweep (2.5k cycles
+//     alone) takes 11k-19k cycles next to one or two MFMA streams, so it cannot be hidden under matrix-core work on
+//     the same SIMD -- but a sweep on SIMD 0 is not slowed at all by MFMAs on SIMDs 1..3.
+//   * fp64 MFMA peak equals fp64 VALU peak (78 TF): the matrix cores only pay if the flop count is minimal.
+// Hence:
+//   1. only the 36 lower-triangle 16x16 tiles of the symmetric block are stored and updated (-44% flops, -44% of
+//      the G = inv(S_i) HBM stream, 72 KB instead of 128 KB per block);
+//   2. waves are dealt round-robin to the SIMDs, so waves w = 0, 4, ... (SIMD 0) are SERVICE waves -- wave 0 is the
+//      sweeper, together they do the 128-long vector work -- and only waves on SIMDs 1..3 hold tiles and issue
+//      MFMAs.  The sweep of panel p+1's diagonal tile runs on SIMD 0 while SIMDs 1..3 do the rank-16 update of
+//      panel p (look-ahead through LDS, released by an LDS flag instead of a workgroup barrier);
+//   3. 8 waves per workgroup (2 service + 6 compute x 6 tiles), two workgroups per CU.
+//
+// Tile (R, C), R >= C, in the MFMA accumulator layout: lane (lq = l >> 4, lc = l & 15), register r <-> entry
+// (16R + lq + 4r, 16C + lc).  Panel Cp (16 pivots = tile column/row Cp), with U = A[:, 16Cp..] (all 128 rows: rows
+// above the diagonal come from the TRANSPOSED tiles of tile row Cp) and P = inv(A[Cp, Cp]):
+//   B. tile (R, Cp), R > Cp:  W_R = U_R P           tile (Cp, C), C < Cp:  W_C^T = P U_C^T        diagonal: -P
+//   C. every other tile (R, C):  A_RC -= W_R U_C^T  (both operands from LDS in operand layout).
+#include "fwd_dev.h"
+#include "sweep16.h"
+
+namespace {
+
+constexpr int NB = 128;
+
+template <int NW>
+struct SCfg {
+    static constexpr int NS = NW / 4;     // service waves (SIMD 0)
+    static constexpr int NC = NW - NS;    // compute waves (SIMDs 1..3)
+    static constexpr int TPW = 36 / NC;   // lower-triangle tiles per compute wave
+    static constexpr int NT = 64 * NW;
+    static constexpr int NCT = 64 * NC;   // compute threads
+};
+
+// Tile -> (compute wave, slot).  Found by local search (every panel: the 7 phase-B tiles on at most 3 per SIMD and 2
+// per wave; phase-C tiles 8..10 per SIMD).  Compute wave c sits on SIMD 1 + c % 3.  Entries are 16*R + C.
+__constant__ unsigned char TILE_TAB8[6][6] = {
+    {0x21, 0x31, 0x43, 0x50, 0x66, 0x77},
+    {0x11, 0x30, 0x53, 0x60, 0x64, 0x72},
+    {0x20, 0x44, 0x52, 0x54, 0x63, 0x71},
+    {0x10, 0x33, 0x42, 0x65, 0x70, 0x76},
+    {0x00, 0x51, 0x55, 0x62, 0x73, 0x74},
+    {0x22, 0x32, 0x40, 0x41, 0x61, 0x75},
+};
+__constant__ unsigned char TILE_TAB16[12][3] = {
+    {0x10, 0x11, 0x75}, {0x21, 0x65, 0x77}, {0x50, 0x55, 0x64}, {0x30, 0x52, 0x74}, {0x22, 0x41, 0x53}, {0x51, 0x60, 0x73},
+    {0x33, 0x43, 0x76}, {0x20, 0x44, 0x71}, {0x00, 0x54, 0x62}, {0x32, 0x61, 0x66}, {0x42, 0x63, 0x70}, {0x31, 0x40, 0x72},
+};
+
+struct __attribute__((aligned(16))) SLds {
+    // (static LDS must stay below 64 KB; rows padded to 17 doubles against bank conflicts of the operand reads)
+    double U[2][NB][17];  // the 16 pivot columns, all 128 rows; double buffered (panel p+1 is published during panel p)
+    double W[NB][17];     // U P
+    double P[16][17];     // inverse of the diagonal tile
+    double Dg[16][17];    // diagonal tile handed to the sweeper
+    double ev[NB], dgv[NB], tyv[NB + 8], yprev[NB], ycur[NB];
+    int flag;             // token of the diagonal tile currently in Dg
+    int pad[3];
+    // mat-vec scratch aliases the panel buffers (idle during the substitution mat-vecs)
+    __device__ double* transpose_buf(int c) { return &U[0][0][0] + c * (16 * 17); }  // [NC][16][17]
+    __device__ double* partial(int c) { return &W[0][0] + c * NB; }                  // [NC][NB]
+};
+
+struct SGeo {
+    int lane, lc, lq;
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // lanes of ONE wave exchange data through LDS: the hardware keeps a wave's LDS operations in order, the compiler
+    // must be told not to move the loads above the other lanes' stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Partial products of t = A v for the tiles of one compute wave (A symmetric, lower tiles stored):
+//   tile (R, C) gives t[16C + j] += sum_i tile[i][j] v[16R + i]      (column-wise: no cross-lane reduction)
+//   and, if R != C,  t[16R + i] += sum_j tile[i][j] v[16C + j]      (the same on the tile transposed through LDS)
+// Lanes differing in lq hold partial sums of the same output: they are combined by LDS atomic adds into the wave's
+// private vector, which the service threads sum over the compute waves after a barrier.
+template <int TPW>
+__device__ __forceinline__ void matvec_partial(const d4 (&acc)[TPW], const int (&tR)[TPW], const int (&tC)[TPW],
+                                               const double* __restrict__ v, double* __restrict__ tw, double* __restrict__ tb,
+                                               const SGeo& g) {
+    tw[g.lane] = 0.0;
+    tw[64 + g.lane] = 0.0;
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+        const int R = tR[s], C = tC[s];
+        double sc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc = fma(acc[s][r], v[16 * R + g.lq + 4 * r], sc);
+        atomicAdd(&tw[16 * C + g.lc], sc);
+        if (R != C) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tb[(g.lq + 4 * r) * 17 + g.lc] = acc[s][r];
+            wave_lds_fence();
+            double sr = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sr = fma(tb[g.lc * 17 + g.lq + 4 * r], v[16 * C + g.lq + 4 * r], sr);
+            atomicAdd(&tw[16 * R + g.lc], sr);
+            wave_lds_fence();
+        }
+    }
+}
+
+template <int NC>
+__device__ __forceinline__ double matvec_total(SLds& L, int j) {
+    double a = L.partial(0)[j], b = L.partial(1)[j];
+#pragma unroll
+    for (int c = 2; c < NC; c += 2) {
+        a += L.partial(c)[j];
+        b += L.partial(c + 1)[j];
+    }
+    return a + b;
+}
+
+template <typename TS, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParams p, const TS* __restrict__ S_base, long long S_stride,
+                                                                       int k) {
+    using Cf = SCfg<NW>;
+    constexpr int NC = Cf::NC, TPW = Cf::TPW, NT = Cf::NT, NCT = Cf::NCT;
+    __shared__ SLds L;
+    const int m = blockIdx.x;
+    const int tid = threadIdx.x;
+    SGeo g;
+    g.lane = tid & 63;
+    g.lc = g.lane & 15;
+    g.lq = g.lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool service = (w & 3) == 0;
+    const bool sweeper = w == 0;
+    const int c = service ? 0 : (w >> 2) * 3 + (w & 3) - 1;  // compute wave index
+    const int j = service ? (w >> 2) * 64 + g.lane : NB;       // vector element of a service thread (< NB: active)
+    const int ct = c * 64 + g.lane;                           // compute thread index (G layout)
+    const int Nx = p.Nx, Nxy = p.Nxy;
+
+    const TS* S = S_base + (long long)m * S_stride;
+    const double* Km = p.K + (long long)m * Nxy;
+    double* TX = p.TX + (long long)m * (Nx + 1) * NB;
+    double* TY = p.TY + (long long)m * Nx * (NB + 1);
+    double2* G = reinterpret_cast<double2*>(p.G + (long long)m * Nx * NB * NB);
+    double* yv = p.yv + (long long)m * Nxy;
+    double* P = p.P + (long long)m * Nxy;
+    double* Vx = p.Vx + (long long)m * (Nx + 1) * NB;
+    double* Vy = p.Vy + (long long)m * Nx * (NB + 1);
+    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+
+    int tR[TPW], tC[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+        const int e = NW == 8 ? TILE_TAB8[c % 6][s % 6] : TILE_TAB16[c % 12][s % 3];
+        tR[s] = __builtin_amdgcn_readfirstlane(e >> 4);
+        tC[s] = __builtin_amdgcn_readfirstlane(e & 15);
+    }
+
+    assemble_transmissibilities<TS>(p, S, Km, P /* scratch for L */, TX, TY, tid, NT);
+    if (tid == 0) L.flag = 0;
+    __syncthreads();  // TX/TY entries written by other threads are read below
+
+    d4 acc[TPW];
+    int bad = 0, cur = 0;
+    // vectors of block i+1 are fetched by the service threads one block ahead
+    double pf_y1 = 0.0, pf_y2 = 0.0, pf_x1 = 0.0, pf_x2 = 0.0, pf_q = 0.0, q_cur = 0.0;
+    if (j < NB) {
+        pf_y1 = TY[j]; pf_y2 = TY[j + 1]; pf_x1 = TX[j]; pf_x2 = TX[NB + j]; pf_q = q[j];
+    }
+
+    // ---- one rank-16 panel --------------------------------------------------------------------------------------
+    auto update_tile = [&](int s, int Cp, double (*U)[17]) {
+        const int R = tR[s], C = tC[s];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-L.W[16 * R + g.lc][4 * kk + g.lq], U[16 * C + g.lc][4 * kk + g.lq], acc[s], 0, 0, 0);
+    };
+    // hand tile s over as part of pivot column Cn: natural rows for a column tile, transposed for a row tile, the
+    // diagonal tile to the sweeper (released by the flag)
+    auto publish_tile = [&](int s, int Cn, double (*Un)[17], int token) {
+        const int R = tR[s], C = tC[s];
+        if (R == Cn && C == Cn) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) L.Dg[g.lq + 4 * r][g.lc] = acc[s][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (g.lane == 0) __hip_atomic_store(&L.flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (C == Cn) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Un[16 * R + g.lq + 4 * r][g.lc] = acc[s][r];
+        } else {  // R == Cn, C < Cn
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Un[16 * C + g.lc][g.lq + 4 * r] = acc[s][r];
+        }
+    };
+    auto sweep_published = [&](int token) {
+        while (__hip_atomic_load(&L.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token) __builtin_amdgcn_s_sleep(1);
+        d4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = L.Dg[g.lq + 4 * r][g.lc];
+        sweep16_inwave(t, g, bad);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L.P[g.lq + 4 * r][g.lc] = -t[r];  // t = -inv(tile)
+    };
+
+    for (int i = 0; i < Nx; ++i) {
+        if (j < NB) {
+            double dg = pf_y1 + pf_y2 + pf_x1 + pf_x2;
+            if (i == 0 && j == 0) dg += Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
+            L.dgv[j] = dg;
+            L.tyv[j] = pf_y1;
+            if (j == NB - 1) L.tyv[NB] = pf_y2;
+            L.ev[j] = pf_x1;
+            q_cur = pf_q;
+        }
+        __syncthreads();
+        if (i > 0) {
+            if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
+            __syncthreads();
+            if (j < NB) L.ycur[j] = q_cur + L.ev[j] * matvec_total<NC>(L, j);
+            if (!service) {
+#pragma unroll
+                for (int s = 0; s < TPW; ++s) {
+                    const double ec = L.ev[16 * tC[s] + g.lc];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[s][r] = -(L.ev[16 * tR[s] + g.lq + 4 * r] * acc[s][r] * ec);
+                }
+            }
+        } else {
+            if (j < NB) L.ycur[j] = q_cur;
+#pragma unroll
+            for (int s = 0; s < TPW; ++s) acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+        if (j < NB && i + 1 < Nx) {  // next block's vectors
+            const int in = i + 1;
+            pf_y1 = TY[in * (NB + 1) + j]; pf_y2 = TY[in * (NB + 1) + j + 1];
+            pf_x1 = TX[in * NB + j]; pf_x2 = TX[(in + 1) * NB + j];
+            pf_q = q[in * NB + j];
+        }
+        __syncthreads();  // the mat-vec scratch (aliases U, W) is free again
+        if (!service) {
+            // add the tridiagonal D_i (diagonal tiles, and the corner entry of the sub-diagonal tiles), then hand over
+            // panel 0: column 0 and the first diagonal tile
+#pragma unroll
+            for (int s = 0; s < TPW; ++s) {
+                const int R = tR[s], C = tC[s];
+                if (R == C) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int lrow = g.lq + 4 * r, row = 16 * R + lrow, col = 16 * C + g.lc;
+                        double add = 0.0;
+                        if (g.lc == lrow) add = L.dgv[row];
+                        else if (g.lc == lrow + 1) add = -L.tyv[col];
+                        else if (lrow == g.lc + 1) add = -L.tyv[row];
+                        acc[s][r] += add;
+                    }
+                } else if (R == C + 1) {  // entry (16R, 16C+15): row == col + 1
+                    if (g.lane == 15) acc[s][0] -= L.tyv[16 * R];
+                }
+                if (C == 0) publish_tile(s, 0, L.U[cur], 8 * i + 1);
+            }
+        } else if (sweeper) {
+            sweep_published(8 * i + 1);
+        }
+        __syncthreads();  // U_0, P_0 visible
+        for (int Cp = 0; Cp < 8; ++Cp) {
+            double (*U)[17] = L.U[cur];
+            double (*Un)[17] = L.U[cur ^ 1];
+            const int Cn = Cp + 1, token = 8 * i + Cn + 1;
+            if (!service) {
+                // ---- phase B: the swept tile column / tile row
+#pragma unroll
+                for (int s = 0; s < TPW; ++s) {
+                    const int R = tR[s], C = tC[s];
+                    if (C == Cp) {
+                        if (R == Cp) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[s][r] = -L.P[g.lq + 4 * r][g.lc];
+                        } else {
+                            d4 wv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk)
+                                wv = __builtin_amdgcn_mfma_f64_16x16x4f64(U[16 * R + g.lc][4 * kk + g.lq], L.P[4 * kk + g.lq][g.lc], wv, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) L.W[16 * R + g.lq + 4 * r][g.lc] = wv[r];
+                            acc[s] = wv;
+                        }
+                    } else if (R == Cp) {  // C < Cp: W_C^T = P U_C^T
+                        d4 wv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            wv = __builtin_amdgcn_mfma_f64_16x16x4f64(L.P[g.lc][4 * kk + g.lq], U[16 * C + g.lc][4 * kk + g.lq], wv, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) L.W[16 * C + g.lc][g.lq + 4 * r] = wv[r];
+                        acc[s] = wv;
+                    }
+                }
+            }
+            __syncthreads();  // W visible; P_p and Dg free
+            if (!service) {
+                // ---- phase C, pass 1: tiles of the NEXT pivot column/row first, handed over at once
+                if (Cn < 8) {
+#pragma unroll
+                    for (int s = 0; s < TPW; ++s) {
+                        const int R = tR[s], C = tC[s];
+                        if (R == Cn || C == Cn) {
+                            if (C != Cp) update_tile(s, Cp, U);
+                            publish_tile(s, Cn, Un, token);
+                        }
+                    }
+                }
+                // ---- pass 2: the rest
+#pragma unroll
+                for (int s = 0; s < TPW; ++s) {
+                    const int R = tR[s], C = tC[s];
+                    if (R == Cp || C == Cp || R == Cn || C == Cn) continue;
+                    update_tile(s, Cp, U);
+                }
+            } else if (sweeper && Cn < 8) {
+                sweep_published(token);
+            }
+            __syncthreads();  // U_{p+1}, P_{p+1} visible; W free
+            cur ^= 1;
+        }
+        // G_i = -A: keep in the accumulators for the next block, stream the 36 tiles to HBM (thread-major 16-byte chunks)
+        if (!service) {
+            double2* Gi = G + (long long)i * (NB * NB / 2);
+#pragma unroll
+            for (int s = 0; s < TPW; ++s) {
+                acc[s] = -acc[s];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double2 v;
+                    v.x = acc[s][2 * h];
+                    v.y = acc[s][2 * h + 1];
+                    Gi[(s * 2 + h) * NCT + ct] = v;
+                }
+            }
+        }
+        if (j < NB) {
+            yv[i * NB + j] = L.ycur[j];
+            L.yprev[j] = L.ycur[j];
+        }
+        __syncthreads();
+    }
+    // back substitution: x_i = G_i (y_i + TX[i+1] * x_{i+1});  ycur holds x_{i+1};  G_{Nx-1} is still in the accumulators
+    for (int i = Nx - 1; i >= 0; --i) {
+        if (!service && i < Nx - 1) {
+            const double2* Gi = G + (long long)i * (NB * NB / 2);
+#pragma unroll
+            for (int s = 0; s < TPW; ++s)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double2 v = Gi[(s * 2 + h) * NCT + ct];
+                    acc[s][2 * h] = v.x;
+                    acc[s][2 * h + 1] = v.y;
+                }
+        }
+        if (j < NB) {
+            double v = yv[i * NB + j];
+            if (i < Nx - 1) v += TX[(i + 1) * NB + j] * L.ycur[j];
+            L.yprev[j] = v;
+        }
+        __syncthreads();
+        if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
+        __syncthreads();
+        if (j < NB) {
+            const double t = matvec_total<NC>(L, j);
+            L.ycur[j] = t;
+            P[i * NB + j] = t;
+        }
+        __syncthreads();
+    }
+    face_fluxes(p, P, TX, TY, Vx, Vy, tid, NT);
+    if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
+}
+
+}  // namespace
+
+// Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
+int launch_pressure_128s(hm_fwd* f, const void* S, long long S_stride, int k) {
+    const FwdParams& p = f->p;
+    if (p.Ny != NB) return -1;
+    hipStream_t s = f->ctx->stream;
+#define LAUNCH(TS, NW) hipLaunchKernelGGL((k_press128s<TS, NW>), dim3(p.N), dim3(64 * NW), 0, s, p, (const TS*)S, S_stride, k)
+    if (f->dtype == 64) {
+        if (f->press_variant == 7) LAUNCH(double, 16);
+        else LAUNCH(double, 8);
+    } else {
+        if (f->press_variant == 7) LAUNCH(float, 16);
+        else LAUNCH(float, 8);
+    }
+#undef LAUNCH
+    HM_HIP(hipGetLastError());
+    return 0;
+}
