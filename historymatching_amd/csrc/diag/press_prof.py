@@ -23,6 +23,21 @@ plan.set_inputs(perms, None, transformed=False)
 plan.run(0, 4)
 st = plan.sync()
 lib = _lib.load()
+if variant not in (3, 4, 5, 8):  # press128s: compute wave 1 and the sweeper
+    buf = (C.c_longlong * 32)()
+    lib.hm_debug_press_prof_s.argtypes = [C.POINTER(C.c_longlong)]
+    assert lib.hm_debug_press_prof_s(buf) == 0
+    names = ["B: W tiles", "barrier Y", "C pass 1 (next column, publish)", "C pass 2", "barrier X", "assembly", "vectors -> LDS + barrier",
+             "mat-vec + scale", "D add + publish 0", "barrier (sweep 0)", "G store + barrier", "back substitution", "face fluxes",
+             "sweeper: wait for tile", "sweeper: sweep", "-"]
+    print(f"pressure launch avg {st['ms_pressure'] / st['n_pressure_launches']:.2f} ms for {n_e} members")
+    for who, off in (("compute wave 1", 0), ("sweeper (wave 0)", 16)):
+        v = np.array(buf[off:off + 16], dtype=np.float64)
+        print(f" {who}: total {v.sum():.0f} cycles")
+        for n, x in zip(names, v):
+            if x:
+                print(f"   {n:34s} {x:12.0f} cycles  {100 * x / v.sum():5.1f} %   per panel {x / 1024:7.0f}")
+    sys.exit(0)
 buf = (C.c_longlong * 16)()
 lib.hm_debug_press_prof.argtypes = [C.POINTER(C.c_longlong)]
 assert lib.hm_debug_press_prof(buf) == 0

@@ -25,6 +25,16 @@
 #include "fwd_dev.h"
 #include "sweep16.h"
 
+#ifdef HM_PRESS_PROF
+// Cycle stamps of workgroup 0: lane 0 of compute wave 1 (slots 0..15) and of the sweeper (slots 16..31).
+__device__ long long hm_press_prof_s_buf[32];
+#define PROF_DECL long long prof_t = clock64(), prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(i) do { const long long now_ = clock64(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
+#else
+#define PROF_DECL
+#define PROF(i)
+#endif
+
 namespace {
 
 constexpr int NB = 128;
@@ -71,6 +81,14 @@ struct SGeo {
     int lane, lc, lq;
 };
 
+// The tile coordinates of a slot are wave-uniform run-time values; left alone, the compiler hoists every LDS address
+// derived from them out of the block/panel loops (dozens of VGPRs per slot) and spills.  Passing them through an
+// empty asm at the point of use keeps the address arithmetic (a few scalar/vector ops) inside the loops.
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
     // lanes of ONE wave exchange data through LDS: the hardware keeps a wave's LDS operations in order, the compiler
     // must be told not to move the loads above the other lanes' stores
@@ -93,7 +111,7 @@ __device__ __forceinline__ void matvec_partial(const d4 (&acc)[TPW], const int (
     wave_lds_fence();
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
-        const int R = tR[s], C = tC[s];
+        const int R = opaque(tR[s]), C = opaque(tC[s]);
         double sc = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc = fma(acc[s][r], v[16 * R + g.lq + 4 * r], sc);
@@ -161,9 +179,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
         tC[s] = __builtin_amdgcn_readfirstlane(e & 15);
     }
 
+    PROF_DECL;
     assemble_transmissibilities<TS>(p, S, Km, P /* scratch for L */, TX, TY, tid, NT);
     if (tid == 0) L.flag = 0;
     __syncthreads();  // TX/TY entries written by other threads are read below
+    PROF(5);
 
     d4 acc[TPW];
     int bad = 0, cur = 0;
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
 
     // ---- one rank-16 panel --------------------------------------------------------------------------------------
     auto update_tile = [&](int s, int Cp, double (*U)[17]) {
-        const int R = tR[s], C = tC[s];
+        const int R = opaque(tR[s]), C = opaque(tC[s]);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
             acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-L.W[16 * R + g.lc][4 * kk + g.lq], U[16 * C + g.lc][4 * kk + g.lq], acc[s], 0, 0, 0);
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
     // hand tile s over as part of pivot column Cn: natural rows for a column tile, transposed for a row tile, the
     // diagonal tile to the sweeper (released by the flag)
     auto publish_tile = [&](int s, int Cn, double (*Un)[17], int token) {
-        const int R = tR[s], C = tC[s];
+        const int R = opaque(tR[s]), C = opaque(tC[s]);
         if (R == Cn && C == Cn) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) L.Dg[g.lq + 4 * r][g.lc] = acc[s][r];
@@ -199,12 +219,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
     };
     auto sweep_published = [&](int token) {
         while (__hip_atomic_load(&L.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token) __builtin_amdgcn_s_sleep(1);
+        PROF(13);
         d4 t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = L.Dg[g.lq + 4 * r][g.lc];
         sweep16_inwave(t, g, bad);
 #pragma unroll
         for (int r = 0; r < 4; ++r) L.P[g.lq + 4 * r][g.lc] = -t[r];  // t = -inv(tile)
+        PROF(14);
     };
 
     for (int i = 0; i < Nx; ++i) {
@@ -218,6 +240,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
             q_cur = pf_q;
         }
         __syncthreads();
+        PROF(6);
         if (i > 0) {
             if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
             __syncthreads();
@@ -225,9 +248,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
             if (!service) {
 #pragma unroll
                 for (int s = 0; s < TPW; ++s) {
-                    const double ec = L.ev[16 * tC[s] + g.lc];
+                    const int R = opaque(tR[s]), C = opaque(tC[s]);
+                    const double ec = L.ev[16 * C + g.lc];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[s][r] = -(L.ev[16 * tR[s] + g.lq + 4 * r] * acc[s][r] * ec);
+                    for (int r = 0; r < 4; ++r) acc[s][r] = -(L.ev[16 * R + g.lq + 4 * r] * acc[s][r] * ec);
                 }
             }
         } else {
@@ -242,12 +266,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
             pf_q = q[in * NB + j];
         }
         __syncthreads();  // the mat-vec scratch (aliases U, W) is free again
+        PROF(7);
         if (!service) {
             // add the tridiagonal D_i (diagonal tiles, and the corner entry of the sub-diagonal tiles), then hand over
             // panel 0: column 0 and the first diagonal tile
 #pragma unroll
             for (int s = 0; s < TPW; ++s) {
-                const int R = tR[s], C = tC[s];
+                const int R = opaque(tR[s]), C = opaque(tC[s]);
                 if (R == C) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -266,7 +291,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
         } else if (sweeper) {
             sweep_published(8 * i + 1);
         }
+        PROF(8);
         __syncthreads();  // U_0, P_0 visible
+        PROF(9);
         for (int Cp = 0; Cp < 8; ++Cp) {
             double (*U)[17] = L.U[cur];
             double (*Un)[17] = L.U[cur ^ 1];
@@ -275,7 +302,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
                 // ---- phase B: the swept tile column / tile row
 #pragma unroll
                 for (int s = 0; s < TPW; ++s) {
-                    const int R = tR[s], C = tC[s];
+                    const int R = opaque(tR[s]), C = opaque(tC[s]);
                     if (C == Cp) {
                         if (R == Cp) {
 #pragma unroll
@@ -300,7 +327,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
                     }
                 }
             }
+            PROF(0);
             __syncthreads();  // W visible; P_p and Dg free
+            PROF(1);
             if (!service) {
                 // ---- phase C, pass 1: tiles of the NEXT pivot column/row first, handed over at once
                 if (Cn < 8) {
@@ -313,6 +342,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
                         }
                     }
                 }
+                PROF(2);
                 // ---- pass 2: the rest
 #pragma unroll
                 for (int s = 0; s < TPW; ++s) {
@@ -323,7 +353,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
             } else if (sweeper && Cn < 8) {
                 sweep_published(token);
             }
+            PROF(3);
             __syncthreads();  // U_{p+1}, P_{p+1} visible; W free
+            PROF(4);
             cur ^= 1;
         }
         // G_i = -A: keep in the accumulators for the next block, stream the 36 tiles to HBM (thread-major 16-byte chunks)
@@ -346,6 +378,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
             L.yprev[j] = L.ycur[j];
         }
         __syncthreads();
+        PROF(10);
     }
     // back substitution: x_i = G_i (y_i + TX[i+1] * x_{i+1});  ycur holds x_{i+1};  G_{Nx-1} is still in the accumulators
     for (int i = Nx - 1; i >= 0; --i) {
@@ -375,11 +408,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
         }
         __syncthreads();
     }
+    PROF(11);
     face_fluxes(p, P, TX, TY, Vx, Vy, tid, NT);
+    PROF(12);
+#ifdef HM_PRESS_PROF
+    if (m == 0 && g.lane == 0 && (w == 0 || w == 1))
+        for (int q_ = 0; q_ < 16; ++q_) hm_press_prof_s_buf[16 * (1 - w) + q_] = prof_acc[q_];
+#endif
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
 }  // namespace
+
+#ifdef HM_PRESS_PROF
+extern "C" int hm_debug_press_prof_s(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hm_press_prof_s_buf), sizeof(long long) * 32);
+}
+#endif
 
 // Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
 int launch_pressure_128s(hm_fwd* f, const void* S, long long S_stride, int k) {
