@@ -30,6 +30,7 @@ class hm_stats(C.Structure):
         ("n_pressure_launches", C.c_longlong),
         ("n_saturation_launches", C.c_longlong),
         ("member_steps", C.c_longlong),
+        ("mean_n_cg", C.c_double),
     ]
 
     def asdict(self):
@@ -60,6 +61,7 @@ SIGNATURES = {
     "hm_fwd_sync": (C.c_int, [_vp, C.POINTER(hm_stats)]),
     "hm_fwd_get_outputs": (C.c_int, [_vp, _vp, _vp, _ip]),
     "hm_fwd_set_variant": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "hm_fwd_set_solver": (C.c_int, [_vp, C.c_double, C.c_int]),
     "hm_fwd_pressure_only": (C.c_int, [_vp, C.c_int]),
     "hm_fwd_saturation_only": (C.c_int, [_vp, C.c_int]),
     "hm_fwd_get_field": (C.c_int, [_vp, C.c_char_p, _vp]),

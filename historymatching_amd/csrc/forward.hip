@@ -339,7 +339,7 @@ extern "C" int hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, doub
                              hm_fwd** out) {
     HM_REQUIRE(ctx && out, "hm_fwd_create: NULL argument");
     HM_REQUIRE(N >= 1 && Nx >= 2 && Ny >= 2, "hm_fwd_create: need N>=1, Nx>=2, Ny>=2 (got %d,%d,%d)", N, Nx, Ny);
-    HM_REQUIRE(Ny <= 128, "hm_fwd_create: Ny=%d > 128 is not supported yet (one workgroup per member)", Ny);
+    HM_REQUIRE(Ny <= 4096 && Nx <= 4096, "hm_fwd_create: grid %dx%d too large (max 4096 per axis)", Nx, Ny);
     HM_REQUIRE(dtype == 64 || dtype == 32, "hm_fwd_create: dtype must be 64 or 32");
     HM_REQUIRE(nTime >= 1 && dt > 0, "hm_fwd_create: need nTime>=1, dt>0");
     HM_REQUIRE(nInj >= 1 && nPrd >= 1, "hm_fwd_create: need at least one injector and one producer");
@@ -369,7 +369,11 @@ extern "C" int hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, doub
     ALLOC(well_cells, (size_t)(nInj + nPrd) * 4);
     ALLOC(TX, n * (Nx + 1) * Ny * 8);
     ALLOC(TY, n * Nx * (Ny + 1) * 8);
-    ALLOC(G, n * Nxy * Ny * 8);
+    const bool direct = Ny <= 128;  // block elimination with explicit inverse Schur complements; else CG
+    if (direct) ALLOC(G, n * Nxy * Ny * 8);
+    ALLOC(cg_r, direct ? 8 : n * Nxy * 8);
+    ALLOC(cg_p, direct ? 8 : n * Nxy * 8);
+    ALLOC(n_cg, n * nTime * 4);
     ALLOC(yv, n * Nxy * 8);
     ALLOC(P, n * Nxy * 8);
     ALLOC(Vx, n * (Nx + 1) * Ny * 8);
@@ -385,6 +389,9 @@ extern "C" int hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, doub
     p.TX = (double*)f->TX.p; p.TY = (double*)f->TY.p; p.G = (double*)f->G.p; p.yv = (double*)f->yv.p;
     p.P = (double*)f->P.p; p.Vx = (double*)f->Vx.p; p.Vy = (double*)f->Vy.p;
     p.status = (int*)f->status.p; p.nts = (int*)f->nts.p;
+    p.cg_r = (double*)f->cg_r.p; p.cg_p = (double*)f->cg_p.p; p.n_cg = (int*)f->n_cg.p;
+    p.cg_rtol = 1e-12; p.cg_max_iter = 40 * (Nx > Ny ? Nx : Ny) + 1000;
+    f->cg_lazy = direct;
     p.por = porosity ? (double*)f->por.p : nullptr;
     p.coef = nullptr; p.fw = nullptr;
     hipStream_t s = ctx->stream;
@@ -394,6 +401,8 @@ extern "C" int hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, doub
     if (porosity) HM_HIP(hipMemcpyAsync(f->por.p, porosity, Nxy * 8, hipMemcpyHostToDevice, s));
     HM_HIP(hipMemsetAsync(f->status.p, 0, n * 4, s));
     HM_HIP(hipMemsetAsync(f->nts.p, 0, n * nTime * 4, s));
+    HM_HIP(hipMemsetAsync(f->n_cg.p, 0, n * nTime * 4, s));
+    HM_HIP(hipMemsetAsync(f->P.p, 0, f->P.bytes, s));  // CG warm start of the first step
     HM_HIP(hipMemsetAsync(f->Vx.p, 0, f->Vx.bytes, s));
     HM_HIP(hipMemsetAsync(f->Vy.p, 0, f->Vy.bytes, s));
     HM_HIP(hipStreamSynchronize(s));
@@ -406,10 +415,18 @@ extern "C" void hm_fwd_destroy(hm_fwd* f) {
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
     DevBuf* bufs[] = {&f->K, &f->por, &f->q, &f->prd_ind, &f->TX, &f->TY, &f->G, &f->yv, &f->P, &f->Vx,
-                      &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells};
+                      &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells, &f->cg_r, &f->cg_p, &f->n_cg};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     f->t_total.destroy(); f->t_press.destroy(); f->t_sat.destroy();
     delete f;
+}
+
+extern "C" int hm_fwd_set_solver(hm_fwd* f, double rtol, int max_iter) {
+    HM_REQUIRE(f, "hm_fwd_set_solver: NULL plan");
+    HM_REQUIRE(rtol > 0 && rtol < 1 && max_iter >= 1, "hm_fwd_set_solver: need 0 < rtol < 1, max_iter >= 1");
+    f->p.cg_rtol = rtol;
+    f->p.cg_max_iter = max_iter;
+    return 0;
 }
 
 extern "C" int hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant) {
@@ -481,7 +498,17 @@ static int launch_pressure(hm_fwd* f, int k) {
     // press_variant: 1 generic, 2 press128 (VALU rank-1), 3/4/5/8 press128m (full tiles: 8w rank-4, 16w rank-4,
     // 16w rank-16, 8w rank-16 x 2 workgroups/CU), 6/7 and every other value press128s (symmetric tiles, 8/16 waves)
     const int pv = f->press_variant;
-    if (pv == 2) done = launch_pressure_128(f, S, stride, k);
+    if (pv == 9 || p.Ny > 128) {
+        if (f->cg_lazy) {  // CG requested on a small grid: the work vectors were not allocated at creation
+            hm_dev_free(f->cg_r); hm_dev_free(f->cg_p);
+            int rc2 = hm_dev_alloc(f->cg_r, (size_t)p.N * p.Nxy * 8);
+            if (!rc2) rc2 = hm_dev_alloc(f->cg_p, (size_t)p.N * p.Nxy * 8);
+            if (rc2) return rc2;
+            f->p.cg_r = (double*)f->cg_r.p; f->p.cg_p = (double*)f->cg_p.p;
+            f->cg_lazy = false;
+        }
+        done = launch_pressure_pcg(f, S, stride, k);
+    } else if (pv == 2) done = launch_pressure_128(f, S, stride, k);
     else if (pv == 3 || pv == 4 || pv == 5 || pv == 8) done = launch_pressure_128m(f, S, stride, k);
     else if (pv != 1) done = launch_pressure_128s(f, S, stride, k);
     if (done > 0) return done;
@@ -575,6 +602,10 @@ extern "C" int hm_fwd_sync(hm_fwd* f, hm_stats* st) {
         double sum = 0; long long cnt = 0;
         for (int v : nts) if (v > 0) { sum += v; ++cnt; }
         st->mean_nts = cnt ? sum / cnt : 0.0;
+        HM_HIP(hipMemcpy(nts.data(), f->n_cg.p, nts.size() * 4, hipMemcpyDeviceToHost));
+        sum = 0; cnt = 0;
+        for (int v : nts) if (v > 0) { sum += v; ++cnt; }
+        st->mean_n_cg = cnt ? sum / cnt : 0.0;
     }
     f->t_total.reset(); f->t_press.reset(); f->t_sat.reset();
     f->n_press = f->n_sat = 0;

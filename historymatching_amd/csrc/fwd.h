@@ -32,6 +32,12 @@ struct FwdParams {
     void* fw;                 // N*Nxy
     int* status;              // N
     int* nts;                 // N*nTime
+    // conjugate-gradient pressure solver (grids with Ny > 128, or press_variant 9)
+    double* cg_r;             // N*Nxy residual
+    double* cg_p;             // N*Nxy search direction   (A p lives in yv, the iterate in P)
+    int* n_cg;                // N*nTime iterations used
+    double cg_rtol;           // stop at ||r|| <= rtol ||q||
+    int cg_max_iter;
 };
 
 struct hm_fwd {
@@ -40,8 +46,9 @@ struct hm_fwd {
     int dtype = 64;
     int keep_history = 0;
     int press_variant = 0, sat_variant = 0;
+    bool cg_lazy = true;  // CG work vectors not allocated yet
     size_t esz = 8;  // bytes per saturation element
-    DevBuf K, por, q, prd_ind, TX, TY, G, yv, P, Vx, Vy, coef, fw, status, nts, perm_in;
+    DevBuf K, por, q, prd_ind, TX, TY, G, yv, P, Vx, Vy, coef, fw, status, nts, perm_in, cg_r, cg_p, n_cg;
     DevBuf S;      // keep_history ? N*(nTime+1)*Nxy : 2*N*Nxy (ping-pong)
     DevBuf prods;  // N*nTime*nPrd
     int cur = 0;   // time index whose saturation is "current" (row in history / ping-pong parity)
@@ -69,4 +76,5 @@ static inline void* fwd_S_ptr(hm_fwd* f, int k, long long* stride) {
 int launch_pressure_128(hm_fwd* f, const void* S, long long S_stride, int k);   // VALU rank-1 sweeps (variant 2)
 int launch_pressure_128m(hm_fwd* f, const void* S, long long S_stride, int k);  // MFMA panels, full tile storage
 int launch_pressure_128s(hm_fwd* f, const void* S, long long S_stride, int k);  // MFMA panels, symmetric tile storage (default)
+int launch_pressure_pcg(hm_fwd* f, const void* S, long long S_stride, int k);   // CG, any grid (press_pcg.hip)
 int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);

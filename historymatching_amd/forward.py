@@ -67,6 +67,12 @@ class ForwardPlan:
         """0 = fastest applicable kernel, 1 = generic kernels (the in-library correctness baseline)."""
         _lib.check(self.lib.hm_fwd_set_variant(self.h, int(pressure), int(saturation)), "hm_fwd_set_variant")
 
+    def set_solver(self, rtol=1e-12, max_iter=None):
+        """Conjugate-gradient pressure solver (always used when Ny > 128; pressure variant 9 elsewhere)."""
+        if max_iter is None:
+            max_iter = 40 * max(self.model.Nx, self.model.Ny) + 1000
+        _lib.check(self.lib.hm_fwd_set_solver(self.h, float(rtol), int(max_iter)), "hm_fwd_set_solver")
+
     def run(self, first_step=0, n_steps=None):
         n = self.nTime - first_step if n_steps is None else n_steps
         _lib.check(self.lib.hm_fwd_run(self.h, int(first_step), int(n)), "hm_fwd_run")

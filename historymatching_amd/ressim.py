@@ -153,7 +153,8 @@ class ResSim:
         if status.any():
             bad = np.flatnonzero(status)
             raise _lib.HmError(f"forward model failed for members {bad[:8].tolist()} (status {status[bad[:8]].tolist()}): "
-                               "1=non-positive pivot in pressure solve, 2=bad CFL, 4=non-finite saturation")
+                               "1=non-positive pivot in pressure solve, 2=bad CFL, 4=non-finite saturation, "
+                               "8=CG pressure solver did not converge")
         self.last_stats = stats.asdict()
         cols = lambda r: np.broadcast_to(r, (r.shape[0], nTime)).copy()  # noqa: E731
         self.actual_rates = dict(inj=cols(inj), prd=cols(prd))  # Optimise.py:175-176

@@ -33,6 +33,7 @@ typedef struct hm_stats {
     long long n_pressure_launches;
     long long n_saturation_launches;
     long long member_steps; /* N * nTime processed                                              */
+    double mean_n_cg;       /* mean CG iterations per member-step (0 when the direct solver ran)   */
 } hm_stats;
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -72,6 +73,7 @@ int hm_forward_batched(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,
 #define HM_MEMBER_BAD_PIVOT     1   /* non-positive pivot in the pressure factorisation (K<=0, NaN) */
 #define HM_MEMBER_BAD_CFL       2   /* CFL sub-step count not finite / out of range               */
 #define HM_MEMBER_NONFINITE     4   /* NaN/Inf in the saturation                                    */
+#define HM_MEMBER_NO_CONVERGENCE 8  /* CG pressure solver hit max_iter before ||r|| <= rtol ||q||   */
 
 /* Device-resident form of the same path (what bench.py times; what ES-MDA/IES drivers chain). */
 int  hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,
@@ -84,7 +86,10 @@ int  hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transformed, con
 int  hm_fwd_run(hm_fwd* f, int first_step, int n_steps);           /* async; steps [first, first+n)  */
 int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
 int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member);     /* D2H */
-int  hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant); /* 0=fastest, 1=generic, 2=VALU-register pressure */
+int  hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant); /* 0=fastest, 1=generic, 2=VALU-register pressure, 9=CG pressure */
+/* Conjugate-gradient pressure solver (always used when Ny > 128): relative residual target and iteration cap
+ * (defaults 1e-12 and 40*max(Nx,Ny)+1000). */
+int  hm_fwd_set_solver(hm_fwd* f, double rtol, int max_iter);
 /* Component hooks used by the parity tests (each maps to one listing of the cited paper):
  * run ONLY the pressure step / ONLY the saturation step of time index k on device state, and read
  * intermediate fields back. */

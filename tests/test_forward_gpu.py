@@ -70,7 +70,8 @@ def test_perm_transform_on_device():
     assert np.max(np.abs(K - ref) / ref) < 4e-16
 
 
-@pytest.mark.parametrize("n,variant", [(20, 1), (20, 0), (128, 1), (128, 2), (128, 3), (128, 4), (128, 5), (128, 7), (128, 8), (128, 0)])
+@pytest.mark.parametrize("n,variant", [(20, 1), (20, 0), (20, 9), (128, 1), (128, 2), (128, 3), (128, 4), (128, 5), (128, 7), (128, 8), (128, 9), (128, 0),
+                                       (160, 0), (256, 0)])
 def test_assembly_bitexact_and_pressure_within_solver_noise(n, variant):
     from oracle.ressim import perm_transf
     from scipy.sparse.linalg import spsolve
@@ -221,7 +222,7 @@ def test_unbalanced_rates_raise():
         gm.sim(DT, 2, np.zeros(400))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7, 8, 0])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7, 8, 9, 0])
 def test_full_sim_128_within_reference_solver_noise(variant):
     """C2-shaped members (128x128): S after a few steps agrees with the oracle to within the spread the
     oracle itself shows when SuperLU's column ordering is changed (the reference's own numerical noise)."""
@@ -240,6 +241,43 @@ def test_full_sim_128_within_reference_solver_noise(variant):
         err = np.abs(w[m] - ref).max()
         assert err <= 10 * noise + 1e-9, (err, noise)
         assert err < 1e-4
+    plan.close()
+
+
+@pytest.mark.parametrize("nx,ny", [(160, 160), (96, 192), (256, 256)])
+def test_large_grid_sim_cg_pressure(nx, ny):
+    """Ny > 128 (BASELINE configs 4/5 are 256x256 and 512x512): the direct block solver does not apply, the
+    pressure system is solved by conjugate gradients (press_pcg.hip); the saturation sweep is the generic kernel.
+    Same acceptance as the 128x128 case: within the oracle's own solver noise."""
+    N, steps = 2, 2
+    om, gm = make_models(nx, ny)
+    x = perms(nx, ny, N, seed=23)
+    plan = _plan(gm, N, nTime=steps)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    st = plan.sync()
+    w, p, status = plan.outputs()
+    assert not status.any()
+    assert 0 < st["mean_n_cg"] < 40 * max(nx, ny) + 1000
+    for m in range(N):
+        ref, noise = oracle_sim_and_noise(om, x[m], DT, steps)
+        err = np.abs(w[m] - ref).max()
+        assert err <= 10 * noise + 1e-9, (err, noise)
+        assert err < 1e-4
+        assert np.array_equal(p[m], w[m][1:, om.xy2ind(*om.prd_xy.T)])  # obs_model gather, HistoryMatch.py:212-213
+    plan.close()
+
+
+def test_cg_solver_reports_non_convergence():
+    n, N = 160, 2
+    om, gm = make_models(n, n)
+    plan = _plan(gm, N, nTime=1)
+    plan.set_solver(rtol=1e-12, max_iter=5)
+    plan.set_inputs(perms(n, n, N, seed=5), transformed=False)
+    plan.run()
+    plan.sync()
+    _, _, status = plan.outputs(want_wsats=False)
+    assert (status & 8).all()  # HM_MEMBER_NO_CONVERGENCE
     plan.close()
 
 
