@@ -140,8 +140,9 @@ def main():
         prs_ms = stats["ms_pressure"] / max(1, stats["n_pressure_launches"])
         # algorithmic bytes per member-step: saturation = read S,Vx,Vy + write S per explicit
         # sub-step; pressure = compulsory (K,S in; P out) + factor write + factor read of the direct block solver
+        # (the symmetric factor: 36 of the 64 16x16 tiles of every 128x128 inverse Schur complement)
         sat_bytes = w * nxy * 4 * nts * n_e
-        prs_bytes = w * nxy * (4 + 2 * NY) * n_e
+        prs_bytes = w * nxy * (4 + 2 * NY * 36 / 64) * n_e
         dominant = "saturation" if stats["ms_saturation"] >= stats["ms_pressure"] else "pressure"
         ach = (sat_bytes / (sat_ms * 1e-3) if dominant == "saturation" else prs_bytes / (prs_ms * 1e-3)) / 1e9
         # measured HBM traffic of the same kernel: PMC passes are taken separately under rocprofv3 (profiles/),
@@ -150,7 +151,7 @@ def main():
         try:
             pmc_file = sorted((ROOT / "profiles").glob("r*/pmc_hbm_traffic.json"))[-1]
             pmc = json.loads(pmc_file.read_text())
-            key = {"saturation": "sat128", "pressure": "press128m"}[dominant]
+            key = {"saturation": "sat128", "pressure": "press128s"}[dominant]
             if args.variant == 0 and key in pmc["kernels"]:
                 traffic = pmc["kernels"][key]["hbm_bytes_per_member_corrected"] * n_e
                 traffic_src = str(pmc_file.relative_to(ROOT))

@@ -11,7 +11,7 @@ from collections import defaultdict
 from pathlib import Path
 
 out_dir, members = Path(sys.argv[1]), int(sys.argv[2])
-KEYS = {"k_perm_transform": "perm_transform", "k_press128m": "press128m", "k_press128<": "press128", "k_sat128": "sat128",
+KEYS = {"k_perm_transform": "perm_transform", "k_press128m": "press128m", "k_press128s": "press128s", "k_pressure_pcg": "pressure_pcg", "k_press128<": "press128", "k_sat128": "sat128",
         "k_pressure_generic": "pressure_generic", "k_saturation_generic": "saturation_generic"}
 
 
@@ -31,7 +31,7 @@ fetch, write = per_launch("FETCH_SIZE"), per_launch("WRITE_SIZE")
 kernels = {}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
-    wide = k in ("perm_transform", "press128m")
+    wide = k in ("perm_transform", "press128m", "press128s")
     kernels[k] = {
         "fetch_bytes_raw_per_launch": f, "write_bytes_per_launch": w,
         "hbm_bytes_per_member_corrected": ((2.0 * f if wide else f) + w) / members,
@@ -40,7 +40,7 @@ for k in sorted(set(fetch) | set(write)):
     }
 print(json.dumps({
     "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --members %d --steps 1; gfx950 "
-            "correction: FETCH_SIZE counts 1/2 of the bytes of wide coalesced reads (x2 applied to press128m and "
+            "correction: FETCH_SIZE counts 1/2 of the bytes of wide coalesced reads (x2 applied to press128s/press128m and "
             "perm_transform, 16 B/lane streams; calibration: k_perm_transform reads 131072 B per member); sat128 "
             "uncorrected (dword scratch reloads), x2 figure given as a bracket" % members,
     "members_per_launch": members, "kernels": kernels}, indent=1))
