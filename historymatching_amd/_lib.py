@@ -77,6 +77,8 @@ SIGNATURES = {
     "hm_upd_destroy": (None, [_vp]),
     "hm_upd_set_inputs": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double]),
     "hm_upd_phase": (C.c_int, [_vp, C.c_int]),
+    "hm_upd_run": (C.c_int, [_vp]),
+    "hm_debug_spd_inverse": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp]),
     "hm_upd_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "hm_upd_reduce_buffer": (_vp, [_vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "hm_upd_sync": (C.c_int, [_vp, C.POINTER(hm_stats)]),

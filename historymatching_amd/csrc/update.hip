@@ -38,6 +38,8 @@ struct hm_upd {
     DevBuf Y, D0, S, D, T1, decorr64, S_T, A_T, Cinv, Wt, Bt, partial, gpart, flags;
     int use_mfma = 1;  // fp32 only: 0 forces the generic VALU GEMMs (tests compare both)
     EvTimer t_upd;
+    hipStream_t stream2 = nullptr;  // hm_upd_run: the small fp64 chain runs beside the big contraction
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -386,7 +388,18 @@ __global__ __launch_bounds__(1024) void k_invert_C_reg(const double* __restrict_
     if (bad) *flag = 1;
 }
 
-static int invert_C(hipStream_t s, const double* G, int n, double ridge, double* W, double* colbuf, int* flag) {
+int spd_inverse_mfma(hipStream_t s, const double* G, int n, double ridge, double* W, int* flag);  // spdinv.hip
+static int g_use_mfma_inverse = 1;
+
+// `blocked_ok`: the rank-16 matrix-core inverse (spdinv.hip) inverts the 16x16 pivot tiles explicitly, which costs a
+// factor ~cond(tile) of forward accuracy against the rank-1 sweeps (reference fixture, cond(C) = 1.7e4: 7e-14 absolute
+// on |C^-1| <= 0.023 -> 2e-8 on the updated ensemble instead of 1e-13).  Far inside the fp32 bar (1e-4), outside the
+// fp64 bar (1e-10): fp64 plans keep the rank-1 register sweeps.
+static int invert_C(hipStream_t s, const double* G, int n, double ridge, double* W, double* colbuf, int* flag, bool blocked_ok) {
+    if (g_use_mfma_inverse && blocked_ok) {
+        const int rc = spd_inverse_mfma(s, G, n, ridge, W, flag);
+        if (rc >= 0) return rc;
+    }
     const int ns = (n + 31) / 32;
 #define L(NS) case NS: hipLaunchKernelGGL(k_invert_C_reg<NS>, dim3(1), dim3(1024), 0, s, G, n, ridge, W, flag); break
     switch (ns) {
@@ -525,6 +538,9 @@ extern "C" void hm_upd_destroy(hm_upd* u) {
                       &u->Wt, &u->Bt, &u->partial, &u->gpart, &u->flags};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     u->t_upd.destroy();
+    if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
+    if (u->ev_join) (void)hipEventDestroy(u->ev_join);
+    if (u->stream2) (void)hipStreamDestroy(u->stream2);
     delete u;
 }
 
@@ -591,7 +607,7 @@ static int upd_phase(hm_upd* u, int phase) {
     } else if (phase == 2) {
         if (!u->localized) {
             if ((rc = invert_C(s, G, no, (double)(u->N_total - 1), (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no,
-                               (int*)u->flags.p))) return rc;
+                               (int*)u->flags.p, std::is_same<T, float>::value))) return rc;
             // T1 = D Cinv ;  E_out = E + T1 Gxt^T                          (HistoryMatch.py:586)
             const bool mm = std::is_same<T, float>::value && u->use_mfma && M % 4 == 0;
             hipLaunchKernelGGL(k_rows_matmul, dim3((nl + RB - 1) / RB), dim3(256), RB * no * sizeof(double), s, (const double*)D,
@@ -637,9 +653,77 @@ static int upd_phase(hm_upd* u, int phase) {
     return u->t_upd.end(s);
 }
 
+// All phases of a single-rank plan in one call.  fp32 matrix-core path, global analysis: the chain of small fp64
+// kernels (G = S^T S -> C^-1 -> D C^-1) runs on a second stream beside the big contraction Gxt = (E - c)^T S, and
+// the pass over E for the column means is dropped (first-member shift, see k_gxt_mfma).
+extern "C" int hm_upd_run(hm_upd* u) {
+    HM_REQUIRE(u, "hm_upd_run: NULL plan");
+    HM_REQUIRE(u->N_local == u->N_total, "hm_upd_run: plan is row-sharded (N_local %d != N_total %d): drive hm_upd_phase "
+               "with the reductions in between", u->N_local, u->N_total);
+    HM_HIP(hipSetDevice(u->ctx->device));
+    const bool fused = u->dtype == 32 && u->use_mfma && !u->localized && u->M % 4 == 0 && u->n_obs % 32 == 0 && u->n_obs <= 256;
+    if (!fused) {
+        for (int ph = 0; ph < 3; ++ph) {
+            int rc = u->dtype == 64 ? upd_phase<double>(u, ph) : upd_phase<float>(u, ph);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    if (!u->stream2) {
+        HM_HIP(hipStreamCreateWithFlags(&u->stream2, hipStreamNonBlocking));
+        HM_HIP(hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming));
+        HM_HIP(hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming));
+    }
+    hipStream_t s = u->ctx->stream, s2 = u->stream2;
+    const int nl = u->N_local, no = u->n_obs, M = u->M;
+    float* E = (float*)u->E.p; float* Eo = (float*)u->E_out.p;
+    double* sumY = (double*)u->red1.p;
+    float* Gxt = (float*)u->red2.p; double* G = (double*)u->red3.p;
+    double *S = (double*)u->S.p, *D = (double*)u->D.p, *T1 = (double*)u->T1.p;
+    float *S_T = (float*)u->S_T.p, *A_T = (float*)u->A_T.p;
+    int rc = u->t_upd.begin(s);
+    if (rc) return rc;
+    const double inv_n = 1.0 / (double)u->N_total;
+    {   // column sums of obs_ens, then S = Y decorr, D = D0 decorr
+        const int splits = std::min(64, std::max(1, nl / 16));
+        const int rps = (nl + splits - 1) / splits;
+        double* part2 = (double*)u->partial.p + (size_t)64 * M;
+        hipLaunchKernelGGL(k_colsum_partial<float>, dim3((no + 255) / 256, splits), dim3(256), 0, s, (const float*)u->obs_ens.p, nl, no, rps, part2);
+        hipLaunchKernelGGL(k_colsum_final<double>, dim3((no + 255) / 256), dim3(256), 0, s, (const double*)part2, splits, no, sumY);
+        hipLaunchKernelGGL(k_obs_products<float>, dim3((nl + RB - 1) / RB), dim3(256), 2 * RB * no * sizeof(double), s,
+                           (const float*)u->obs_ens.p, (const float*)u->perturbs.p, (const float*)u->obs.p, (const double*)sumY, inv_n,
+                           (const float*)u->decorr.p, nl, no, S, D, S_T);
+        HM_HIP(hipGetLastError());
+    }
+    HM_HIP(hipEventRecord(u->ev_fork, s));
+    HM_HIP(hipStreamWaitEvent(s2, u->ev_fork, 0));
+    // stream 2: G = S^T S, C^-1, T1 = D C^-1 (and its fp32 transpose A_T)
+    {
+        const int nparts = (nl + GRB - 1) / GRB;
+        hipLaunchKernelGGL(k_gram_partial, dim3(nparts), dim3(256), GRB * no * sizeof(double), s2, (const double*)S, nl, no, (double*)u->gpart.p);
+        hipLaunchKernelGGL(k_gram_reduce, dim3((no * no + 255) / 256), dim3(256), 0, s2, (const double*)u->gpart.p, nparts, no * no, G);
+        HM_HIP(hipGetLastError());
+        if ((rc = invert_C(s2, G, no, (double)(u->N_total - 1), (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p, true))) return rc;
+        hipLaunchKernelGGL(k_rows_matmul, dim3((nl + RB - 1) / RB), dim3(256), RB * no * sizeof(double), s2, (const double*)D,
+                           (const double*)u->Cinv.p, nl, no, T1, (float*)A_T);
+        HM_HIP(hipGetLastError());
+        HM_HIP(hipEventRecord(u->ev_join, s2));
+    }
+    // stream 1: the big contraction, then (after the join) the apply
+    if ((rc = mfma_gxt(s, nl, M, no, E, nullptr, inv_n, S_T, Gxt)) > 0) return rc;
+    HM_REQUIRE(rc == 0, "hm_upd_run: matrix-core kernel not applicable");
+    if ((rc = transpose_f2f(s, Gxt, (float*)u->Bt.p, M, no))) return rc;
+    HM_HIP(hipStreamWaitEvent(s, u->ev_join, 0));
+    rc = mfma_apply(s, nl, M, no, E, A_T, (const float*)u->Bt.p, Eo);
+    if (rc > 0) return rc;
+    HM_REQUIRE(rc == 0, "hm_upd_run: matrix-core apply kernel not applicable");
+    return u->t_upd.end(s);
+}
+
 extern "C" int hm_upd_set_option(hm_upd* u, const char* name, int value) {
     HM_REQUIRE(u && name, "hm_upd_set_option: NULL argument");
     if (std::string(name) == "use_mfma") { u->use_mfma = value; return 0; }
+    if (std::string(name) == "mfma_inverse") { g_use_mfma_inverse = value; return 0; }  // 0: rank-1 register sweeps
     hm_set_error("hm_upd_set_option: unknown option '%s'", name);
     return 2;
 }
@@ -760,7 +844,7 @@ static int es_update_host(hm_ctx* ctx, int N, int M, int n_obs, const void* E, c
     int rc = hm_upd_create(ctx, N, N, M, n_obs, dtype, localized, &u);
     if (rc) return rc;
     rc = hm_upd_set_inputs(u, E, obs_ens, obs, perturbs, decorr, taper, cutoff);
-    for (int ph = 0; ph < 3 && !rc; ++ph) rc = hm_upd_phase(u, ph);
+    if (!rc) rc = hm_upd_run(u);
     if (!rc) rc = hm_upd_sync(u, stats);
     if (!rc) rc = hm_upd_get_output(u, E_out);
     hm_upd_destroy(u);

@@ -39,12 +39,15 @@ __global__ __launch_bounds__(256) void k_gxt_mfma(int N, int M, int n_obs, const
                                                   const float* __restrict__ colsum, float inv_n,
                                                   const float* __restrict__ S, float* __restrict__ Gxt) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NJ*16 regs][64 lanes]
-    constexpr int UN = 4;
+    constexpr int UN = 4;  // k-pairs in flight per wave (operands come straight from global/L2; 8 measured slower)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i0 = blockIdx.x * 32;
     const int il = lane & 31, kh = lane >> 5;
     const int i = min(i0 + il, M - 1);
-    const float mean = colsum[i] * inv_n;
+    // any shift c_i leaves (E - c)^T S = X^T S unchanged when the columns of S sum to zero over ALL rows (S = centred
+    // obs * decorr); single-rank plans pass colsum = nullptr and shift by the first member instead of the exact mean
+    // (same conditioning, no extra pass over E)
+    const float mean = colsum ? colsum[i] * inv_n : E[i];
     f32x16 acc[NJ];
 #pragma unroll
     for (int t = 0; t < NJ; ++t)
@@ -119,16 +122,26 @@ __global__ __launch_bounds__(256) void k_apply_mfma(int N, int M, int n_obs, con
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const int npairs = (n_obs + 1) / 2;
 
-    for (int jp = 0; jp < npairs; ++jp) {
-        const int j = 2 * jp + kh;
-        const bool ok = j < n_obs;
-        const int jc = ok ? j : n_obs - 1;
-        const float a = ok ? At[(size_t)jc * N + n] : 0.0f;
-        const float* brow = Bs + jc * 128 + nl;
+    // the A operand comes straight from global memory (At is L2 resident): fetch UA k-pairs ahead of the MFMAs that
+    // consume them, otherwise every group of 4 MFMAs waits for one load round trip
+    constexpr int UA = 16;
+    for (int jp0 = 0; jp0 < npairs; jp0 += UA) {
+        float av[UA];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float b = ok ? brow[32 * t] : 0.0f;
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        for (int u = 0; u < UA; ++u) {
+            const int j = 2 * (jp0 + u) + kh;
+            av[u] = (j < n_obs) ? At[(size_t)j * N + n] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int j = 2 * (jp0 + u) + kh;
+            const bool ok = j < n_obs;
+            const float* brow = Bs + (ok ? j : 0) * 128 + nl;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float b = ok ? brow[32 * t] : 0.0f;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b, acc[t], 0, 0, 0);
+            }
         }
     }
     // C/D: col = lane&31 -> state element, rows -> member

@@ -147,9 +147,8 @@ class UpdatePlan:
         return self.lib.hm_upd_device_ptr(self.h, name.encode())
 
     def run_local(self):
-        """All three phases with no cross-rank reduction (N_local == N_total)."""
-        for k in range(3):
-            self.phase(k)
+        """All three phases with no cross-rank reduction (N_local == N_total), fused in the library (`hm_upd_run`)."""
+        _lib.check(self.lib.hm_upd_run(self.h), "hm_upd_run")
         return self.sync()
 
 

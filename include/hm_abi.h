@@ -133,7 +133,13 @@ int   hm_upd_create(hm_ctx* ctx, int N_total, int N_local, int M, int n_obs, int
 void  hm_upd_destroy(hm_upd* u);
 int   hm_upd_set_inputs(hm_upd* u, const void* E_local, const void* obs_ens_local, const void* obs,
                         const void* perturbs_local, const void* decorr, const void* taper /* or NULL */, double cutoff);
+/* Self-test hook: W = inv(G + ridge I) for one SPD matrix of order n (multiple of 16, <= 256) through the matrix-core
+ * inverse used for C = S^T S + (N-1) I (HistoryMatch.py:585-586).  Host buffers. */
+int   hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double ridge, double* W);
 int   hm_upd_phase(hm_upd* u, int phase);
+/* All three phases of a plan that holds every member (N_local == N_total), no reduction points: the small fp64 chain
+ * overlaps the big contraction on a second stream. */
+int   hm_upd_run(hm_upd* u);
 int   hm_upd_set_option(hm_upd* u, const char* name, int value);  /* "use_mfma": 1 (default) | 0 = generic fp32 GEMMs */
 void* hm_upd_reduce_buffer(hm_upd* u, int which /*0..3*/, long long* n_elems, int* elem_bytes); /* device pointer */
 int   hm_upd_sync(hm_upd* u, hm_stats* stats);

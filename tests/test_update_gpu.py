@@ -225,3 +225,28 @@ def test_fp32_matrix_core_path_matches_generic_and_oracle(N, M, n_obs, localized
     assert np.abs(outs[0] - ref).max() <= 1e-4 * inc
     assert np.abs(outs[1] - ref).max() <= 1e-4 * inc
     assert np.abs(outs[0].astype(np.float64) - outs[1]).max() <= 2e-5 * inc
+
+
+@pytest.mark.parametrize("n", [16, 48, 160, 256])
+def test_matrix_core_spd_inverse(n, golden):
+    """spdinv.hip (rank-16 panels on the fp64 matrix cores, the C^-1 of fp32 plans) against numpy on C = S^T S + (N-1) I:
+    random S, and at n = 160 the reference's own case (cond 1.7e4)."""
+    import ctypes as C
+
+    from historymatching_amd import _lib
+
+    ctx, lib = _lib.Context.get(0), _lib.load()
+    rng = np.random.RandomState(n)
+    cases = [(rng.randn(40, n), 39.0)]
+    if n == 160:
+        _, f3, _, kw = _hm(golden)
+        Y = kw["obs_ens"] - kw["obs_ens"].mean(0)
+        cases.append((Y @ kw["decorr"], float(Y.shape[0] - 1)))
+    for S, ridge in cases:
+        G = np.ascontiguousarray(S.T @ S)
+        W = np.empty_like(G)
+        dp = C.POINTER(C.c_double)
+        _lib.check(lib.hm_debug_spd_inverse(ctx.handle, n, G.ctypes.data_as(dp), ridge, W.ctypes.data_as(dp)), "hm_debug_spd_inverse")
+        ref = np.linalg.inv(G + ridge * np.eye(n))
+        assert np.abs(W - ref).max() <= 1e-9 * np.abs(ref).max()
+        assert np.array_equal(W, W.T)
