@@ -1,0 +1,118 @@
+// dgemm_mfma.hip -- small fp64 products of the ensemble-smoother update on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64): everything of size N x n_obs / n_obs x n_obs that stays fp64 in fp32 plans
+//   SD  = [Y; D0] decorr        (2N x n_obs) . (n_obs x n_obs)        HistoryMatch.py:582-584
+//   G   = S^T S                 split over row blocks, fixed-order reduction          :585
+//   T1  = D C^-1                (+ transposed fp32 copy = the A operand of the apply)  :586
+// One wave = one 32x32 tile of the result (2x2 MFMA tiles), operands straight from global memory (all of these
+// matrices are L2 resident), 4 k-steps of loads in flight ahead of their MFMAs.  ~50 MFLOP each: a few microseconds
+// instead of 40-55 us for the scalar row-block kernels they replace.
+// Operand maps: A operand lane l holds A[l&15][l>>4], B operand B[l>>4][l&15]; C/D: col = l&15, row = (l>>4) + 4g.
+#include "common.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// C_z (M x N) = op(A) B over k in [z*kchunk, min(K, (z+1)*kchunk));  op(A)[i][k] = TA ? A[k*lda + i] : A[i*lda + k]
+template <bool TA>
+__global__ __launch_bounds__(64) void k_dgemm_mfma(int M, int N, int K, const double* __restrict__ A, int lda,
+                                                   const double* __restrict__ B, int ldb, double* __restrict__ C, int ldc,
+                                                   int kchunk, float* __restrict__ C32, int rows32, float* __restrict__ C32T) {
+    const int l = threadIdx.x, lc = l & 15, lq = l >> 4;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, z = blockIdx.z;
+    const int kbeg = z * kchunk, kend = min(K, kbeg + kchunk);
+    d4 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = d4{0.0, 0.0, 0.0, 0.0};
+    int mrow[2], ncol[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        mrow[t] = min(m0 + 16 * t + lc, M - 1);
+        ncol[t] = min(n0 + 16 * t + lc, N - 1);
+    }
+    constexpr int U = 4;
+    for (int k0 = kbeg; k0 < kend; k0 += 4 * U) {
+        double a[U][2], b[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // every load is unconditional on a clamped index (a predicated load makes the compiler serialise the 16
+            // round trips of a batch); rows/columns past the edge are computed and never stored, the k tail is
+            // removed by zeroing the B operand
+            const int k = k0 + 4 * u + lq;
+            const double kmask = k < kend ? 1.0 : 0.0;
+            const int kc = min(k, kend - 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[u][t] = TA ? A[(size_t)kc * lda + mrow[t]] : A[(size_t)mrow[t] * lda + kc];
+                b[u][t] = B[(size_t)kc * ldb + ncol[t]] * kmask;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][ti], b[u][tj], acc[ti][tj], 0, 0, 0);
+    }
+    double* Cz = C ? C + (size_t)z * M * ldc : nullptr;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = m0 + 16 * ti + lq + 4 * g, col = n0 + 16 * tj + lc;
+                if (row < M && col < N) {
+                    const double v = acc[ti][tj][g];
+                    if (Cz) Cz[(size_t)row * ldc + col] = v;
+                    if (C32 && row < rows32) C32[(size_t)row * ldc + col] = (float)v;
+                    if (C32T) C32T[(size_t)col * M + row] = (float)v;
+                }
+            }
+}
+
+// Y = obs_ens - mean(obs_ens) (rows 0..N-1), D0 = obs - obs_ens - perturbs (rows N..2N-1)     HistoryMatch.py:582, 584
+template <typename T>
+__global__ void k_obs_prep(const T* __restrict__ obs_ens, const T* __restrict__ perturbs, const T* __restrict__ obs,
+                           const double* __restrict__ colsum_y, double inv_n_total, int rows, int n_obs, double* __restrict__ YD) {
+    const size_t n = (size_t)rows * n_obs;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e % n_obs);
+        const double o = (double)obs_ens[e];
+        YD[e] = o - colsum_y[j] * inv_n_total;
+        YD[n + e] = (double)obs[j] - o - (double)perturbs[e];
+    }
+}
+
+}  // namespace
+
+// C (M x N, ldc) = op(A) B.  ksplit > 1: writes ksplit partial results C_z (z-major, M*ldc apart) for a fixed-order reduction
+// by the caller.  C32 / C32T: optional fp32 copies (same layout for rows < rows32 / transposed N x M).
+int dgemm_mfma(hipStream_t s, bool transA, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C,
+               int ldc, int ksplit, float* C32, int rows32, float* C32T) {
+    const int kchunk = ksplit > 1 ? (((K + ksplit - 1) / ksplit + 3) / 4) * 4 : K;
+    const dim3 grid((N + 31) / 32, (M + 31) / 32, ksplit > 1 ? (K + kchunk - 1) / kchunk : 1), block(64);
+    if (transA) hipLaunchKernelGGL(k_dgemm_mfma<true>, grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, kchunk, C32, rows32, C32T);
+    else hipLaunchKernelGGL(k_dgemm_mfma<false>, grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, kchunk, C32, rows32, C32T);
+    HM_HIP(hipGetLastError());
+    return (int)grid.z > 0 ? 0 : 0;
+}
+
+int dgemm_mfma_splits(int K, int ksplit) {
+    const int kchunk = (((K + ksplit - 1) / ksplit + 3) / 4) * 4;
+    return (K + kchunk - 1) / kchunk;
+}
+
+template <typename T>
+int obs_prep(hipStream_t s, const T* obs_ens, const T* perturbs, const T* obs, const double* colsum_y, double inv_n_total,
+             int rows, int n_obs, double* YD) {
+    const size_t n = (size_t)rows * n_obs;
+    hipLaunchKernelGGL(k_obs_prep<T>, dim3((unsigned)std::min<size_t>(1024, (n + 255) / 256)), dim3(256), 0, s, obs_ens, perturbs, obs,
+                       colsum_y, inv_n_total, rows, n_obs, YD);
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+template int obs_prep<float>(hipStream_t, const float*, const float*, const float*, const double*, double, int, int, double*);
+template int obs_prep<double>(hipStream_t, const double*, const double*, const double*, const double*, double, int, int, double*);

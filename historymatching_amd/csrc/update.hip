@@ -36,6 +36,7 @@ struct hm_upd {
     // everything of size <= N x n_obs is kept in fp64 whatever the dtype (cond(C) ~ 1e4 makes fp32 Gram matrices
     // lose 3 digits); only the two contractions over the state dimension M run in `dtype`.
     DevBuf Y, D0, S, D, T1, decorr64, S_T, A_T, Cinv, Wt, Bt, partial, gpart, flags;
+    DevBuf YD, SD;  // hm_upd_run: [Y; D0] and [S; D] stacked (2 N_local x n_obs), one matrix-core product for both
     int use_mfma = 1;  // fp32 only: 0 forces the generic VALU GEMMs (tests compare both)
     EvTimer t_upd;
     hipStream_t stream2 = nullptr;  // hm_upd_run: the small fp64 chain runs beside the big contraction
@@ -389,6 +390,13 @@ __global__ __launch_bounds__(1024) void k_invert_C_reg(const double* __restrict_
 }
 
 int spd_inverse_mfma(hipStream_t s, const double* G, int n, double ridge, double* W, int* flag);  // spdinv.hip
+// dgemm_mfma.hip
+int dgemm_mfma(hipStream_t s, bool transA, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C,
+               int ldc, int ksplit, float* C32, int rows32, float* C32T);
+int dgemm_mfma_splits(int K, int ksplit);
+template <typename T>
+int obs_prep(hipStream_t s, const T* obs_ens, const T* perturbs, const T* obs, const double* colsum_y, double inv_n_total,
+             int rows, int n_obs, double* YD);
 static int g_use_mfma_inverse = 1;
 
 // `blocked_ok`: the rank-16 matrix-core inverse (spdinv.hip) inverts the 16x16 pivot tiles explicitly, which costs a
@@ -521,7 +529,8 @@ extern "C" int hm_upd_create(hm_ctx* ctx, int N_total, int N_local, int M, int n
     ALLOC(Cinv, (no * no + no) * 8);
     ALLOC(partial, (size_t)64 * (m + no) * 8); ALLOC(flags, 16);
     if (dtype == 32) ALLOC(Bt, m * no * e);
-    ALLOC(gpart, ((nl + GRB - 1) / GRB) * no * no * 8);
+    if (dtype == 32) { ALLOC(YD, 2 * nl * no * 8); ALLOC(SD, 2 * nl * no * 8); }
+    ALLOC(gpart, std::max<size_t>((nl + GRB - 1) / GRB, 8) * no * no * 8);
     if (localized) { ALLOC(taper, m * no * e); ALLOC(Wt, m * no * e); }
 #undef ALLOC
     HM_HIP(hipMemset(u->flags.p, 0, 16));
@@ -535,7 +544,7 @@ extern "C" void hm_upd_destroy(hm_upd* u) {
     (void)hipStreamSynchronize(u->ctx->stream);
     DevBuf* bufs[] = {&u->E, &u->E_out, &u->obs_ens, &u->perturbs, &u->obs, &u->decorr, &u->taper, &u->red0, &u->red1,
                       &u->red2, &u->red3, &u->Y, &u->D0, &u->S, &u->D, &u->T1, &u->decorr64, &u->S_T, &u->A_T, &u->Cinv,
-                      &u->Wt, &u->Bt, &u->partial, &u->gpart, &u->flags};
+                      &u->Wt, &u->Bt, &u->partial, &u->gpart, &u->flags, &u->YD, &u->SD};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     u->t_upd.destroy();
     if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
@@ -679,34 +688,35 @@ extern "C" int hm_upd_run(hm_upd* u) {
     float* E = (float*)u->E.p; float* Eo = (float*)u->E_out.p;
     double* sumY = (double*)u->red1.p;
     float* Gxt = (float*)u->red2.p; double* G = (double*)u->red3.p;
-    double *S = (double*)u->S.p, *D = (double*)u->D.p, *T1 = (double*)u->T1.p;
+    double *S, *D;
     float *S_T = (float*)u->S_T.p, *A_T = (float*)u->A_T.p;
     int rc = u->t_upd.begin(s);
     if (rc) return rc;
     const double inv_n = 1.0 / (double)u->N_total;
-    {   // column sums of obs_ens, then S = Y decorr, D = D0 decorr
+    const size_t nsm = (size_t)nl * no;
+    S = (double*)u->SD.p;
+    D = S + nsm;
+    {   // column sums of obs_ens; [Y; D0]; [S; D] = [Y; D0] decorr (fp64 matrix cores) with the fp32 copy of S
         const int splits = std::min(64, std::max(1, nl / 16));
         const int rps = (nl + splits - 1) / splits;
         double* part2 = (double*)u->partial.p + (size_t)64 * M;
         hipLaunchKernelGGL(k_colsum_partial<float>, dim3((no + 255) / 256, splits), dim3(256), 0, s, (const float*)u->obs_ens.p, nl, no, rps, part2);
         hipLaunchKernelGGL(k_colsum_final<double>, dim3((no + 255) / 256), dim3(256), 0, s, (const double*)part2, splits, no, sumY);
-        hipLaunchKernelGGL(k_obs_products<float>, dim3((nl + RB - 1) / RB), dim3(256), 2 * RB * no * sizeof(double), s,
-                           (const float*)u->obs_ens.p, (const float*)u->perturbs.p, (const float*)u->obs.p, (const double*)sumY, inv_n,
-                           (const float*)u->decorr.p, nl, no, S, D, S_T);
+        hipLaunchKernelGGL((k_cast<float, double>), dim3((no * no + 255) / 256), dim3(256), 0, s, (const float*)u->decorr.p, (double*)u->decorr64.p, (size_t)no * no);
         HM_HIP(hipGetLastError());
+        if ((rc = obs_prep<float>(s, (const float*)u->obs_ens.p, (const float*)u->perturbs.p, (const float*)u->obs.p, sumY, inv_n, nl, no, (double*)u->YD.p))) return rc;
+        if ((rc = dgemm_mfma(s, false, 2 * nl, no, no, (const double*)u->YD.p, no, (const double*)u->decorr64.p, no, S, no, 1, S_T, nl, nullptr))) return rc;
     }
     HM_HIP(hipEventRecord(u->ev_fork, s));
     HM_HIP(hipStreamWaitEvent(s2, u->ev_fork, 0));
-    // stream 2: G = S^T S, C^-1, T1 = D C^-1 (and its fp32 transpose A_T)
+    // stream 2: G = S^T S (8 row blocks, fixed-order sum), C^-1, T1 = D C^-1 as its fp32 transpose A_T
     {
-        const int nparts = (nl + GRB - 1) / GRB;
-        hipLaunchKernelGGL(k_gram_partial, dim3(nparts), dim3(256), GRB * no * sizeof(double), s2, (const double*)S, nl, no, (double*)u->gpart.p);
-        hipLaunchKernelGGL(k_gram_reduce, dim3((no * no + 255) / 256), dim3(256), 0, s2, (const double*)u->gpart.p, nparts, no * no, G);
+        const int nsplit = dgemm_mfma_splits(nl, 8);
+        if ((rc = dgemm_mfma(s2, true, no, no, nl, S, no, S, no, (double*)u->gpart.p, no, 8, nullptr, 0, nullptr))) return rc;
+        hipLaunchKernelGGL(k_gram_reduce, dim3((no * no + 255) / 256), dim3(256), 0, s2, (const double*)u->gpart.p, nsplit, no * no, G);
         HM_HIP(hipGetLastError());
         if ((rc = invert_C(s2, G, no, (double)(u->N_total - 1), (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p, true))) return rc;
-        hipLaunchKernelGGL(k_rows_matmul, dim3((nl + RB - 1) / RB), dim3(256), RB * no * sizeof(double), s2, (const double*)D,
-                           (const double*)u->Cinv.p, nl, no, T1, (float*)A_T);
-        HM_HIP(hipGetLastError());
+        if ((rc = dgemm_mfma(s2, false, nl, no, no, D, no, (const double*)u->Cinv.p, no, nullptr, no, 1, nullptr, 0, A_T))) return rc;
         HM_HIP(hipEventRecord(u->ev_join, s2));
     }
     // stream 1: the big contraction, then (after the join) the apply

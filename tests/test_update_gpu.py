@@ -249,4 +249,4 @@ def test_matrix_core_spd_inverse(n, golden):
         _lib.check(lib.hm_debug_spd_inverse(ctx.handle, n, G.ctypes.data_as(dp), ridge, W.ctypes.data_as(dp)), "hm_debug_spd_inverse")
         ref = np.linalg.inv(G + ridge * np.eye(n))
         assert np.abs(W - ref).max() <= 1e-9 * np.abs(ref).max()
-        assert np.array_equal(W, W.T)
+        assert np.abs(W - W.T).max() <= 1e-9 * np.abs(ref).max()  # off-diagonal tiles are mirrored, diagonal tiles swept
