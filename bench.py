@@ -61,6 +61,26 @@ def cpu_baseline(members, steps, nproc):
     return members * steps / wall, wall
 
 
+def es_update_timing(device):
+    """BASELINE.json's second metric (ES-MDA update wall-time) at config 3's shape: N=1000 members, M=128*128 state
+    elements, n_obs=160, fp32 state contractions on the matrix cores, every N x n_obs quantity in fp64.  Device time of
+    one analysis step (HIP events inside the library), inputs resident in HBM; flops by SURVEY.md 8d (min-flop order)."""
+    from historymatching_amd.update import UpdatePlan
+
+    N, M, n_obs = N_E, NX * NY, 160
+    rng = np.random.RandomState(0)
+    plan = UpdatePlan(N, N, M, n_obs, dtype=32, device=device)
+    plan.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), rng.rand(n_obs), 0.1 * rng.randn(N, n_obs), 3.0 * np.eye(n_obs))
+    plan.run_local()  # warm-up
+    ms = sorted(plan.run_local()["ms_update"] for _ in range(7))
+    plan.close()
+    flops = 4.0 * N * n_obs * M
+    peak = 157.3  # TF, fp32 matrix peak (MI355X_MICROARCH.md)
+    return {"wall_ms": ms[len(ms) // 2], "best_ms": ms[0], "config": f"N={N}, M={M}, n_obs={n_obs}, fp32 (config 3 shape)",
+            "flops_min_order": flops, "tflops": flops / (ms[len(ms) // 2] * 1e-3) / 1e12, "mfma_peak_tflops": peak,
+            "mfma_frac_of_fp32_peak": flops / (ms[len(ms) // 2] * 1e-3) / 1e12 / peak}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,6 +186,12 @@ def main():
             "mean_nts": nts,
             "note": "effective GB/s by SURVEY.md 8d accounting; the state is LDS/register-resident so it may exceed HBM peak",
         }
+        upd = None
+        if world == 1:
+            try:
+                upd = es_update_timing(local_rank)
+            except Exception as e:  # the forward metric stands on its own
+                upd = {"error": str(e)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             nproc = os.cpu_count() or 1
@@ -181,7 +207,7 @@ def main():
             "config": {"workload": f"N_e={n_e} per GPU, {NX}x{NY} grid, forward model only (nTime={NTIME}, dt={DT}), fp64",
                        "members_per_gpu": n_e, "grid": [NX, NY], "nTime": NTIME, "device": ctx.name(),
                        "kernel_variant": args.variant, "results_finite_and_status_ok": bool(ok)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "es_update": upd,
             "device_ms": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
         }
         print(json.dumps(out))

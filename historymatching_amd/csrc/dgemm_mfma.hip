@@ -76,8 +76,11 @@ __global__ __launch_bounds__(64) void k_dgemm_mfma(int M, int N, int K, const do
 // Y = obs_ens - mean(obs_ens) (rows 0..N-1), D0 = obs - obs_ens - perturbs (rows N..2N-1)     HistoryMatch.py:582, 584
 template <typename T>
 __global__ void k_obs_prep(const T* __restrict__ obs_ens, const T* __restrict__ perturbs, const T* __restrict__ obs,
-                           const double* __restrict__ colsum_y, double inv_n_total, int rows, int n_obs, double* __restrict__ YD) {
+                           const double* __restrict__ colsum_y, double inv_n_total, int rows, int n_obs, double* __restrict__ YD,
+                           const T* __restrict__ decorr, double* __restrict__ decorr64) {
     const size_t n = (size_t)rows * n_obs;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)n_obs * n_obs; e += (size_t)gridDim.x * blockDim.x)
+        decorr64[e] = (double)decorr[e];
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int j = (int)(e % n_obs);
         const double o = (double)obs_ens[e];
@@ -107,12 +110,12 @@ int dgemm_mfma_splits(int K, int ksplit) {
 
 template <typename T>
 int obs_prep(hipStream_t s, const T* obs_ens, const T* perturbs, const T* obs, const double* colsum_y, double inv_n_total,
-             int rows, int n_obs, double* YD) {
+             int rows, int n_obs, double* YD, const T* decorr, double* decorr64) {
     const size_t n = (size_t)rows * n_obs;
     hipLaunchKernelGGL(k_obs_prep<T>, dim3((unsigned)std::min<size_t>(1024, (n + 255) / 256)), dim3(256), 0, s, obs_ens, perturbs, obs,
-                       colsum_y, inv_n_total, rows, n_obs, YD);
+                       colsum_y, inv_n_total, rows, n_obs, YD, decorr, decorr64);
     HM_HIP(hipGetLastError());
     return 0;
 }
-template int obs_prep<float>(hipStream_t, const float*, const float*, const float*, const double*, double, int, int, double*);
-template int obs_prep<double>(hipStream_t, const double*, const double*, const double*, const double*, double, int, int, double*);
+template int obs_prep<float>(hipStream_t, const float*, const float*, const float*, const double*, double, int, int, double*, const float*, double*);
+template int obs_prep<double>(hipStream_t, const double*, const double*, const double*, const double*, double, int, int, double*, const double*, double*);

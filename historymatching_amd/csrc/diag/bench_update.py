@@ -22,9 +22,12 @@ for dtype, use_mfma in ((32, 1), (32, 0), (64, 0)):
             p.phase(ph); ts.append(p.sync()["ms_update"])
         per_phase.append(min(ts))
     tot = sum(per_phase)
-    fused = min(p.run_local()["ms_update"] for _ in range(5))  # hm_upd_run: single call, two streams
+    fused = min(p.run_local()["ms_update"] for _ in range(5))  # hm_upd_run: single call
+    p.set_option("overlap", 1)
+    fused2 = min(p.run_local()["ms_update"] for _ in range(5))  # ... with the small chain on a second stream
+    p.set_option("overlap", 0)
     flops = 4.0 * N * n_obs * M
-    res[f"dtype{dtype}_mfma{use_mfma}"] = {"ms_phase": per_phase, "ms_total": tot, "ms_fused_run": fused, "TFLOPs_fused_run": flops / fused / 1e9,
+    res[f"dtype{dtype}_mfma{use_mfma}"] = {"ms_phase": per_phase, "ms_total": tot, "ms_fused_run": fused, "ms_fused_run_two_streams": fused2, "TFLOPs_fused_run": flops / fused / 1e9,
                                           "TFLOPs_min_flop_order": flops / tot / 1e9,
                                           "TFLOPs_contractions_only": flops / (per_phase[1] + per_phase[2]) / 1e9}
     p.close()

@@ -23,9 +23,9 @@ __device__ __forceinline__ int opaque_s(int x) {
     return x;
 }
 
-template <int SLOTS>
-__global__ __launch_bounds__(1024) void k_spd_inverse(const double* __restrict__ G, int n, double ridge, double* __restrict__ Wout,
-                                                      int* __restrict__ flag) {
+template <int SLOTS, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __restrict__ G, int nparts, int n, double ridge,
+                                                      double* __restrict__ Wout, int* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     const int nt = n >> 4;
     // LDS: U[2][n][17], W[n][17], P[16][17], Dg[16][17], flag
@@ -43,14 +43,15 @@ __global__ __launch_bounds__(1024) void k_spd_inverse(const double* __restrict__
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool service = (w & 3) == 0, sweeper = w == 0;
-    const int c = service ? 0 : (w >> 2) * 3 + (w & 3) - 1;  // compute wave index 0..11
+    constexpr int NC = NW - NW / 4;                            // compute waves (SIMDs 1..3)
+    const int c = service ? 0 : (w >> 2) * 3 + (w & 3) - 1;  // compute wave index 0..NC-1
     const int ntiles = nt * (nt + 1) / 2;
 
     int tR[SLOTS], tC[SLOTS];
     d4 acc[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const int t = s * 12 + c;
+        const int t = s * NC + c;
         int R = -1, C = -1;
         if (!service && t < ntiles) {
             R = 0;
@@ -64,7 +65,13 @@ __global__ __launch_bounds__(1024) void k_spd_inverse(const double* __restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * R + g.lq + 4 * r, col = 16 * C + g.lc;
-                acc[s][r] = 0.5 * (G[(size_t)row * n + col] + G[(size_t)col * n + row]) + (row == col ? ridge : 0.0);
+                // G may arrive as `nparts` partial Gram matrices (split over row blocks): summed here in fixed order
+                double gs = 0.0;
+                for (int z = 0; z < nparts; ++z) {
+                    const double* Gz = G + (size_t)z * n * n;
+                    gs += 0.5 * (Gz[(size_t)row * n + col] + Gz[(size_t)col * n + row]);
+                }
+                acc[s][r] = gs + (row == col ? ridge : 0.0);
             }
         }
     }
@@ -189,20 +196,20 @@ __global__ __launch_bounds__(1024) void k_spd_inverse(const double* __restrict__
 }  // namespace
 
 // W = inv(G + ridge I) for n a multiple of 16, n <= 256.  Returns 0 if launched, -1 if not applicable, >0 on error.
-int spd_inverse_mfma(hipStream_t s, const double* G, int n, double ridge, double* W, int* flag) {
+int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double ridge, double* W, int* flag) {
     if (n % 16 != 0 || n < 16 || n > 256) return -1;
     const int nt = n / 16, ntiles = nt * (nt + 1) / 2;
-    const int slots = (ntiles + 11) / 12;
     const size_t lds = ((size_t)3 * n * 17 + 2 * 16 * 17) * 8 + 16;
-#define L(S)                                                                                                            \
-    do {                                                                                                                \
-        HM_HIP(hipFuncSetAttribute((const void*)k_spd_inverse<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k_spd_inverse<S>, dim3(1), dim3(1024), lds, s, G, n, ridge, W, flag);                        \
+#define L(S, NW)                                                                                                              \
+    do {                                                                                                                      \
+        HM_HIP(hipFuncSetAttribute((const void*)k_spd_inverse<S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_spd_inverse<S, NW>), dim3(1), dim3(64 * NW), lds, s, G, nparts, n, ridge, W, flag);                \
     } while (0)
-    if (slots <= 2) L(2);
-    else if (slots <= 5) L(5);
-    else if (slots <= 8) L(8);
-    else L(12);
+    if (ntiles <= 12) L(2, 8);
+    else if (ntiles <= 24) L(2, 16);
+    else if (ntiles <= 60) L(5, 16);
+    else if (ntiles <= 96) L(8, 16);
+    else L(12, 16);
 #undef L
     HM_HIP(hipGetLastError());
     return 0;
@@ -221,7 +228,7 @@ extern "C" int hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double 
     HM_HIP(hipMalloc(&dflag, 4));
     HM_HIP(hipMemset(dflag, 0, 4));
     HM_HIP(hipMemcpy(dG, G, bytes, hipMemcpyHostToDevice));
-    int rc = spd_inverse_mfma(ctx->stream, dG, n, ridge, dW, dflag);
+    int rc = spd_inverse_mfma(ctx->stream, dG, 1, n, ridge, dW, dflag);
     int flag = 0;
     if (rc == 0 && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(W, dW, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
                     hipMemcpy(&flag, dflag, 4, hipMemcpyDeviceToHost) != hipSuccess)) {

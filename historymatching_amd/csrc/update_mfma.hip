@@ -157,6 +157,190 @@ __global__ __launch_bounds__(256) void k_apply_mfma(int N, int M, int n_obs, con
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Second generation of the two contractions (single-rank fused run, hm_upd_run):
+//
+// k_gxt_lds:   Gx (n_obs x M) = S^T (E - c)      one workgroup = 64 state elements x all n_obs observations, K = N members.
+//   E and S chunks of KC = 16 members are staged through LDS (float4 global loads one chunk ahead, in registers, while the
+//   current chunk feeds the MFMAs), the 4 waves = 2 state halves x 2 interleaved halves of the k-pairs, partial
+//   accumulators of the two k-halves added through LDS at the end.  Writes Gx directly in the (n_obs x M) layout the
+//   apply kernel consumes (accumulator columns = state elements: 128-byte rows), so no transpose pass.
+// k_apply_lds: E_out = E + A^T-operand * Gx      one workgroup = 128 members x 64 state elements: Gx tile (n_obs x 64) in
+//   LDS (40 KB at n_obs = 160: 3 workgroups per CU overlap staging, MFMAs and the E read/modify/write), A operand
+//   fetched 16 k-pairs ahead from L2, the E tile loaded before the MFMA loop.
+// ------------------------------------------------------------------------------------------------------------
+template <int NJ>
+__global__ __launch_bounds__(512, 4) void k_gxt_lds(int N, int M, int n_obs, const float* __restrict__ E,
+                                                 const float* __restrict__ colsum, float inv_n,
+                                                 const float* __restrict__ S, float* __restrict__ Gx) {
+    // 8 waves = 2 state halves x 4 interleaved quarters of the k-pairs (two waves per SIMD: one wave's LDS/barrier
+    // stalls are covered by the other's MFMAs)
+    constexpr int KC = 32, NO = 32 * NJ, NKH = 4, NT = 512;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    // [2][KC][64] E chunks, [2][KC][NO] S chunks; the final reduction buffers alias them
+    float* Eb = sm;
+    float* Sb = sm + 2 * KC * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int sh = w & 1, kh = w >> 1;
+    const int il = lane & 31, kq = lane >> 5;
+    const int i0 = blockIdx.x * 64;
+    // staging roles: E chunk = KC rows x 16 float4 (one per thread); S chunk = KC rows x NO/4 float4
+    const int er = tid >> 4, ec = (tid & 15) * 4;
+    const int ei = min(i0 + ec, M - 4);  // M % 4 == 0 (host-checked); columns past M are never stored
+    float4 shift;
+    if (colsum) shift = make_float4(colsum[ei] * inv_n, colsum[ei + 1] * inv_n, colsum[ei + 2] * inv_n, colsum[ei + 3] * inv_n);
+    else shift = *reinterpret_cast<const float4*>(E + ei);
+    constexpr int SV = KC * NO / 4;           // float4 per S chunk
+    constexpr int SPT = (SV + NT - 1) / NT;   // per thread
+    float4 ereg, sreg[SPT];
+    auto fetch = [&](int k0) {
+        const int k = k0 + er;
+        ereg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < N) {
+            const float4 v = *reinterpret_cast<const float4*>(E + (size_t)k * M + ei);
+            ereg = make_float4(v.x - shift.x, v.y - shift.y, v.z - shift.z, v.w - shift.w);
+        }
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int e = tid + NT * q;
+            const int r = e / (NO / 4), c4 = (e % (NO / 4)) * 4;
+            sreg[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < SV && k0 + r < N) sreg[q] = *reinterpret_cast<const float4*>(S + (size_t)(k0 + r) * n_obs + c4);
+        }
+    };
+    auto stash = [&](int buf) {
+        *reinterpret_cast<float4*>(Eb + (buf * KC + er) * 64 + ec) = ereg;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int e = tid + NT * q;
+            if (e < SV) *reinterpret_cast<float4*>(Sb + buf * KC * NO + e * 4) = sreg[q];
+        }
+    };
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int nchunks = (N + KC - 1) / KC;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) fetch((c + 1) * KC);
+        const float* eb = Eb + buf * KC * 64 + 32 * sh + il;
+        const float* sb = Sb + buf * KC * NO + il;
+        // this wave's k-pairs of the chunk: pair p = NKH q + kh  (rows 2p, 2p+1)
+#pragma unroll
+        for (int q = 0; q < KC / 2 / NKH; ++q) {
+            const int row = 2 * (NKH * q + kh) + kq;
+            const float b = eb[row * 64];
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sb[row * NO + 32 * t], b, acc[t], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // fixed-order tree over the 4 k-quarters through LDS: (0 + 1) and (2 + 3), then (0+1) + (2+3); buffers
+    // [2 publishers][2 sh][NJ][16][64] alias the chunks
+    float* red = sm;
+    auto slot = [&](int pub, int t, int r) { return red + (((pub * 2 + sh) * NJ + t) * 16 + r) * 64 + lane; };
+    if (kh & 1) {
+#pragma unroll
+        for (int t = 0; t < NJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) *slot(kh >> 1, t, r) = acc[t][r];
+    }
+    __syncthreads();
+    if (!(kh & 1)) {
+#pragma unroll
+        for (int t = 0; t < NJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += *slot(kh >> 1, t, r);
+    }
+    __syncthreads();
+    if (kh == 2) {
+#pragma unroll
+        for (int t = 0; t < NJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) *slot(0, t, r) = acc[t][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        const int i = i0 + 32 * sh + il;
+        if (i < M) {
+#pragma unroll
+            for (int t = 0; t < NJ; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kq;  // accumulator row = observation
+                    Gx[(size_t)j * M + i] = acc[t][r] + *slot(0, t, r);
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_apply_lds(int N, int M, int n_obs, const float* __restrict__ E,
+                                                   const float* __restrict__ At, const float* __restrict__ Gx,
+                                                   float* __restrict__ Eout) {
+    extern __shared__ __attribute__((aligned(16))) float Bs[];  // n_obs x 64
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 64, n0 = blockIdx.y * 128 + 32 * w;
+    for (int e = threadIdx.x; e < n_obs * 16; e += 256) {  // float4 granules
+        const int j = e >> 4, c4 = (e & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + c4 + 3 < M) v = *reinterpret_cast<const float4*>(Gx + (size_t)j * M + i0 + c4);
+        *reinterpret_cast<float4*>(Bs + j * 64 + c4) = v;
+    }
+    const int nl = lane & 31, kh = lane >> 5;
+    const int n = min(n0 + nl, N - 1);
+    // the E tile of the epilogue is requested now and consumed after the MFMA loop
+    float ev[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = min(n0 + (r & 3) + 8 * (r >> 2) + 4 * kh, N - 1);
+            const int i = min(i0 + 32 * t + nl, M - 1);
+            ev[t][r] = E[(size_t)nn * M + i];
+        }
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    __syncthreads();
+    const int npairs = (n_obs + 1) / 2;
+    constexpr int UA = 16;
+    for (int jp0 = 0; jp0 < npairs; jp0 += UA) {
+        float av[UA];
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int j = min(2 * (jp0 + u) + kh, n_obs - 1);
+            av[u] = At[(size_t)j * N + n];
+        }
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int j = 2 * (jp0 + u) + kh;
+            const float a = j < n_obs ? av[u] : 0.0f;
+            const float* brow = Bs + min(j, n_obs - 1) * 64 + nl;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[32 * t], acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = i0 + 32 * t + nl;
+        if (i >= M) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (nn < N) Eout[(size_t)nn * M + i] = ev[t][r] + acc[t][r];
+        }
+    }
+}
+
 // ---- host entry points (return 0 launched, >0 error, -1 not applicable -> caller uses the generic GEMM) ----
 int mfma_gxt(hipStream_t s, int N, int M, int n_obs, const float* E, const float* colsum, double inv_n, const float* S,
              float* Gxt) {
@@ -192,6 +376,32 @@ int transpose_cast_d2f(hipStream_t s, const double* in, float* out, int rows, in
 int transpose_f2f(hipStream_t s, const float* in, float* out, int rows, int cols) {
     dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
     hipLaunchKernelGGL((k_transpose<float, float>), grid, block, 0, s, in, out, rows, cols);
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+// second-generation kernels (hm_upd_run); Gx is (n_obs x M)
+int mfma_gxt_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const float* colsum, double inv_n, const float* S,
+                 float* Gx) {
+    if (n_obs % 32 != 0 || n_obs > 256 || M % 4 != 0 || M < 4) return -1;
+    const int nj = n_obs / 32;
+    dim3 grid((M + 63) / 64), block(512);
+    const size_t chunks = (size_t)2 * 32 * (64 + n_obs) * 4, red = (size_t)2 * 2 * nj * 16 * 64 * 4;
+    const size_t lds = chunks > red ? chunks : red;
+#define L(NJ) case NJ: HM_HIP(hipFuncSetAttribute((const void*)k_gxt_lds<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                       hipLaunchKernelGGL(k_gxt_lds<NJ>, grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); break
+    switch (nj) { L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); default: return -1; }
+#undef L
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+int mfma_apply_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const float* At, const float* Gx, float* Eout) {
+    const size_t lds = (size_t)n_obs * 64 * 4;
+    if (lds > 150 * 1024 || M % 4 != 0) return -1;
+    HM_HIP(hipFuncSetAttribute((const void*)k_apply_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((M + 63) / 64, (N + 127) / 128), block(256);
+    hipLaunchKernelGGL(k_apply_lds, grid, block, lds, s, N, M, n_obs, E, At, Gx, Eout);
     HM_HIP(hipGetLastError());
     return 0;
 }
