@@ -51,6 +51,29 @@ class Comm:
         self.td.all_reduce(t, group=self.group)
         return t.numpy()
 
+    @property
+    def backend(self):
+        return self.td.get_backend(self.group) if self.td else None
+
+    def all_reduce_device(self, ptr, n, dtype, force=False):
+        """In-place sum over ranks of ``n`` elements of ``dtype`` at DEVICE address ``ptr`` (a buffer owned by the C-ABI
+        library) with RCCL: the buffer is wrapped zero-copy as a torch tensor through ``__cuda_array_interface__``;
+        no host staging.  The caller has synchronised the library's stream (``plan.sync()``); this call returns
+        after the collective has completed on the device."""
+        if not self.td or (self.world_size == 1 and not force):
+            return
+        import torch
+
+        class _Dev:  # minimal CUDA-array-interface carrier
+            pass
+
+        d = _Dev()
+        d.__cuda_array_interface__ = {"shape": (int(n),), "typestr": np.dtype(dtype).str, "data": (int(ptr), False), "version": 2}
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        t = torch.as_tensor(d, device=dev)
+        self.td.all_reduce(t, group=self.group)
+        torch.cuda.synchronize(dev)
+
     def all_gather_rows(self, arr):
         """Concatenate per-rank row blocks (possibly ragged) in rank order."""
         if not self.td or self.world_size == 1:
@@ -86,10 +109,17 @@ def sharded_update(plan, comm=None):
     ``phase / get_reduce / set_reduce / sync / output`` methods) through its three phases, summing the two
     reduce buffers over ranks in between.  Returns this rank's rows of the updated ensemble."""
     comm = comm or Comm()
+    device_direct = comm.backend == "nccl" and hasattr(plan, "reduce_buffer")
     for ph in range(3):
         plan.phase(ph)
         if ph < 2 and comm.world_size > 1:
-            for which in plan.REDUCE_AFTER_PHASE[ph]:
-                plan.set_reduce(which, comm.all_reduce_sum(plan.get_reduce(which)))
+            if device_direct:  # RCCL on the library's own device buffers (xGMI), no PCIe round trip
+                plan.sync()
+                for which in plan.REDUCE_AFTER_PHASE[ph]:
+                    ptr, n, dt = plan.reduce_buffer(which)
+                    comm.all_reduce_device(ptr, n, dt)
+            else:  # gloo / CPU test doubles: host-staged
+                for which in plan.REDUCE_AFTER_PHASE[ph]:
+                    plan.set_reduce(which, comm.all_reduce_sum(plan.get_reduce(which)))
     plan.sync()
     return plan.output()

@@ -250,3 +250,42 @@ def test_matrix_core_spd_inverse(n, golden):
         ref = np.linalg.inv(G + ridge * np.eye(n))
         assert np.abs(W - ref).max() <= 1e-9 * np.abs(ref).max()
         assert np.abs(W - W.T).max() <= 1e-9 * np.abs(ref).max()  # off-diagonal tiles are mirrored, diagonal tiles swept
+
+
+def test_rccl_all_reduce_on_library_buffers():
+    """The multi-rank update sums its reduce buffers with RCCL directly on the library's device memory
+    (dist.Comm.all_reduce_device, zero-copy through __cuda_array_interface__).  One rank here (one GPU per box): the
+    collective must run on the wrapped pointer and leave the single contribution unchanged; the two-rank arithmetic is
+    covered on CPU (tests/test_dist_cpu.py) and by the two-shard test above."""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as td
+
+    from historymatching_amd.dist import Comm
+    from historymatching_amd.update import UpdatePlan
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    td.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.RandomState(3)
+        N, M, n_obs = 24, 64, 32
+        p = UpdatePlan(N, N, M, n_obs, dtype=32)
+        p.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), rng.rand(n_obs), 0.1 * rng.randn(N, n_obs), np.eye(n_obs))
+        p.phase(0)
+        p.phase(1)
+        p.sync()
+        comm = Comm()
+        assert comm.backend == "nccl"
+        for which in (2, 3):
+            before = p.get_reduce(which).copy()
+            ptr, n, dt = p.reduce_buffer(which)
+            comm.all_reduce_device(ptr, n, dt, force=True)
+            assert np.array_equal(p.get_reduce(which), before)
+        p.close()
+    finally:
+        td.destroy_process_group()

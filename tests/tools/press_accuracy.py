@@ -5,7 +5,7 @@ from pathlib import Path
 import numpy as np
 import scipy.sparse.linalg as sla
 
-ROOT = Path(__file__).resolve().parents[3]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 import oracle.ressim as R  # noqa: E402
