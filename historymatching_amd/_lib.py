@@ -62,6 +62,7 @@ SIGNATURES = {
     "hm_fwd_get_outputs": (C.c_int, [_vp, _vp, _vp, _ip]),
     "hm_fwd_set_variant": (C.c_int, [_vp, C.c_int, C.c_int]),
     "hm_fwd_set_solver": (C.c_int, [_vp, C.c_double, C.c_int]),
+    "hm_fwd_set_inputs_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "hm_fwd_pressure_only": (C.c_int, [_vp, C.c_int]),
     "hm_fwd_saturation_only": (C.c_int, [_vp, C.c_int]),
     "hm_fwd_get_field": (C.c_int, [_vp, C.c_char_p, _vp]),
@@ -78,6 +79,8 @@ SIGNATURES = {
     "hm_upd_set_inputs": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double]),
     "hm_upd_phase": (C.c_int, [_vp, C.c_int]),
     "hm_upd_run": (C.c_int, [_vp]),
+    "hm_upd_set_inputs_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),
+    "hm_upd_swap": (C.c_int, [_vp]),
     "hm_debug_spd_inverse": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp]),
     "hm_upd_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "hm_upd_reduce_buffer": (_vp, [_vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),

@@ -470,6 +470,38 @@ extern "C" int hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transf
     return 0;
 }
 
+template <typename TI, typename TO>
+__global__ void k_convert(const TI* __restrict__ in, TO* __restrict__ out, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (TO)in[i];
+}
+
+// Device-resident chaining: the permeability input comes from a DEVICE buffer (e.g. the updated
+// ensemble of an hm_upd plan, hm_upd_device_ptr(u, "E_out")), converted to fp64 if needed; initial saturation zero.
+// Same stream as the producer when both plans share the context: no synchronisation, no PCIe.
+extern "C" int hm_fwd_set_inputs_device(hm_fwd* f, const void* perm_dev, int perm_dtype, int perm_is_transformed) {
+    HM_REQUIRE(f && perm_dev, "hm_fwd_set_inputs_device: NULL argument");
+    HM_REQUIRE(perm_dtype == 64 || perm_dtype == 32, "hm_fwd_set_inputs_device: perm_dtype must be 64 or 32");
+    HM_HIP(hipSetDevice(f->ctx->device));
+    hipStream_t s = f->ctx->stream;
+    const FwdParams& p = f->p;
+    const long long n = (long long)p.N * p.Nxy;
+    double* dst = (double*)(perm_is_transformed ? f->K.p : f->perm_in.p);
+    if (perm_dtype == 64) HM_HIP(hipMemcpyAsync(dst, perm_dev, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+    else hipLaunchKernelGGL((k_convert<float, double>), dim3(2048), dim3(256), 0, s, (const float*)perm_dev, dst, n);
+    if (!perm_is_transformed)
+        hipLaunchKernelGGL(k_perm_transform, dim3(2048), dim3(256), 0, s, (const double*)f->perm_in.p, (double*)f->K.p, n);
+    HM_HIP(hipGetLastError());
+    long long stride;
+    void* S0 = fwd_S_ptr(f, 0, &stride);
+    if (f->keep_history) HM_HIP(hipMemset2DAsync(S0, (size_t)stride * f->esz, 0, (size_t)p.Nxy * f->esz, p.N, s));
+    else HM_HIP(hipMemsetAsync(S0, 0, (size_t)n * f->esz, s));
+    HM_HIP(hipMemsetAsync(f->status.p, 0, (size_t)p.N * 4, s));
+    f->cur = 0;
+    return 0;
+}
+
 static int ensure_generic_sat_scratch(hm_fwd* f) {
     if (f->coef.p) return 0;
     size_t n = (size_t)f->p.N * f->p.Nxy;

@@ -600,6 +600,38 @@ extern "C" int hm_upd_set_inputs(hm_upd* u, const void* E, const void* obs_ens, 
     return 0;
 }
 
+// Device-resident chaining: the ensemble and/or the simulated observations come from DEVICE buffers (an hm_fwd plan's
+// producer series hm_fwd_device_ptr(f, "prods") is exactly vect(prods): (N, nTime*nPrd) row-major, HistoryMatch.py:413-421),
+// converted to the plan's dtype if needed.  NULL = keep the current contents.
+extern "C" int hm_upd_set_inputs_device(hm_upd* u, const void* E_dev, int E_dtype, const void* obs_ens_dev, int obs_dtype) {
+    HM_REQUIRE(u, "hm_upd_set_inputs_device: NULL plan");
+    HM_HIP(hipSetDevice(u->ctx->device));
+    hipStream_t s = u->ctx->stream;
+    auto put = [&](void* dst, const void* src, int src_dtype, size_t n) -> int {
+        HM_REQUIRE(src_dtype == 64 || src_dtype == 32, "hm_upd_set_inputs_device: dtype must be 64 or 32");
+        if (src_dtype == u->dtype) {
+            HM_HIP(hipMemcpyAsync(dst, src, n * u->esz, hipMemcpyDeviceToDevice, s));
+        } else {
+            const unsigned gs = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
+            if (src_dtype == 64) hipLaunchKernelGGL((k_cast<double, float>), dim3(gs), dim3(256), 0, s, (const double*)src, (float*)dst, n);
+            else hipLaunchKernelGGL((k_cast<float, double>), dim3(gs), dim3(256), 0, s, (const float*)src, (double*)dst, n);
+            HM_HIP(hipGetLastError());
+        }
+        return 0;
+    };
+    int rc = 0;
+    if (E_dev && (rc = put(u->E.p, E_dev, E_dtype, (size_t)u->N_local * u->M))) return rc;
+    if (obs_ens_dev && (rc = put(u->obs_ens.p, obs_ens_dev, obs_dtype, (size_t)u->N_local * u->n_obs))) return rc;
+    return 0;
+}
+
+// posterior -> prior for the next pass of an iterative smoother (pointer swap, no copy)
+extern "C" int hm_upd_swap(hm_upd* u) {
+    HM_REQUIRE(u, "hm_upd_swap: NULL plan");
+    std::swap(u->E, u->E_out);
+    return 0;
+}
+
 template <typename T>
 static int upd_phase(hm_upd* u, int phase) {
     hipStream_t s = u->ctx->stream;

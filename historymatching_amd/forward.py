@@ -63,6 +63,12 @@ class ForwardPlan:
         _lib.check(self.lib.hm_fwd_set_inputs(self.h, _lib.ptr(perms), int(bool(transformed)), _lib.ptr(wsat0s)),
                    "hm_fwd_set_inputs")
 
+    def set_inputs_device(self, perm_ptr, perm_dtype=64, transformed=False):
+        """Permeability input from a DEVICE buffer of this context (e.g. ``UpdatePlan.device_ptr("E_out")``); initial
+        saturation zero.  Asynchronous: ordered on the context's stream behind whatever produced the buffer."""
+        _lib.check(self.lib.hm_fwd_set_inputs_device(self.h, C.c_void_p(perm_ptr), int(perm_dtype), int(bool(transformed))),
+                   "hm_fwd_set_inputs_device")
+
     def set_variant(self, pressure=0, saturation=0):
         """0 = fastest applicable kernel, 1 = generic kernels (the in-library correctness baseline)."""
         _lib.check(self.lib.hm_fwd_set_variant(self.h, int(pressure), int(saturation)), "hm_fwd_set_variant")

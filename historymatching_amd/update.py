@@ -105,6 +105,16 @@ class UpdatePlan:
         arrs = [_lib.as_c(v, self.ft) for v in (E, obs_ens, obs, perturbs, decorr, taper)]
         _lib.check(self.lib.hm_upd_set_inputs(self.h, *(_lib.ptr(v) for v in arrs), float(cutoff)), "hm_upd_set_inputs")
 
+    def set_inputs_device(self, E_ptr=None, E_dtype=64, obs_ens_ptr=None, obs_dtype=64):
+        """Ensemble / simulated observations from DEVICE buffers of this context (``ForwardPlan.device_ptr("prods")`` is
+        ``vect(prods)``), converted to the plan's dtype on the device.  None = keep."""
+        _lib.check(self.lib.hm_upd_set_inputs_device(self.h, C.c_void_p(E_ptr), int(E_dtype), C.c_void_p(obs_ens_ptr), int(obs_dtype)),
+                   "hm_upd_set_inputs_device")
+
+    def swap(self):
+        """Make the last posterior the next prior (pointer swap on the device)."""
+        _lib.check(self.lib.hm_upd_swap(self.h), "hm_upd_swap")
+
     def phase(self, k):
         _lib.check(self.lib.hm_upd_phase(self.h, int(k)), "hm_upd_phase")
 
@@ -167,3 +177,51 @@ def es_mda(forward, prior_ens, obs, R12, n_iter=4, rng=None, dtype=64, device=No
         perturbs = np.sqrt(alpha) * (rng.randn(len(E), len(obs)) @ R12.T)
         E = ens_update0(E, obs_ens, obs, perturbs, decorr, dtype=dtype, device=device).astype(float)
     return E
+
+
+def es_mda_device(model, prior_ens, obs, R12, dt, nTime, n_iter=4, rng=None, dtype=32, device=None, stats=None):
+    """ES-MDA with the ensemble resident in HBM for the whole assimilation (BASELINE.json config 3):
+    per pass  forward model (fp64 kernels, permeability taken from the update plan's ensemble on the device) ->
+    simulated observations = the forward plan's producer series, handed over on the device -> analysis step (``dtype``
+    32: matrix-core contractions) -> the posterior becomes the next prior by pointer swap.  Only the perturbations
+    (N x n_obs) and decorr go up per pass and the final ensemble comes down once; the reference moves the whole ensemble
+    and the saturation history through the host every pass (HistoryMatch.py:383-387, 959).
+    Same arithmetic per pass as `es_mda` with ``forward = vect(forward_model(E)[1])``."""
+    import scipy.linalg as sla
+
+    from .forward import ForwardPlan
+
+    rng = np.random if rng is None else rng
+    E0 = np.asarray(prior_ens)
+    N, M = E0.shape
+    n_obs = len(obs)
+    if n_obs != nTime * model.nPrd:
+        raise ValueError(f"len(obs) = {n_obs} != nTime * nPrd = {nTime * model.nPrd}")
+    fwd = ForwardPlan(model, N, dt, nTime, keep_history=False, device=device)
+    upd = UpdatePlan(N, N, M, n_obs, dtype=dtype, device=device)
+    alpha = float(n_iter)
+    decorr = sla.inv(R12.T) / np.sqrt(alpha)
+    upd.set_inputs(E=E0, obs=obs, decorr=decorr)
+    ms_fwd = ms_upd = 0.0
+    try:
+        for _ in range(n_iter):
+            fwd.set_inputs_device(upd.device_ptr("E"), dtype, transformed=False)
+            fwd.run()
+            upd.set_inputs_device(obs_ens_ptr=fwd.device_ptr("prods"), obs_dtype=model.dtype)
+            upd.set_inputs(perturbs=np.sqrt(alpha) * (rng.randn(N, n_obs) @ R12.T))
+            st = fwd.sync()
+            ms_fwd += st["ms_total"]
+            _, _, status = fwd.outputs(want_wsats=False)
+            if status.any():
+                raise _lib.HmError(f"forward model failed for members {np.flatnonzero(status)[:8].tolist()}")
+            ms_upd += upd.run_local()["ms_update"]
+            upd.swap()
+        out = np.empty((N, M), dtype=upd.ft)
+        _lib.check(upd.lib.hm_copy_to_host(upd.ctx.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(upd.device_ptr("E")),
+                                           out.nbytes), "hm_copy_to_host")
+    finally:
+        fwd.close()
+        upd.close()
+    if stats is not None:
+        stats.update(ms_forward=ms_fwd, ms_update=ms_upd)
+    return out.astype(float)

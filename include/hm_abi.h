@@ -83,6 +83,9 @@ int  hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,
                    const double* porosity, int dtype, int keep_history, hm_fwd** out);
 void hm_fwd_destroy(hm_fwd* f);
 int  hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transformed, const void* wsat0); /* H2D */
+/* Device-resident chaining (forward -> update -> forward without PCIe): permeability input from a device buffer
+ * (fp64 or fp32), initial saturation zero.  Asynchronous on the context's stream. */
+int  hm_fwd_set_inputs_device(hm_fwd* f, const void* perm_dev, int perm_dtype, int perm_is_transformed);
 int  hm_fwd_run(hm_fwd* f, int first_step, int n_steps);           /* async; steps [first, first+n)  */
 int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
 int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member);     /* D2H */
@@ -136,6 +139,10 @@ int   hm_upd_set_inputs(hm_upd* u, const void* E_local, const void* obs_ens_loca
 /* Self-test hook: W = inv(G + ridge I) for one SPD matrix of order n (multiple of 16, <= 256) through the matrix-core
  * inverse used for C = S^T S + (N-1) I (HistoryMatch.py:585-586).  Host buffers. */
 int   hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double ridge, double* W);
+/* Device-resident chaining: ensemble and/or simulated observations from device buffers (NULL = keep); hm_upd_swap makes
+ * the last posterior the next prior (ES-MDA / iterative smoothers, HistoryMatch.py:906-959). */
+int   hm_upd_set_inputs_device(hm_upd* u, const void* E_dev, int E_dtype, const void* obs_ens_dev, int obs_dtype);
+int   hm_upd_swap(hm_upd* u);
 int   hm_upd_phase(hm_upd* u, int phase);
 /* All three phases of a plan that holds every member (N_local == N_total), no reduction points: the small fp64 chain
  * overlaps the big contraction on a second stream. */

@@ -11,10 +11,10 @@ OUT=gpurun_out/profiles/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 W=/tmp/hmprof; rm -rf $W; mkdir -p $W
-rocprofv3 --kernel-trace --stats --output-format csv -d $W/ks -o ks -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $W/ks.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/ks -o ks -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-esmda > $OUT/bench_under_rocprof.json 2> $W/ks.err
 cp "$(find $W/ks -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_bench_steps2_warmup1.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $W/$C -o pmc -- python3 bench.py --members 256 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $W/$C.err
+  rocprofv3 --pmc $C --output-format csv -d $W/$C -o pmc -- python3 bench.py --members 256 --steps 1 --warmup 0 --no-cpu-baseline --no-esmda > /dev/null 2> $W/$C.err
   cp "$(find $W/$C -name '*counter_collection.csv' | head -1)" $OUT/pmc_${C}_counter_collection.csv
 done
 python3 profiles/tools/pmc_to_json.py $OUT 256 > $OUT/pmc_hbm_traffic.json

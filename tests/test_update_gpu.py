@@ -196,6 +196,31 @@ def test_es_mda_driver_matches_oracle_loop():
     assert np.abs(post_gpu - prior).max() > 1e-3  # it did update
 
 
+@pytest.mark.parametrize("dtype,tol", [(64, 1e-9), (32, 2e-3)])
+def test_es_mda_device_resident_matches_host_driver(dtype, tol):
+    """The device-resident ES-MDA (forward -> update -> forward chained in HBM: hm_fwd_set_inputs_device,
+    hm_upd_set_inputs_device, hm_upd_swap) reproduces the host-driven loop pass for pass (same RNG stream)."""
+    from historymatching_amd.forward import make_forward_model
+    from historymatching_amd.update import es_mda, es_mda_device
+    from oracle import es
+    from tests.helpers import make_models, perms
+
+    nTime, N = 40, 16
+    _, gm = make_models(20, 20)
+    x = perms(20, 20, N + 1, seed=21, scale=0.5)
+    truth, prior = x[0], x[1:]
+    _, R12, _ = es.obs_error_model(nTime, 4)
+    fm = make_forward_model(gm, 0.025, nTime, return_history=False)
+    fwd_gpu = lambda E: es.vect(fm(E)[1], nTime)  # noqa: E731
+    obs = fwd_gpu(truth[None])[0] + R12 @ np.random.RandomState(5).randn(4 * nTime)
+    host = es_mda(fwd_gpu, prior, obs, R12, n_iter=2, rng=np.random.RandomState(7), dtype=64)
+    st = {}
+    dev = es_mda_device(gm, prior, obs, R12, 0.025, nTime, n_iter=2, rng=np.random.RandomState(7), dtype=dtype, stats=st)
+    assert dev.shape == prior.shape and st["ms_forward"] > 0 and st["ms_update"] > 0
+    assert np.abs(dev - host).max() < tol * max(1.0, np.abs(host - prior).max())
+    assert np.abs(dev - prior).max() > 1e-3  # it did update
+
+
 @pytest.mark.parametrize("N,M,n_obs,localized", [(1000, 4096, 160, False), (999, 4100, 160, False), (130, 1024, 64, True),
                                                   (64, 512, 48, False)])
 def test_fp32_matrix_core_path_matches_generic_and_oracle(N, M, n_obs, localized):
