@@ -914,6 +914,33 @@ extern "C" int hm_center(hm_ctx* ctx, int N, int M, const void* E, int dtype, in
     return rc;
 }
 
+// E = x0 + W X0: the ensemble of an iterative smoother re-composed from its weights in ensemble subspace
+// (IES: E = x0 + W @ X0, HistoryMatch.py:921), 2 N^2 M flops.  Host buffers.
+extern "C" int hm_recompose(hm_ctx* ctx, int N, int M, const void* W, const void* X0, const void* x0, int dtype, void* E_out) {
+    HM_REQUIRE(ctx && W && X0 && x0 && E_out && N >= 1 && M >= 1, "hm_recompose: bad arguments");
+    HM_REQUIRE(dtype == 64 || dtype == 32, "hm_recompose: dtype must be 64 or 32");
+    HM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t e = dtype == 64 ? 8 : 4;
+    DevBuf dW, dX, dx, dE;
+    int rc = hm_dev_alloc(dW, (size_t)N * N * e);
+    if (!rc) rc = hm_dev_alloc(dX, (size_t)N * M * e);
+    if (!rc) rc = hm_dev_alloc(dx, (size_t)M * e);
+    if (!rc) rc = hm_dev_alloc(dE, (size_t)N * M * e);
+    if (!rc && (hipMemcpyAsync(dW.p, W, (size_t)N * N * e, hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(dX.p, X0, (size_t)N * M * e, hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(dx.p, x0, (size_t)M * e, hipMemcpyHostToDevice, s) != hipSuccess)) { hm_set_error("hm_recompose: H2D failed"); rc = 1; }
+    if (!rc) {
+        // C[i][j] = sum_k W[i][k] X0[k][j] + x0[j]   (row stride 0 broadcasts x0 over the members)
+        if (dtype == 64) rc = gemm<double>(s, N, M, N, (const double*)dW.p, N, 1, (const double*)dX.p, M, 1, (double*)dE.p, M, (const double*)dx.p, 0);
+        else rc = gemm<float>(s, N, M, N, (const float*)dW.p, N, 1, (const float*)dX.p, M, 1, (float*)dE.p, M, (const float*)dx.p, 0);
+    }
+    if (!rc && (hipMemcpyAsync(E_out, dE.p, (size_t)N * M * e, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)) { hm_set_error("hm_recompose: device error"); rc = 1; }
+    hm_dev_free(dW); hm_dev_free(dX); hm_dev_free(dx); hm_dev_free(dE);
+    return rc;
+}
+
 static int es_update_host(hm_ctx* ctx, int N, int M, int n_obs, const void* E, const void* obs_ens, const void* obs,
                           const void* perturbs, const void* decorr, const void* taper, double cutoff, int dtype,
                           int localized, void* E_out, hm_stats* stats) {

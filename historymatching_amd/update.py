@@ -225,3 +225,53 @@ def es_mda_device(model, prior_ens, obs, R12, dt, nTime, n_iter=4, rng=None, dty
     if stats is not None:
         stats.update(ms_forward=ms_fwd, ms_update=ms_upd)
     return out.astype(float)
+
+
+def recompose(W, X0, x0, dtype=64, device=None):
+    """``x0 + W @ X0`` on the GPU (`hm_recompose`): the ensemble from its subspace weights."""
+    ft = _ft(dtype)
+    W, X0, x0 = _lib.as_c(W, ft), _lib.as_c(X0, ft), _lib.as_c(x0, ft)
+    N, M = X0.shape
+    if W.shape != (N, N) or x0.shape != (M,):
+        raise ValueError(f"shapes: W {W.shape}, X0 {X0.shape}, x0 {x0.shape}")
+    ctx = _lib.Context.get(device)
+    out = np.empty((N, M), dtype=ft)
+    _lib.check(ctx.lib.hm_recompose(ctx.handle, N, M, _lib.ptr(W), _lib.ptr(X0), _lib.ptr(x0), int(dtype), _lib.ptr(out)), "hm_recompose")
+    return out
+
+
+def ies(prior_ens, obs_ens, obs, perturbs, decorr, xStep=1.0, iMax=4, dtype=64, device=None):
+    """Iterative ensemble smoother in ensemble subspace, same call surface as the reference's `IES`
+    (notebooks/HistoryMatch.py:906-944): ``obs_ens`` is the forward/observation *function* ``E -> (N, n_obs)``; returns
+    ``(posterior_ens, stats)`` with ``stats["E"]``, ``stats["Eo"]`` the iterates.
+
+    Gauss-Newton on the weights ``W`` of ``E = x0 + W X0``: with ``Y0 = center(W^+) Eo decorr`` the ensemble sensitivity,
+    the step is ``[(y - D - Eo decorr) Y0^T + (N-1)(I - W)] (Y0 Y0^T + (N-1) I)^-1``.  The N x N subspace algebra (a
+    pseudo-inverse and a thin SVD per iterate) stays on the host in fp64 like the reference's; the two O(N^2 M) pieces --
+    centring the prior and re-composing the ensemble -- and the forward model behind ``obs_ens`` run on the GPU."""
+    import scipy.linalg as sla
+
+    prior_ens = np.asarray(prior_ens, dtype=float)
+    N = len(prior_ens)
+    X0, x0 = center(prior_ens, dtype=64, device=device)
+    y = np.asarray(obs, float) @ decorr
+    Dp = np.asarray(perturbs, float) @ decorr
+    eye = np.eye(N)
+    W = eye.copy()
+    stats = {"E": [], "Eo": []}
+    for _ in range(int(iMax)):
+        E = recompose(W, X0, x0, dtype=dtype, device=device).astype(float)
+        Eo = np.asarray(obs_ens(E), dtype=float)
+        stats["E"].append(E)
+        stats["Eo"].append(Eo)
+        Eo = Eo @ decorr
+        Winv = sla.pinv(W)
+        Y0 = (Winv - Winv.mean(0)) @ Eo  # sensitivity of the (decorrelated) observations to the weights
+        grad = (y - Dp - Eo) @ Y0.T + (N - 1) * (eye - W)
+        # (Y0 Y0^T + (N-1) I)^-1 through the SVD of Y0; directions outside its range keep the prior precision N-1
+        full = Y0.shape[0] > Y0.shape[1]
+        V, sv, _ = sla.svd(Y0, full_matrices=full)
+        spec = np.full(V.shape[1], float(N - 1))
+        spec[: len(sv)] += sv**2
+        W = W + xStep * ((grad @ (V / spec)) @ V.T)
+    return recompose(W, X0, x0, dtype=dtype, device=device).astype(float), stats

@@ -136,6 +136,9 @@ int   hm_upd_create(hm_ctx* ctx, int N_total, int N_local, int M, int n_obs, int
 void  hm_upd_destroy(hm_upd* u);
 int   hm_upd_set_inputs(hm_upd* u, const void* E_local, const void* obs_ens_local, const void* obs,
                         const void* perturbs_local, const void* decorr, const void* taper /* or NULL */, double cutoff);
+/* E (N x M) = x0 (M) + W (N x N) X0 (N x M): re-composition of the ensemble from subspace weights, the 2 N^2 M flop
+ * step of the iterative ensemble smoother (IES, notebooks/HistoryMatch.py:921, 944).  Host buffers. */
+int   hm_recompose(hm_ctx* ctx, int N, int M, const void* W, const void* X0, const void* x0, int dtype, void* E_out);
 /* Self-test hook: W = inv(G + ridge I) for one SPD matrix of order n (multiple of 16, <= 256) through the matrix-core
  * inverse used for C = S^T S + (N-1) I (HistoryMatch.py:585-586).  Host buffers. */
 int   hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double ridge, double* W);
