@@ -127,12 +127,34 @@ def as_c(a, dtype):
     return None if a is None else np.ascontiguousarray(a, dtype=dtype)
 
 
+def _torch_first():
+    """PyTorch-ROCm wheels carry their own copy of the HIP runtime; libhm_amd.so links the system one.  Both can live in
+    one process only if torch's copy opens the device FIRST (the other order leaves torch with "no GPUs found": RCCL
+    process groups then fail).  So: if torch is already imported, or this is a torch.distributed launch
+    (RANK/WORLD_SIZE set), let torch initialise its runtime before the first hm_create.  Plain single-process use never
+    imports torch."""
+    import sys
+
+    if os.environ.get("HM_AMD_NO_TORCH_PREINIT") == "1":
+        return
+    if "torch" not in sys.modules and "WORLD_SIZE" not in os.environ:
+        return
+    try:
+        import torch
+
+        if torch.cuda.device_count() > 0:
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 class Context:
     """One HIP context (device + stream).  Reused process-wide per device."""
 
     _cache = {}
 
     def __init__(self, device=0):
+        _torch_first()
         lib = load()
         h = C.c_void_p()
         check(lib.hm_create(int(device), C.byref(h)), "hm_create")
