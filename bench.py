@@ -82,12 +82,12 @@ def es_update_timing(device):
 
 
 def es_mda_c3(device, perms, n_iter=4):
-    """BASELINE.json config 3: N_e=1000, 128x128, 4 ES-MDA passes (forward model fp64 + fp32 matrix-core analysis), the
+    """BASELINE.json config 3: N_e=1000, 128x128, 4 ES-MDA passes (forward model in fp32 mode + fp32 matrix-core analysis), the
     ensemble resident in HBM throughout (update.es_mda_device).  Observations = member 0's simulated production + noise."""
     from historymatching_amd.forward import ForwardPlan
     from historymatching_amd.update import es_mda_device
 
-    model = build_model(64, device=device)
+    model = build_model(32, device=device)  # config 3 is the fp32 configuration: fp32 saturation sweep (sat128f), fp64 pressure
     n_obs = NTIME * 4
     rng = np.random.RandomState(4)
     R12 = 0.1 * np.eye(n_obs)  # HistoryMatch.py:243-259 uses a correlated R; the update cost does not depend on it
@@ -105,7 +105,8 @@ def es_mda_c3(device, perms, n_iter=4):
     return {"iterations": n_iter, "wall_s": wall, "device_ms_forward": st["ms_forward"], "device_ms_update": st["ms_update"],
             "ensemble_steps_per_s_incl_updates": len(perms) * NTIME * n_iter / wall,
             "posterior_finite": bool(np.isfinite(post).all()),
-            "config": f"N_e={len(perms)}, {NX}x{NY}, {n_iter} ES-MDA passes, forward fp64 + analysis fp32 (config 3)"}
+            "config": f"N_e={len(perms)}, {NX}x{NY}, {n_iter} ES-MDA passes, forward model dtype=32 (fp32 saturation sweep, fp64 "
+                      "pressure solve) + fp32 matrix-core analysis, ensemble resident in HBM (config 3)"}
 
 
 def main():

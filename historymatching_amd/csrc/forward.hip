@@ -570,7 +570,10 @@ static int launch_saturation(hm_fwd* f, int k) {
     int rc = f->t_sat.begin(s);
     if (rc) return rc;
     int done = -1;
-    if (f->sat_variant != 1) done = launch_saturation_128(f, Sin, Sout, stride, k);
+    if (f->sat_variant != 1) {
+        done = launch_saturation_128(f, Sin, Sout, stride, k);                  // fp64, register/LDS resident
+        if (done < 0) done = launch_saturation_128f(f, Sin, Sout, stride, k);  // fp32 twin
+    }
     if (done > 0) return done;
     if (done < 0) {
         rc = ensure_generic_sat_scratch(f);

@@ -78,3 +78,4 @@ int launch_pressure_128m(hm_fwd* f, const void* S, long long S_stride, int k);  
 int launch_pressure_128s(hm_fwd* f, const void* S, long long S_stride, int k);  // MFMA panels, symmetric tile storage (default)
 int launch_pressure_pcg(hm_fwd* f, const void* S, long long S_stride, int k);   // CG, any grid (press_pcg.hip)
 int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);
+int launch_saturation_128f(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // dtype = 32 plans

@@ -1,0 +1,27 @@
+"""Timing of the large-grid path (CG pressure + generic saturation kernels) on shards of BASELINE configs 4 and 5.
+   python tests/tools/large_grid_timing.py [n members nTime]"""
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+from helpers import perms, wells_4corners  # noqa: E402
+from historymatching_amd.forward import ForwardPlan  # noqa: E402
+from historymatching_amd.ressim import ResSim  # noqa: E402
+
+cases = [(256, 64, 2), (512, 16, 1)] if len(sys.argv) < 4 else [tuple(int(a) for a in sys.argv[1:4])]
+for n, N, nTime in cases:
+    gm = wells_4corners(ResSim(n, n, 2, 1))
+    plan = ForwardPlan(gm, N, 0.025, nTime, keep_history=False, device=0)
+    plan.set_inputs(perms(n, n, N, seed=3), None, transformed=False)
+    t0 = time.perf_counter()
+    plan.run()
+    st = plan.sync()
+    wall = time.perf_counter() - t0
+    _, _, status = plan.outputs(want_wsats=False)
+    print(f"{n}x{n}, {N} members, {nTime} steps: wall {wall:.2f} s; pressure {st['ms_pressure'] / st['n_pressure_launches']:.1f} ms/launch "
+          f"(mean CG iterations {st['mean_n_cg']:.0f}), saturation {st['ms_saturation'] / st['n_saturation_launches']:.1f} ms/launch "
+          f"(mean Nts {st['mean_nts']:.0f}); status ok: {not status.any()}")
+    plan.close()
