@@ -415,7 +415,8 @@ extern "C" void hm_fwd_destroy(hm_fwd* f) {
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
     DevBuf* bufs[] = {&f->K, &f->por, &f->q, &f->prd_ind, &f->TX, &f->TY, &f->G, &f->yv, &f->P, &f->Vx,
-                      &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells, &f->cg_r, &f->cg_p, &f->n_cg};
+                      &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells, &f->cg_r, &f->cg_p, &f->n_cg,
+                      &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     f->t_total.destroy(); f->t_press.destroy(); f->t_sat.destroy();
     delete f;
@@ -539,7 +540,8 @@ static int launch_pressure(hm_fwd* f, int k) {
             f->p.cg_r = (double*)f->cg_r.p; f->p.cg_p = (double*)f->cg_p.p;
             f->cg_lazy = false;
         }
-        done = launch_pressure_pcg(f, S, stride, k);
+        if (pv != 9 && f->cg_precond == 0 && pressure_two_level_applies(p)) done = launch_pressure_two_level(f, S, stride, k);
+        else done = launch_pressure_pcg(f, S, stride, k);
     } else if (pv == 2) done = launch_pressure_128(f, S, stride, k);
     else if (pv == 3 || pv == 4 || pv == 5 || pv == 8) done = launch_pressure_128m(f, S, stride, k);
     else if (pv != 1) done = launch_pressure_128s(f, S, stride, k);

@@ -38,6 +38,7 @@ struct FwdParams {
     int* n_cg;                // N*nTime iterations used
     double cg_rtol;           // stop at ||r|| <= rtol ||q||
     int cg_max_iter;
+    const double* pin;        // N: SPD pin per member (coarse level of the two-level preconditioner only)
 };
 
 struct hm_fwd {
@@ -49,6 +50,10 @@ struct hm_fwd {
     bool cg_lazy = true;  // CG work vectors not allocated yet
     size_t esz = 8;  // bytes per saturation element
     DevBuf K, por, q, prd_ind, TX, TY, G, yv, P, Vx, Vy, coef, fw, status, nts, perm_in, cg_r, cg_p, n_cg;
+    // two-level CG preconditioner (allocated on first use): coarse transmissibilities, pin, restricted residual, coarse
+    // correction, coarse scratch, coarse factor, per-member CG scalars and convergence flags
+    DevBuf tl_TXc, tl_TYc, tl_pin, tl_rc, tl_yc, tl_yv, tl_G, tl_cgs, tl_done, tl_ndone;
+    int cg_precond = 0;  // 0 = two-level where it applies, 1 = Jacobi
     DevBuf S;      // keep_history ? N*(nTime+1)*Nxy : 2*N*Nxy (ping-pong)
     DevBuf prods;  // N*nTime*nPrd
     int cur = 0;   // time index whose saturation is "current" (row in history / ping-pong parity)
@@ -76,6 +81,8 @@ static inline void* fwd_S_ptr(hm_fwd* f, int k, long long* stride) {
 int launch_pressure_128(hm_fwd* f, const void* S, long long S_stride, int k);   // VALU rank-1 sweeps (variant 2)
 int launch_pressure_128m(hm_fwd* f, const void* S, long long S_stride, int k);  // MFMA panels, full tile storage
 int launch_pressure_128s(hm_fwd* f, const void* S, long long S_stride, int k);  // MFMA panels, symmetric tile storage (default)
-int launch_pressure_pcg(hm_fwd* f, const void* S, long long S_stride, int k);   // CG, any grid (press_pcg.hip)
+int launch_pressure_pcg(hm_fwd* f, const void* S, long long S_stride, int k);   // Jacobi-CG, any grid (press_pcg.hip)
+bool pressure_two_level_applies(const FwdParams& p);
+int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int k);  // two-level CG, Ny = 128 c
 int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);
 int launch_saturation_128f(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // dtype = 32 plans

@@ -140,7 +140,10 @@ __device__ __forceinline__ double matvec_total(SLds& L, int j) {
     return a + b;
 }
 
-template <typename TS, int NW>
+// FACTOR = true: factor-only entry for the coarse level of the two-level CG preconditioner (press_pcg.hip): the face
+// transmissibilities TX, TY and the SPD pin are GIVEN (p.TX, p.TY, p.pin), nothing is assembled, no right-hand side is
+// eliminated, only the inverse Schur complements G_i are produced (p.G) for k_coarse_solve below.
+template <typename TS, int NW, bool FACTOR = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParams p, const TS* __restrict__ S_base, long long S_stride,
                                                                        int k) {
     using Cf = SCfg<NW>;
@@ -180,7 +183,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
     }
 
     PROF_DECL;
-    assemble_transmissibilities<TS>(p, S, Km, P /* scratch for L */, TX, TY, tid, NT);
+    if constexpr (!FACTOR) assemble_transmissibilities<TS>(p, S, Km, P /* scratch for L */, TX, TY, tid, NT);
+    const double pin = FACTOR ? p.pin[m] : Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
     if (tid == 0) L.flag = 0;
     __syncthreads();  // TX/TY entries written by other threads are read below
     PROF(5);
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
     // vectors of block i+1 are fetched by the service threads one block ahead
     double pf_y1 = 0.0, pf_y2 = 0.0, pf_x1 = 0.0, pf_x2 = 0.0, pf_q = 0.0, q_cur = 0.0;
     if (j < NB) {
-        pf_y1 = TY[j]; pf_y2 = TY[j + 1]; pf_x1 = TX[j]; pf_x2 = TX[NB + j]; pf_q = q[j];
+        pf_y1 = TY[j]; pf_y2 = TY[j + 1]; pf_x1 = TX[j]; pf_x2 = TX[NB + j]; pf_q = FACTOR ? 0.0 : q[j];
     }
 
     // ---- one rank-16 panel --------------------------------------------------------------------------------------
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
     for (int i = 0; i < Nx; ++i) {
         if (j < NB) {
             double dg = pf_y1 + pf_y2 + pf_x1 + pf_x2;
-            if (i == 0 && j == 0) dg += Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
+            if (i == 0 && j == 0) dg += pin;
             L.dgv[j] = dg;
             L.tyv[j] = pf_y1;
             if (j == NB - 1) L.tyv[NB] = pf_y2;
@@ -242,9 +246,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
         __syncthreads();
         PROF(6);
         if (i > 0) {
-            if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
-            __syncthreads();
-            if (j < NB) L.ycur[j] = q_cur + L.ev[j] * matvec_total<NC>(L, j);
+            if constexpr (!FACTOR) {
+                if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
+                __syncthreads();
+                if (j < NB) L.ycur[j] = q_cur + L.ev[j] * matvec_total<NC>(L, j);
+            }
             if (!service) {
 #pragma unroll
                 for (int s = 0; s < TPW; ++s) {
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
             const int in = i + 1;
             pf_y1 = TY[in * (NB + 1) + j]; pf_y2 = TY[in * (NB + 1) + j + 1];
             pf_x1 = TX[in * NB + j]; pf_x2 = TX[(in + 1) * NB + j];
-            pf_q = q[in * NB + j];
+            pf_q = FACTOR ? 0.0 : q[in * NB + j];
         }
         __syncthreads();  // the mat-vec scratch (aliases U, W) is free again
         PROF(7);
@@ -373,12 +379,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
                 }
             }
         }
-        if (j < NB) {
+        if (!FACTOR && j < NB) {
             yv[i * NB + j] = L.ycur[j];
             L.yprev[j] = L.ycur[j];
         }
         __syncthreads();
         PROF(10);
+    }
+    if constexpr (FACTOR) {
+        if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
+        return;
     }
     // back substitution: x_i = G_i (y_i + TX[i+1] * x_{i+1});  ycur holds x_{i+1};  G_{Nx-1} is still in the accumulators
     for (int i = Nx - 1; i >= 0; --i) {
@@ -420,6 +430,87 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------
+// x = A^-1 b for a system factored by k_press128s<.., FACTOR = true>: the two substitution passes of the block
+// elimination with the stored inverse Schur complements (36 tiles per block, 72 KB), one right-hand side per member.
+//   forward   y_0 = b_0,  y_i = b_i + e_i o (G_{i-1} y_{i-1})          e_i = TX[i] (coupling to block i-1)
+//   backward  x_{Nx-1} = G_{Nx-1} y_{Nx-1},  x_i = G_i (y_i + e_{i+1} o x_{i+1})
+// Coarse solve of the two-level CG preconditioner (press_pcg.hip): 2 Nx mat-vecs, the G stream read twice.
+// `skip[m] != 0`: member already converged, nothing to do.
+// ------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_coarse_solve(FwdParams p, const double* __restrict__ b_base, double* __restrict__ x_base,
+                                                              const int* __restrict__ skip) {
+    using Cf = SCfg<NW>;
+    constexpr int NC = Cf::NC, TPW = Cf::TPW, NCT = Cf::NCT;
+    __shared__ SLds L;
+    const int m = blockIdx.x;
+    if (skip && skip[m]) return;
+    const int tid = threadIdx.x;
+    SGeo g;
+    g.lane = tid & 63;
+    g.lc = g.lane & 15;
+    g.lq = g.lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool service = (w & 3) == 0;
+    const int c = service ? 0 : (w >> 2) * 3 + (w & 3) - 1;
+    const int j = service ? (w >> 2) * 64 + g.lane : NB;
+    const int ct = c * 64 + g.lane;
+    const int Nx = p.Nx, Nxy = p.Nxy;
+    const double* TX = p.TX + (long long)m * (Nx + 1) * NB;
+    const double2* G = reinterpret_cast<const double2*>(p.G + (long long)m * Nx * NB * NB);
+    double* yv = p.yv + (long long)m * Nxy;
+    const double* b = b_base + (long long)m * Nxy;
+    double* x = x_base + (long long)m * Nxy;
+    int tR[TPW], tC[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+        const int e = NW == 8 ? TILE_TAB8[c % 6][s % 6] : TILE_TAB16[c % 12][s % 3];
+        tR[s] = __builtin_amdgcn_readfirstlane(e >> 4);
+        tC[s] = __builtin_amdgcn_readfirstlane(e & 15);
+    }
+    d4 acc[TPW];
+    auto load_G = [&](int i) {
+        const double2* Gi = G + (long long)i * (NB * NB / 2);
+#pragma unroll
+        for (int s = 0; s < TPW; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double2 v = Gi[(s * 2 + h) * NCT + ct];
+                acc[s][2 * h] = v.x;
+                acc[s][2 * h + 1] = v.y;
+            }
+    };
+    if (j < NB) {
+        const double v = b[j];
+        yv[j] = v;
+        L.yprev[j] = v;
+    }
+    for (int i = 1; i < Nx; ++i) {
+        if (!service) load_G(i - 1);
+        __syncthreads();
+        if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
+        __syncthreads();
+        if (j < NB) {
+            const double v = b[i * NB + j] + TX[i * NB + j] * matvec_total<NC>(L, j);
+            yv[i * NB + j] = v;
+            L.yprev[j] = v;
+        }
+    }
+    for (int i = Nx - 1; i >= 0; --i) {
+        if (!service) load_G(i);
+        if (j < NB && i < Nx - 1) L.yprev[j] = yv[i * NB + j] + TX[(i + 1) * NB + j] * L.ycur[j];
+        __syncthreads();
+        if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
+        __syncthreads();
+        if (j < NB) {
+            const double t = matvec_total<NC>(L, j);
+            L.ycur[j] = t;
+            x[i * NB + j] = t;
+        }
+    }
+}
+
 #ifdef HM_PRESS_PROF
 extern "C" int hm_debug_press_prof_s(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hm_press_prof_s_buf), sizeof(long long) * 32);
@@ -440,6 +531,22 @@ int launch_pressure_128s(hm_fwd* f, const void* S, long long S_stride, int k) {
         else LAUNCH(float, 8);
     }
 #undef LAUNCH
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+// Coarse level of the two-level CG preconditioner (press_pcg.hip).  `pc`: parameter block of the coarse system (Ny = 128,
+// TX/TY/pin given, G and yv scratch).  Factor once per time step, then one solve per CG iteration.
+int launch_coarse_factor_128(hipStream_t s, const FwdParams& pc) {
+    if (pc.Ny != NB) return -1;
+    hipLaunchKernelGGL((k_press128s<double, 8, true>), dim3(pc.N), dim3(512), 0, s, pc, (const double*)nullptr, 0LL, 0);
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_coarse_solve_128(hipStream_t s, const FwdParams& pc, const double* b, double* x, const int* skip) {
+    if (pc.Ny != NB) return -1;
+    hipLaunchKernelGGL(k_coarse_solve<8>, dim3(pc.N), dim3(512), 0, s, pc, b, x, skip);
     HM_HIP(hipGetLastError());
     return 0;
 }

@@ -244,7 +244,7 @@ def test_full_sim_128_within_reference_solver_noise(variant):
     plan.close()
 
 
-@pytest.mark.parametrize("nx,ny", [(160, 160), (96, 192), (256, 256)])
+@pytest.mark.parametrize("nx,ny", [(160, 160), (96, 192), (256, 256), (64, 256)])
 def test_large_grid_sim_cg_pressure(nx, ny):
     """Ny > 128 (BASELINE configs 4/5 are 256x256 and 512x512): the direct block solver does not apply, the
     pressure system is solved by conjugate gradients (press_pcg.hip); the saturation sweep is the generic kernel.
