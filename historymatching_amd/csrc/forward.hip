@@ -279,6 +279,97 @@ __global__ void k_saturation_generic(FwdParams p, const T* __restrict__ Sin_base
 }
 
 // ------------------------------------------------------------------------------------------------
+// STREAMING saturation step for grids too large for on-chip residency (Ny > 128; sat_variant 2 at any size): the same
+// arithmetic as k_saturation_generic with a third of its memory traffic.  Per sub-step and cell the generic kernel moves
+// ~96 B (fw written and re-read, six coefficient arrays, S read and written); here the upwind coefficients are re-derived
+// from the face fluxes (Vx, Vy: 2 arrays) and the fractional flow of the four neighbours is re-evaluated from their
+// saturations (cached reads) instead of being stored, so a sub-step is ONE pass -- read S_old, Vx, Vy, q; write S_new --
+// and ONE barrier, ping-ponging between the output row and a scratch image, and the six coefficient images are not
+// allocated at all (1.5 GB at N = 125, 512^2).  Five fw evaluations per cell instead of one make it ALU bound (fp64
+// divisions) at about the generic kernel's memory-bound speed (measured 0.54 vs 0.61 ms per sub-step at 512^2); sharing
+// the fw evaluations through LDS tiles is the next step for this path.
+// Every expression is the generic kernel's (same operands, same order): bit-identical results.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_saturation_stream(FwdParams p, const T* __restrict__ Sin_base, T* __restrict__ Sout_base, long long S_stride,
+                                    T* __restrict__ prods, int k) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int m = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    const int Nx = p.Nx, Ny = p.Ny, Nxy = p.Nxy;
+    double* red = smem;
+    const T* Sin = Sin_base + (long long)m * S_stride;
+    T* Sout = Sout_base + (long long)m * S_stride;
+    T* Sbuf = (T*)p.fw + (long long)m * Nxy;  // second image of the ping-pong
+    const double* Vx = p.Vx + (long long)m * (Nx + 1) * Ny;
+    const double* Vy = p.Vy + (long long)m * Nx * (Ny + 1);
+    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+
+    // --- CFL: pm = min(pv / (Vi + fi))
+    double lmin = INFINITY;
+    for (int j = tid; j < Nxy; j += NT) {
+        const int ix = j / Ny, iy = j - ix * Ny;
+        const double xp = fmax(Vx[ix * Ny + iy], 0.0), yp = fmax(Vy[ix * (Ny + 1) + iy], 0.0);
+        const double xn = fmin(Vx[(ix + 1) * Ny + iy], 0.0), yn = fmin(Vy[ix * (Ny + 1) + iy + 1], 0.0);
+        const double Vi = xp + yp - xn - yn;
+        const double fi = fmax(q[j], 0.0);
+        const double pv = p.h2 * (p.por ? p.por[j] : 1.0);
+        lmin = fmin(lmin, pv / (Vi + fi));
+    }
+    const double pm = block_min(lmin, red, tid, NT);
+    const double cfl = ((1.0 - (p.swc + p.sor)) / 3.0) * pm;
+    const double ntsd = ceil(p.dt / cfl);
+    const int bad = !(ntsd >= 1.0 && ntsd <= 1.0e7);
+    const int Nts = bad ? 0 : (int)ntsd;
+    if (tid == 0) {
+        p.nts[(long long)m * p.nTime + k] = Nts;
+        if (bad) atomicOr(&p.status[m], HM_MEMBER_BAD_CFL);
+    }
+    if (Nts == 0) {
+        for (int j = tid; j < Nxy; j += NT) Sout[j] = Sin[j];
+        __syncthreads();
+    }
+    auto fwf = [&](T s) {
+        T mw, mo;
+        rel_perm<T>(p, s, mw, mo);
+        return mw / (mw + mo);
+    };
+    const double d_uniform = Nts ? (p.dt / (double)Nts) / (p.h2 * 1.0) : 0.0;
+    // sub-step it reads `src`, writes `dst`; the last one must write Sout
+    for (int it = 0; it < Nts; ++it) {
+        const T* __restrict__ src = it == 0 ? Sin : (((Nts - it) & 1) ? Sbuf : Sout);  // = destination of sub-step it-1
+        T* __restrict__ dst = ((Nts - 1 - it) & 1) ? Sbuf : Sout;
+        for (int j = tid; j < Nxy; j += NT) {
+            const int ix = j / Ny, iy = j - ix * Ny;
+            const double d = p.por ? (p.dt / (double)Nts) / (p.h2 * p.por[j]) : d_uniform;  // same value, two divisions less
+            const double vxw = Vx[ix * Ny + iy], vxe = Vx[(ix + 1) * Ny + iy];
+            const double vys = Vy[ix * (Ny + 1) + iy], vyn = Vy[ix * (Ny + 1) + iy + 1];
+            const double qj = q[j];
+            const double fp = fmin(qj, 0.0), fi = fmax(qj, 0.0);
+            const double x1 = fmin(vxw, 0.0), x2 = fmax(vxe, 0.0), y1 = fmin(vys, 0.0), y2 = fmax(vyn, 0.0);
+            const T cC = (T)(d * (fp + x1 - x2 + y1 - y2));
+            const T cW = (T)(d * fmax(vxw, 0.0));
+            const T cE = (T)(d * (-fmin(vxe, 0.0)));
+            const T cS = (T)(d * fmax(vys, 0.0));
+            const T cN = (T)(d * (-fmin(vyn, 0.0)));
+            const T fid = (T)(fi * d);
+            const T sc = src[j];
+            T acc = (ix + 1 < Nx) ? cE * fwf(src[j + Ny]) : T(0);
+            if (iy + 1 < Ny) acc = acc + cN * fwf(src[j + 1]);
+            acc = acc + cC * fwf(sc);
+            if (iy > 0) acc = acc + cS * fwf(src[j - 1]);
+            if (ix > 0) acc = acc + cW * fwf(src[j - Ny]);
+            dst[j] = sc + (acc + fid);
+        }
+        __syncthreads();
+    }
+    int nonfinite = 0;
+    for (int j = tid; j < Nxy; j += NT)
+        if (!isfinite((double)Sout[j])) nonfinite = 1;
+    if (nonfinite) atomicOr(&p.status[m], HM_MEMBER_NONFINITE);
+    if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = Sout[p.prd_ind[tid]];
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -503,15 +594,17 @@ extern "C" int hm_fwd_set_inputs_device(hm_fwd* f, const void* perm_dev, int per
     return 0;
 }
 
-static int ensure_generic_sat_scratch(hm_fwd* f) {
-    if (f->coef.p) return 0;
+static int ensure_generic_sat_scratch(hm_fwd* f, bool need_coef) {
     size_t n = (size_t)f->p.N * f->p.Nxy;
-    int rc = hm_dev_alloc(f->coef, 6 * n * f->esz);
-    if (rc) return rc;
-    rc = hm_dev_alloc(f->fw, n * f->esz);
-    if (rc) return rc;
-    f->p.coef = f->coef.p;
-    f->p.fw = f->fw.p;
+    int rc = 0;
+    if (need_coef && !f->coef.p) {
+        if ((rc = hm_dev_alloc(f->coef, 6 * n * f->esz))) return rc;
+        f->p.coef = f->coef.p;
+    }
+    if (!f->fw.p) {
+        if ((rc = hm_dev_alloc(f->fw, n * f->esz))) return rc;
+        f->p.fw = f->fw.p;
+    }
     return 0;
 }
 
@@ -572,20 +665,22 @@ static int launch_saturation(hm_fwd* f, int k) {
     int rc = f->t_sat.begin(s);
     if (rc) return rc;
     int done = -1;
-    if (f->sat_variant != 1) {
+    if (f->sat_variant != 1 && f->sat_variant != 2) {
         done = launch_saturation_128(f, Sin, Sout, stride, k);                  // fp64, register/LDS resident
         if (done < 0) done = launch_saturation_128f(f, Sin, Sout, stride, k);  // fp32 twin
     }
     if (done > 0) return done;
     if (done < 0) {
-        rc = ensure_generic_sat_scratch(f);
+        // sat_variant 1: generic (coefficient arrays + fw image); 2: streaming; otherwise streaming beyond 128 x 128
+        const bool stream = f->sat_variant == 2 || (f->sat_variant != 1 && p.Nxy > 128 * 128);
+        rc = ensure_generic_sat_scratch(f, !stream);
         if (rc) return rc;
         int T = p.Nxy >= 4096 ? 1024 : 256;
         size_t lds = (size_t)T * 8;
-        if (f->dtype == 64)
-            hipLaunchKernelGGL(k_saturation_generic<double>, dim3(p.N), dim3(T), lds, s, f->p, (const double*)Sin, (double*)Sout, stride, (double*)f->prods.p, k);
-        else
-            hipLaunchKernelGGL(k_saturation_generic<float>, dim3(p.N), dim3(T), lds, s, f->p, (const float*)Sin, (float*)Sout, stride, (float*)f->prods.p, k);
+#define SAT(KERN, TT) hipLaunchKernelGGL(KERN<TT>, dim3(p.N), dim3(T), lds, s, f->p, (const TT*)Sin, (TT*)Sout, stride, (TT*)f->prods.p, k)
+        if (stream) { if (f->dtype == 64) SAT(k_saturation_stream, double); else SAT(k_saturation_stream, float); }
+        else { if (f->dtype == 64) SAT(k_saturation_generic, double); else SAT(k_saturation_generic, float); }
+#undef SAT
         HM_HIP(hipGetLastError());
     }
     rc = f->t_sat.end(s);
