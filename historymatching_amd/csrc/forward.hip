@@ -370,6 +370,144 @@ __global__ void k_saturation_stream(FwdParams p, const T* __restrict__ Sin_base,
 }
 
 // ------------------------------------------------------------------------------------------------
+// TILED saturation step (default beyond 128 x 128; sat_variant 3 at any size): k_saturation_stream with the fractional
+// flow shared through LDS.  The grid is swept in tiles of 64 x 256 cells; per tile the workgroup evaluates fw once for the
+// tile and its one-cell halo into LDS (136 KB in fp64), then updates the tile from it.  One fw division per cell (+3 %
+// halo) instead of five, still one pass over HBM per sub-step (read S_old, Vx, Vy, q; write S_new).  Same expressions,
+// same order as the generic kernel: bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T* __restrict__ Sin_base, T* __restrict__ Sout_base,
+                                                           long long S_stride, T* __restrict__ prods, int k) {
+    constexpr int TH = 64, TW = 256, LW = TW + 2;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int m = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    const int Nx = p.Nx, Ny = p.Ny, Nxy = p.Nxy;
+    double* red = smem;                          // NT doubles
+    T* fwt = reinterpret_cast<T*>(smem + 1024);  // (TH + 2) x LW
+    const T* Sin = Sin_base + (long long)m * S_stride;
+    T* Sout = Sout_base + (long long)m * S_stride;
+    T* Sbuf = (T*)p.fw + (long long)m * Nxy;
+    const double* Vx = p.Vx + (long long)m * (Nx + 1) * Ny;
+    const double* Vy = p.Vy + (long long)m * Nx * (Ny + 1);
+    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+
+    double lmin = INFINITY;
+    for (int j = tid; j < Nxy; j += NT) {
+        const int ix = j / Ny, iy = j - ix * Ny;
+        const double xp = fmax(Vx[ix * Ny + iy], 0.0), yp = fmax(Vy[ix * (Ny + 1) + iy], 0.0);
+        const double xn = fmin(Vx[(ix + 1) * Ny + iy], 0.0), yn = fmin(Vy[ix * (Ny + 1) + iy + 1], 0.0);
+        const double Vi = xp + yp - xn - yn;
+        const double fi = fmax(q[j], 0.0);
+        const double pv = p.h2 * (p.por ? p.por[j] : 1.0);
+        lmin = fmin(lmin, pv / (Vi + fi));
+    }
+    const double pm = block_min(lmin, red, tid, NT);
+    const double cfl = ((1.0 - (p.swc + p.sor)) / 3.0) * pm;
+    const double ntsd = ceil(p.dt / cfl);
+    const int bad = !(ntsd >= 1.0 && ntsd <= 1.0e7);
+    const int Nts = bad ? 0 : (int)ntsd;
+    if (tid == 0) {
+        p.nts[(long long)m * p.nTime + k] = Nts;
+        if (bad) atomicOr(&p.status[m], HM_MEMBER_BAD_CFL);
+    }
+    if (Nts == 0) {
+        for (int j = tid; j < Nxy; j += NT) Sout[j] = Sin[j];
+        __syncthreads();
+    }
+    auto fwf = [&](T s) {
+        T mw, mo;
+        rel_perm<T>(p, s, mw, mo);
+        return mw / (mw + mo);
+    };
+    const double d_uniform = Nts ? (p.dt / (double)Nts) / (p.h2 * 1.0) : 0.0;
+    const int tx = tid >> 6, ty = tid & 63;  // 16 x 64 threads over a tile: rows stride 16, columns stride 64
+    for (int it = 0; it < Nts; ++it) {
+        const T* __restrict__ src = it == 0 ? Sin : (((Nts - it) & 1) ? Sbuf : Sout);
+        T* __restrict__ dst = ((Nts - 1 - it) & 1) ? Sbuf : Sout;
+        for (int x0 = 0; x0 < Nx; x0 += TH)
+            for (int y0 = 0; y0 < Ny; y0 += TW) {
+                const int th = min(TH, Nx - x0), tw = min(TW, Ny - y0);
+                // fw of the tile and its halo (cells outside the grid: never used, their coefficients are skipped)
+                for (int li = tx; li < th + 2; li += 16) {
+                    const int ix = x0 + li - 1;
+                    const bool rin = ix >= 0 && ix < Nx;
+                    const int ixc = min(max(ix, 0), Nx - 1);
+                    if (tw == TW) {  // full-width tile: 4 loads in flight, then the 4 divisions
+                        T sv[4];
+                        bool in[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int iy = y0 + ty + 64 * u - 1;
+                            in[u] = rin && iy >= 0 && iy < Ny;
+                            sv[u] = src[ixc * Ny + min(max(iy, 0), Ny - 1)];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) fwt[li * LW + ty + 64 * u] = in[u] ? fwf(sv[u]) : T(0);
+                        if (ty < 2) {
+                            const int iy = y0 + ty + 255;
+                            fwt[li * LW + ty + 256] = (rin && iy < Ny) ? fwf(src[ixc * Ny + min(iy, Ny - 1)]) : T(0);
+                        }
+                    } else {
+                        for (int lj = ty; lj < tw + 2; lj += 64) {
+                            const int iy = y0 + lj - 1;
+                            const bool in = rin && iy >= 0 && iy < Ny;
+                            fwt[li * LW + lj] = in ? fwf(src[ixc * Ny + min(max(iy, 0), Ny - 1)]) : T(0);
+                        }
+                    }
+                }
+                __syncthreads();
+                auto update_cell = [&](int li, int lj, double vxw, double vxe, double vys, double vyn, double qj, T sc) {
+                    const int ix = x0 + li, iy = y0 + lj, j = ix * Ny + iy;
+                    const double d = p.por ? (p.dt / (double)Nts) / (p.h2 * p.por[j]) : d_uniform;
+                    const double fp = fmin(qj, 0.0), fi = fmax(qj, 0.0);
+                    const double x1 = fmin(vxw, 0.0), x2 = fmax(vxe, 0.0), y1 = fmin(vys, 0.0), y2 = fmax(vyn, 0.0);
+                    const T cC = (T)(d * (fp + x1 - x2 + y1 - y2));
+                    const T cW = (T)(d * fmax(vxw, 0.0));
+                    const T cE = (T)(d * (-fmin(vxe, 0.0)));
+                    const T cS = (T)(d * fmax(vys, 0.0));
+                    const T cN = (T)(d * (-fmin(vyn, 0.0)));
+                    const T fid = (T)(fi * d);
+                    const T* f = fwt + (li + 1) * LW + lj + 1;
+                    T acc = (ix + 1 < Nx) ? cE * f[LW] : T(0);
+                    if (iy + 1 < Ny) acc = acc + cN * f[1];
+                    acc = acc + cC * f[0];
+                    if (iy > 0) acc = acc + cS * f[-1];
+                    if (ix > 0) acc = acc + cW * f[-LW];
+                    dst[j] = sc + (acc + fid);
+                };
+                for (int li = tx; li < th; li += 16) {
+                    const int ix = x0 + li;
+                    if (tw == TW) {  // full-width tile: the loads of the thread's 4 cells of this row are issued together
+                        double a[4], b[4], c2[4], e[4], qq[4];
+                        T sc[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int iy = y0 + ty + 64 * u, j = ix * Ny + iy;
+                            a[u] = Vx[ix * Ny + iy]; b[u] = Vx[(ix + 1) * Ny + iy];
+                            c2[u] = Vy[ix * (Ny + 1) + iy]; e[u] = Vy[ix * (Ny + 1) + iy + 1];
+                            qq[u] = q[j]; sc[u] = src[j];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) update_cell(li, ty + 64 * u, a[u], b[u], c2[u], e[u], qq[u], sc[u]);
+                    } else {
+                        for (int lj = ty; lj < tw; lj += 64) {
+                            const int iy = y0 + lj, j = ix * Ny + iy;
+                            update_cell(li, lj, Vx[ix * Ny + iy], Vx[(ix + 1) * Ny + iy], Vy[ix * (Ny + 1) + iy], Vy[ix * (Ny + 1) + iy + 1], q[j], src[j]);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+    }
+    int nonfinite = 0;
+    for (int j = tid; j < Nxy; j += NT)
+        if (!isfinite((double)Sout[j])) nonfinite = 1;
+    if (nonfinite) atomicOr(&p.status[m], HM_MEMBER_NONFINITE);
+    if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = Sout[p.prd_ind[tid]];
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -665,20 +803,24 @@ static int launch_saturation(hm_fwd* f, int k) {
     int rc = f->t_sat.begin(s);
     if (rc) return rc;
     int done = -1;
-    if (f->sat_variant != 1 && f->sat_variant != 2) {
+    if (f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
         done = launch_saturation_128(f, Sin, Sout, stride, k);                  // fp64, register/LDS resident
         if (done < 0) done = launch_saturation_128f(f, Sin, Sout, stride, k);  // fp32 twin
     }
     if (done > 0) return done;
     if (done < 0) {
-        // sat_variant 1: generic (coefficient arrays + fw image); 2: streaming; otherwise streaming beyond 128 x 128
-        const bool stream = f->sat_variant == 2 || (f->sat_variant != 1 && p.Nxy > 128 * 128);
-        rc = ensure_generic_sat_scratch(f, !stream);
+        // sat_variant 1: generic (coefficient arrays + fw image); 2: streaming; 3: tiled; otherwise tiled beyond 128 x 128
+        const bool tiled = f->sat_variant == 3 || (f->sat_variant != 1 && f->sat_variant != 2 && p.Nxy > 128 * 128);
+        const bool stream = f->sat_variant == 2;
+        rc = ensure_generic_sat_scratch(f, !(stream || tiled));
         if (rc) return rc;
-        int T = p.Nxy >= 4096 ? 1024 : 256;
-        size_t lds = (size_t)T * 8;
+        int T = tiled ? 1024 : (p.Nxy >= 4096 ? 1024 : 256);
+        size_t lds = tiled ? (size_t)1024 * 8 + (size_t)66 * 258 * f->esz : (size_t)T * 8;
 #define SAT(KERN, TT) hipLaunchKernelGGL(KERN<TT>, dim3(p.N), dim3(T), lds, s, f->p, (const TT*)Sin, (TT*)Sout, stride, (TT*)f->prods.p, k)
-        if (stream) { if (f->dtype == 64) SAT(k_saturation_stream, double); else SAT(k_saturation_stream, float); }
+        if (tiled) {
+            if (f->dtype == 64) { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, double); }
+            else { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, float); }
+        } else if (stream) { if (f->dtype == 64) SAT(k_saturation_stream, double); else SAT(k_saturation_stream, float); }
         else { if (f->dtype == 64) SAT(k_saturation_generic, double); else SAT(k_saturation_generic, float); }
 #undef SAT
         HM_HIP(hipGetLastError());

@@ -403,17 +403,18 @@ def test_fp32_saturation_128_register_kernel_bitexact_vs_generic(general_fluid):
         assert np.abs(out[0][0][0] - ref).max() < 1e-3
 
 
-@pytest.mark.parametrize("nx,ny,dtype", [(20, 20, 64), (128, 128, 64), (160, 96, 64), (192, 160, 64), (128, 128, 32), (96, 192, 32)])
+@pytest.mark.parametrize("nx,ny,dtype", [(20, 20, 64), (128, 128, 64), (160, 96, 64), (192, 160, 64), (70, 300, 64), (128, 128, 32), (96, 192, 32)])
 def test_streaming_saturation_kernel_bitexact_vs_generic(nx, ny, dtype):
-    """k_saturation_stream (the sweep used beyond 128 x 128: coefficients and neighbour fractional flows re-derived
-    instead of stored, one pass and one barrier per sub-step) is bit-identical to k_saturation_generic on the same fluxes."""
+    """k_saturation_stream (coefficients and neighbour fractional flows re-derived instead of stored, one pass and one
+    barrier per sub-step) and k_saturation_tiled (the sweep used beyond 128 x 128: the same with fw shared through LDS
+    tiles) are bit-identical to k_saturation_generic on the same fluxes."""
     N, steps = 2, 2
     _, gm = make_models(nx, ny, dtype=dtype)
     x = perms(nx, ny, N, seed=29)
     out = {}
-    for sat_variant in (1, 2):
+    for sat_variant in (1, 2, 3):
         plan = _plan(gm, N, nTime=steps)
-        plan.set_variant(9 if ny > 128 else 1, sat_variant)  # same pressure kernel for both runs
+        plan.set_variant(9 if ny > 128 else 1, sat_variant)  # same pressure kernel for all runs
         plan.set_inputs(x, transformed=False)
         plan.run()
         plan.sync()
@@ -421,5 +422,6 @@ def test_streaming_saturation_kernel_bitexact_vs_generic(nx, ny, dtype):
         assert not status.any()
         out[sat_variant] = (w, p, plan.get_field("nts"))
         plan.close()
-    assert np.array_equal(out[1][2], out[2][2]) and out[1][2].min() >= 1
-    assert np.array_equal(out[1][0], out[2][0]) and np.array_equal(out[1][1], out[2][1])
+    for v in (2, 3):
+        assert np.array_equal(out[1][2], out[v][2]) and out[1][2].min() >= 1
+        assert np.array_equal(out[1][0], out[v][0]) and np.array_equal(out[1][1], out[v][1])
