@@ -43,7 +43,8 @@ const char* hm_last_error(void);
 int         hm_device_name(hm_ctx* ctx, char* buf, int buflen);   /* e.g. "gfx950:..."           */
 int         hm_abi_version(void);
 /* Raw copies between caller host buffers and device pointers handed out by hm_*_device_ptr /
- * hm_upd_reduce_buffer (used by the host-staged all-reduce of the multi-rank update). Synchronous. */
+ * hm_upd_reduce_buffer (host-staged fallback of the multi-rank update's all-reduce; with the nccl backend the
+ * reduction runs in place on those device buffers, historymatching_amd/dist.py). Synchronous. */
 int         hm_copy_to_host(hm_ctx* ctx, void* dst_host, const void* src_device, long long bytes);
 int         hm_copy_to_device(hm_ctx* ctx, void* dst_device, const void* src_host, long long bytes);
 
@@ -86,10 +87,18 @@ int  hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transformed, con
 /* Device-resident chaining (forward -> update -> forward without PCIe): permeability input from a device buffer
  * (fp64 or fp32), initial saturation zero.  Asynchronous on the context's stream. */
 int  hm_fwd_set_inputs_device(hm_fwd* f, const void* perm_dev, int perm_dtype, int perm_is_transformed);
-int  hm_fwd_run(hm_fwd* f, int first_step, int n_steps);           /* async; steps [first, first+n)  */
+int  hm_fwd_run(hm_fwd* f, int first_step, int n_steps);           /* steps [first, first+n); asynchronous for Ny <= 128
+                                                                     * (grids beyond poll CG convergence on the host)        */
 int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
 int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member);     /* D2H */
-int  hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant); /* 0=fastest, 1=generic, 2=VALU-register pressure, 9=CG pressure */
+/* Kernel selection (tests and diagnostics; 0/0 = the fastest applicable kernels).
+ *   pressure  : 1 generic block elimination in LDS (any Ny <= 128) | at Ny = 128: 0 symmetric-tile MFMA solver (press128s),
+ *               7 its 16-wave form, 3/4/5/8 full-tile MFMA solver (press128m: 8w rank-4, 16w rank-4, 16w rank-16, 8w rank-16),
+ *               2 rank-1 VALU solver (press128) | 9 Jacobi-CG (any grid; beyond 128 the default is two-level CG where
+ *               Ny = 128 c, Nx = c Nx_c, else Jacobi-CG)
+ *   saturation: 1 generic (coefficient + fw images) | 2 streaming | 3 LDS-tiled (default beyond 128 x 128) | at 128 x 128:
+ *               0 register/LDS-resident sweep (sat128 fp64 / sat128f fp32) */
+int  hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant);
 /* Conjugate-gradient pressure solver (always used when Ny > 128): relative residual target and iteration cap
  * (defaults 1e-12 and 40*max(Nx,Ny)+1000). */
 int  hm_fwd_set_solver(hm_fwd* f, double rtol, int max_iter);
@@ -147,10 +156,12 @@ int   hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double ridge, do
 int   hm_upd_set_inputs_device(hm_upd* u, const void* E_dev, int E_dtype, const void* obs_ens_dev, int obs_dtype);
 int   hm_upd_swap(hm_upd* u);
 int   hm_upd_phase(hm_upd* u, int phase);
-/* All three phases of a plan that holds every member (N_local == N_total), no reduction points: the small fp64 chain
- * overlaps the big contraction on a second stream. */
+/* All three phases of a plan that holds every member (N_local == N_total), no reduction points.  fp32 plans run the
+ * second-generation matrix-core kernels here (LDS-staged contractions, fp64 matrix-core products for the N x n_obs
+ * quantities, matrix-core inverse of C); option "overlap" = 1 puts the small fp64 chain on a second stream. */
 int   hm_upd_run(hm_upd* u);
-int   hm_upd_set_option(hm_upd* u, const char* name, int value);  /* "use_mfma": 1 (default) | 0 = generic fp32 GEMMs */
+int   hm_upd_set_option(hm_upd* u, const char* name, int value);  /* "use_mfma": 1 (default) | 0 = generic fp32 GEMMs;
+                                                                   * "mfma_inverse": 1 | 0; "overlap": 0 | 1        */
 void* hm_upd_reduce_buffer(hm_upd* u, int which /*0..3*/, long long* n_elems, int* elem_bytes); /* device pointer */
 int   hm_upd_sync(hm_upd* u, hm_stats* stats);
 int   hm_upd_get_output(hm_upd* u, void* E_out_local);
