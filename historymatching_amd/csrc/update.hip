@@ -643,6 +643,9 @@ static int upd_phase(hm_upd* u, int phase) {
     T *S_T = (T*)u->S_T.p, *A_T = (T*)u->A_T.p;
     const size_t n_small = (size_t)nl * no;
     const unsigned gs = (unsigned)std::min<size_t>(2048, (n_small + 255) / 256);
+    // fp32 global analysis on the matrix cores: second-generation kernels in the phased (row-sharded) path as well
+    const bool fast2 = std::is_same<T, float>::value && u->use_mfma && !u->localized && M % 4 == 0 && no % 32 == 0 && no <= 256 &&
+                       u->SD.p != nullptr;
     int rc = u->t_upd.begin(s);
     if (rc) return rc;
     if (phase == 0) {
@@ -657,6 +660,22 @@ static int upd_phase(hm_upd* u, int phase) {
         HM_HIP(hipGetLastError());
     } else if (phase == 1) {
         const double inv_n = 1.0 / (double)u->N_total;
+        if constexpr (std::is_same<T, float>::value) {
+            if (fast2) {
+                // second-generation kernels (see hm_upd_run), with the exact all-reduced column means as the shift;
+                // Gx (n_obs x M) goes straight into reduce buffer 2 (an element-wise sum: the layout is the library's)
+                double* Sd = (double*)u->SD.p;
+                if ((rc = obs_prep<float>(s, (const float*)u->obs_ens.p, (const float*)u->perturbs.p, (const float*)u->obs.p, sumY, inv_n, nl, no,
+                                          (double*)u->YD.p, (const float*)u->decorr.p, (double*)u->decorr64.p))) return rc;
+                if ((rc = dgemm_mfma(s, false, 2 * nl, no, no, (const double*)u->YD.p, no, (const double*)u->decorr64.p, no, Sd, no, 1, S_T, nl, nullptr))) return rc;
+                const int nsplit = dgemm_mfma_splits(nl, 8);
+                if ((rc = dgemm_mfma(s, true, no, no, nl, Sd, no, Sd, no, (double*)u->gpart.p, no, 8, nullptr, 0, nullptr))) return rc;
+                hipLaunchKernelGGL(k_gram_reduce, dim3((no * no + 255) / 256), dim3(256), 0, s, (const double*)u->gpart.p, nsplit, no * no, G);
+                HM_HIP(hipGetLastError());
+                if ((rc = mfma_gxt_lds(s, nl, M, no, E, sumE, inv_n, S_T, Gxt)) != 0) return rc > 0 ? rc : 2;
+                return u->t_upd.end(s);
+            }
+        }
         // S = Y decorr, D = D0 decorr (fp64) and the dtype copy of S, one launch          (HistoryMatch.py:582-584)
         hipLaunchKernelGGL(k_obs_products<T>, dim3((nl + RB - 1) / RB), dim3(256), 2 * RB * no * sizeof(double), s,
                            (const T*)u->obs_ens.p, (const T*)u->perturbs.p, (const T*)u->obs.p, (const double*)sumY, inv_n,
@@ -675,6 +694,15 @@ static int upd_phase(hm_upd* u, int phase) {
         if (done > 0) return done;
         if (done < 0 && (rc = gemm<T>(s, M, no, nl, E, 1, M, S_T, no, 1, Gxt, no, nullptr, 0, sumE, inv_n))) return rc;
     } else if (phase == 2) {
+        if constexpr (std::is_same<T, float>::value) {
+            if (fast2) {
+                const double* Dd = (const double*)u->SD.p + n_small;
+                if ((rc = invert_C(s, G, no, (double)(u->N_total - 1), (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p, true))) return rc;
+                if ((rc = dgemm_mfma(s, false, nl, no, no, Dd, no, (const double*)u->Cinv.p, no, nullptr, no, 1, nullptr, 0, A_T))) return rc;
+                if ((rc = mfma_apply_lds(s, nl, M, no, E, A_T, Gxt, Eo)) != 0) return rc > 0 ? rc : 2;
+                return u->t_upd.end(s);
+            }
+        }
         if (!u->localized) {
             if ((rc = invert_C(s, G, no, (double)(u->N_total - 1), (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no,
                                (int*)u->flags.p, std::is_same<T, float>::value))) return rc;
