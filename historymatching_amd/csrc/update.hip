@@ -503,15 +503,12 @@ __global__ __launch_bounds__(256) void k_local_analysis(int M, int n_obs, int N_
         for (int r = k + 1 + tid; r < nl; r += NT) L[r * (r + 1) / 2 + k] *= inv;
         if (tid == 0) L[kk + k] = dk;
         __syncthreads();
-        // trailing update A[r][c] -= L[r][k] L[c][k],  k < c <= r
-        int nt = nl - k - 1;
-        for (int e = tid; e < nt * (nt + 1) / 2; e += NT) {
-            int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while ((r + 1) * (r + 2) / 2 <= e) ++r;
-            while (r * (r + 1) / 2 > e) --r;
-            int c = e - r * (r + 1) / 2;
-            int R = r + k + 1, Cc = c + k + 1;
-            L[R * (R + 1) / 2 + Cc] = fma(-L[R * (R + 1) / 2 + k], L[Cc * (Cc + 1) / 2 + k], L[R * (R + 1) / 2 + Cc]);
+        // trailing update A[r][c] -= L[r][k] L[c][k],  k < c <= r: 16 x 16 thread grid striding rows and columns (the
+        // flat index -> (r, c) decode of a packed triangle needs a square root per entry and dominated this kernel)
+        for (int r = k + 1 + (tid >> 4); r < nl; r += 16) {
+            const int rbase = r * (r + 1) / 2;
+            const double lrk = L[rbase + k];
+            for (int c = k + 1 + (tid & 15); c <= r; c += 16) L[rbase + c] = fma(-lrk, L[c * (c + 1) / 2 + k], L[rbase + c]);
         }
         __syncthreads();
     }
