@@ -245,30 +245,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
         }
         __syncthreads();
         PROF(6);
-        // look-ahead for panel 0 of this block: the owner of tile (0,0) forms S_i(0,0) = D_i(0,0) - e G_{i-1}(0,0) e in a
-        // temporary (the tile itself must stay G_{i-1} for the mat-vec below; the same expressions give the same bits when
-        // the tile is formed in place later) and hands it to the sweeper, whose 16-pivot sweep then runs under the
-        // substitution mat-vec instead of between two barriers of its own
-        if (!service) {
-#pragma unroll
-            for (int s = 0; s < TPW; ++s) {
-                if (tR[s] != 0 || tC[s] != 0) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int lrow = g.lq + 4 * r;
-                    const double v = i > 0 ? -(L.ev[lrow] * acc[s][r] * L.ev[g.lc]) : 0.0;
-                    double add = 0.0;
-                    if (g.lc == lrow) add = L.dgv[lrow];
-                    else if (g.lc == lrow + 1) add = -L.tyv[g.lc];
-                    else if (lrow == g.lc + 1) add = -L.tyv[lrow];
-                    L.Dg[lrow][g.lc] = v + add;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (g.lane == 0) __hip_atomic_store(&L.flag, 8 * i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        } else if (sweeper) {
-            sweep_published(8 * i + 1);
-        }
         if (i > 0) {
             if constexpr (!FACTOR) {
                 if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
@@ -316,8 +292,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
                 } else if (R == C + 1) {  // entry (16R, 16C+15): row == col + 1
                     if (g.lane == 15) acc[s][0] -= L.tyv[16 * R];
                 }
-                if (C == 0 && R != 0) publish_tile(s, 0, L.U[cur], 8 * i + 1);  // tile (0,0) went to the sweeper above
+                if (C == 0) publish_tile(s, 0, L.U[cur], 8 * i + 1);
             }
+        } else if (sweeper) {
+            sweep_published(8 * i + 1);
         }
         PROF(8);
         __syncthreads();  // U_0, P_0 visible
