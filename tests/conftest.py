@@ -25,11 +25,13 @@ def _torch_runtime_first(request):
     """GPU sessions that also use torch.distributed (the RCCL test) need torch's bundled HIP runtime initialised before
     libhm_amd.so opens the device (see historymatching_amd/_lib.py:_torch_first): import torch up front so that the
     library's first context creation lets it go first.  No-op on CPU-only boxes."""
-    try:
-        import torch
+    markexpr = request.config.getoption("-m") or ""
+    if "gpu" in markexpr and "not gpu" not in markexpr:
+        try:
+            import torch
 
-        if torch.cuda.device_count() > 0:
-            torch.cuda.init()
-    except Exception:
-        pass
+            if torch.cuda.device_count() > 0:
+                torch.cuda.init()
+        except Exception:
+            pass
     yield

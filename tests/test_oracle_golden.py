@@ -84,3 +84,20 @@ def test_taper_from_restated_grid(golden):
     d = es.pairwise_distances(xy_prm.T, xy_obs.T)
     assert np.array_equal(d, f4["distances_to_obs"])
     assert np.array_equal(es.bump(d / 1.2), f4["taper"])
+
+
+def test_product_obs_helpers_match_reference_fixture(golden):
+    """historymatching_amd.obs (host-side inputs of the update) against the fixture captured from
+    the reference's own construction (HistoryMatch.py:243-259, 639) and its seed-1 RNG replay (:600-603)."""
+    from historymatching_amd import obs as pobs
+
+    f1, f2 = _load(golden, "f1_rng_replay.npz"), _load(golden, "f2_obs_error.npz")
+    R, R12 = pobs.obs_error_model(40, 4)
+    assert np.array_equal(R, f2["R"]) and np.array_equal(R12, f2["R12"])
+    assert np.abs(pobs.decorr(R12) - f2["decorr"]).max() < 1e-12
+    x = np.arange(2 * 40 * 4.0).reshape(2, 40, 4)
+    assert np.array_equal(pobs.vect(pobs.vect(x), 40, undo=True), x) and pobs.vect(x).shape == (2, 160)
+    rng = np.random.RandomState(3)
+    z = rng.randn(5, 160)
+    rng = np.random.RandomState(3)
+    assert np.array_equal(pobs.perturbations(5, R12, rng), z @ R12.T)
