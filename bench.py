@@ -214,6 +214,13 @@ def main():
             "compulsory_floor_bytes_per_member_step": 4 * w * nxy,
             "mean_nts": nts,
             "note": "effective GB/s by SURVEY.md 8d accounting; the state is LDS/register-resident so it may exceed HBM peak",
+            # what actually bounds the two kernels: the CU's fp64 pipe.  Saturation: 37 double-precision
+            # VALU instructions per cell and explicit sub-step (sat128.hip ISA), peak = CUs x 4 SIMDs x 16 lanes x clock
+            "compute_view": {
+                "saturation_fp64_valu_frac": (37.0 * nxy * nts * n_e / (sat_ms * 1e-3)) / (256 * 4 * 16 * 2.4e9),
+                "pressure_fp64_mfma_frac": (2.0 * 36 * 16 * 16 * 16 * 8 * NX * n_e / (prs_ms * 1e-3)) / 78.6e12,
+                "assumes": "2.4 GHz, 256 CUs; pressure flops = rank-16 updates of the 36 stored tiles x 8 panels x Nx blocks",
+            },
         }
         upd = None
         if world == 1:

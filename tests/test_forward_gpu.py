@@ -425,3 +425,23 @@ def test_streaming_saturation_kernel_bitexact_vs_generic(nx, ny, dtype):
     for v in (2, 3):
         assert np.array_equal(out[1][2], out[v][2]) and out[1][2].min() >= 1
         assert np.array_equal(out[1][0], out[v][0]) and np.array_equal(out[1][1], out[v][1])
+
+
+@pytest.mark.parametrize("nx,ny", [(64, 128), (200, 128), (128, 64)])
+def test_rectangular_grids_mixed_kernels(nx, ny):
+    """Ny = 128 with Nx != 128 runs the matrix-core pressure solver (any number of 128-wide blocks) with the generic
+    saturation sweep; Ny != 128 runs the generic pair.  Same acceptance as the square case."""
+    N, steps = 2, 2
+    om, gm = make_models(nx, ny)
+    x = perms(nx, ny, N, seed=31)
+    plan = _plan(gm, N, nTime=steps)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    plan.sync()
+    w, p, status = plan.outputs()
+    assert not status.any()
+    for m in range(N):
+        ref, noise = oracle_sim_and_noise(om, x[m], DT, steps)
+        err = np.abs(w[m] - ref).max()
+        assert err <= 10 * noise + 1e-9, (err, noise)
+    plan.close()
