@@ -445,3 +445,22 @@ def test_rectangular_grids_mixed_kernels(nx, ny):
         err = np.abs(w[m] - ref).max()
         assert err <= 10 * noise + 1e-9, (err, noise)
     plan.close()
+
+
+def test_whole_run_40_steps_at_config2_shape():
+    """BASELINE config 2 shape (128x128, nTime = 40, dt = 0.025, wells of HistoryMatch.py:177-190): one member of the
+    synthetic prior through the default kernels for the full run stays within the oracle's own solver noise at every
+    stored step, and the producer series equals the saturation history at the producer cells."""
+    n, steps = 128, 40
+    om, gm = make_models(n, n)
+    x = perms(n, n, 1, seed=1)
+    plan = _plan(gm, 1, nTime=steps)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    st = plan.sync()
+    w, p, status = plan.outputs()
+    plan.close()
+    assert not status.any() and st["mean_nts"] > 100
+    ref, noise = oracle_sim_and_noise(om, x[0], DT, steps)
+    assert np.abs(w[0] - ref).max() <= 10 * noise + 1e-9
+    assert np.array_equal(p[0], w[0][1:, om.xy2ind(*om.prd_xy.T)])
