@@ -157,4 +157,12 @@ def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True
                                           return_history=return_history)
         return [wsats, prods]
 
+    def comp1(perm, wsat0=None):
+        """The reference's per-member composite (HistoryMatch.py:358-364): one pre-permeability field ``(Nxy,)`` ->
+        ``(wsats (nTime+1, Nxy), prods (nTime, nPrd))``; a batch of one through the same device path."""
+        w0 = default_wsat0 if wsat0 is None else np.asarray(wsat0, dtype=float)
+        wsats, prods = forward_model(np.asarray(perm)[None, :], w0[None, :])
+        return wsats[0], prods[0]
+
+    forward_model.comp1 = comp1
     return forward_model

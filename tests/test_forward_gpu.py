@@ -464,3 +464,17 @@ def test_whole_run_40_steps_at_config2_shape():
     ref, noise = oracle_sim_and_noise(om, x[0], DT, steps)
     assert np.abs(w[0] - ref).max() <= 10 * noise + 1e-9
     assert np.array_equal(p[0], w[0][1:, om.xy2ind(*om.prd_xy.T)])
+
+
+def test_comp1_single_member_composite():
+    """`comp1(perm, wsat0)` (HistoryMatch.py:358-364) = a batch of one through the same device path: identical to the
+    member's row of the ensemble run."""
+    from historymatching_amd.forward import make_forward_model
+
+    _, gm = make_models(20, 20)
+    x = perms(20, 20, 3, seed=2)
+    fm = make_forward_model(gm, DT, 6)
+    w, p = fm(x)
+    w1, p1 = fm.comp1(x[1])
+    assert w1.shape == (7, 400) and p1.shape == (6, 4)
+    assert np.array_equal(w1, w[1]) and np.array_equal(p1, p[1])
