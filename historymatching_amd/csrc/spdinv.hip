@@ -193,6 +193,217 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
     if (bad && g.lane == 0) atomicOr(flag, 1);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Localised analysis on the matrix cores (fp32 plans): one workgroup per state element i          HistoryMatch.py:783-793
+//   jj = { j : c_j = sqrt(taper[i][j]) > cutoff },  Ci = (c c^T) o G[jj,jj] + (N-1) I,  w = Ci^-1 (c o Gxt[i,jj]),
+//   Wt[i, jj] = c o w          (elements without an observation in range: Wt = 0, the element stays unchanged)
+// Same panel machinery as k_spd_inverse, used as a SOLVE: the right-hand side rides along as one extra tile row below
+// the (zero-padded to 16 nt) matrix that is never pivoted.  Sweeping the nt pivot panels of [[C, b], [b^T, .]] leaves
+// b^T C^-1 = w^T in that row (the sweep operator), so no inverse is formed and no mat-vec is needed afterwards.
+// fp64 plans keep the packed LDS Cholesky (k_local_analysis in update.hip): the explicit 16x16 pivot-tile inverses cost
+// a factor cond(tile) of forward accuracy, inside the fp32 bar only.
+// ------------------------------------------------------------------------------------------------------------
+template <int SLOTS>
+__global__ __launch_bounds__(1024, 4) void k_local_analysis_mfma(int M, int n_obs, int N_total, double cutoff, const float* __restrict__ taper,
+                                                                 const double* __restrict__ G, const float* __restrict__ Gxt,
+                                                                 float* __restrict__ Wt, int* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds_d[];
+    const int i = blockIdx.x;
+    const int nmax = ((n_obs + 15) / 16) * 16 + 16;  // rows of U / W: padded matrix + the right-hand-side tile row
+    double (*U0)[17] = reinterpret_cast<double (*)[17]>(lds_d);
+    double (*U1)[17] = U0 + nmax;
+    double (*Wp)[17] = U1 + nmax;
+    double (*P)[17] = Wp + nmax;
+    double (*Dg)[17] = P + 16;
+    double* cv = reinterpret_cast<double*>(Dg + 16);   // n_obs: taper weights of the selected observations
+    double* rhs = cv + n_obs;                           // n_obs
+    int* jj = reinterpret_cast<int*>(rhs + n_obs);      // n_obs
+    int* misc = jj + n_obs;                             // [0] n_loc  [1] flag token  [2..5] per-wave selection counts
+
+    const int tid = threadIdx.x;
+    IGeo g;
+    g.lane = tid & 63;
+    g.lc = g.lane & 15;
+    g.lq = g.lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool service = (w & 3) == 0, sweeper = w == 0;
+    const int c = service ? 0 : (w >> 2) * 3 + (w & 3) - 1;
+
+    // selection, order-preserving (the reference's observation order): ballot + prefix count over the first 4 waves
+    for (int j = tid; j < n_obs; j += 1024) Wt[(size_t)i * n_obs + j] = 0.0f;
+    {
+        const bool inr = tid < n_obs;  // n_obs <= 256 (host-checked)
+        const double cj = inr ? sqrt((double)taper[(size_t)i * n_obs + tid]) : 0.0;
+        const double gx = inr ? (double)Gxt[(size_t)i * n_obs + tid] : 0.0;
+        const bool sel = inr && cj > cutoff;
+        const unsigned long long mask = __ballot(sel);
+        if (g.lane == 0 && w < 4) misc[2 + w] = __popcll(mask);
+        if (tid == 0) misc[1] = 0;
+        __syncthreads();
+        if (w < 4) {
+            int base = 0;
+            for (int q = 0; q < w; ++q) base += misc[2 + q];
+            const int pos = base + __popcll(mask & ((1ull << g.lane) - 1ull));
+            if (sel) {
+                jj[pos] = tid;
+                cv[pos] = cj;
+                rhs[pos] = cj * gx;
+            }
+        }
+        if (tid == 0) misc[0] = misc[2] + misc[3] + misc[4] + misc[5];
+    }
+    __syncthreads();
+    const int nloc = misc[0];
+    if (nloc == 0) return;  // no observation in range: element unchanged (HistoryMatch.py:787-788)
+    const int nt = (nloc + 15) >> 4;                  // pivot panels
+    const int ntiles = (nt + 1) * (nt + 2) / 2;       // lower triangle of nt + 1 tile rows (the last = right-hand side)
+    const double ridge = (double)(N_total - 1);
+    int* lflag = misc + 1;
+
+    int tR[SLOTS], tC[SLOTS];
+    d4 acc[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int t = s * 12 + c;
+        int R = -1, C = -1;
+        if (!service && t < ntiles) {
+            R = 0;
+            while ((R + 1) * (R + 2) / 2 <= t) ++R;
+            C = t - R * (R + 1) / 2;
+        }
+        tR[s] = __builtin_amdgcn_readfirstlane(R);
+        tC[s] = __builtin_amdgcn_readfirstlane(C);
+        acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+        if (R >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lrow = g.lq + 4 * r, col = 16 * C + g.lc;
+                double v = 0.0;
+                if (R < nt) {
+                    const int row = 16 * R + lrow;
+                    if (row < nloc && col < nloc) {
+                        const int a = jj[row], b = jj[col];
+                        v = cv[row] * (0.5 * (G[(size_t)a * n_obs + b] + G[(size_t)b * n_obs + a])) * cv[col];
+                    }
+                    if (row == col) v += ridge;
+                } else if (lrow == 0 && C < nt && col < nloc) {
+                    v = rhs[col];
+                }
+                acc[s][r] = v;
+            }
+        }
+    }
+    int bad = 0, cur = 0;
+
+    auto publish_tile = [&](int s, int Cn, double (*Un)[17], int token) {
+        const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+        if (R == Cn && C == Cn) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Dg[g.lq + 4 * r][g.lc] = acc[s][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (g.lane == 0) __hip_atomic_store(lflag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (C == Cn) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Un[16 * R + g.lq + 4 * r][g.lc] = acc[s][r];
+        } else {  // R == Cn, C < Cn: transposed
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Un[16 * C + g.lc][g.lq + 4 * r] = acc[s][r];
+        }
+    };
+    auto sweep_published = [&](int token) {
+        while (__hip_atomic_load(lflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token) __builtin_amdgcn_s_sleep(1);
+        d4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = Dg[g.lq + 4 * r][g.lc];
+        sweep16_inwave(t, g, bad);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[g.lq + 4 * r][g.lc] = -t[r];
+    };
+    auto update_tile = [&](int s, double (*U)[17]) {
+        const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wp[16 * R + g.lc][4 * kk + g.lq], U[16 * C + g.lc][4 * kk + g.lq], acc[s], 0, 0, 0);
+    };
+
+    __syncthreads();
+    if (!service) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (tC[s] == 0) publish_tile(s, 0, U0, 1);
+    } else if (sweeper) {
+        sweep_published(1);
+    }
+    __syncthreads();
+    for (int Cp = 0; Cp < nt; ++Cp) {
+        double (*U)[17] = cur ? U1 : U0;
+        double (*Un)[17] = cur ? U0 : U1;
+        const int Cn = Cp + 1, token = Cn + 1;
+        if (!service) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+                if (C == Cp) {
+                    if (R == Cp) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[s][r] = -P[g.lq + 4 * r][g.lc];
+                    } else {
+                        d4 wv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            wv = __builtin_amdgcn_mfma_f64_16x16x4f64(U[16 * R + g.lc][4 * kk + g.lq], P[4 * kk + g.lq][g.lc], wv, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Wp[16 * R + g.lq + 4 * r][g.lc] = wv[r];
+                        acc[s] = wv;
+                    }
+                } else if (R == Cp) {
+                    d4 wv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        wv = __builtin_amdgcn_mfma_f64_16x16x4f64(P[g.lc][4 * kk + g.lq], U[16 * C + g.lc][4 * kk + g.lq], wv, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Wp[16 * C + g.lc][g.lq + 4 * r] = wv[r];
+                    acc[s] = wv;
+                }
+            }
+        }
+        __syncthreads();
+        if (!service) {
+            if (Cn < nt) {
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+                    if (R >= 0 && (R == Cn || C == Cn)) {
+                        if (C != Cp) update_tile(s, U);
+                        publish_tile(s, Cn, Un, token);
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+                if (R < 0 || R == Cp || C == Cp || (Cn < nt && (R == Cn || C == Cn))) continue;
+                update_tile(s, U);
+            }
+        } else if (sweeper && Cn < nt) {
+            sweep_published(token);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // the right-hand-side tile row now holds w^T = b^T Ci^-1 in its first row
+    if (!service) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int R = tR[s], C = tC[s];
+            if (R != nt || C >= nt || g.lq != 0) continue;
+            const int col = 16 * C + g.lc;
+            if (col < nloc) Wt[(size_t)i * n_obs + jj[col]] = (float)(cv[col] * acc[s][0]);
+        }
+    }
+    if (bad && g.lane == 0) atomicOr(flag, 1);
+}
+
 }  // namespace
 
 // W = inv(G + ridge I) for n a multiple of 16, n <= 256.  Returns 0 if launched, -1 if not applicable, >0 on error.
@@ -238,4 +449,26 @@ extern "C" int hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double 
     (void)hipFree(dG); (void)hipFree(dW); (void)hipFree(dflag);
     if (!rc && flag) { hm_set_error("hm_debug_spd_inverse: non-positive pivot"); rc = 4; }
     return rc;
+}
+
+// Localised analysis of an fp32 plan on the matrix cores.  Returns 0 if launched, -1 if not applicable, >0 on error.
+int local_analysis_mfma(hipStream_t s, int M, int n_obs, int N_total, double cutoff, const float* taper, const double* G,
+                        const float* Gxt, float* Wt, int* flag) {
+    if (n_obs > 240) return -1;  // selection by the first 4 waves; LDS
+    const int nmax = ((n_obs + 15) / 16) * 16 + 16;
+    const int ntmax = nmax / 16, ntiles = ntmax * (ntmax + 1) / 2;
+    const size_t lds = ((size_t)3 * nmax * 17 + 2 * 16 * 17 + 2 * n_obs) * 8 + (size_t)n_obs * 4 + 32;
+    if (lds > 160 * 1024 - 256) return -1;
+#define L(S)                                                                                                                    \
+    do {                                                                                                                        \
+        HM_HIP(hipFuncSetAttribute((const void*)k_local_analysis_mfma<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_local_analysis_mfma<S>, dim3(M), dim3(1024), lds, s, M, n_obs, N_total, cutoff, taper, G, Gxt, Wt, flag); \
+    } while (0)
+    if (ntiles <= 36) L(3);
+    else if (ntiles <= 72) L(6);
+    else if (ntiles <= 108) L(9);
+    else L(12);
+#undef L
+    HM_HIP(hipGetLastError());
+    return 0;
 }

@@ -421,6 +421,8 @@ int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double r
 int dgemm_mfma(hipStream_t s, bool transA, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C,
                int ldc, int ksplit, float* C32, int rows32, float* C32T);
 int dgemm_mfma_splits(int K, int ksplit);
+int local_analysis_mfma(hipStream_t s, int M, int n_obs, int N_total, double cutoff, const float* taper, const double* G,
+                        const float* Gxt, float* Wt, int* flag);  // spdinv.hip
 int mfma_gxt_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const float* colsum, double inv_n, const float* S, float* Gx);
 int mfma_apply_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const float* At, const float* Gx, float* Eout);
 template <typename T>
@@ -722,11 +724,19 @@ static int upd_phase(hm_upd* u, int phase) {
                 if ((rc = gemm<T>(s, nl, M, no, A_T, no, 1, Gxt, 1, no, Eo, M, E, M))) return rc;
             }
         } else {
-            size_t lds = ((size_t)no * (no + 1) / 2 + 2 * no) * 8 + (size_t)no * 4 + 16;
-            HM_HIP(hipFuncSetAttribute((const void*)k_local_analysis<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_local_analysis<T>, dim3(M), dim3(256), lds, s, M, no, u->N_total, u->cutoff,
-                               (const T*)u->taper.p, (const double*)G, (const T*)Gxt, (T*)u->Wt.p, (int*)u->flags.p);
-            HM_HIP(hipGetLastError());
+            int la = -1;
+            if constexpr (std::is_same<T, float>::value)
+                if (u->use_mfma && g_use_mfma_inverse)  // fp32 plans: the per-element solves on the matrix cores
+                    la = local_analysis_mfma(s, M, no, u->N_total, u->cutoff, (const float*)u->taper.p, (const double*)G, (const float*)Gxt,
+                                             (float*)u->Wt.p, (int*)u->flags.p);
+            if (la > 0) return la;
+            if (la < 0) {
+                size_t lds = ((size_t)no * (no + 1) / 2 + 2 * no) * 8 + (size_t)no * 4 + 16;
+                HM_HIP(hipFuncSetAttribute((const void*)k_local_analysis<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_local_analysis<T>, dim3(M), dim3(256), lds, s, M, no, u->N_total, u->cutoff,
+                                   (const T*)u->taper.p, (const double*)G, (const T*)Gxt, (T*)u->Wt.p, (int*)u->flags.p);
+                HM_HIP(hipGetLastError());
+            }
             int done = -1;
             if constexpr (std::is_same<T, float>::value)
                 if (u->use_mfma && M % 4 == 0) {
