@@ -478,3 +478,27 @@ def test_comp1_single_member_composite():
     w1, p1 = fm.comp1(x[1])
     assert w1.shape == (7, 400) and p1.shape == (6, 4)
     assert np.array_equal(w1, w[1]) and np.array_equal(p1, p[1])
+
+
+def test_fp32_mode_default_kernels_128():
+    """dtype=32 at 128x128 through the DEFAULT kernels (matrix-core pressure solver reading the fp32 saturation, fp32
+    register-resident sweep): within the fp32 bar of the fp64 oracle (<= 1e-3 abs on S), same Nts."""
+    n, N, steps = 128, 2, 4
+    om, gm = make_models(n, n, dtype=32)
+    x = perms(n, n, N, seed=43)
+    plan = _plan(gm, N, nTime=steps)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    plan.sync()
+    w, p, status = plan.outputs()
+    nts = plan.get_field("nts")
+    plan.close()
+    assert not status.any() and w.dtype == np.float32
+    from oracle.ressim import set_perm
+
+    for m in range(N):
+        set_perm(om, x[m])
+        ref = om.sim(DT, steps, np.zeros(n * n))
+        assert np.abs(w[m] - ref).max() < 1e-3
+        assert np.abs(p[m] - ref[1:, om.xy2ind(*om.prd_xy.T)]).max() < 1e-3
+    assert nts.min() >= 100
