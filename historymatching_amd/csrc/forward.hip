@@ -809,8 +809,10 @@ static int launch_saturation(hm_fwd* f, int k) {
     }
     if (done > 0) return done;
     if (done < 0) {
-        // sat_variant 1: generic (coefficient arrays + fw image); 2: streaming; 3: tiled; otherwise tiled beyond 128 x 128
-        const bool tiled = f->sat_variant == 3 || (f->sat_variant != 1 && f->sat_variant != 2 && p.Nxy > 128 * 128);
+        // sat_variant 1: generic (coefficient arrays + fw image); 2: streaming; 3: tiled; otherwise (no 128 x 128 specialisation
+        // applies: other sizes, porosity field, two wells in one patch) tiled from 64 x 64 cells up (67.9 vs 124 ms per launch at
+        // 128 x 128, N = 1000), generic below
+        const bool tiled = f->sat_variant == 3 || (f->sat_variant != 1 && f->sat_variant != 2 && p.Nxy >= 64 * 64);
         const bool stream = f->sat_variant == 2;
         rc = ensure_generic_sat_scratch(f, !(stream || tiled));
         if (rc) return rc;

@@ -96,8 +96,9 @@ int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status
  *               7 its 16-wave form, 3/4/5/8 full-tile MFMA solver (press128m: 8w rank-4, 16w rank-4, 16w rank-16, 8w rank-16),
  *               2 rank-1 VALU solver (press128) | 9 Jacobi-CG (any grid; beyond 128 the default is two-level CG where
  *               Ny = 128 c, Nx = c Nx_c, else Jacobi-CG)
- *   saturation: 1 generic (coefficient + fw images) | 2 streaming | 3 LDS-tiled (default beyond 128 x 128) | at 128 x 128:
- *               0 register/LDS-resident sweep (sat128 fp64 / sat128f fp32) */
+ *   saturation: 1 generic (coefficient + fw images) | 2 streaming | 3 LDS-tiled | 0: at 128 x 128 the register/LDS-resident
+ *               sweep (sat128 fp64 / sat128f fp32; needs uniform porosity and at most one well per 8 x 4 cell patch), else the
+ *               tiled sweep from 64 x 64 cells up, the generic one below */
 int  hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant);
 /* Conjugate-gradient pressure solver (always used when Ny > 128): relative residual target and iteration cap
  * (defaults 1e-12 and 40*max(Nx,Ny)+1000). */
