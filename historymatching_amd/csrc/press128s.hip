@@ -222,7 +222,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
         }
     };
     auto sweep_published = [&](int token) {
-        while (__hip_atomic_load(&L.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token) __builtin_amdgcn_s_sleep(1);
+        // bounded spin: the tile arrives within a few thousand cycles; if it never does (a defect), flag the member and go
+        // on rather than hang the GPU -- the workgroup barriers below still match
+        for (int spins = 0; __hip_atomic_load(&L.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token; ++spins) {
+            if (spins > (1 << 24)) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
         PROF(13);
         d4 t;
 #pragma unroll

@@ -94,7 +94,12 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
         }
     };
     auto sweep_published = [&](int token) {
-        while (__hip_atomic_load(lflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token) __builtin_amdgcn_s_sleep(1);
+        // bounded spin: the tile arrives within a few thousand cycles; if it never does (a defect), flag the member and go
+        // on rather than hang the GPU -- the workgroup barriers below still match
+        for (int spins = 0; __hip_atomic_load(lflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token; ++spins) {
+            if (spins > (1 << 24)) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
         d4 t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = Dg[g.lq + 4 * r][g.lc];
@@ -311,7 +316,12 @@ __global__ __launch_bounds__(1024, 4) void k_local_analysis_mfma(int M, int n_ob
         }
     };
     auto sweep_published = [&](int token) {
-        while (__hip_atomic_load(lflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token) __builtin_amdgcn_s_sleep(1);
+        // bounded spin: the tile arrives within a few thousand cycles; if it never does (a defect), flag the member and go
+        // on rather than hang the GPU -- the workgroup barriers below still match
+        for (int spins = 0; __hip_atomic_load(lflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token; ++spins) {
+            if (spins > (1 << 24)) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
         d4 t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = Dg[g.lq + 4 * r][g.lc];
