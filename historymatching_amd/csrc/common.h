@@ -38,7 +38,14 @@ struct hm_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
     int num_cu = 0;
+    // two pinned staging buffers + events of hm_d2h_large (allocated on first use)
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
 };
+
+// Device -> pageable host copy of a large buffer: chunks go to pinned staging buffers at PCIe rate while worker threads
+// move the previous chunk into the destination (first-touch page faults included) in parallel.  Synchronous.
+int hm_d2h_large(hm_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
 
 // RAII-less device buffer bookkeeping (plans free what they allocate).
 struct DevBuf {

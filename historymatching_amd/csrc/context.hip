@@ -1,6 +1,9 @@
 // context.hip -- context lifetime, error string, device buffers, event timers.
 #include "common.h"
 
+#include <algorithm>
+#include <thread>
+
 static thread_local std::string g_last_error;
 
 void hm_set_error(const char* fmt, ...) {
@@ -34,6 +37,10 @@ extern "C" int hm_create(int device_id, hm_ctx** out) {
 extern "C" void hm_destroy(hm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (int b = 0; b < 2; ++b) {
+        if (ctx->pin[b]) (void)hipHostFree(ctx->pin[b]);
+        if (ctx->pin_ev[b]) (void)hipEventDestroy(ctx->pin_ev[b]);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -90,6 +97,43 @@ void EvTimer::destroy() {
     }
     evs.clear();
     used = 0;
+}
+
+int hm_d2h_large(hm_ctx* ctx, void* dst_host, const void* src_device, size_t bytes) {
+    constexpr size_t CHUNK = (size_t)64 << 20;
+    constexpr int NTHREADS = 8;
+    if (bytes < 4 * CHUNK) {
+        HM_HIP(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    for (int b = 0; b < 2; ++b) {
+        if (!ctx->pin[b]) HM_HIP(hipHostMalloc(&ctx->pin[b], CHUNK, hipHostMallocDefault));
+        if (!ctx->pin_ev[b]) HM_HIP(hipEventCreateWithFlags(&ctx->pin_ev[b], hipEventDisableTiming));
+    }
+    const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
+    auto issue = [&](size_t k) -> int {
+        const size_t off = k * CHUNK, len = std::min(CHUNK, bytes - off);
+        HM_HIP(hipMemcpyAsync(ctx->pin[k & 1], (const char*)src_device + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        HM_HIP(hipEventRecord(ctx->pin_ev[k & 1], ctx->stream));
+        return 0;
+    };
+    int rc = issue(0);
+    if (rc) return rc;
+    for (size_t k = 0; k < nchunks; ++k) {
+        HM_HIP(hipEventSynchronize(ctx->pin_ev[k & 1]));
+        if (k + 1 < nchunks && (rc = issue(k + 1))) return rc;
+        const size_t off = k * CHUNK, len = std::min(CHUNK, bytes - off);
+        const char* src = (const char*)ctx->pin[k & 1];
+        char* dst = (char*)dst_host + off;
+        std::thread workers[NTHREADS];
+        const size_t slice = ((len / NTHREADS) + 4095) & ~(size_t)4095;
+        for (int t = 0; t < NTHREADS; ++t) {
+            const size_t a = std::min(len, (size_t)t * slice), e = std::min(len, a + slice);
+            workers[t] = std::thread([=]() { if (e > a) memcpy(dst + a, src + a, e - a); });
+        }
+        for (auto& wkr : workers) wkr.join();
+    }
+    return 0;
 }
 
 extern "C" int hm_copy_to_host(hm_ctx* ctx, void* dst_host, const void* src_device, long long bytes) {

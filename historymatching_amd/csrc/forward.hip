@@ -895,7 +895,8 @@ extern "C" int hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, i
     const FwdParams& p = f->p;
     if (wsats_out) {
         if (f->keep_history) {
-            HM_HIP(hipMemcpy(wsats_out, f->S.p, (size_t)p.N * (p.nTime + 1) * p.Nxy * f->esz, hipMemcpyDeviceToHost));
+            int rc = hm_d2h_large(f->ctx, wsats_out, f->S.p, (size_t)p.N * (p.nTime + 1) * p.Nxy * f->esz);
+            if (rc) return rc;
         } else {
             long long stride;
             void* S = fwd_S_ptr(f, f->cur, &stride);

@@ -18,9 +18,11 @@ for hist in (True, False):
     t0 = time.perf_counter()
     fm(x)  # first call: builds the device plan (22 GB of buffers)
     first = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    w, p = fm(x)
-    wall = time.perf_counter() - t0
+    wall = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        w, p = fm(x)
+        wall = min(wall, time.perf_counter() - t0)
     st = model.last_stats
-    print(f"return_history={hist}: first call {first:.2f} s, next call wall {wall:.2f} s, device {st['ms_total'] / 1e3:.2f} s, output {w.nbytes / 1e9:.2f} GB -> "
+    print(f"return_history={hist}: first call {first:.2f} s, best-of-3 call wall {wall:.2f} s, device {st['ms_total'] / 1e3:.2f} s, output {w.nbytes / 1e9:.2f} GB -> "
           f"{N * bench.NTIME / wall:.0f} ensemble-steps/s PCIe-inclusive")
