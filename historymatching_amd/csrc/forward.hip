@@ -645,7 +645,7 @@ extern "C" void hm_fwd_destroy(hm_fwd* f) {
     (void)hipStreamSynchronize(f->ctx->stream);
     DevBuf* bufs[] = {&f->K, &f->por, &f->q, &f->prd_ind, &f->TX, &f->TY, &f->G, &f->yv, &f->P, &f->Vx,
                       &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells, &f->cg_r, &f->cg_p, &f->n_cg,
-                      &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone};
+                      &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->team_mem};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     f->t_total.destroy(); f->t_press.destroy(); f->t_sat.destroy();
     delete f;
@@ -806,6 +806,7 @@ static int launch_saturation(hm_fwd* f, int k) {
     if (f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
         done = launch_saturation_128(f, Sin, Sout, stride, k);                  // fp64, register/LDS resident
         if (done < 0) done = launch_saturation_128f(f, Sin, Sout, stride, k);  // fp32 twin
+        if (done < 0) done = launch_saturation_128t(f, Sin, Sout, stride, k);  // fp64, grids of 128 x 128 tiles (workgroup teams)
     }
     if (done > 0) return done;
     if (done < 0) {

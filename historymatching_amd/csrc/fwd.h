@@ -62,6 +62,7 @@ struct hm_fwd {
     std::vector<double> q_host;
     std::vector<int> well_cells_host;
     DevBuf well_cells;
+    DevBuf team_mem;  // synchronisation blocks of the multi-tile saturation sweep (sat128t.hip), allocated on first use
 };
 
 // Pointer to the saturation of (member 0, time index k) and the member stride in elements.
@@ -86,3 +87,4 @@ bool pressure_two_level_applies(const FwdParams& p);
 int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int k);  // two-level CG, Ny = 128 c
 int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);
 int launch_saturation_128f(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // dtype = 32 plans
+int launch_saturation_128t(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // grids of 128 x 128 tiles

@@ -75,6 +75,7 @@ int hm_forward_batched(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,
 #define HM_MEMBER_BAD_CFL       2   /* CFL sub-step count not finite / out of range               */
 #define HM_MEMBER_NONFINITE     4   /* NaN/Inf in the saturation                                    */
 #define HM_MEMBER_NO_CONVERGENCE 8  /* CG pressure solver hit max_iter before ||r|| <= rtol ||q||   */
+#define HM_MEMBER_SYNC_TIMEOUT   16  /* a tile workgroup of the multi-tile saturation sweep gave up waiting for a neighbour */
 
 /* Device-resident form of the same path (what bench.py times; what ES-MDA/IES drivers chain). */
 int  hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,

@@ -427,6 +427,40 @@ def test_streaming_saturation_kernel_bitexact_vs_generic(nx, ny, dtype):
         assert np.array_equal(out[1][0], out[v][0]) and np.array_equal(out[1][1], out[v][1])
 
 
+@pytest.mark.parametrize("nx,ny,N,wells", [(256, 256, 3, "default"), (256, 128, 2, "default"), (128, 256, 2, "default"),
+                                           (384, 256, 2, "edges"), (256, 256, 67, "default")])
+def test_multi_tile_saturation_teams_bitexact_vs_tiled(nx, ny, N, wells):
+    """Grids made of 128 x 128 tiles run the saturation sweep as teams of workgroups (sat128t.hip: one workgroup per tile,
+    tile edges exchanged once per sub-step).  Saturations, producer series and sub-step counts are bit-identical to the
+    single-workgroup tiled kernel (sat_variant 3).  The default injector sits on a tile corner (its exact fractional flow
+    travels in the published edges); "edges" puts wells on every kind of tile border; 67 members = more members than
+    teams that fit the chip at once (a second, partial round)."""
+    steps = 1 if N > 8 else 2
+    _, gm = make_models(nx, ny, dtype=64)
+    if wells == "edges":
+        hx, hy = gm.Lx / nx, gm.Ly / ny
+        cells = [(127, 40), (128, 200), (200, 127), (300, 128), (255, 255), (256, 0)]   # last/first rows and columns of tiles
+        gm.inj_xy = [[(ix + 0.5) * hx, (iy + 0.5) * hy] for ix, iy in cells[:2]]
+        gm.prd_xy = [[(ix + 0.5) * hx, (iy + 0.5) * hy] for ix, iy in cells[2:]]
+        gm.inj_rates = np.ones((2, 1)) / 2
+        gm.prd_rates = np.ones((4, 1)) / 4
+    x = perms(nx, ny, N, seed=37)
+    out = {}
+    for sat_variant in (0, 3):
+        plan = _plan(gm, N, nTime=steps)
+        plan.set_variant(0, sat_variant)
+        plan.set_inputs(x, transformed=False)
+        plan.run()
+        plan.sync()
+        w, p, status = plan.outputs()
+        assert not status.any()
+        out[sat_variant] = (w, p, plan.get_field("nts"))
+        plan.close()
+    assert np.array_equal(out[0][2], out[3][2]) and out[0][2].min() >= 1
+    assert np.array_equal(out[0][0], out[3][0]) and np.array_equal(out[0][1], out[3][1])
+    assert out[0][0][:, -1].max() > 0.5  # the front has left the injector
+
+
 @pytest.mark.parametrize("nx,ny", [(64, 128), (200, 128), (128, 64)])
 def test_rectangular_grids_mixed_kernels(nx, ny):
     """Ny = 128 with Nx != 128 runs the matrix-core pressure solver (any number of 128-wide blocks) with the generic
