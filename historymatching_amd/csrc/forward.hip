@@ -807,6 +807,7 @@ static int launch_saturation(hm_fwd* f, int k) {
         done = launch_saturation_128(f, Sin, Sout, stride, k);                  // fp64, register/LDS resident
         if (done < 0) done = launch_saturation_128f(f, Sin, Sout, stride, k);  // fp32 twin
         if (done < 0) done = launch_saturation_128t(f, Sin, Sout, stride, k);  // fp64, grids of 128 x 128 tiles (workgroup teams)
+        if (done < 0) done = launch_saturation_128ft(f, Sin, Sout, stride, k); // fp32 twin
     }
     if (done > 0) return done;
     if (done < 0) {

@@ -26,11 +26,12 @@
 // HM_MEMBER_SYNC_TIMEOUT and the workgroup stops waiting.
 //
 // Compiled with -ffp-contract=off (no FMA contraction: every product and sum is rounded separately, as NumPy does).
-#include "fwd.h"
+#include "sat_team.h"
 
 namespace {
 
-constexpr int TS = 128;                     // tile size (cells per side)
+using namespace sat_team;
+
 constexpr int PX = 8, PY = 4;
 constexpr int NPY = TS / PY;                // 32 patches along iy = 32 lanes
 constexpr int NT = (TS / PX) * NPY;         // 512 threads
@@ -45,44 +46,6 @@ constexpr int VSP_BYTES = 3 * NT * 16;      // per-thread LDS home of 6 face flu
 constexpr int MISC_BASE = VSP_BASE + VSP_BYTES;  // team CFL minima (32 doubles)
 constexpr int LDS_TOTAL = MISC_BASE + 32 * 8;
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
-
-constexpr int MAX_TILES = 32;
-constexpr int SPIN_LIMIT = 1 << 22;
-
-// Per-team hand-off block in global memory.  Everything in it is a GRANULE: a naturally aligned 8-byte word
-// {tag = event number + 1 (high half), 32 bits of payload (low half)} written by one write-through (sc1) store and polled
-// with sc1 loads until the tag matches -- the data is its own flag, there is no separate counter, drain or cache-wide
-// release/acquire (MI355X_MICROARCH.md, inter-workgroup visibility, form R2).  A double travels as two granules.
-typedef unsigned long long u64;
-struct TeamLayout {
-    int T;
-    __host__ __device__ size_t cfl_off() const { return 0; }                                                // [2][T][2] granules
-    __host__ __device__ size_t pub_off() const { return ((size_t)2 * T * 2 * 8 + 127) & ~(size_t)127; }     // [T][2][4][2][128] granules
-    __host__ __device__ size_t bytes() const { return pub_off() + (size_t)T * 2 * 4 * 2 * TS * 8; }
-};
-
-__device__ __forceinline__ void put_granules(u64* lo, u64* hi, double v, unsigned tag) {
-    const u64 t = (u64)tag << 32;
-    __hip_atomic_store(lo, t | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(hi, t | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// poll the two granules of one double until both carry `tag`; every active lane polls its own pair, the wave leaves together
-__device__ __forceinline__ bool get_granules(const u64* lo, const u64* hi, unsigned tag, double& v, int* dead) {
-    for (int spins = 0;; ++spins) {
-        const u64 x = __hip_atomic_load(lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u64 y = __hip_atomic_load(hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ok = (unsigned)(x >> 32) == tag && (unsigned)(y >> 32) == tag;
-        if (__all(ok)) {
-            v = __hiloint2double((int)(unsigned)y, (int)(unsigned)x);
-            return true;
-        }
-        if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || spins > SPIN_LIMIT) {
-            __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
 
 __device__ __forceinline__ int lds_off(int ix, int iy) {
     // byte offset of fw(ix, iy): rows of 1 KB; each thread's 32-byte row segment = two 16-byte chunks whose
@@ -140,8 +103,8 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
 
     const int tid = threadIdx.x;
     const int T = TXn * TYn;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int team = (slot / T) * 8 + xcd, tile = slot % T;
+    int team, tile;
+    team_of_block(T, team, tile);
     const int m = first_member + team;
     if (m >= p.N) return;
     const int tx = tile / TYn, ty = tile % TYn;
@@ -149,7 +112,7 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
     const int Ny = p.Ny;
     const bool hasW = tx > 0, hasE = tx + 1 < TXn, hasS = ty > 0, hasN = ty + 1 < TYn;
 
-    const TeamLayout lay{T};
+    const TeamLayout<2> lay{T};
     char* tm = team_mem + (size_t)team * lay.bytes();
     u64* cflg = reinterpret_cast<u64*>(tm + lay.cfl_off());
     u64* pub = reinterpret_cast<u64*>(tm + lay.pub_off());
@@ -160,14 +123,6 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
     const int py = tid & (NPY - 1), px = tid >> 5;
     const int ix0 = px * PX, iy0 = py * PY;      // tile-local origin of this thread's patch
     const bool isS = py == 0, isN = py == NPY - 1;
-    // halo fetch role of this thread: edge e (0 W, 1 E, 2 S, 3 N) entry idx
-    const int fe = tid >> 7, fidx = tid & (TS - 1);
-    const bool f_has = fe == 0 ? hasW : fe == 1 ? hasE : fe == 2 ? hasS : hasN;
-    const int f_tile = fe == 0 ? tile - TYn : fe == 1 ? tile + TYn : fe == 2 ? tile - 1 : tile + 1;
-    const int f_edge = fe ^ 1;                   // the neighbour's opposite edge
-    const int f_src = fe == 0 ? lds_off(0, fidx) : fe == 1 ? lds_off(TS - 1, fidx) : fe == 2 ? lds_off(fidx, 0) : lds_off(fidx, TS - 1);
-    const int f_dst = fe == 0 ? lds_off(TS, fidx) : fe == 1 ? lds_off(TS + 1, fidx) : EDGE_BASE + ((fe - 2) * TS + fidx) * 16;
-
     // halos without a neighbour stay 0 (their coefficients are 0: boundary faces carry no flux)
     for (int i = tid; i < 2 * TS; i += NT) reinterpret_cast<double*>(lds + TS * 1024)[i] = 0.0;
     for (int i = tid; i < 4 * TS; i += NT) reinterpret_cast<double*>(lds + EDGE_BASE)[i] = 0.0;
@@ -269,11 +224,11 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
         __syncthreads();
     }
     // team-wide minimum: one all-tiles event
-    if (tid == 0) put_granules(cflg + (tile) * 2, cflg + (tile) * 2 + 1, red[0], ev + 1);
+    if (tid == 0) put_double(cflg + (tile) * 2, cflg + (tile) * 2 + 1, red[0], ev + 1);
     if (tid < 64) {   // wave 0: lane t collects tile t's minimum
         const int t = tid < T ? tid : 0;
         double v = INFINITY;
-        if (!get_granules(cflg + (t) * 2, cflg + (t) * 2 + 1, ev + 1, v, dead)) v = INFINITY;
+        if (!get_double(cflg + (t) * 2, cflg + (t) * 2 + 1, ev + 1, v, dead)) v = INFINITY;
         if (tid < T) team_min[tid] = v;
     }
     ++ev;
@@ -366,11 +321,11 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
             const bool has = e == 0 ? hasW : e == 1 ? hasE : e == 2 ? hasS : hasN;
             const int nb = e == 0 ? tile - TYn : e == 1 ? tile + TYn : e == 2 ? tile - 1 : tile + 1;
             u64* mine = pub + ((size_t)(tile * 2 + (ev & 1)) * 4 + e) * 2 * TS + idx;
-            put_granules(mine, mine + TS, *reinterpret_cast<const double*>(lds + src), ev + 1);
+            put_double(mine, mine + TS, *reinterpret_cast<const double*>(lds + src), ev + 1);
             if (has) {
                 const u64* theirs = pub + ((size_t)(nb * 2 + (ev & 1)) * 4 + (e ^ 1)) * 2 * TS + idx;
                 double v;
-                if (get_granules(theirs, theirs + TS, ev + 1, v, dead)) *reinterpret_cast<double*>(lds + dst) = v;
+                if (get_double(theirs, theirs + TS, ev + 1, v, dead)) *reinterpret_cast<double*>(lds + dst) = v;
             }
         }
         __syncthreads();
@@ -474,13 +429,10 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
 }
 
 template <bool FD>
-int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, int TXn, int TYn) {
+int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, int TXn, int TYn, int max_teams) {
     const FwdParams& p = f->p;
     const int T = TXn * TYn;
-    const int slots = f->ctx->num_cu / 8;          // workgroups per XCD that are resident at once (one per CU)
-    const int teams_per_xcd = slots / T;
-    const int max_teams = 8 * teams_per_xcd;
-    const TeamLayout lay{T};
+    const TeamLayout<2> lay{T};
     const size_t need = lay.bytes() * (size_t)max_teams;
     if (f->team_mem.bytes < need) {
         hm_dev_free(f->team_mem);
@@ -507,18 +459,8 @@ int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, 
 // Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
 int launch_saturation_128t(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
     const FwdParams& p = f->p;
-    if (p.Nx % TS || p.Ny % TS || f->dtype != 64 || p.por != nullptr) return -1;
-    const int TXn = p.Nx / TS, TYn = p.Ny / TS, T = TXn * TYn;
-    const int slots = f->ctx->num_cu / 8;
-    if (T < 2 || T > MAX_TILES || T > slots) return -1;
-    if ((int)f->well_cells_host.size() > MAX_WELLS) return -1;
-    std::vector<long long> seen;  // at most one well per 8x4 patch
-    for (int cell : f->well_cells_host) {
-        long long id = (long long)((cell / p.Ny) >> 3) * 100000 + ((cell % p.Ny) >> 2);
-        for (long long s : seen)
-            if (s == id) return -1;
-        seen.push_back(id);
-    }
-    return p.fluid_default ? launch<true>(f, S_in, S_out, S_stride, k, TXn, TYn)
-                           : launch<false>(f, S_in, S_out, S_stride, k, TXn, TYn);
+    int TXn, TYn, max_teams;
+    if (f->dtype != 64 || p.por != nullptr || !tiles_of(f, TXn, TYn, max_teams) || !wells_fit_patches(f, MAX_WELLS)) return -1;
+    return p.fluid_default ? launch<true>(f, S_in, S_out, S_stride, k, TXn, TYn, max_teams)
+                           : launch<false>(f, S_in, S_out, S_stride, k, TXn, TYn, max_teams);
 }

@@ -427,16 +427,17 @@ def test_streaming_saturation_kernel_bitexact_vs_generic(nx, ny, dtype):
         assert np.array_equal(out[1][0], out[v][0]) and np.array_equal(out[1][1], out[v][1])
 
 
-@pytest.mark.parametrize("nx,ny,N,wells", [(256, 256, 3, "default"), (256, 128, 2, "default"), (128, 256, 2, "default"),
-                                           (384, 256, 2, "edges"), (256, 256, 67, "default")])
-def test_multi_tile_saturation_teams_bitexact_vs_tiled(nx, ny, N, wells):
-    """Grids made of 128 x 128 tiles run the saturation sweep as teams of workgroups (sat128t.hip: one workgroup per tile,
-    tile edges exchanged once per sub-step).  Saturations, producer series and sub-step counts are bit-identical to the
+@pytest.mark.parametrize("nx,ny,N,wells,dtype", [(256, 256, 3, "default", 64), (256, 128, 2, "default", 64), (128, 256, 2, "default", 64),
+                                                 (384, 256, 2, "edges", 64), (256, 256, 67, "default", 64),
+                                                 (256, 256, 3, "default", 32), (384, 256, 2, "edges", 32), (128, 256, 67, "default", 32)])
+def test_multi_tile_saturation_teams_bitexact_vs_tiled(nx, ny, N, wells, dtype):
+    """Grids made of 128 x 128 tiles run the saturation sweep as teams of workgroups (sat128t.hip / sat128ft.hip for dtype = 32
+    plans: one workgroup per tile, tile edges exchanged once per sub-step).  Saturations, producer series and sub-step counts are bit-identical to the
     single-workgroup tiled kernel (sat_variant 3).  The default injector sits on a tile corner (its exact fractional flow
     travels in the published edges); "edges" puts wells on every kind of tile border; 67 members = more members than
     teams that fit the chip at once (a second, partial round)."""
     steps = 1 if N > 8 else 2
-    _, gm = make_models(nx, ny, dtype=64)
+    _, gm = make_models(nx, ny, dtype=dtype)
     if wells == "edges":
         hx, hy = gm.Lx / nx, gm.Ly / ny
         cells = [(127, 40), (128, 200), (200, 127), (300, 128), (255, 255), (256, 0)]   # last/first rows and columns of tiles

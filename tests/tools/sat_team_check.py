@@ -1,6 +1,6 @@
 """Multi-tile saturation sweep (sat128t.hip: teams of workgroups) against the tiled single-workgroup kernel (sat_variant 3):
 bit-identical saturations / producer series / sub-step counts, and launch averages.
-   python tests/tools/sat_team_check.py [nx ny members nTime]"""
+   python tests/tools/sat_team_check.py [nx ny members nTime [dtype]]"""
 import sys
 from pathlib import Path
 
@@ -16,8 +16,9 @@ from historymatching_amd.ressim import ResSim  # noqa: E402
 cases = [(256, 256, 5, 2), (256, 128, 3, 2), (128, 256, 3, 2), (512, 512, 2, 1), (256, 256, 70, 1), (256, 256, 64, 2), (512, 512, 16, 1)]
 if len(sys.argv) >= 5:
     cases = [tuple(int(a) for a in sys.argv[1:5])]
+dtype = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 for nx, ny, N, nTime in cases:
-    gm = wells_4corners(ResSim(nx, ny, 2, 1))
+    gm = wells_4corners(ResSim(nx, ny, 2, 1, dtype=dtype))
     x = perms(nx, ny, N, seed=3)
     out = {}
     for v in (0, 3):
