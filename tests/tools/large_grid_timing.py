@@ -12,9 +12,11 @@ from historymatching_amd.forward import ForwardPlan  # noqa: E402
 from historymatching_amd.ressim import ResSim  # noqa: E402
 
 cases = [(256, 64, 2), (512, 16, 1)] if len(sys.argv) < 4 else [tuple(int(a) for a in sys.argv[1:4])]
+pressure_variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # 9: Jacobi-CG instead of the two-level preconditioner
 for n, N, nTime in cases:
     gm = wells_4corners(ResSim(n, n, 2, 1))
     plan = ForwardPlan(gm, N, 0.025, nTime, keep_history=False, device=0)
+    plan.set_variant(pressure_variant, 0)
     plan.set_inputs(perms(n, n, N, seed=3), None, transformed=False)
     t0 = time.perf_counter()
     plan.run()
