@@ -81,6 +81,39 @@ def es_update_timing(device):
             "mfma_frac_of_fp32_peak": flops / (ms[len(ms) // 2] * 1e-3) / 1e12 / peak}
 
 
+def es_update_sharded_timing(device, world, reps=5):
+    """The analysis step row-sharded over the ranks (weak scaling like the forward metric: every rank holds
+    N_e=1000 members of an N_e x world ensemble, M=128*128, n_obs=160, fp32 state): three local phases with two RCCL
+    all-reduces on the library's own device buffers in between (column sums; X^T S and S^T S).  Wall time per update,
+    barrier + device synchronisation on both sides, maximum over ranks.  Called by EVERY rank."""
+    import torch
+    import torch.distributed as td
+
+    from historymatching_amd.dist import Comm, sharded_update
+    from historymatching_amd.update import UpdatePlan
+
+    N, M, n_obs = N_E, NX * NY, 160
+    rng = np.random.RandomState(100 + td.get_rank())
+    plan = UpdatePlan(N * world, N, M, n_obs, dtype=32, device=device)
+    plan.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), np.random.RandomState(7).rand(n_obs), 0.1 * rng.randn(N, n_obs), 3.0 * np.eye(n_obs))
+    comm = Comm()
+    sharded_update(plan, comm, fetch=False)  # warm-up (RCCL communicator set-up included)
+    td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sharded_update(plan, comm, fetch=False)
+    td.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device="cuda")
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    nbytes = sum(plan.reduce_buffer(w)[1] * np.dtype(plan.reduce_buffer(w)[2]).itemsize for w in (0, 1, 2, 3))
+    plan.close()
+    return {"wall_ms": 1e3 * float(t.item()), "n_ranks": world, "members_total": N * world, "members_per_rank": N, "M": M, "n_obs": n_obs,
+            "allreduce_bytes_per_update": int(nbytes), "collective": "RCCL all-reduce in place on the library's device buffers",
+            "config": "row-sharded global analysis step, fp32 state contractions on the matrix cores, weak scaling"}
+
+
 def es_mda_c3(device, perms, n_iter=4):
     """BASELINE.json config 3: N_e=1000, 128x128, 4 ES-MDA passes (forward model in fp32 mode + fp32 matrix-core analysis), the
     ensemble resident in HBM throughout (update.es_mda_device).  Observations = member 0's simulated production + noise."""
@@ -178,6 +211,13 @@ def main():
     _, prods, status = plan.outputs(want_wsats=False)
     ok = not status.any() and np.isfinite(prods).all()
 
+    upd_sharded = None
+    if td is not None:  # every rank: the analysis step sharded over the ranks (outside the timed region of `value`)
+        try:
+            upd_sharded = es_update_sharded_timing(local_rank, world)
+        except Exception as e:
+            upd_sharded = {"error": str(e)}
+
     if rank == 0:
         member_steps = n_e * NTIME * args.steps * world
         value = member_steps / elapsed
@@ -222,12 +262,12 @@ def main():
                 "assumes": "2.4 GHz, 256 CUs; pressure flops = rank-16 updates of the 36 stored tiles x 8 panels x Nx blocks",
             },
         }
-        upd = None
+        upd = None if upd_sharded is None else {"sharded": upd_sharded}
         if world == 1:
             try:
-                upd = es_update_timing(local_rank)
+                upd = dict(upd or {}, **es_update_timing(local_rank))
             except Exception as e:  # the forward metric stands on its own
-                upd = {"error": str(e)}
+                upd = dict(upd or {}, error=str(e))
             if not args.no_esmda:
                 try:
                     upd = dict(upd or {}, es_mda_config3=es_mda_c3(local_rank, perms))

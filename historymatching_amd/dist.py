@@ -104,10 +104,11 @@ def forward_model_sharded(local_forward, perms, wsat0s=None, comm=None, gather=T
     return [wsats, prods]
 
 
-def sharded_update(plan, comm=None):
+def sharded_update(plan, comm=None, fetch=True):
     """Drive a row-sharded update plan (``update.UpdatePlan`` or any object with the same
     ``phase / get_reduce / set_reduce / sync / output`` methods) through its three phases, summing the two
-    reduce buffers over ranks in between.  Returns this rank's rows of the updated ensemble."""
+    reduce buffers over ranks in between.  Returns this rank's rows of the updated ensemble (``fetch=False``: leaves
+    them on the device and returns the plan's statistics instead)."""
     comm = comm or Comm()
     device_direct = comm.backend == "nccl" and hasattr(plan, "reduce_buffer")
     for ph in range(3):
@@ -121,5 +122,5 @@ def sharded_update(plan, comm=None):
             else:  # gloo / CPU test doubles: host-staged
                 for which in plan.REDUCE_AFTER_PHASE[ph]:
                     plan.set_reduce(which, comm.all_reduce_sum(plan.get_reduce(which)))
-    plan.sync()
-    return plan.output()
+    st = plan.sync()
+    return plan.output() if fetch else st
