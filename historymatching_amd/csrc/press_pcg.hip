@@ -141,14 +141,20 @@ __global__ __launch_bounds__(PT) void k_pressure_pcg(FwdParams p, const TS* __re
 
 
 // ------------------------------------------------------------------------------------------------------------
-// Two-level preconditioned CG (grids with Ny = 128 c, Nx = c Nx_c):  M^-1 = D^-1 + P A_c^-1 P^T  (additive), P = piecewise
-// constant prolongation over c x c aggregates.  Aggregating a TPFA system gives a TPFA system: the coarse face
+// Two-level preconditioned CG (grids with Ny = 128 c, Nx = c Nx_c), P = piecewise constant prolongation over c x c
+// aggregates.  The preconditioner is the SYMMETRIC MULTIPLICATIVE two-grid cycle with one damped-Jacobi sweep on either
+// side of the coarse correction (omega = 0.8 < 2 / lambda_max(D^-1 A), so the cycle is symmetric positive definite):
+//     z1 = w D^-1 r;   z2 = z1 + P A_c^-1 P^T (r - A z1);   z = z2 + w D^-1 (r - A z2)
+// (press_variant 11 keeps the first version, the additive M^-1 = D^-1 + P A_c^-1 P^T: 59 / 98 iterations at 256^2 / 512^2
+// against 27 / 50 for the cycle on the same systems, NumPy/SciPy prototype and device alike; the cycle costs two more
+// fine-grid operator passes per iteration but halves the coarse solves, which are the larger part of an iteration.)  Aggregating a TPFA system gives a TPFA system: the coarse face
 // transmissibility is the sum of the fine ones across the shared aggregate boundary, interior faces cancel, the SPD pin
 // stays on (coarse) cell 0.  With c = Ny / 128 the coarse system has Ny_c = 128 and is factored ONCE per time step by the
 // direct block solver (press128s.hip, FACTOR mode); every CG iteration then costs one coarse solve (two substitution
 // passes over the stored factor).  Measured on the same systems (NumPy/SciPy prototype): 59 iterations at 256^2, 98 at
 // 512^2, against 2 000 / 4 500 with the Jacobi preconditioner.
-// One iteration = k_tl_iter (A p, alpha, x, r, restriction) -> k_coarse_solve -> k_tl_dir (z, beta, p); per-member
+// One iteration = k_tl_iter (A p, alpha, x, r, pre-smoothing, restriction) -> k_coarse_solve -> k_tl_dir (correction,
+// post-smoothing, beta, p); per-member
 // scalars and convergence flags live in device memory, converged members drop out of every kernel.
 // cgs[m]: [0] r.z  [1] stop^2  [2] iterations  [3] ||q||^2
 // ------------------------------------------------------------------------------------------------------------
@@ -162,6 +168,9 @@ struct TlArgs {
     int* done;     // N: 0 running, 1 converged, 2 breakdown
     int* ndone;    // 1: members no longer running
     int c, Nxc;
+    double* z1;    // N x Nxy   pre-smoothed iterate of the cycle (then z2, in place)
+    double* dinv;  // N x Nxy   1 / diagonal
+    double omega;  // Jacobi damping of the cycle; 0 = additive preconditioner (no smoothing passes)
 };
 
 __device__ __forceinline__ double block_sum1(double a, double* red, int tid) {
@@ -207,6 +216,24 @@ __device__ __forceinline__ void restrict_residual(const double* __restrict__ r, 
     }
 }
 
+// Pre-smoothing half of the cycle: z1 = w D^-1 r (stored), then rc = P^T (r - A z1).  Ends with the block's writes visible.
+__device__ __forceinline__ void presmooth_and_restrict(const FineOp& A, const double* __restrict__ r, const double* __restrict__ dinv,
+                                                       double* __restrict__ z1, double* __restrict__ rc, double omega, int c, int Nxc, int tid) {
+    const int Ny = A.Ny, Nxy = A.Nx * A.Ny;
+    for (int j = tid; j < Nxy; j += PT) z1[j] = omega * (r[j] * dinv[j]);
+    __syncthreads();
+    for (int J = tid; J < Nxc * 128; J += PT) {
+        const int I = J >> 7, Jy = J & 127;
+        double s = 0.0;
+        for (int a = 0; a < c; ++a)
+            for (int b = 0; b < c; ++b) {
+                const int ix = I * c + a, iy = Jy * c + b, j = ix * Ny + iy;
+                s += r[j] - A.row(z1, j, ix, iy);
+            }
+        rc[J] = s;
+    }
+}
+
 template <typename TS>
 __global__ __launch_bounds__(PT) void k_tl_setup(FwdParams p, TlArgs t, const TS* __restrict__ S_base, long long S_stride, int k) {
     __shared__ double red[2 * PT];
@@ -241,17 +268,20 @@ __global__ __launch_bounds__(PT) void k_tl_setup(FwdParams p, TlArgs t, const TS
     }
     const FineOp A{TX, TY, Nx, Ny, Km[0] + Km[0]};
     if (tid == 0) t.pin[m] = A.pin;
+    double* dinv = t.dinv + (long long)m * Nxy;
     double rr = 0.0, bb = 0.0;
     for (int j = tid; j < Nxy; j += PT) {
         const int ix = j / Ny, iy = j - ix * Ny;
         const double b = q[j];
         const double rj = b - A.row(x, j, ix, iy);
         r[j] = rj;
+        if (t.omega != 0.0) dinv[j] = 1.0 / A.diag(j, ix, iy);
         rr += rj * rj;
         bb += b * b;
     }
     block_sum2(rr, bb, red, tid);  // (its barriers also publish r)
-    restrict_residual(r, t.rc + (long long)m * Nxc * 128, Ny, c, Nxc, tid);
+    if (t.omega != 0.0) presmooth_and_restrict(A, r, dinv, t.z1 + (long long)m * Nxy, t.rc + (long long)m * Nxc * 128, t.omega, c, Nxc, tid);
+    else restrict_residual(r, t.rc + (long long)m * Nxc * 128, Ny, c, Nxc, tid);
     if (tid == 0) {
         const double stop2 = p.cg_rtol * p.cg_rtol * bb;
         double* cg = t.cgs + 4 * m;
@@ -262,7 +292,8 @@ __global__ __launch_bounds__(PT) void k_tl_setup(FwdParams p, TlArgs t, const TS
     }
 }
 
-// z = D^-1 r + P yc;  first: p = z, rz = r.z;  else beta = (r.z)_new / (r.z)_old, p = z + beta p
+// additive: z = D^-1 r + P yc.   cycle: z2 = z1 + P yc, z = z2 + w D^-1 (r - A z2).
+// first: p = z, rz = r.z;  else beta = (r.z)_new / (r.z)_old, p = z + beta p
 __global__ __launch_bounds__(PT) void k_tl_dir(FwdParams p, TlArgs t, int first) {
     __shared__ double red[2 * PT];
     const int m = blockIdx.x, tid = threadIdx.x;
@@ -276,11 +307,27 @@ __global__ __launch_bounds__(PT) void k_tl_dir(FwdParams p, TlArgs t, int first)
     const double* yc = t.yc + (long long)m * Nxc * 128;
     const FineOp A{TX, TY, Nx, Ny, t.pin[m]};
     double rz = 0.0;
-    for (int j = tid; j < Nxy; j += PT) {
-        const int ix = j / Ny, iy = j - ix * Ny;
-        const double zj = r[j] / A.diag(j, ix, iy) + yc[(ix / c) * 128 + iy / c];
-        z[j] = zj;
-        rz += r[j] * zj;
+    if (t.omega != 0.0) {
+        double* z2 = t.z1 + (long long)m * Nxy;
+        const double* dinv = t.dinv + (long long)m * Nxy;
+        for (int j = tid; j < Nxy; j += PT) {
+            const int ix = j / Ny, iy = j - ix * Ny;
+            z2[j] += yc[(ix / c) * 128 + iy / c];
+        }
+        __syncthreads();
+        for (int j = tid; j < Nxy; j += PT) {
+            const int ix = j / Ny, iy = j - ix * Ny;
+            const double zj = z2[j] + t.omega * ((r[j] - A.row(z2, j, ix, iy)) * dinv[j]);
+            z[j] = zj;
+            rz += r[j] * zj;
+        }
+    } else {
+        for (int j = tid; j < Nxy; j += PT) {
+            const int ix = j / Ny, iy = j - ix * Ny;
+            const double zj = r[j] / A.diag(j, ix, iy) + yc[(ix / c) * 128 + iy / c];
+            z[j] = zj;
+            rz += r[j] * zj;
+        }
     }
     rz = block_sum1(rz, red, tid);
     double* cg = t.cgs + 4 * m;
@@ -330,7 +377,10 @@ __global__ __launch_bounds__(PT) void k_tl_iter(FwdParams p, TlArgs t) {
         if (tid == 0) { t.done[m] = 1; atomicAdd(t.ndone, 1); }
         return;
     }
-    restrict_residual(r, t.rc + (long long)m * t.Nxc * 128, Ny, t.c, t.Nxc, tid);
+    if (t.omega != 0.0)
+        presmooth_and_restrict(A, r, t.dinv + (long long)m * Nxy, t.z1 + (long long)m * Nxy, t.rc + (long long)m * t.Nxc * 128, t.omega, t.c,
+                               t.Nxc, tid);
+    else restrict_residual(r, t.rc + (long long)m * t.Nxc * 128, Ny, t.c, t.Nxc, tid);
 }
 
 __global__ __launch_bounds__(PT) void k_tl_final(FwdParams p, TlArgs t, int k) {
@@ -376,11 +426,13 @@ int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int 
 #define A_(buf, bytes) if (!rc) rc = hm_dev_alloc(f->buf, (bytes))
         A_(tl_TXc, n * (Nxc + 1) * 128 * 8); A_(tl_TYc, n * Nxc * 129 * 8); A_(tl_pin, n * 8); A_(tl_rc, n * nc * 8); A_(tl_yc, n * nc * 8);
         A_(tl_yv, n * nc * 8); A_(tl_G, n * nc * 128 * 8); A_(tl_cgs, n * 4 * 8); A_(tl_done, n * 4); A_(tl_ndone, 16);
+        A_(tl_z1, n * (size_t)p.Nxy * 8); A_(tl_dinv, n * (size_t)p.Nxy * 8);
 #undef A_
         if (rc) return rc;
     }
     TlArgs t{(double*)f->tl_TXc.p, (double*)f->tl_TYc.p, (double*)f->tl_pin.p, (double*)f->tl_rc.p, (double*)f->tl_yc.p,
-             (double*)f->tl_cgs.p, (int*)f->tl_done.p, (int*)f->tl_ndone.p, c, Nxc};
+             (double*)f->tl_cgs.p, (int*)f->tl_done.p, (int*)f->tl_ndone.p, c, Nxc,
+             (double*)f->tl_z1.p, (double*)f->tl_dinv.p, f->press_variant == 11 ? 0.0 : 0.8};
     FwdParams pc = p;  // the coarse system as the direct solver sees it
     pc.Nx = Nxc; pc.Ny = 128; pc.Nxy = (int)nc;
     pc.TX = t.TXc; pc.TY = t.TYc; pc.G = (double*)f->tl_G.p; pc.yv = (double*)f->tl_yv.p; pc.pin = t.pin;

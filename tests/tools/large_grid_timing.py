@@ -1,5 +1,5 @@
 """Timing of the large-grid path (CG pressure + generic saturation kernels) on shards of BASELINE configs 4 and 5.
-   python tests/tools/large_grid_timing.py [n members nTime]"""
+   python tests/tools/large_grid_timing.py [n members nTime [pressure_variant [dtype]]]"""
 import sys
 import time
 from pathlib import Path
@@ -13,8 +13,9 @@ from historymatching_amd.ressim import ResSim  # noqa: E402
 
 cases = [(256, 64, 2), (512, 16, 1)] if len(sys.argv) < 4 else [tuple(int(a) for a in sys.argv[1:4])]
 pressure_variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # 9: Jacobi-CG instead of the two-level preconditioner
+dtype = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 for n, N, nTime in cases:
-    gm = wells_4corners(ResSim(n, n, 2, 1))
+    gm = wells_4corners(ResSim(n, n, 2, 1, dtype=dtype))
     plan = ForwardPlan(gm, N, 0.025, nTime, keep_history=False, device=0)
     plan.set_variant(pressure_variant, 0)
     plan.set_inputs(perms(n, n, N, seed=3), None, transformed=False)
@@ -23,7 +24,7 @@ for n, N, nTime in cases:
     st = plan.sync()
     wall = time.perf_counter() - t0
     _, _, status = plan.outputs(want_wsats=False)
-    print(f"{n}x{n}, {N} members, {nTime} steps: wall {wall:.2f} s; pressure {st['ms_pressure'] / st['n_pressure_launches']:.1f} ms/launch "
+    print(f"{n}x{n}, {N} members, {nTime} steps, dtype {dtype}: wall {wall:.2f} s; pressure {st['ms_pressure'] / st['n_pressure_launches']:.1f} ms/launch "
           f"(mean CG iterations {st['mean_n_cg']:.0f}), saturation {st['ms_saturation'] / st['n_saturation_launches']:.1f} ms/launch "
           f"(mean Nts {st['mean_nts']:.0f}); status ok: {not status.any()}")
     plan.close()
