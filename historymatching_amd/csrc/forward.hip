@@ -645,7 +645,7 @@ extern "C" void hm_fwd_destroy(hm_fwd* f) {
     (void)hipStreamSynchronize(f->ctx->stream);
     DevBuf* bufs[] = {&f->K, &f->por, &f->q, &f->prd_ind, &f->TX, &f->TY, &f->G, &f->yv, &f->P, &f->Vx,
                       &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells, &f->cg_r, &f->cg_p, &f->n_cg,
-                      &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->tl_z1, &f->tl_dinv, &f->team_mem};
+                      &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->tl_z1, &f->tl_dinv, &f->tl_parts, &f->team_mem};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     f->t_total.destroy(); f->t_press.destroy(); f->t_sat.destroy();
     delete f;

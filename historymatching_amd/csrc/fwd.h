@@ -52,7 +52,7 @@ struct hm_fwd {
     DevBuf K, por, q, prd_ind, TX, TY, G, yv, P, Vx, Vy, coef, fw, status, nts, perm_in, cg_r, cg_p, n_cg;
     // two-level CG preconditioner (allocated on first use): coarse transmissibilities, pin, restricted residual, coarse
     // correction, coarse scratch, coarse factor, per-member CG scalars and convergence flags
-    DevBuf tl_TXc, tl_TYc, tl_pin, tl_rc, tl_yc, tl_yv, tl_G, tl_cgs, tl_done, tl_ndone, tl_z1, tl_dinv;
+    DevBuf tl_TXc, tl_TYc, tl_pin, tl_rc, tl_yc, tl_yv, tl_G, tl_cgs, tl_done, tl_ndone, tl_z1, tl_dinv, tl_parts;
     int cg_precond = 0;  // 0 = two-level where it applies, 1 = Jacobi
     DevBuf S;      // keep_history ? N*(nTime+1)*Nxy : 2*N*Nxy (ping-pong)
     DevBuf prods;  // N*nTime*nPrd

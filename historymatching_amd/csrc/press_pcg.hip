@@ -153,8 +153,8 @@ __global__ __launch_bounds__(PT) void k_pressure_pcg(FwdParams p, const TS* __re
 // direct block solver (press128s.hip, FACTOR mode); every CG iteration then costs one coarse solve (two substitution
 // passes over the stored factor).  Measured on the same systems (NumPy/SciPy prototype): 59 iterations at 256^2, 98 at
 // 512^2, against 2 000 / 4 500 with the Jacobi preconditioner.
-// One iteration = k_tl_iter (A p, alpha, x, r, pre-smoothing, restriction) -> k_coarse_solve -> k_tl_dir (correction,
-// post-smoothing, beta, p); per-member
+// One iteration of the cycle = k_tg_spmv, k_tg_update, k_tg_restrict -> k_coarse_solve -> k_tg_correct, k_tg_postsmooth,
+// k_tg_direction (below: G workgroups per member); of the additive form = k_tl_iter -> k_coarse_solve -> k_tl_dir; per-member
 // scalars and convergence flags live in device memory, converged members drop out of every kernel.
 // cgs[m]: [0] r.z  [1] stop^2  [2] iterations  [3] ||q||^2
 // ------------------------------------------------------------------------------------------------------------
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(PT) void k_tl_setup(FwdParams p, TlArgs t, const TS
     }
 }
 
-// additive: z = D^-1 r + P yc.   cycle: z2 = z1 + P yc, z = z2 + w D^-1 (r - A z2).
+// additive preconditioner (press_variant 11), one workgroup per member:  z = D^-1 r + P yc;
 // first: p = z, rz = r.z;  else beta = (r.z)_new / (r.z)_old, p = z + beta p
 __global__ __launch_bounds__(PT) void k_tl_dir(FwdParams p, TlArgs t, int first) {
     __shared__ double red[2 * PT];
@@ -307,27 +307,11 @@ __global__ __launch_bounds__(PT) void k_tl_dir(FwdParams p, TlArgs t, int first)
     const double* yc = t.yc + (long long)m * Nxc * 128;
     const FineOp A{TX, TY, Nx, Ny, t.pin[m]};
     double rz = 0.0;
-    if (t.omega != 0.0) {
-        double* z2 = t.z1 + (long long)m * Nxy;
-        const double* dinv = t.dinv + (long long)m * Nxy;
-        for (int j = tid; j < Nxy; j += PT) {
-            const int ix = j / Ny, iy = j - ix * Ny;
-            z2[j] += yc[(ix / c) * 128 + iy / c];
-        }
-        __syncthreads();
-        for (int j = tid; j < Nxy; j += PT) {
-            const int ix = j / Ny, iy = j - ix * Ny;
-            const double zj = z2[j] + t.omega * ((r[j] - A.row(z2, j, ix, iy)) * dinv[j]);
-            z[j] = zj;
-            rz += r[j] * zj;
-        }
-    } else {
-        for (int j = tid; j < Nxy; j += PT) {
-            const int ix = j / Ny, iy = j - ix * Ny;
-            const double zj = r[j] / A.diag(j, ix, iy) + yc[(ix / c) * 128 + iy / c];
-            z[j] = zj;
-            rz += r[j] * zj;
-        }
+    for (int j = tid; j < Nxy; j += PT) {
+        const int ix = j / Ny, iy = j - ix * Ny;
+        const double zj = r[j] / A.diag(j, ix, iy) + yc[(ix / c) * 128 + iy / c];
+        z[j] = zj;
+        rz += r[j] * zj;
     }
     rz = block_sum1(rz, red, tid);
     double* cg = t.cgs + 4 * m;
@@ -377,11 +361,177 @@ __global__ __launch_bounds__(PT) void k_tl_iter(FwdParams p, TlArgs t) {
         if (tid == 0) { t.done[m] = 1; atomicAdd(t.ndone, 1); }
         return;
     }
-    if (t.omega != 0.0)
-        presmooth_and_restrict(A, r, t.dinv + (long long)m * Nxy, t.z1 + (long long)m * Nxy, t.rc + (long long)m * t.Nxc * 128, t.omega, t.c,
-                               t.Nxc, tid);
-    else restrict_residual(r, t.rc + (long long)m * t.Nxc * 128, Ny, t.c, t.Nxc, tid);
+    restrict_residual(r, t.rc + (long long)m * t.Nxc * 128, Ny, t.c, t.Nxc, tid);
 }
+
+// ---- the same iteration with G workgroups per member (blockIdx.y = g: contiguous cell / aggregate ranges) ------------------
+// With fewer members than CUs (config 5's shard: 125 members of 512 x 512 cells) one workgroup per member leaves half the
+// chip idle and every pass latency-bound on a single CU.  Here a member's passes are split over G workgroups; every point
+// where a pass needs ALL of the previous one (a dot product, or neighbour values across the range boundary) is a kernel
+// boundary, dot products are two-stage with a fixed order (per-workgroup LDS tree, then the G partial sums in order g = 0..G-1
+// by every consumer) -> bit-reproducible.  parts[kind][parity][m][g]: 0 = p.Ap, 1 = r.r, 2 = r.z; the parity alternates per
+// iteration so r.z of the previous iteration stays readable while the new one is written.
+struct TgArgs {
+    double* parts;
+    int G, par;
+};
+__device__ __forceinline__ double* part_slot(const TgArgs& a, int N, int kind, int par, int m, int g) {
+    return a.parts + (((size_t)(kind * 2 + par) * N + m) * a.G + g);
+}
+__device__ __forceinline__ double sum_parts(const TgArgs& a, int N, int kind, int par, int m) {
+    const double* q = part_slot(a, N, kind, par, m, 0);
+    double s = 0.0;
+    for (int g = 0; g < a.G; ++g) s += q[g];
+    return s;
+}
+#define TG_PROLOGUE                                                                                   \
+    const int m = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;                                       \
+    if (t.done[m]) return;                                                                             \
+    const int Nx = p.Nx, Ny = p.Ny, Nxy = p.Nxy;                                                       \
+    const int j0 = (int)((long long)Nxy * g / a.G), j1 = (int)((long long)Nxy * (g + 1) / a.G);        \
+    const double* TX = p.TX + (long long)m * (Nx + 1) * Ny;                                            \
+    const double* TY = p.TY + (long long)m * Nx * (Ny + 1);                                            \
+    const FineOp A{TX, TY, Nx, Ny, t.pin[m]};                                                          \
+    (void)j0; (void)j1; (void)A; (void)tid
+
+// a: Ap = A p, partial p.Ap
+__global__ __launch_bounds__(PT) void k_tg_spmv(FwdParams p, TlArgs t, TgArgs a) {
+    __shared__ double red[2 * PT];
+    TG_PROLOGUE;
+    const double* pv = p.cg_p + (long long)m * Nxy;
+    double* Ap = p.yv + (long long)m * Nxy;
+    double pAp = 0.0;
+    for (int j = j0 + tid; j < j1; j += PT) {
+        const int ix = j / Ny, iy = j - ix * Ny;
+        const double v = A.row(pv, j, ix, iy);
+        Ap[j] = v;
+        pAp += pv[j] * v;
+    }
+    pAp = block_sum1(pAp, red, tid);
+    if (tid == 0) *part_slot(a, p.N, 0, a.par, m, g) = pAp;
+}
+
+// b: alpha = (r.z)_old / p.Ap, x += alpha p, r -= alpha Ap, partial r.r, z1 = w D^-1 r
+__global__ __launch_bounds__(PT) void k_tg_update(FwdParams p, TlArgs t, TgArgs a) {
+    __shared__ double red[2 * PT];
+    TG_PROLOGUE;
+    const double pAp = sum_parts(a, p.N, 0, a.par, m);
+    if (!(pAp > 0.0)) {  // not SPD (K <= 0, NaN): every workgroup of the member sees the same value
+        if (g == 0 && tid == 0) { t.done[m] = 2; atomicAdd(t.ndone, 1); }
+        return;
+    }
+    const double alpha = sum_parts(a, p.N, 2, a.par ^ 1, m) / pAp;
+    double* x = p.P + (long long)m * Nxy;
+    double* r = p.cg_r + (long long)m * Nxy;
+    const double* pv = p.cg_p + (long long)m * Nxy;
+    const double* Ap = p.yv + (long long)m * Nxy;
+    const double* dinv = t.dinv + (long long)m * Nxy;
+    double* z1 = t.z1 + (long long)m * Nxy;
+    double rr = 0.0;
+    for (int j = j0 + tid; j < j1; j += PT) {
+        x[j] += alpha * pv[j];
+        const double rj = r[j] - alpha * Ap[j];
+        r[j] = rj;
+        rr += rj * rj;
+        z1[j] = t.omega * (rj * dinv[j]);
+    }
+    rr = block_sum1(rr, red, tid);
+    if (tid == 0) *part_slot(a, p.N, 1, a.par, m, g) = rr;
+}
+
+// c: convergence test, rc = P^T (r - A z1)
+__global__ __launch_bounds__(PT) void k_tg_restrict(FwdParams p, TlArgs t, TgArgs a) {
+    __shared__ double red[PT];
+    TG_PROLOGUE;
+    const double rr = sum_parts(a, p.N, 1, a.par, m);
+    double* cg = t.cgs + 4 * m;
+    if (g == 0 && tid == 0) cg[2] += 1.0;
+    if (rr <= cg[1]) {
+        if (g == 0 && tid == 0) { t.done[m] = 1; atomicAdd(t.ndone, 1); }
+        return;
+    }
+    const double* r = p.cg_r + (long long)m * Nxy;
+    const double* z1 = t.z1 + (long long)m * Nxy;
+    double* rc = t.rc + (long long)m * t.Nxc * 128;
+    const int c = t.c;
+    const int I0 = (int)((long long)t.Nxc * g / a.G), I1 = (int)((long long)t.Nxc * (g + 1) / a.G);
+    if (Ny <= PT) {
+        // cell-parallel (coalesced): a thread sums the c cells of its column iy inside coarse row I, the c columns of an
+        // aggregate are then added through LDS in a fixed order
+        const int rpp = PT / Ny;                       // coarse rows per pass
+        const int lr = tid / Ny, iy = tid - lr * Ny;
+        for (int Ib = I0; Ib < I1; Ib += rpp) {
+            const int I = Ib + lr;
+            const bool valid = lr < rpp && I < I1;
+            double sacc = 0.0;
+            if (valid)
+                for (int u = 0; u < c; ++u) {
+                    const int ix = I * c + u, j = ix * Ny + iy;
+                    sacc += r[j] - A.row(z1, j, ix, iy);
+                }
+            red[tid] = sacc;
+            __syncthreads();
+            if (valid && iy % c == 0) {
+                double tot = 0.0;
+                for (int v = 0; v < c; ++v) tot += red[tid + v];
+                rc[I * 128 + iy / c] = tot;
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int J = I0 * 128 + tid; J < I1 * 128; J += PT) {
+            const int I = J >> 7, Jy = J & 127;
+            double sacc = 0.0;
+            for (int u = 0; u < c; ++u)
+                for (int v = 0; v < c; ++v) {
+                    const int ix = I * c + u, iy = Jy * c + v, j = ix * Ny + iy;
+                    sacc += r[j] - A.row(z1, j, ix, iy);
+                }
+            rc[J] = sacc;
+        }
+    }
+}
+
+// d: z2 = z1 + P yc (in place)
+__global__ __launch_bounds__(PT) void k_tg_correct(FwdParams p, TlArgs t, TgArgs a) {
+    TG_PROLOGUE;
+    double* z2 = t.z1 + (long long)m * Nxy;
+    const double* yc = t.yc + (long long)m * t.Nxc * 128;
+    const int c = t.c;
+    for (int j = j0 + tid; j < j1; j += PT) {
+        const int ix = j / Ny, iy = j - ix * Ny;
+        z2[j] += yc[(ix / c) * 128 + iy / c];
+    }
+}
+
+// e: z = z2 + w D^-1 (r - A z2), partial r.z
+__global__ __launch_bounds__(PT) void k_tg_postsmooth(FwdParams p, TlArgs t, TgArgs a) {
+    __shared__ double red[2 * PT];
+    TG_PROLOGUE;
+    const double* r = p.cg_r + (long long)m * Nxy;
+    const double* z2 = t.z1 + (long long)m * Nxy;
+    const double* dinv = t.dinv + (long long)m * Nxy;
+    double* z = p.yv + (long long)m * Nxy;
+    double rz = 0.0;
+    for (int j = j0 + tid; j < j1; j += PT) {
+        const int ix = j / Ny, iy = j - ix * Ny;
+        const double zj = z2[j] + t.omega * ((r[j] - A.row(z2, j, ix, iy)) * dinv[j]);
+        z[j] = zj;
+        rz += r[j] * zj;
+    }
+    rz = block_sum1(rz, red, tid);
+    if (tid == 0) *part_slot(a, p.N, 2, a.par, m, g) = rz;
+}
+
+// f: beta = (r.z)_new / (r.z)_old, p = z + beta p   (first: p = z)
+__global__ __launch_bounds__(PT) void k_tg_direction(FwdParams p, TlArgs t, TgArgs a, int first) {
+    TG_PROLOGUE;
+    const double beta = first ? 0.0 : sum_parts(a, p.N, 2, a.par, m) / sum_parts(a, p.N, 2, a.par ^ 1, m);
+    double* pv = p.cg_p + (long long)m * Nxy;
+    const double* z = p.yv + (long long)m * Nxy;
+    for (int j = j0 + tid; j < j1; j += PT) pv[j] = first ? z[j] : z[j] + beta * pv[j];
+}
+#undef TG_PROLOGUE
 
 __global__ __launch_bounds__(PT) void k_tl_final(FwdParams p, TlArgs t, int k) {
     const int m = blockIdx.x, tid = threadIdx.x;
@@ -426,7 +576,7 @@ int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int 
 #define A_(buf, bytes) if (!rc) rc = hm_dev_alloc(f->buf, (bytes))
         A_(tl_TXc, n * (Nxc + 1) * 128 * 8); A_(tl_TYc, n * Nxc * 129 * 8); A_(tl_pin, n * 8); A_(tl_rc, n * nc * 8); A_(tl_yc, n * nc * 8);
         A_(tl_yv, n * nc * 8); A_(tl_G, n * nc * 128 * 8); A_(tl_cgs, n * 4 * 8); A_(tl_done, n * 4); A_(tl_ndone, 16);
-        A_(tl_z1, n * (size_t)p.Nxy * 8); A_(tl_dinv, n * (size_t)p.Nxy * 8);
+        A_(tl_z1, n * (size_t)p.Nxy * 8); A_(tl_dinv, n * (size_t)p.Nxy * 8); A_(tl_parts, (size_t)3 * 2 * n * 8 * 8);
 #undef A_
         if (rc) return rc;
     }
@@ -443,18 +593,44 @@ int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int 
     int rc = launch_coarse_factor_128(s, pc);
     if (rc) return rc > 0 ? rc : 1;
     if ((rc = launch_coarse_solve_128(s, pc, t.rc, t.yc, t.done))) return rc > 0 ? rc : 1;
-    hipLaunchKernelGGL(k_tl_dir, dim3(p.N), dim3(PT), 0, s, p, t, 1);
-    HM_HIP(hipGetLastError());
     int ndone = 0;
-    for (int it = 0; it < p.cg_max_iter; ++it) {
-        hipLaunchKernelGGL(k_tl_iter, dim3(p.N), dim3(PT), 0, s, p, t);
-        if ((rc = launch_coarse_solve_128(s, pc, t.rc, t.yc, t.done))) return rc > 0 ? rc : 1;
-        hipLaunchKernelGGL(k_tl_dir, dim3(p.N), dim3(PT), 0, s, p, t, 0);
+    if (t.omega != 0.0) {
+        // the cycle: six fine-grid kernels per iteration, G workgroups per member (enough to put two on every CU)
+        const int G = std::max(1, std::min(8, (2 * f->ctx->num_cu + p.N - 1) / p.N));  // tl_parts holds 8 per member
+        TgArgs a{(double*)f->tl_parts.p, G, 1};
+        const dim3 grid(p.N, G);
+        hipLaunchKernelGGL(k_tg_correct, grid, dim3(PT), 0, s, p, t, a);
+        hipLaunchKernelGGL(k_tg_postsmooth, grid, dim3(PT), 0, s, p, t, a);
+        hipLaunchKernelGGL(k_tg_direction, grid, dim3(PT), 0, s, p, t, a, 1);
+        for (int it = 0; it < p.cg_max_iter; ++it) {
+            a.par = it & 1;
+            hipLaunchKernelGGL(k_tg_spmv, grid, dim3(PT), 0, s, p, t, a);
+            hipLaunchKernelGGL(k_tg_update, grid, dim3(PT), 0, s, p, t, a);
+            hipLaunchKernelGGL(k_tg_restrict, grid, dim3(PT), 0, s, p, t, a);
+            if ((rc = launch_coarse_solve_128(s, pc, t.rc, t.yc, t.done))) return rc > 0 ? rc : 1;
+            hipLaunchKernelGGL(k_tg_correct, grid, dim3(PT), 0, s, p, t, a);
+            hipLaunchKernelGGL(k_tg_postsmooth, grid, dim3(PT), 0, s, p, t, a);
+            hipLaunchKernelGGL(k_tg_direction, grid, dim3(PT), 0, s, p, t, a, 0);
+            HM_HIP(hipGetLastError());
+            if ((it & 7) == 7) {
+                HM_HIP(hipMemcpyAsync(&ndone, t.ndone, 4, hipMemcpyDeviceToHost, s));
+                HM_HIP(hipStreamSynchronize(s));
+                if (ndone >= p.N) break;
+            }
+        }
+    } else {
+        hipLaunchKernelGGL(k_tl_dir, dim3(p.N), dim3(PT), 0, s, p, t, 1);
         HM_HIP(hipGetLastError());
-        if ((it & 7) == 7) {
-            HM_HIP(hipMemcpyAsync(&ndone, t.ndone, 4, hipMemcpyDeviceToHost, s));
-            HM_HIP(hipStreamSynchronize(s));
-            if (ndone >= p.N) break;
+        for (int it = 0; it < p.cg_max_iter; ++it) {
+            hipLaunchKernelGGL(k_tl_iter, dim3(p.N), dim3(PT), 0, s, p, t);
+            if ((rc = launch_coarse_solve_128(s, pc, t.rc, t.yc, t.done))) return rc > 0 ? rc : 1;
+            hipLaunchKernelGGL(k_tl_dir, dim3(p.N), dim3(PT), 0, s, p, t, 0);
+            HM_HIP(hipGetLastError());
+            if ((it & 7) == 7) {
+                HM_HIP(hipMemcpyAsync(&ndone, t.ndone, 4, hipMemcpyDeviceToHost, s));
+                HM_HIP(hipStreamSynchronize(s));
+                if (ndone >= p.N) break;
+            }
         }
     }
     hipLaunchKernelGGL(k_tl_final, dim3(p.N), dim3(PT), 0, s, p, t, k);
