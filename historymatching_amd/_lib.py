@@ -62,6 +62,7 @@ SIGNATURES = {
     "hm_fwd_get_outputs": (C.c_int, [_vp, _vp, _vp, _ip]),
     "hm_fwd_set_variant": (C.c_int, [_vp, C.c_int, C.c_int]),
     "hm_fwd_set_solver": (C.c_int, [_vp, C.c_double, C.c_int]),
+    "hm_fwd_set_member_wells": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "hm_fwd_set_inputs_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "hm_fwd_pressure_only": (C.c_int, [_vp, C.c_int]),
     "hm_fwd_saturation_only": (C.c_int, [_vp, C.c_int]),

@@ -73,7 +73,7 @@ __global__ void k_pressure_generic(FwdParams p, const TS* __restrict__ S_base, l
     double* P = p.P + (long long)m * Nxy;
     double* Vx = p.Vx + (long long)m * (Nx + 1) * Ny;
     double* Vy = p.Vy + (long long)m * Nx * (Ny + 1);
-    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+    const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
     double* L = P;  // temporarily holds L = 1/(Mt*K)
 
     // --- mobility-weighted inverse permeability, harmonic-mean face transmissibilities
@@ -207,7 +207,7 @@ __global__ void k_saturation_generic(FwdParams p, const T* __restrict__ Sin_base
     T* S = Sout_base + (long long)m * S_stride;
     const double* Vx = p.Vx + (long long)m * (Nx + 1) * Ny;
     const double* Vy = p.Vy + (long long)m * Nx * (Ny + 1);
-    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+    const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
     T* cE = (T*)p.coef + (long long)m * 6 * Nxy;
     T *cN = cE + Nxy, *cC = cN + Nxy, *cS = cC + Nxy, *cW = cS + Nxy, *fid = cW + Nxy;
     T* fw = (T*)p.fw + (long long)m * Nxy;
@@ -275,7 +275,7 @@ __global__ void k_saturation_generic(FwdParams p, const T* __restrict__ Sin_base
     for (int j = tid; j < Nxy; j += NT)
         if (!isfinite((double)S[j])) nonfinite = 1;
     if (nonfinite) atomicOr(&p.status[m], HM_MEMBER_NONFINITE);
-    if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = S[p.prd_ind[tid]];
+    if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = S[p.prd_ind[m * p.prd_mstride + tid]];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -302,7 +302,7 @@ __global__ void k_saturation_stream(FwdParams p, const T* __restrict__ Sin_base,
     T* Sbuf = (T*)p.fw + (long long)m * Nxy;  // second image of the ping-pong
     const double* Vx = p.Vx + (long long)m * (Nx + 1) * Ny;
     const double* Vy = p.Vy + (long long)m * Nx * (Ny + 1);
-    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+    const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
 
     // --- CFL: pm = min(pv / (Vi + fi))
     double lmin = INFINITY;
@@ -366,7 +366,7 @@ __global__ void k_saturation_stream(FwdParams p, const T* __restrict__ Sin_base,
     for (int j = tid; j < Nxy; j += NT)
         if (!isfinite((double)Sout[j])) nonfinite = 1;
     if (nonfinite) atomicOr(&p.status[m], HM_MEMBER_NONFINITE);
-    if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = Sout[p.prd_ind[tid]];
+    if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = Sout[p.prd_ind[m * p.prd_mstride + tid]];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T*
     T* Sbuf = (T*)p.fw + (long long)m * Nxy;
     const double* Vx = p.Vx + (long long)m * (Nx + 1) * Ny;
     const double* Vy = p.Vy + (long long)m * Nx * (Ny + 1);
-    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+    const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
 
     double lmin = INFINITY;
     for (int j = tid; j < Nxy; j += NT) {
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T*
     for (int j = tid; j < Nxy; j += NT)
         if (!isfinite((double)Sout[j])) nonfinite = 1;
     if (nonfinite) atomicOr(&p.status[m], HM_MEMBER_NONFINITE);
-    if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = Sout[p.prd_ind[tid]];
+    if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = Sout[p.prd_ind[m * p.prd_mstride + tid]];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -656,6 +656,29 @@ extern "C" int hm_fwd_set_solver(hm_fwd* f, double rtol, int max_iter) {
     HM_REQUIRE(rtol > 0 && rtol < 1 && max_iter >= 1, "hm_fwd_set_solver: need 0 < rtol < 1, max_iter >= 1");
     f->p.cg_rtol = rtol;
     f->p.cg_max_iter = max_iter;
+    return 0;
+}
+
+extern "C" int hm_fwd_set_member_wells(hm_fwd* f, const double* q_all, int q_cols, const int* prd_ind_all) {
+    HM_REQUIRE(f && q_all && prd_ind_all, "hm_fwd_set_member_wells: NULL argument");
+    FwdParams& p = f->p;
+    HM_REQUIRE(q_cols == 1 || q_cols == p.nTime, "hm_fwd_set_member_wells: q_cols must be 1 or nTime (%d), got %d", p.nTime, q_cols);
+    for (long long i = 0; i < (long long)p.N * p.nPrd; ++i)
+        HM_REQUIRE(prd_ind_all[i] >= 0 && prd_ind_all[i] < p.Nxy, "hm_fwd_set_member_wells: producer cell %d outside the grid", prd_ind_all[i]);
+    HM_HIP(hipSetDevice(f->ctx->device));
+    hipStream_t s = f->ctx->stream;
+    HM_HIP(hipStreamSynchronize(s));
+    const size_t qb = (size_t)p.N * q_cols * p.Nxy * 8, pb = (size_t)p.N * p.nPrd * 4;
+    int rc;
+    if (f->q.bytes < qb) { hm_dev_free(f->q); if ((rc = hm_dev_alloc(f->q, qb))) return rc; }
+    if (f->prd_ind.bytes < pb) { hm_dev_free(f->prd_ind); if ((rc = hm_dev_alloc(f->prd_ind, pb))) return rc; }
+    HM_HIP(hipMemcpy(f->q.p, q_all, qb, hipMemcpyHostToDevice));
+    HM_HIP(hipMemcpy(f->prd_ind.p, prd_ind_all, pb, hipMemcpyHostToDevice));
+    p.q = (double*)f->q.p;
+    p.prd_ind = (int*)f->prd_ind.p;
+    p.q_cols = q_cols;
+    p.q_mstride = (long long)q_cols * p.Nxy;
+    p.prd_mstride = p.nPrd;
     return 0;
 }
 

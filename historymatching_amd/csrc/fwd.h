@@ -17,6 +17,8 @@ struct FwdParams {
     const double* por;        // Nxy porosity or nullptr (=1)
     const double* q;          // q_cols*Nxy source field per time column
     int q_cols;
+    long long q_mstride;      // 0: all members share q; else member m's source field starts at q + m*q_mstride (hm_fwd_set_member_wells)
+    int prd_mstride;          // 0: shared producer cells; else nPrd (member m's cells at prd_ind + m*nPrd)
     const int* prd_ind;       // nPrd flat cell indices
     const int* well_cells;    // nInj+nPrd flat cell indices of all wells (injectors first)
     // pressure scratch (fp64 always)

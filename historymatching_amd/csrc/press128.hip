@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NT) void k_press128(FwdParams p, const TS* __restri
     double* P = p.P + (long long)m * Nxy;
     double* Vx = p.Vx + (long long)m * (Nx + 1) * NB;
     double* Vy = p.Vy + (long long)m * Nx * (NB + 1);
-    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+    const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
 
     assemble_transmissibilities<TS>(p, S, Km, P /* scratch for L */, TX, TY, tid, NT);
 

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
     double* P = p.P + (long long)m * Nxy;
     double* Vx = p.Vx + (long long)m * (Nx + 1) * NB;
     double* Vy = p.Vy + (long long)m * Nx * (NB + 1);
-    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+    const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
 
     int tR[TPW], tC[TPW];
 #pragma unroll

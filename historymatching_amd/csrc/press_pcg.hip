@@ -49,7 +49,7 @@ __global__ __launch_bounds__(PT) void k_pressure_pcg(FwdParams p, const TS* __re
     double* Ap = p.yv + (long long)m * Nxy;  // also the scratch of the assembly
     double* Vx = p.Vx + (long long)m * (Nx + 1) * Ny;
     double* Vy = p.Vy + (long long)m * Nx * (Ny + 1);
-    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+    const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
     const double pin = Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
 
     assemble_transmissibilities<TS>(p, S, Km, Ap /* scratch for L */, TX, TY, tid, PT);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(PT) void k_tl_setup(FwdParams p, TlArgs t, const TS
     double* x = p.P + (long long)m * Nxy;
     double* r = p.cg_r + (long long)m * Nxy;
     double* Ap = p.yv + (long long)m * Nxy;
-    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+    const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
     assemble_transmissibilities<TS>(p, S, Km, Ap /* scratch for L */, TX, TY, tid, PT);
     __syncthreads();
     // coarse transmissibilities = sums of the fine ones across the aggregate boundaries

@@ -255,6 +255,7 @@ int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) 
 // Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
 int launch_saturation_128f(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
     const FwdParams& p = f->p;
+    if (p.q_mstride != 0) return -1;  // per-member wells: the well side path works from one shared well list
     if (p.Nx != N128 || p.Ny != N128 || f->dtype != 32 || p.por != nullptr) return -1;
     if ((int)f->well_cells_host.size() > MAX_WELLS) return -1;
     std::vector<int> seen;  // at most one well per 8x4 patch

@@ -347,6 +347,7 @@ int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, 
 int launch_saturation_128ft(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
     const FwdParams& p = f->p;
     int TXn, TYn, max_teams;
+    if (p.q_mstride != 0) return -1;  // per-member wells: the well side path works from one shared well list
     if (f->dtype != 32 || p.por != nullptr || !tiles_of(f, TXn, TYn, max_teams) || !wells_fit_patches(f, MAX_WELLS)) return -1;
     return p.fluid_default ? launch<true>(f, S_in, S_out, S_stride, k, TXn, TYn, max_teams)
                            : launch<false>(f, S_in, S_out, S_stride, k, TXn, TYn, max_teams);

@@ -1,0 +1,148 @@
+"""Batched objective of the production-optimisation tutorial: the GPU replacement of ``apply(obj, U)``.
+
+The reference evaluates an ensemble of control vectors by mapping ``npv(model, **params)`` over the members
+(notebooks/Optimise.py:112-125 through ``utils.apply`` at Optimise.py:259, 441, 514, 655): every member re-configures
+a copy of the base model (well positions and/or rates, ``remake`` Optimise.py:130-135), simulates ``nTime`` steps and
+turns the producers' saturations into a net present value (``accounting`` Optimise.py:170-200); a member whose
+configuration is invalid (a well outside the domain, unbalanced rates) is worth 0 (the ``except`` branch,
+Optimise.py:119-124).  Here the members run as ONE device batch with a different source field per member
+(``hm_fwd_set_member_wells``); the accounting stays NumPy on the (N, nTime+1, nPrd) producer saturations.
+
+The number of wells is the same for every member of a batch; permeability is the base model's (or one field per member).
+Rates are taken as given: the upstream simulator's ``actual_rates`` (its rate controller) is not part of the reference
+repository (parity unpinned for everything inside ``TPFA_ResSim``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .forward import ForwardPlan
+from .ressim import ResSim
+
+# Optimise.py:151-162 -- prices "not grounded in reality", the tutorial's values
+ONE_YEAR = 0.1
+
+
+def default_prices(dt):
+    return {"inj": 20, "oil": 100, "turbo": 1, "wat": 6, "diffs": 1, "fixed": 0.8 * dt / ONE_YEAR, "/well": 0.3 * dt / ONE_YEAR}
+
+
+def discounts(dt, nTime):
+    return 0.96 ** (dt / ONE_YEAR * np.arange(nTime))  # Optimise.py:162
+
+
+def accounting(prd_wsats, inj_rates, prd_rates, dt, price, disc, rate0):
+    """Monetary value from simulation results (Optimise.py:170-200).  ``prd_wsats`` (nPrd, nTime): producer saturations per
+    time INTERVAL (trapezoidal mean of the interval's end points, Optimise.py:205-208); rates (nWell, nTime)."""
+    inj_volumes = dt * inj_rates * 1
+    oil_volumes = dt * prd_rates * (1 - prd_wsats)
+    wat_volumes = dt * prd_rates * prd_wsats
+    inj_total = inj_volumes.sum(0) @ disc
+    oil_total = oil_volumes.sum(0) @ disc
+    wat_total = wat_volumes.sum(0) @ disc
+    values = {"oil": +price["oil"] * oil_total, "inj": -price["inj"] * inj_total, "wat": -price["wat"] * wat_total}
+    excess = (prd_rates.sum(0) - rate0).clip(0)
+    diffs = np.diff(inj_rates, 1)
+    values["pwell"] = -price["/well"] * np.sum(prd_rates != 0)
+    values["iwell"] = -price["/well"] * np.sum(inj_rates != 0)
+    values["turbo"] = -price["turbo"] * excess.sum() ** 2 * dt
+    values["diffs"] = -price["diffs"] * (np.abs(diffs) ** 0.1).sum()
+    return values
+
+
+def _member_config(model: ResSim, params, nTime):
+    """Well cells and (nWell, nTime) rates of ``remake(model, **params)``; raises like the model would when run."""
+    inj_xy = params.get("inj_xy", model.inj_xy)
+    prd_xy = params.get("prd_xy", model.prd_xy)
+    inj_xy = np.asarray(inj_xy, dtype=float).reshape(-1, 2)
+    prd_xy = np.asarray(prd_xy, dtype=float).reshape(-1, 2)
+    inj = np.asarray(params.get("inj_rates", model.inj_rates), dtype=float).reshape(len(inj_xy), -1)
+    prd = np.asarray(params.get("prd_rates", model.prd_rates), dtype=float).reshape(len(prd_xy), -1)
+    for r in (inj, prd):
+        if r.shape[1] not in (1, nTime):
+            raise ValueError("rates must have 1 or nTime columns")
+    inj = np.broadcast_to(inj, (len(inj_xy), nTime))
+    prd = np.broadcast_to(prd, (len(prd_xy), nTime))
+    if not np.allclose(inj.sum(0), prd.sum(0)):
+        raise ValueError("total injection rate must equal total production rate")  # HistoryMatch.py:182-184
+    inj_ind = model.xy2ind(inj_xy[:, 0], inj_xy[:, 1])  # raises outside the domain (Optimise.py:549-554)
+    prd_ind = model.xy2ind(prd_xy[:, 0], prd_xy[:, 1])
+    return inj_ind, inj, prd_ind, prd
+
+
+class NpvBatch:
+    """``values = NpvBatch(model, dt, nTime)(list_of_params)`` == ``[npv(model, **params)[0] for params in ...]``.
+
+    ``perms``: None (the base model's permeability for every member, Optimise.py:69), or ``(N, Nxy)`` permeabilities
+    (one per member: the robust objectives over an uncertainty ensemble, Optimise.py:908, 1006-1011)."""
+
+    def __init__(self, model: ResSim, dt, nTime, wsat0=None, price=None, rate0=1.5):
+        self.model, self.dt, self.nTime = model, float(dt), int(nTime)
+        self.wsat0 = np.zeros(model.Nxy) if wsat0 is None else np.asarray(wsat0, dtype=float)
+        self.price = default_prices(self.dt) if price is None else dict(price)
+        self.disc = discounts(self.dt, self.nTime)
+        self.rate0 = float(rate0)
+        self.last = None
+
+    def __call__(self, params_list, perms=None):
+        m, nT = self.model, self.nTime
+        N = len(params_list)
+        if N == 0:
+            return np.zeros(0)
+        nInj = nPrd = None
+        cfgs, valid = [], np.ones(N, dtype=bool)
+        for n, params in enumerate(params_list):
+            try:
+                cfg = _member_config(m, params, nT)
+            except Exception:  # invalid model params => penalised member (Optimise.py:119-124)
+                valid[n] = False
+                cfg = None
+            cfgs.append(cfg)
+            if cfg is not None:
+                if nInj is None:
+                    nInj, nPrd = len(cfg[0]), len(cfg[2])
+                elif (nInj, nPrd) != (len(cfg[0]), len(cfg[2])):
+                    raise ValueError("all members of a batch must have the same number of injectors and producers")
+        values = np.zeros(N)
+        if not valid.any():
+            return values
+        steady = all(c is None or ((c[1] == c[1][:, :1]).all() and (c[3] == c[3][:, :1]).all()) for c in cfgs)
+        cols = 1 if steady else nT  # one source field per member, or one per member and time step
+        q_all = np.zeros((N, cols, m.Nxy))
+        prd_all = np.zeros((N, nPrd), dtype=np.int32)
+        for n, cfg in enumerate(cfgs):
+            if cfg is None:
+                continue  # q = 0: the member takes no step and is flagged by the device; its value stays 0
+            inj_ind, inj, prd_ind, prd = cfg
+            np.add.at(q_all[n], (slice(None), inj_ind), inj.T[:cols])      # q[inj] += rate
+            np.subtract.at(q_all[n], (slice(None), prd_ind), prd.T[:cols])  # q[prd] -= rate
+            prd_all[n] = prd_ind
+        # a plan with the base wells (the per-member ones replace them), same fluid / porosity / dtype
+        base = ResSim(m.Nx, m.Ny, m.Lx, m.Ly, dtype=m.dtype, device=m.device)
+        for a in ("vw", "vo", "swc", "sor", "por"):
+            setattr(base, a, getattr(m, a))
+        base.inj_xy, base.prd_xy = [[m.Lx / 2, m.Ly / 2]] * nInj, [[m.Lx / 2, m.Ly / 2]] * nPrd
+        base.inj_rates, base.prd_rates = np.ones((nInj, 1)) / nInj, np.ones((nPrd, 1)) / nPrd
+        plan = ForwardPlan(base, N, self.dt, nT, keep_history=True)
+        try:
+            _lib.check(plan.lib.hm_fwd_set_member_wells(plan.h, q_all.ctypes.data_as(C.c_void_p), cols, prd_all.ctypes.data_as(C.c_void_p)),
+                       "hm_fwd_set_member_wells")
+            K = np.broadcast_to(np.asarray(m.K[0], dtype=float).reshape(1, -1), (N, m.Nxy)) if perms is None else np.asarray(perms, dtype=float)
+            plan.set_inputs(np.ascontiguousarray(K), np.broadcast_to(self.wsat0, (N, m.Nxy)), transformed=True)
+            plan.run()
+            plan.sync()
+            wsats, _, status = plan.outputs()
+        finally:
+            plan.close()
+        ok = valid & (status == 0)
+        for n in np.flatnonzero(ok):
+            inj_ind, inj, prd_ind, prd = cfgs[n]
+            s = wsats[n][:, prd_ind]                       # prd_sats, Optimise.py:205-208
+            ledger = accounting(((s[:-1] + s[1:]) / 2).T, inj, prd, self.dt, self.price, self.disc, self.rate0)
+            values[n] = sum(ledger.values())
+        self.last = {"wsats": wsats, "status": status, "valid": valid}
+        return values

@@ -99,11 +99,22 @@ int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status
  *               Ny = 128 c, Nx = c Nx_c, else Jacobi-CG)
  *   saturation: 1 generic (coefficient + fw images) | 2 streaming | 3 LDS-tiled | 0: at 128 x 128 the register/LDS-resident
  *               sweep (sat128 fp64 / sat128f fp32; needs uniform porosity and at most one well per 8 x 4 cell patch), else the
- *               tiled sweep from 64 x 64 cells up, the generic one below */
+ *               tiled sweep from 64 x 64 cells up, the generic one below; grids of 128 x 128 tiles (256^2, 512^2 ...): teams of
+ *               workgroups, one per tile (sat128t / sat128ft) | pressure 11: two-level CG with the additive preconditioner
+ *               instead of the two-grid cycle */
 int  hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant);
 /* Conjugate-gradient pressure solver (always used when Ny > 128): relative residual target and iteration cap
  * (defaults 1e-12 and 40*max(Nx,Ny)+1000). */
 int  hm_fwd_set_solver(hm_fwd* f, double rtol, int max_iter);
+/* A different well configuration per member -- the batch of `npv(model, **params)` evaluations of the optimisation tutorial
+ * (Optimise.py:112-125 run through utils.apply at Optimise.py:259,441,514,655): member m uses the source field
+ * q_all[m] (q_cols x Nxy: injection rate > 0, production rate < 0 at the well cells, column k for time step k when
+ * q_cols = nTime, else column 0) and gathers its producer series at prd_ind_all[m] (nPrd cells, nPrd as at creation).
+ * The caller builds q_all from each member's well positions and rates exactly as hm_fwd_create does for the shared ones
+ *  and has checked each member's rate balance; a member with q = 0 everywhere takes no step and is
+ * flagged HM_MEMBER_BAD_CFL.  The 128 x 128 register-resident saturation kernels keep one shared well list: with per-member
+ * wells the tiled/generic sweep runs instead. */
+int  hm_fwd_set_member_wells(hm_fwd* f, const double* q_all /* N*q_cols*Nxy */, int q_cols, const int* prd_ind_all /* N*nPrd */);
 /* Component hooks used by the parity tests (each maps to one listing of the cited paper):
  * run ONLY the pressure step / ONLY the saturation step of time index k on device state, and read
  * intermediate fields back. */

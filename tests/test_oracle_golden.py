@@ -1,5 +1,6 @@
 """Pins oracle/es.py against fixtures captured from the reference's own functions (oracle/make_golden.py)."""
 import numpy as np
+import pytest
 
 from oracle import es
 
@@ -114,3 +115,33 @@ def test_product_iles_matches_reference_fixture(golden):
     assert len(stats["E"]) == 4
     assert np.abs(post - f6["iles_gg"]).max() < 1e-9
     assert np.allclose(post, f4["gg_postr_loc"])
+
+
+def test_npv_accounting_and_member_validation_host_logic():
+    """historymatching_amd/opt.py host side (no GPU): the accounting equals the oracle's restatement of
+    Optimise.py:170-200 on the same saturations, and invalid member configurations are recognised the way the reference's
+    npv() penalises them (Optimise.py:119-124)."""
+    from historymatching_amd import opt
+    from historymatching_amd.ressim import ResSim
+    from oracle import opt as oopt
+    from oracle.ressim import ResSim as OResSim
+
+    n, dt, nT = 12, 0.025, 6
+    om = OResSim(n, n, 2, 1)
+    om.K = 0.1 + np.exp(np.random.RandomState(3).randn(n * n))
+    om.inj_xy, om.prd_xy = [[1.0, 0.5]], [[0.2, 0.2], [1.8, 0.8]]
+    om.inj_rates, om.prd_rates = 1.5 * np.ones((1, 1)), 0.75 * np.ones((2, 1))
+    value, wsats = oopt.npv(om, dt, nT, np.zeros(n * n))
+    s = wsats[:, om.xy2ind(*om.prd_xy.T)]
+    ledger = opt.accounting(((s[:-1] + s[1:]) / 2).T, np.broadcast_to(om.inj_rates, (1, nT)), np.broadcast_to(om.prd_rates, (2, nT)),
+                            dt, opt.default_prices(dt), opt.discounts(dt, nT), 1.5)
+    assert abs(sum(ledger.values()) - value) <= 1e-12 * abs(value)
+    gm = ResSim.__new__(ResSim)  # grid conventions only: no device is touched
+    gm.__dict__.update(Nx=n, Ny=n, Lx=2.0, Ly=1.0)
+    gm._inj_xy, gm._prd_xy = np.array([[1.0, 0.5]]), np.array([[0.2, 0.2], [1.8, 0.8]])
+    gm.inj_rates, gm.prd_rates = om.inj_rates, om.prd_rates
+    inj_ind, inj, prd_ind, prd = opt._member_config(gm, {"inj_xy": [[0.4, 0.9]]}, nT)
+    assert inj_ind[0] == om.xy2ind(0.4, 0.9) and inj.shape == (1, nT) and list(prd_ind) == list(om.xy2ind(*om.prd_xy.T))
+    for bad in ({"inj_xy": [[2.2, 0.5]]}, {"prd_rates": np.ones((2, 1))}, {"inj_rates": np.ones((1, 3))}):
+        with pytest.raises(ValueError):
+            opt._member_config(gm, bad, nT)
