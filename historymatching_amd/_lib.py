@@ -81,6 +81,7 @@ SIGNATURES = {
     "hm_upd_phase": (C.c_int, [_vp, C.c_int]),
     "hm_upd_run": (C.c_int, [_vp]),
     "hm_recompose": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
+    "hm_sample_kron": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "hm_upd_set_inputs_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),
     "hm_upd_swap": (C.c_int, [_vp]),
     "hm_debug_spd_inverse": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp]),

@@ -976,6 +976,35 @@ extern "C" int hm_recompose(hm_ctx* ctx, int N, int M, const void* W, const void
     return rc;
 }
 
+// Separable Gaussian prior fields: X_n = Ux^T Z_n Uy for n = 0..N-1 (Cov = Cx (x) Cy, Ux / Uy the upper Cholesky factors of the
+// per-axis covariances), on the fp64 matrix cores: one GEMM of all (N Nx) rows of Z with Uy, then one Nx x Ny x Nx GEMM per member.
+extern "C" int hm_sample_kron(hm_ctx* ctx, int N, int Nx, int Ny, const double* Ux, const double* Uy, const double* Z, double* X_out,
+                              void* X_device) {
+    HM_REQUIRE(ctx && Ux && Uy && Z && (X_out || X_device) && N >= 1 && Nx >= 1 && Ny >= 1, "hm_sample_kron: bad arguments");
+    HM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t nxy = (size_t)Nx * Ny, tot = (size_t)N * nxy * 8;
+    DevBuf dZ, dT, dX, dUx, dUy;
+    int rc = hm_dev_alloc(dZ, tot);
+    if (!rc) rc = hm_dev_alloc(dT, tot);
+    if (!rc && !X_device) rc = hm_dev_alloc(dX, tot);
+    if (!rc) rc = hm_dev_alloc(dUx, (size_t)Nx * Nx * 8);
+    if (!rc) rc = hm_dev_alloc(dUy, (size_t)Ny * Ny * 8);
+    double* X = X_device ? (double*)X_device : (double*)dX.p;
+    if (!rc && (hipMemcpyAsync(dZ.p, Z, tot, hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(dUx.p, Ux, (size_t)Nx * Nx * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(dUy.p, Uy, (size_t)Ny * Ny * 8, hipMemcpyHostToDevice, s) != hipSuccess)) { hm_set_error("hm_sample_kron: H2D failed"); rc = 1; }
+    // T (N Nx x Ny) = Z Uy
+    if (!rc) rc = dgemm_mfma(s, false, N * Nx, Ny, Ny, (const double*)dZ.p, Ny, (const double*)dUy.p, Ny, (double*)dT.p, Ny, 1, nullptr, 0, nullptr);
+    // X_n (Nx x Ny) = Ux^T T_n
+    for (int n = 0; n < N && !rc; ++n)
+        rc = dgemm_mfma(s, true, Nx, Ny, Nx, (const double*)dUx.p, Nx, (const double*)dT.p + n * nxy, Ny, X + n * nxy, Ny, 1, nullptr, 0, nullptr);
+    if (!rc && X_out && hipMemcpyAsync(X_out, X, tot, hipMemcpyDeviceToHost, s) != hipSuccess) { hm_set_error("hm_sample_kron: D2H failed"); rc = 1; }
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) { hm_set_error("hm_sample_kron: device error"); rc = 1; }
+    hm_dev_free(dZ); hm_dev_free(dT); hm_dev_free(dX); hm_dev_free(dUx); hm_dev_free(dUy);
+    return rc;
+}
+
 static int es_update_host(hm_ctx* ctx, int N, int M, int n_obs, const void* E, const void* obs_ens, const void* obs,
                           const void* perturbs, const void* decorr, const void* taper, double cutoff, int dtype,
                           int localized, void* E_out, hm_stats* stats) {

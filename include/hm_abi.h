@@ -161,6 +161,13 @@ int   hm_upd_set_inputs(hm_upd* u, const void* E_local, const void* obs_ens_loca
 /* E (N x M) = x0 (M) + W (N x N) X0 (N x M): re-composition of the ensemble from subspace weights, the 2 N^2 M flop
  * step of the iterative ensemble smoother (IES, notebooks/HistoryMatch.py:921, 944).  Host buffers. */
 int   hm_recompose(hm_ctx* ctx, int N, int M, const void* W, const void* X0, const void* x0, int dtype, void* E_out);
+/* Prior sampler for grids the reference's dense sampler (geostat.gaussian_fields, notebooks/tools/geostat.py:86-99: Cholesky
+ * of the Nxy x Nxy covariance) cannot reach: the Gaussian-variogram covariance is separable, Cov = Cx (x) Cy, so
+ * X_n = Ux^T Z_n Uy with Ux, Uy the upper Cholesky factors per axis and Z_n (Nx x Ny) the caller's standard normals
+ * (host RNG: seeds replay).  N fields (N x Nx x Ny) to a host buffer and/or a device buffer of this context (e.g. the
+ * permeability input of a forward plan: hm_fwd_set_inputs_device); either may be NULL, not both. */
+int   hm_sample_kron(hm_ctx* ctx, int N, int Nx, int Ny, const double* Ux /* Nx*Nx */, const double* Uy /* Ny*Ny */,
+                     const double* Z /* N*Nx*Ny */, double* X_out, void* X_device);
 /* Self-test hook: W = inv(G + ridge I) for one SPD matrix of order n (multiple of 16, <= 256) through the matrix-core
  * inverse used for C = S^T S + (N-1) I (HistoryMatch.py:585-586).  Host buffers. */
 int   hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double ridge, double* W);

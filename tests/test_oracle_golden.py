@@ -145,3 +145,22 @@ def test_npv_accounting_and_member_validation_host_logic():
     for bad in ({"inj_xy": [[2.2, 0.5]]}, {"prd_rates": np.ones((2, 1))}, {"inj_rates": np.ones((1, 3))}):
         with pytest.raises(ValueError):
             opt._member_config(gm, bad, nT)
+
+
+def test_kronecker_prior_has_the_reference_covariance():
+    """The reference samples the prior from the dense covariance 1 - variogram_gauss(pairwise distances) of all cell centres
+    (notebooks/tools/geostat.py:86-99).  With the Gaussian variogram that matrix is exactly Cx (x) Cy in the C-order cell
+    index ix*Ny + iy, which is what historymatching_amd.geostat samples per axis; the sampler's factors reproduce it."""
+    from historymatching_amd.geostat import _axis_factors, variogram_gauss
+
+    Nx, Ny, Lx, Ly, r = 7, 5, 2.0, 1.0, 0.8
+    xc, yc = (np.arange(Nx) + 0.5) * Lx / Nx, (np.arange(Ny) + 0.5) * Ly / Ny
+    X, Y = np.meshgrid(xc, yc, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel()], 1)
+    dense = 1 - variogram_gauss(es.pairwise_distances(pts), r)
+    Cx = 1 - variogram_gauss(np.abs(xc[:, None] - xc), r)
+    Cy = 1 - variogram_gauss(np.abs(yc[:, None] - yc), r)
+    assert np.abs(dense - np.kron(Cx, Cy)).max() < 1e-14
+    Ux, Uy = _axis_factors(Nx, Ny, Lx, Ly, r)
+    # Cov of vec(Ux^T Z Uy) = (Ux^T Ux) (x) (Uy^T Uy)
+    assert np.abs(np.kron(Ux.T @ Ux, Uy.T @ Uy) - dense).max() < 1e-9
