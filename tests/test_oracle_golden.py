@@ -164,3 +164,24 @@ def test_kronecker_prior_has_the_reference_covariance():
     Ux, Uy = _axis_factors(Nx, Ny, Lx, Ly, r)
     # Cov of vec(Ux^T Z Uy) = (Ux^T Ux) (x) (Uy^T Uy)
     assert np.abs(np.kron(Ux.T @ Ux, Uy.T @ Uy) - dense).max() < 1e-9
+
+
+def test_rectangular_partitioning_matches_reference_fixture():
+    """historymatching_amd.localization.rectangular_partitioning against outputs of the reference helper
+    (notebooks/tools/localization.py:95-145; fixture F7, oracle/make_golden_partitioning.py)."""
+    from pathlib import Path
+
+    from historymatching_amd.localization import rectangular_partitioning
+
+    f7 = np.load(Path(__file__).parent / "golden" / "f7_partitioning.npz")
+    c = 0
+    while f"c{c}_shape" in f7:
+        shape, steps = list(f7[f"c{c}_shape"]), list(f7[f"c{c}_steps"])
+        batches = rectangular_partitioning(shape, steps)
+        assert [len(b) for b in batches] == list(f7[f"c{c}_len"])
+        assert np.array_equal(np.concatenate(batches), f7[f"c{c}_ind"])
+        sub = rectangular_partitioning(shape, steps, do_ind=False)
+        assert np.array_equal(np.concatenate([np.stack(b, 0) for b in sub], axis=1), f7[f"c{c}_sub"])
+        assert sorted(np.concatenate(batches)) == list(range(int(np.prod(shape))))  # a partition of the grid
+        c += 1
+    assert c == 5
