@@ -87,6 +87,14 @@ class NpvBatch:
         self.disc = discounts(self.dt, self.nTime)
         self.rate0 = float(rate0)
         self.last = None
+        self._plan, self._plan_key = None, None  # the device plan is kept between calls of the same batch shape (EnOpt iterations)
+
+    def close(self):
+        if self._plan is not None:
+            self._plan.close()
+            self._plan = None
+
+    __del__ = close
 
     def __call__(self, params_list, perms=None):
         m, nT = self.model, self.nTime
@@ -121,23 +129,24 @@ class NpvBatch:
             np.add.at(q_all[n], (slice(None), inj_ind), inj.T[:cols])      # q[inj] += rate
             np.subtract.at(q_all[n], (slice(None), prd_ind), prd.T[:cols])  # q[prd] -= rate
             prd_all[n] = prd_ind
-        # a plan with the base wells (the per-member ones replace them), same fluid / porosity / dtype
-        base = ResSim(m.Nx, m.Ny, m.Lx, m.Ly, dtype=m.dtype, device=m.device)
-        for a in ("vw", "vo", "swc", "sor", "por"):
-            setattr(base, a, getattr(m, a))
-        base.inj_xy, base.prd_xy = [[m.Lx / 2, m.Ly / 2]] * nInj, [[m.Lx / 2, m.Ly / 2]] * nPrd
-        base.inj_rates, base.prd_rates = np.ones((nInj, 1)) / nInj, np.ones((nPrd, 1)) / nPrd
-        plan = ForwardPlan(base, N, self.dt, nT, keep_history=True)
-        try:
-            _lib.check(plan.lib.hm_fwd_set_member_wells(plan.h, q_all.ctypes.data_as(C.c_void_p), cols, prd_all.ctypes.data_as(C.c_void_p)),
-                       "hm_fwd_set_member_wells")
-            K = np.broadcast_to(np.asarray(m.K[0], dtype=float).reshape(1, -1), (N, m.Nxy)) if perms is None else np.asarray(perms, dtype=float)
-            plan.set_inputs(np.ascontiguousarray(K), np.broadcast_to(self.wsat0, (N, m.Nxy)), transformed=True)
-            plan.run()
-            plan.sync()
-            wsats, _, status = plan.outputs()
-        finally:
-            plan.close()
+        key = (N, nInj, nPrd)
+        if self._plan is None or self._plan_key != key:
+            self.close()
+            # a plan with placeholder wells (the per-member ones replace them), same fluid / porosity / dtype
+            base = ResSim(m.Nx, m.Ny, m.Lx, m.Ly, dtype=m.dtype, device=m.device)
+            for a in ("vw", "vo", "swc", "sor", "por"):
+                setattr(base, a, getattr(m, a))
+            base.inj_xy, base.prd_xy = [[m.Lx / 2, m.Ly / 2]] * nInj, [[m.Lx / 2, m.Ly / 2]] * nPrd
+            base.inj_rates, base.prd_rates = np.ones((nInj, 1)) / nInj, np.ones((nPrd, 1)) / nPrd
+            self._plan, self._plan_key = ForwardPlan(base, N, self.dt, nT, keep_history=True), key
+        plan = self._plan
+        _lib.check(plan.lib.hm_fwd_set_member_wells(plan.h, q_all.ctypes.data_as(C.c_void_p), cols, prd_all.ctypes.data_as(C.c_void_p)),
+                   "hm_fwd_set_member_wells")
+        K = np.broadcast_to(np.asarray(m.K[0], dtype=float).reshape(1, -1), (N, m.Nxy)) if perms is None else np.asarray(perms, dtype=float)
+        plan.set_inputs(np.ascontiguousarray(K), np.broadcast_to(self.wsat0, (N, m.Nxy)), transformed=True)
+        plan.run()
+        plan.sync()
+        wsats, _, status = plan.outputs()
         ok = valid & (status == 0)
         for n in np.flatnonzero(ok):
             inj_ind, inj, prd_ind, prd = cfgs[n]

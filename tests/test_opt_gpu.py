@@ -53,6 +53,10 @@ def test_npv_batch_matches_per_member_oracle(n):
     np.testing.assert_allclose(values, ref, rtol=1e-7, atol=1e-7)
     # the invalid members were flagged by the device as well (no flow -> no CFL step)
     assert batch.last["status"][5] != 0 and batch.last["status"][6] != 0
+    # the device plan is reused by the next call of the same batch shape (an EnOpt iteration): steady rates only -> one
+    # source-field column per member this time
+    again = batch([params[k] for k in (7, 3, 2, 1, 0, 5, 6, 0)])
+    np.testing.assert_allclose(again, ref[[7, 3, 2, 1, 0, 5, 6, 0]], rtol=1e-7, atol=1e-7)
 
 
 def test_npv_batch_one_permeability_per_member():
