@@ -29,6 +29,7 @@ struct hm_upd {
     int N_total = 0, N_local = 0, M = 0, n_obs = 0, dtype = 64, localized = 0;
     size_t esz = 8;
     double cutoff = 1e-2;
+    bool taper_set = false;
     DevBuf E, E_out, obs_ens, perturbs, obs, decorr, taper;
     // reduce buffers (summed over ranks by the host): 0: colsum E (M, dtype)   1: colsum obs_ens (n_obs, fp64)
     //                                                  2: Gxt = X^T S (M*n_obs, dtype)   3: G = S^T S (n_obs^2, fp64)
@@ -584,7 +585,7 @@ extern "C" void hm_upd_destroy(hm_upd* u) {
 extern "C" int hm_upd_set_inputs(hm_upd* u, const void* E, const void* obs_ens, const void* obs, const void* perturbs,
                                  const void* decorr, const void* taper, double cutoff) {
     HM_REQUIRE(u, "hm_upd_set_inputs: NULL plan");
-    HM_REQUIRE(!u->localized || taper, "hm_upd_set_inputs: localised plan needs a taper");
+    HM_REQUIRE(!u->localized || taper || u->taper_set, "hm_upd_set_inputs: localised plan needs a taper");
     HM_HIP(hipSetDevice(u->ctx->device));
     hipStream_t s = u->ctx->stream;
     size_t e = u->esz, nl = u->N_local, no = u->n_obs, m = u->M;
@@ -593,7 +594,10 @@ extern "C" int hm_upd_set_inputs(hm_upd* u, const void* E, const void* obs_ens, 
     if (obs) HM_HIP(hipMemcpyAsync(u->obs.p, obs, no * e, hipMemcpyHostToDevice, s));
     if (perturbs) HM_HIP(hipMemcpyAsync(u->perturbs.p, perturbs, nl * no * e, hipMemcpyHostToDevice, s));
     if (decorr) HM_HIP(hipMemcpyAsync(u->decorr.p, decorr, no * no * e, hipMemcpyHostToDevice, s));
-    if (taper && u->localized) HM_HIP(hipMemcpyAsync(u->taper.p, taper, m * no * e, hipMemcpyHostToDevice, s));
+    if (taper && u->localized) {
+        HM_HIP(hipMemcpyAsync(u->taper.p, taper, m * no * e, hipMemcpyHostToDevice, s));
+        u->taper_set = true;
+    }
     u->cutoff = cutoff;
     HM_HIP(hipStreamSynchronize(s));
     return 0;

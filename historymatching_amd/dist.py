@@ -124,3 +124,61 @@ def sharded_update(plan, comm=None, fetch=True):
                     plan.set_reduce(which, comm.all_reduce_sum(plan.get_reduce(which)))
     st = plan.sync()
     return plan.output() if fetch else st
+
+
+def es_mda_sharded(model, prior_local, obs, R12, dt, nTime, n_iter=4, seed=0, comm=None, dtype=32, taper=None, device=None,
+                   stats=None):
+    """ES-MDA over ranks with every rank's members resident in its GPU's HBM for the whole assimilation (BASELINE configs 4
+    and 5; the single-GPU form is ``update.es_mda_device``).  ``prior_local``: this rank's contiguous block of the
+    ``(N_total, M)`` prior (``shard_bounds``).  Per pass: forward model of the local members (no communication) -> their
+    simulated observations handed to the update plan on the device -> the three phases of the row-sharded analysis step with
+    its two all-reduces (RCCL on the library's buffers with the nccl backend, host-staged with gloo) -> pointer swap.
+    ``taper``: ``(M, n_obs)`` localisation coefficients for the localised analysis (``ens_update0_loc``,
+    HistoryMatch.py:774-797); None = global.  The observation perturbations are rows of ONE ``(N_total, n_obs)`` normal
+    matrix drawn identically on every rank from ``seed``, so the result does not depend on the number of ranks.
+    Returns this rank's rows of the posterior."""
+    import ctypes as C
+
+    import scipy.linalg as sla
+
+    from . import _lib
+    from .forward import ForwardPlan
+    from .update import UpdatePlan
+
+    comm = comm or Comm()
+    E0 = np.asarray(prior_local)
+    Nl, M = E0.shape
+    counts = comm.all_gather_rows(np.array([[Nl]]))[:, 0] if comm.world_size > 1 else np.array([Nl])
+    N, lo = int(counts.sum()), int(counts[: comm.rank].sum())
+    n_obs = len(obs)
+    if n_obs != nTime * model.nPrd:
+        raise ValueError(f"len(obs) = {n_obs} != nTime * nPrd = {nTime * model.nPrd}")
+    rng = np.random.RandomState(seed)
+    fwd = ForwardPlan(model, Nl, dt, nTime, keep_history=False, device=device)
+    upd = UpdatePlan(N, Nl, M, n_obs, dtype=dtype, localized=taper is not None, device=device)
+    alpha = float(n_iter)
+    upd.set_inputs(E=E0, obs=obs, decorr=sla.inv(R12.T) / np.sqrt(alpha), taper=taper)
+    ms_fwd = ms_upd = 0.0
+    try:
+        for _ in range(n_iter):
+            fwd.set_inputs_device(upd.device_ptr("E"), dtype, transformed=False)
+            fwd.run()
+            upd.set_inputs_device(obs_ens_ptr=fwd.device_ptr("prods"), obs_dtype=model.dtype)
+            upd.set_inputs(perturbs=np.sqrt(alpha) * (rng.randn(N, n_obs)[lo:lo + Nl] @ R12.T))
+            ms_fwd += fwd.sync()["ms_total"]
+            _, _, status = fwd.outputs(want_wsats=False)
+            bad = comm.all_reduce_sum(np.array([float(status.any())]))[0] if comm.world_size > 1 else float(status.any())
+            if bad:  # every rank leaves together
+                raise _lib.HmError(f"forward model failed on {int(bad)} rank(s); here for members {np.flatnonzero(status)[:8].tolist()}")
+            st = sharded_update(upd, comm, fetch=False) if comm.world_size > 1 else upd.run_local()
+            ms_upd += st["ms_update"]
+            upd.swap()
+        out = np.empty((Nl, M), dtype=upd.ft)
+        _lib.check(upd.lib.hm_copy_to_host(upd.ctx.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(upd.device_ptr("E")), out.nbytes),
+                   "hm_copy_to_host")
+    finally:
+        fwd.close()
+        upd.close()
+    if stats is not None:
+        stats.update(ms_forward=ms_fwd, ms_update=ms_upd)
+    return out.astype(float)
