@@ -1,0 +1,75 @@
+"""TEST INFRASTRUCTURE ONLY -- end-to-end soft check of the oracle simulator: execute the REAL reference script
+notebooks/HistoryMatch.py, unmodified, with oracle/ressim.py standing in for the absent `TPFA_ResSim` package (and no-op stand-ins
+for the plotting-only packages: mpl_tools, ipywidgets, IPython, adjustText, struct_tools.DotDict, tools.plotting, the model's
+plt_* / anim methods).  Runs only where /root/reference exists (this build container, CPU, ~3 min); nothing is copied.
+It shows (1) which attributes and methods of the simulator object the notebook really uses -- the surface
+historymatching_amd.ressim.ResSim mirrors -- and (2) that the whole workflow (truth run, prior, ES, localised ES, IES, ILES,
+prediction) runs on the restated simulator and reduces the errors it prints (HistoryMatch.py:1187-1196).
+
+Usage:  python oracle/run_reference_script.py"""
+import sys, types, time
+from unittest import mock
+import numpy as np
+import matplotlib
+matplotlib.use("Agg")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+REF = "/root/reference/notebooks"
+sys.path.insert(0, REF)
+
+class Anything(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"): raise AttributeError(k)
+        return mock.MagicMock(name=f"{self.__name__}.{k}")
+
+for name in ("adjustText", "mpl_tools", "mpl_tools.place", "mpl_tools.misc", "ipywidgets", "IPython", "IPython.display"):
+    sys.modules[name] = Anything(name)
+sys.modules["mpl_tools.misc"].nRowCol = lambda *a, **k: {"nrows": 1, "ncols": 1}
+st = types.ModuleType("struct_tools")
+class DotDict(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+    def __dir__(self): return list(self.keys())
+st.DotDict = DotDict
+sys.modules["struct_tools"] = st
+
+import oracle.ressim as oressim
+used = set()
+class ResSim(oressim.ResSim):
+    def __getattr__(self, k):
+        if k.startswith("plt_") or k in ("plt_field", "anim"):
+            used.add("plotting:" + k)
+            return lambda *a, **kw: mock.MagicMock()
+        raise AttributeError(k)
+    def __getattribute__(self, k):
+        if not k.startswith("_"): used.add(k)
+        return object.__getattribute__(self, k)
+sim = types.ModuleType("TPFA_ResSim"); sim.ResSim = ResSim
+simp = types.ModuleType("TPFA_ResSim.plotting"); simp.styles = mock.MagicMock()
+sys.modules["TPFA_ResSim"] = sim; sys.modules["TPFA_ResSim.plotting"] = simp
+
+class PlotStub(Anything):
+    @staticmethod
+    def freshfig(*a, ncols=1, **k):
+        ax = mock.MagicMock()
+        return mock.MagicMock(), (ax if ncols == 1 else tuple(mock.MagicMock() for _ in range(ncols)))
+import tools
+plotting = PlotStub("tools.plotting")
+plotting.styles = {"oil": {}, "pperm": {"levels": np.linspace(-4, 4, 21)}, "corr": {}, "NPV": {}}
+sys.modules["tools.plotting"] = plotting
+tools.plotting = plotting
+del sys.modules["IPython"], sys.modules["IPython.display"]
+import tools.utils as utils
+utils.nCPU = 1
+src = open(f"{REF}/HistoryMatch.py").read()
+import re
+src = re.sub(r"utils\.nCPU = .*", "utils.nCPU = 1", src)
+t0 = time.time()
+ns = {"__name__": "__main__"}
+try:
+    exec(compile(src, "HistoryMatch.py", "exec"), ns)
+    print("SCRIPT COMPLETED in %.0f s" % (time.time() - t0))
+except Exception as e:
+    import traceback; traceback.print_exc()
+    print("FAILED after %.0f s" % (time.time() - t0))
+print("model attributes used:", sorted(used))
