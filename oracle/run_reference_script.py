@@ -6,7 +6,10 @@ It shows (1) which attributes and methods of the simulator object the notebook r
 historymatching_amd.ressim.ResSim mirrors -- and (2) that the whole workflow (truth run, prior, ES, localised ES, IES, ILES,
 prediction) runs on the restated simulator and reduces the errors it prints (HistoryMatch.py:1187-1196).
 
-Usage:  python oracle/run_reference_script.py"""
+The same harness runs notebooks/Optimise.py (`python oracle/run_reference_script.py Optimise.py`, ~50 min on one core: EnOpt loops
+over thousands of simulations); that script additionally uses `K`, `actual_rates`, `domain`, `name` of the simulator object.
+
+Usage:  python oracle/run_reference_script.py [HistoryMatch.py | Optimise.py]"""
 import sys, types, time
 from unittest import mock
 import numpy as np
@@ -50,9 +53,13 @@ sys.modules["TPFA_ResSim"] = sim; sys.modules["TPFA_ResSim.plotting"] = simp
 
 class PlotStub(Anything):
     @staticmethod
-    def freshfig(*a, ncols=1, **k):
-        ax = mock.MagicMock()
-        return mock.MagicMock(), (ax if ncols == 1 else tuple(mock.MagicMock() for _ in range(ncols)))
+    def freshfig(*a, ncols=1, nrows=1, **k):
+        n = ncols * nrows
+        return mock.MagicMock(), (mock.MagicMock() if n == 1 else tuple(mock.MagicMock() for _ in range(n)))
+
+    @staticmethod
+    def figure12(*a, **k):
+        return mock.MagicMock(), [mock.MagicMock() for _ in range(3)]
 import tools
 plotting = PlotStub("tools.plotting")
 plotting.styles = {"oil": {}, "pperm": {"levels": np.linspace(-4, 4, 21)}, "corr": {}, "NPV": {}}
@@ -61,13 +68,14 @@ tools.plotting = plotting
 del sys.modules["IPython"], sys.modules["IPython.display"]
 import tools.utils as utils
 utils.nCPU = 1
-src = open(f"{REF}/HistoryMatch.py").read()
+SCRIPT = sys.argv[1] if len(sys.argv) > 1 else "HistoryMatch.py"
+src = open(f"{REF}/{SCRIPT}").read()
 import re
 src = re.sub(r"utils\.nCPU = .*", "utils.nCPU = 1", src)
 t0 = time.time()
 ns = {"__name__": "__main__"}
 try:
-    exec(compile(src, "HistoryMatch.py", "exec"), ns)
+    exec(compile(src, SCRIPT, "exec"), ns)
     print("SCRIPT COMPLETED in %.0f s" % (time.time() - t0))
 except Exception as e:
     import traceback; traceback.print_exc()
