@@ -76,13 +76,14 @@ def test_npv_batch_one_permeability_per_member():
     np.testing.assert_allclose(values, np.array(ref), rtol=1e-7)
 
 
-def test_npv_batch_128_uses_matrix_core_pressure_with_per_member_wells():
+@pytest.mark.parametrize("n,nT", [(128, 3), (256, 2)])
+def test_npv_batch_large_grids_with_per_member_wells(n, nT):
     """At 128 x 128 the per-member source fields go through the matrix-core pressure solver (it only reads q) and the tiled
-    saturation sweep (the register-resident kernel keeps one shared well list and steps aside)."""
+    saturation sweep (the register-resident kernels keep one shared well list and step aside); at 256 x 256 through the
+    two-level CG pressure solver."""
     from historymatching_amd.opt import NpvBatch
     from oracle.opt import npv as oracle_npv
 
-    n, nT = 128, 3
     om, gm = _models(n)
     params = [{}, {"inj_xy": [[0.31, 0.77]]}, {"inj_xy": [[-0.1, 0.5]]}, {"prd_rates": 1.5 * np.array([[0.4], [0.3], [0.2], [0.1]])}]
     values = NpvBatch(gm, DT, nT)(params)
