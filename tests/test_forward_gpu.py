@@ -537,3 +537,45 @@ def test_fp32_mode_default_kernels_128():
         assert np.abs(w[m] - ref).max() < 1e-3
         assert np.abs(p[m] - ref[1:, om.xy2ind(*om.prd_xy.T)]).max() < 1e-3
     assert nts.min() >= 100
+
+
+def test_config2_full_size_properties():
+    """BASELINE config 2 at full size (N_e = 1000, 128 x 128, 40 steps; too large for the oracle in a test) through
+    size-independent properties of the scheme:
+    (1) mass balance: the explicit upwind sweep is conservative, so with unit porosity the water in place equals the injected
+        volume minus the produced water.  Production of a step is dt q_prd fw(S_prd) with S_prd between its values at the two
+        ends of the step (producer saturations only grow), which brackets the water in place from the stored producer series;
+    (2) 0 <= S <= 1;
+    (3) members are independent: a sub-ensemble run alone reproduces its members bit for bit;
+    (4) the producer series is the saturation history at the producer cells."""
+    n, N, steps = 128, 1000, 40
+    _, gm = make_models(n, n)
+    x = perms(n, n, N, seed=1)
+    plan = _plan(gm, N, nTime=steps, keep_history=False)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    plan.sync()
+    S_end, prods, status = plan.outputs()
+    plan.close()
+    assert not status.any()
+    assert S_end.shape == (N, n * n) and prods.shape == (N, steps, 4)
+    assert S_end.min() >= 0.0 and S_end.max() <= 1.0 and np.isfinite(prods).all()
+    assert (np.diff(prods, axis=1) >= -1e-12).all()                     # producer saturations only grow
+    fw = lambda s: s * s / (s * s + (1 - s) * (1 - s))                  # noqa: E731  (vw = vo = 1, swc = sor = 0)
+    water = S_end.sum(1) * (gm.Lx / n) * (gm.Ly / n)
+    injected = steps * DT * 1.0
+    at_end = DT * 0.25 * fw(prods).sum((1, 2))                          # >= the water produced
+    at_start = DT * 0.25 * fw(np.concatenate([np.zeros((N, 1, 4)), prods[:, :-1]], 1)).sum((1, 2))   # <= the water produced
+    assert (water >= injected - at_end - 1e-9).all() and (water <= injected - at_start + 1e-9).all()
+    assert (at_end > at_start).mean() > 0.5                             # most members have seen breakthrough: the bracket is not trivial
+    # (3) + (4) on a sub-ensemble with history
+    sub = [0, 17, 503, 999]
+    plan = _plan(gm, len(sub), nTime=steps)
+    plan.set_inputs(x[sub], transformed=False)
+    plan.run()
+    plan.sync()
+    w, p, st2 = plan.outputs()
+    plan.close()
+    assert not st2.any()
+    assert np.array_equal(w[:, -1, :], S_end[sub]) and np.array_equal(p, prods[sub])
+    assert np.array_equal(p, w[:, 1:, gm.xy2ind(*gm.prd_xy.T)])
