@@ -579,3 +579,41 @@ def test_config2_full_size_properties():
     assert not st2.any()
     assert np.array_equal(w[:, -1, :], S_end[sub]) and np.array_equal(p, prods[sub])
     assert np.array_equal(p, w[:, 1:, gm.xy2ind(*gm.prd_xy.T)])
+
+
+@pytest.mark.parametrize("dtype", [64, 32])
+def test_large_grid_whole_run_properties(dtype):
+    """256 x 256 (config 4's grid), 70 members (two rounds of workgroup teams), all 40 steps, default kernels (two-grid-cycle CG
+    + tile teams): the mass-balance bracket of test_config2_full_size_properties, bounds, and member independence across
+    team rounds: a sub-ensemble run alone gives the same members bit for bit (both runs split a member's CG passes over the
+    same number of workgroups, G = 8 here, so the fixed-order dot products are identical; a different G changes the solve at
+    rounding level only)."""
+    n, N, steps = 256, 70, 40
+    _, gm = make_models(n, n, dtype=dtype)
+    x = perms(n, n, N, seed=2)
+    plan = _plan(gm, N, nTime=steps, keep_history=False)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    st = plan.sync()
+    S_end, prods, status = plan.outputs()
+    plan.close()
+    assert not status.any() and 0 < st["mean_n_cg"] < 60
+    S_end = S_end.astype(float)
+    tol = 1e-9 if dtype == 64 else 2e-4
+    assert S_end.min() >= -tol and S_end.max() <= 1.0 + tol
+    fw = lambda s: s * s / (s * s + (1 - s) * (1 - s))  # noqa: E731
+    water = S_end.sum(1) * (gm.Lx / n) * (gm.Ly / n)
+    injected = steps * DT * 1.0
+    p64 = prods.astype(float)
+    at_end = DT * 0.25 * fw(p64).sum((1, 2))
+    at_start = DT * 0.25 * fw(np.concatenate([np.zeros((N, 1, 4)), p64[:, :-1]], 1)).sum((1, 2))
+    assert (water >= injected - at_end - tol).all() and (water <= injected - at_start + tol).all()
+    sub = [3, 64, 69]  # members of the first and of the second round
+    plan = _plan(gm, len(sub), nTime=steps, keep_history=False)
+    plan.set_inputs(x[sub], transformed=False)
+    plan.run()
+    plan.sync()
+    S_sub, p_sub, st2 = plan.outputs()
+    plan.close()
+    assert not st2.any()
+    assert np.array_equal(S_sub, S_end[sub].astype(S_sub.dtype)) and np.array_equal(p_sub, prods[sub])
