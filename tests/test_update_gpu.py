@@ -350,3 +350,33 @@ def test_device_kronecker_prior_sampler_matches_host(nx, ny, N):
     dev = gaussian_fields_kron_device(nx, ny, 2, 1, N, r=0.8, seed=11)
     assert dev.shape == host.shape
     assert np.abs(dev - host).max() <= 1e-12 * max(1.0, np.abs(host).max())
+
+
+def test_torch_kernels_read_and_write_library_buffers():
+    """dist.Comm.all_reduce_device hands RCCL a tensor that aliases a device buffer of the library (two HIP runtime copies
+    live in the process: PyTorch's bundled one and the library's).  A one-rank all-reduce never touches the buffer, so this
+    pins the assumption directly: kernels launched by PyTorch's runtime read and modify the library's reduce buffer."""
+    import torch
+
+    from historymatching_amd.update import UpdatePlan
+
+    N, M, n_obs = 8, 256, 16
+    rng = np.random.RandomState(0)
+    plan = UpdatePlan(N, N, M, n_obs, dtype=32)
+    plan.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), rng.rand(n_obs), 0.1 * rng.randn(N, n_obs), np.eye(n_obs))
+    plan.phase(0)
+    plan.sync()
+    ptr, n, dt = plan.reduce_buffer(0)
+    before = plan.get_reduce(0).copy()
+
+    class _Dev:
+        pass
+
+    d = _Dev()
+    d.__cuda_array_interface__ = {"shape": (int(n),), "typestr": np.dtype(dt).str, "data": (int(ptr), False), "version": 2}
+    t = torch.as_tensor(d, device=torch.device("cuda", 0))
+    assert np.array_equal(t.cpu().numpy(), before)
+    t.mul_(2.0).add_(1.0)
+    torch.cuda.synchronize()
+    assert np.allclose(plan.get_reduce(0), 2 * before + 1)
+    plan.close()
