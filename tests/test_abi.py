@@ -87,3 +87,12 @@ def test_host_model_mirrors_the_surface_the_notebook_uses():
     assert np.array_equal(np.asarray(gm.ind2sub(ind)), np.asarray(om.ind2sub(ind)))
     ix, iy = gm.ind2sub(ind)
     assert np.array_equal(gm.sub2ind(ix, iy), ind) and np.array_equal(np.asarray(gm.sub2xy(ix, iy)), np.asarray(om.sub2xy(ix, iy)))
+    # every task of the reference deep-copies the model (HistoryMatch.py:360) and its process pool pickles it (utils.py:211)
+    import copy
+    import pickle
+
+    gm.K = 0.1 + np.exp(rng.randn(gm.Nxy))
+    for clone in (copy.deepcopy(gm), pickle.loads(pickle.dumps(gm))):
+        assert np.array_equal(clone.K, gm.K) and np.array_equal(clone.prd_xy, gm.prd_xy) and clone.nPrd == gm.nPrd
+        clone.K = clone.K * 2
+        assert not np.array_equal(clone.K, gm.K)  # isolated state
