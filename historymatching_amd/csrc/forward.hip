@@ -861,6 +861,13 @@ extern "C" int hm_fwd_run(hm_fwd* f, int first_step, int n_steps) {
     HM_REQUIRE(f, "hm_fwd_run: NULL plan");
     HM_REQUIRE(first_step >= 0 && n_steps >= 0 && first_step + n_steps <= f->p.nTime,
                "hm_fwd_run: steps [%d,%d) outside [0,%d)", first_step, first_step + n_steps, f->p.nTime);
+    // the saturation of time index first_step must exist: a history plan holds rows 0..cur, a ping-pong plan
+    // (keep_history = 0) only row cur -- its slot of index 0 is overwritten by step 1, so a re-run needs fresh inputs
+    if (f->keep_history)
+        HM_REQUIRE(first_step <= f->cur, "hm_fwd_run: first_step %d is beyond the last computed time index %d", first_step, f->cur);
+    else
+        HM_REQUIRE(first_step == f->cur, "hm_fwd_run: a plan without history continues at time index %d (got first_step %d); "
+                   "call hm_fwd_set_inputs* to restart", f->cur, first_step);
     HM_HIP(hipSetDevice(f->ctx->device));
     int rc = f->t_total.begin(f->ctx->stream);
     if (rc) return rc;

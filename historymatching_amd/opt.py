@@ -36,22 +36,30 @@ def discounts(dt, nTime):
 
 
 def accounting(prd_wsats, inj_rates, prd_rates, dt, price, disc, rate0):
-    """Monetary value from simulation results (Optimise.py:170-200).  ``prd_wsats`` (nPrd, nTime): producer saturations per
-    time INTERVAL (trapezoidal mean of the interval's end points, Optimise.py:205-208); rates (nWell, nTime)."""
-    inj_volumes = dt * inj_rates * 1
-    oil_volumes = dt * prd_rates * (1 - prd_wsats)
-    wat_volumes = dt * prd_rates * prd_wsats
-    inj_total = inj_volumes.sum(0) @ disc
-    oil_total = oil_volumes.sum(0) @ disc
-    wat_total = wat_volumes.sum(0) @ disc
-    values = {"oil": +price["oil"] * oil_total, "inj": -price["inj"] * inj_total, "wat": -price["wat"] * wat_total}
-    excess = (prd_rates.sum(0) - rate0).clip(0)
-    diffs = np.diff(inj_rates, 1)
-    values["pwell"] = -price["/well"] * np.sum(prd_rates != 0)
-    values["iwell"] = -price["/well"] * np.sum(inj_rates != 0)
-    values["turbo"] = -price["turbo"] * excess.sum() ** 2 * dt
-    values["diffs"] = -price["diffs"] * (np.abs(diffs) ** 0.1).sum()
-    return values
+    """Ledger of one member's net present value; formulas of Optimise.py:170-200.
+
+    ``prd_wsats`` (nPrd, nTime): water cut at each producer per time INTERVAL (mean of the interval's end points,
+    Optimise.py:205-208); ``inj_rates`` / ``prd_rates`` (nWell, nTime); ``disc`` (nTime,) discount factors.
+    Revenue and running costs are discounted field-wide volumes (a producer's stream splits into water and oil by its
+    water cut); the remaining terms are penalties on the controls themselves: a charge per (well, interval) in operation,
+    a quadratic charge on field production above ``rate0``, and a charge on every change of an injection rate."""
+    step_w = dt * np.asarray(disc)                                # discounted length of every interval
+    water_cut = np.asarray(prd_wsats)
+    produced = np.asarray(prd_rates).sum(axis=0)                  # field totals per interval
+    produced_water = (np.asarray(prd_rates) * water_cut).sum(axis=0)
+    injected = np.asarray(inj_rates).sum(axis=0)
+    in_operation = np.count_nonzero(prd_rates), np.count_nonzero(inj_rates)
+    over_capacity = np.maximum(produced - rate0, 0.0).sum()
+    rate_changes = np.abs(np.asarray(inj_rates)[:, 1:] - np.asarray(inj_rates)[:, :-1])
+    return {
+        "oil": price["oil"] * float((produced - produced_water) @ step_w),
+        "wat": -price["wat"] * float(produced_water @ step_w),
+        "inj": -price["inj"] * float(injected @ step_w),
+        "pwell": -price["/well"] * in_operation[0],
+        "iwell": -price["/well"] * in_operation[1],
+        "turbo": -price["turbo"] * dt * over_capacity**2,
+        "diffs": -price["diffs"] * float((rate_changes**0.1).sum()),
+    }
 
 
 def _member_config(model: ResSim, params, nTime):

@@ -44,3 +44,50 @@ def oracle_sim_and_noise(om, x, dt, nTime, wsat0=None):
     finally:
         orc.spsolve = orig
     return ref, float(np.abs(ref2 - ref).max())
+
+
+def _oracle_sim_task(args):
+    """One oracle simulation with a given SuperLU column ordering (worker of `oracle_sims_and_noise_parallel`)."""
+    import oracle.ressim as orc
+    from oracle.ressim import ResSim as OracleResSim
+    from scipy.sparse.linalg import spsolve
+
+    nx, ny, x, dt, nTime, permc = args
+    om = wells_4corners(OracleResSim(nx, ny, 2, 1))
+    orc.set_perm(om, x)
+    if permc != "COLAMD":
+        orc.spsolve = lambda A, b: spsolve(A.tocsc(), b, permc_spec=permc)
+    return om.sim(dt, nTime, np.zeros(om.Nxy))
+
+
+def oracle_sims_and_noise_parallel(nx, ny, xs, dt, nTime, permc2="NATURAL"):
+    """`oracle_sim_and_noise` for several members at once, one process per simulation (the 512 x 512 oracle takes ~40 s
+    per member-step, nearly all of it the 9 831 explicit sub-steps).  `permc2`: the second column ordering whose result
+    measures the oracle's own solver noise (NATURAL fills in too much at 512 x 512: MMD_AT_PLUS_A there)."""
+    import multiprocessing as mp
+
+    tasks = [(nx, ny, x, dt, nTime, permc) for x in xs for permc in ("COLAMD", permc2)]
+    with mp.get_context("spawn").Pool(min(len(tasks), 8)) as pool:
+        res = pool.map(_oracle_sim_task, tasks, chunksize=1)
+    return [(res[2 * m], float(np.abs(res[2 * m + 1] - res[2 * m]).max())) for m in range(len(xs))]
+
+
+def _oracle_loc_task(args):
+    import threadpoolctl
+
+    from oracle import es
+
+    with threadpoolctl.threadpool_limits(1):  # 8 BLAS threads are 25x slower on these tiny matrices (SURVEY.md Appendix B)
+        return es.ens_update0_loc(*args)
+
+
+def oracle_update_loc_columns(E_cols, obs_ens, obs, perturbs, decorr, taper_rows, nproc=8):
+    """oracle.es.ens_update0_loc on a subset of state columns (each local analysis only reads its own column of E and
+    its own row of the taper, HistoryMatch.py:783-793), the columns split over `nproc` single-threaded processes."""
+    import multiprocessing as mp
+
+    parts = np.array_split(np.arange(E_cols.shape[1]), nproc)
+    tasks = [(np.ascontiguousarray(E_cols[:, p]), obs_ens, obs, perturbs, decorr, taper_rows[p]) for p in parts if len(p)]
+    with mp.get_context("spawn").Pool(len(tasks)) as pool:  # spawn: the parent may hold a HIP context
+        res = pool.map(_oracle_loc_task, tasks, chunksize=1)
+    return np.concatenate(res, axis=1)

@@ -1,0 +1,222 @@
+"""BASELINE.json configurations 3, 4 and 5 at their own sizes, against the oracle (-m gpu, through the C ABI).
+
+  config 3: N_e = 1000, 128 x 128, fp32 matrix-core Kalman update, the reference's correlated observation error
+  config 4: N_e = 4096, 256 x 256 over 8 GPUs  -> one rank's shard: 512 members
+  config 5: N_e = 1000, 512 x 512, localised update (tapered covariance), fp32, over 8 GPUs -> shards of 125 members
+
+What the oracle finishes in seconds is compared directly (a sample of state columns for the localised update, one time step
+of two members at 512 x 512); the rest goes through size-independent properties."""
+import numpy as np
+import pytest
+
+from tests.helpers import make_models, oracle_sims_and_noise_parallel, oracle_update_loc_columns, perms
+
+pytestmark = pytest.mark.gpu
+
+DT = 0.025
+
+
+def _hm_inputs(N, M, n_obs, seed, nTime=40):
+    """History-matching-shaped inputs with the reference's observation-error model (HistoryMatch.py:243-267, 638-639):
+    R = kron(1e-2 toeplitz(exp(-k/2), cut below 1e-2), I_4), R12 its Cholesky factor, decorr = inv(R12^T), perturbations
+    randn @ R12^T; the simulated observations depend linearly on a few state elements plus noise."""
+    from oracle import es
+
+    rng = np.random.RandomState(seed)
+    E = (rng.randn(N, M) + rng.randn(M)).astype(np.float32).astype(np.float64)  # exactly representable in the fp32 plan
+    _, R12, decorr = es.obs_error_model(nTime, n_obs // nTime)
+    cols = rng.choice(M, n_obs, replace=False)
+    obs_ens = 0.3 * E[:, cols] + 0.1 * rng.randn(N, n_obs)
+    obs = obs_ens[0] + R12 @ rng.randn(n_obs)
+    perturbs = rng.randn(N, n_obs) @ R12.T
+    return E, obs_ens, obs, perturbs, decorr
+
+
+def test_config3_full_size_fp32_update_vs_oracle():
+    """N = 1000, M = 128 * 128, n_obs = 160, fp32 state contractions on the matrix cores, the correlated R of
+    HistoryMatch.py:243-259: every element of the posterior against oracle.es.ens_update0 (fp64, the reference's
+    association and pinv), bar 1e-4 of the largest increment."""
+    from historymatching_amd.update import UpdatePlan, ens_update0
+    from oracle import es
+
+    N, M, n_obs = 1000, 128 * 128, 160
+    E, obs_ens, obs, perturbs, decorr = _hm_inputs(N, M, n_obs, seed=33)
+    ref = es.ens_update0(E, obs_ens, obs, perturbs, decorr)
+    inc = np.abs(ref - E).max()
+    assert inc > 0.1
+    out32 = ens_update0(E, obs_ens, obs, perturbs, decorr, dtype=32)
+    assert out32.dtype == np.float32 and np.abs(out32 - ref).max() <= 1e-4 * inc
+    # the device-resident plan bench.py times (hm_upd_run: LDS-staged contractions, matrix-core inverse) is the same arithmetic
+    plan = UpdatePlan(N, N, M, n_obs, dtype=32)
+    plan.set_inputs(E, obs_ens, obs, perturbs, decorr)
+    plan.run_local()
+    out_plan = plan.output()
+    plan.close()
+    assert np.abs(out_plan - ref).max() <= 1e-4 * inc
+    out64 = ens_update0(E, obs_ens, obs, perturbs, decorr, dtype=64)
+    assert np.abs(out64 - ref).max() < 1e-10
+
+
+def test_config4_shard_whole_run_properties():
+    """One rank's shard of config 4: 512 members at 256 x 256, all 40 steps, default kernels (two-level CG + tile teams: 8 rounds
+    of 64 teams).  Mass-balance bracket, bounds, monotone producer series, and a sub-ensemble from different team rounds run
+    alone agrees (the CG passes of a member are split over a member-count-dependent number of workgroups, so the two
+    solves may differ at rounding level: bar = the CG tolerance amplified as in the oracle comparisons)."""
+    n, N, steps = 256, 512, 40
+    _, gm = make_models(n, n)
+    from historymatching_amd.forward import ForwardPlan
+
+    x = perms(n, n, N, seed=4)
+    plan = ForwardPlan(gm, N, DT, steps, keep_history=False)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    st = plan.sync()
+    S_end, prods, status = plan.outputs()
+    plan.close()
+    assert not status.any() and 0 < st["mean_n_cg"] < 80 and st["mean_nts"] > 2000
+    assert S_end.min() >= -1e-9 and S_end.max() <= 1 + 1e-9 and np.isfinite(prods).all()
+    assert (np.diff(prods, axis=1) >= -1e-9).all()
+    fw = lambda s: s * s / (s * s + (1 - s) * (1 - s))  # noqa: E731
+    water = S_end.sum(1) * (gm.Lx / n) * (gm.Ly / n)
+    injected = steps * DT * 1.0
+    at_end = DT * 0.25 * fw(prods).sum((1, 2))
+    at_start = DT * 0.25 * fw(np.concatenate([np.zeros((N, 1, 4)), prods[:, :-1]], 1)).sum((1, 2))
+    assert (water >= injected - at_end - 1e-9).all() and (water <= injected - at_start + 1e-9).all()
+    sub = [0, 63, 64, 300, 511]
+    plan = ForwardPlan(gm, len(sub), DT, steps, keep_history=False)
+    plan.set_inputs(x[sub], transformed=False)
+    plan.run()
+    plan.sync()
+    S_sub, p_sub, st2 = plan.outputs()
+    plan.close()
+    assert not st2.any()
+    assert np.abs(S_sub - S_end[sub]).max() < 1e-6 and np.abs(p_sub - prods[sub]).max() < 1e-6
+
+
+def test_config5_grid_forward_vs_oracle():
+    """512 x 512 (config 5's grid): two members, one time step (9 831 explicit sub-steps), default kernels -- two-level CG
+    pressure solver with its 128-wide coarse direct solve, saturation sweep by teams of 16 tile workgroups -- against the
+    oracle, within the oracle's own solver noise (second SuperLU ordering: MMD_AT_PLUS_A; NATURAL fills in too much here)."""
+    from historymatching_amd.forward import ForwardPlan
+
+    n, N = 512, 2
+    om, gm = make_models(n, n)
+    x = perms(n, n, N, seed=23)
+    plan = ForwardPlan(gm, N, DT, 1)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    st = plan.sync()
+    w, p, status = plan.outputs()
+    nts = plan.get_field("nts")
+    plan.close()
+    assert not status.any() and 0 < st["mean_n_cg"] < 200
+    assert (nts[:, 0] == 9831).all()  # ceil(9830.4), SURVEY.md Appendix B: the injector cell sets the CFL limit
+    for m, (ref, noise) in enumerate(oracle_sims_and_noise_parallel(n, n, x, DT, 1, permc2="MMD_AT_PLUS_A")):
+        err = np.abs(w[m] - ref).max()
+        assert err <= 10 * noise + 1e-9, (m, err, noise)
+        assert err < 1e-4
+        assert np.array_equal(p[m], w[m][1:, om.xy2ind(*om.prd_xy.T)])
+
+
+@pytest.mark.parametrize("dtype", [64, 32])
+def test_config5_grid_properties_over_steps(dtype):
+    """512 x 512, 4 members, 3 steps: no producer has seen water yet, so the water in place is exactly the injected volume;
+    bounds; members independent of their batch (same split of the CG passes: both batches have fewer members than CUs / 8)."""
+    from historymatching_amd.forward import ForwardPlan
+
+    n, N, steps = 512, 4, 3
+    _, gm = make_models(n, n, dtype=dtype)
+    x = perms(n, n, N, seed=6)
+    plan = ForwardPlan(gm, N, DT, steps, keep_history=False)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    plan.sync()
+    S_end, prods, status = plan.outputs()
+    plan.close()
+    tol = 1e-9 if dtype == 64 else 2e-4
+    assert not status.any() and np.abs(prods).max() == 0
+    S_end = S_end.astype(float)
+    assert S_end.min() >= -tol and S_end.max() <= 1 + tol
+    water = S_end.sum(1) * (gm.Lx / n) * (gm.Ly / n)
+    assert np.abs(water - steps * DT).max() < (1e-9 if dtype == 64 else 1e-4)
+    plan = ForwardPlan(gm, 2, DT, steps, keep_history=False)
+    plan.set_inputs(x[[3, 1]], transformed=False)
+    plan.run()
+    plan.sync()
+    S_sub, _, st2 = plan.outputs()
+    plan.close()
+    assert not st2.any() and np.abs(S_sub.astype(float) - S_end[[3, 1]]).max() < (1e-6 if dtype == 64 else 1e-4)
+
+
+def test_config5_localised_update_at_shard_shape_vs_oracle():
+    """Config 5's analysis step at its own size: N = 1000 members in 8 row shards of 125 (one per GPU of the node), M = 512 * 512
+    state elements, n_obs = 160, fp32 plans (matrix-core contractions and local analyses), taper = bump(dist / 1.2) from the
+    product's `taper_for_wells` on the 512 x 512 grid with the reference wells (HistoryMatch.py:700-717, 863).  The eight
+    shards run one after the other on this GPU through the same three phases the ranks run, their reduce buffers summed
+    on the host where the ranks all-reduce.  Compared with oracle.es.ens_update0_loc on 2 048 random state columns (all
+    1000 members), bar 1e-4 of the largest increment."""
+    from historymatching_amd.localization import taper_for_wells
+    from historymatching_amd.update import UpdatePlan
+
+    n, N, G, n_obs = 512, 1000, 8, 160
+    M = n * n
+    _, gm = make_models(n, n)
+    taper = taper_for_wells(gm, gm.xy2ind(*gm.prd_xy.T), 40, radius=1.2)
+    assert taper.shape == (M, n_obs) and (taper > 0).any(1).mean() > 0.9
+    E, obs_ens, obs, perturbs, decorr = _hm_inputs(N, M, n_obs, seed=55)
+    Nl = N // G
+    plans = []
+    for r in range(G):
+        sl = slice(r * Nl, (r + 1) * Nl)
+        p = UpdatePlan(N, Nl, M, n_obs, dtype=32, localized=True)
+        p.set_inputs(E[sl], obs_ens[sl], obs, perturbs[sl], decorr, taper)
+        plans.append(p)
+    for ph in range(3):
+        for p in plans:
+            p.phase(ph)
+        if ph < 2:
+            for which in UpdatePlan.REDUCE_AFTER_PHASE[ph]:
+                tot = sum(p.get_reduce(which).astype(np.float64) for p in plans)
+                for p in plans:
+                    p.set_reduce(which, tot)
+    cols = np.sort(np.random.RandomState(3).choice(M, 2048, replace=False))
+    out = np.concatenate([(p.sync(), p.output()[:, cols])[1] for p in plans])
+    for p in plans:
+        p.close()
+    ref = oracle_update_loc_columns(E[:, cols], obs_ens, obs, perturbs, decorr, taper[cols])
+    inc = np.abs(ref - E[:, cols]).max()
+    assert inc > 0.05
+    n_loc = (np.sqrt(taper[cols]) > 1e-2).sum(1)
+    assert n_loc.max() == n_obs and n_loc.min() < n_obs  # the sample spans full and partial local domains
+    assert np.abs(out - ref).max() <= 1e-4 * inc
+
+
+def test_config5_localised_es_mda_pass_wiring():
+    """One localised ES-MDA pass end to end at 512 x 512 (16 members, all 40 steps, fp32 plans): `dist.es_mda_sharded` on one
+    rank -- forward model, producer series handed to the update plan on the device, localised analysis, posterior fetched --
+    equals oracle.es.ens_update0_loc applied to the same prior with the GPU's own simulated observations (sampled columns)."""
+    from historymatching_amd.dist import es_mda_sharded
+    from historymatching_amd.forward import ForwardPlan
+    from historymatching_amd.localization import taper_for_wells
+    from oracle import es
+
+    n, N, nTime = 512, 16, 40
+    _, gm = make_models(n, n, dtype=32)
+    prior = perms(n, n, N, seed=8).astype(np.float32).astype(np.float64)
+    taper = taper_for_wells(gm, gm.xy2ind(*gm.prd_xy.T), nTime, radius=1.2)
+    _, R12, decorr = es.obs_error_model(nTime, 4)
+    fwd = ForwardPlan(gm, N, DT, nTime, keep_history=False)
+    fwd.set_inputs(prior, transformed=False)
+    fwd.run()
+    fwd.sync()
+    _, prods, status = fwd.outputs(want_wsats=False)
+    fwd.close()
+    assert not status.any()
+    obs_ens = es.vect(prods.astype(np.float64), nTime)
+    obs = np.clip(obs_ens[0] + R12 @ np.random.RandomState(2).randn(4 * nTime), 0, 1)
+    post = es_mda_sharded(gm, prior, obs, R12, DT, nTime, n_iter=1, seed=11, dtype=32, taper=taper)
+    perturbs = np.random.RandomState(11).randn(N, 4 * nTime) @ R12.T
+    cols = np.sort(np.random.RandomState(4).choice(n * n, 256, replace=False))
+    ref = oracle_update_loc_columns(prior[:, cols], obs_ens, obs, perturbs, decorr, taper[cols], nproc=4)
+    inc = np.abs(ref - prior[:, cols]).max()
+    assert np.abs(post[:, cols] - ref).max() <= 1e-4 * max(inc, 1e-3)

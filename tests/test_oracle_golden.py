@@ -87,6 +87,30 @@ def test_taper_from_restated_grid(golden):
     assert np.array_equal(es.bump(d / 1.2), f4["taper"])
 
 
+def test_product_localization_helpers_match_reference_fixtures(golden):
+    """The PRODUCT's taper construction (historymatching_amd/localization.py: bump, pairwise_distances, taper_for_wells;
+    inputs of ens_update0_loc) against the values captured from the reference's own functions: F5 (localization.py:31-60
+    doctests, bump for the six sharpness values of HistoryMatch.py:687-690) and F4 (the wiring of HistoryMatch.py:700-717,
+    863 on the 20x20 grid).  No GPU: only the grid conventions of the GPU-backed model are touched."""
+    from historymatching_amd import localization as loc
+    from historymatching_amd.ressim import ResSim
+    from tests.helpers import wells_4corners
+
+    f5 = _load(golden, "f5_helpers.npz")
+    for s, ref in zip(f5["bump_sharp"], f5["bumps"]):
+        assert np.array_equal(loc.bump(f5["bump_x"], s), ref)
+    assert np.array_equal(loc.pairwise_distances(f5["pd_A"]), f5["pd_AA"])
+    assert np.array_equal(loc.pairwise_distances(np.arange(4)[:, None], [[2]]), f5["pd_1d"])
+    assert np.array_equal(loc.pairwise_distances(np.arange(4)[:, None], domain=(4,)), f5["pd_periodic"])
+    f4 = _load(golden, "f4_ens_update0_loc.npz")
+    gm = wells_4corners(ResSim(20, 20, 2, 1))
+    prod_inds = gm.xy2ind(*gm.prd_xy.T)
+    assert np.array_equal(prod_inds, f4["prod_inds"])
+    xy_obs = np.tile(gm.ind2xy(prod_inds), 40)
+    assert np.array_equal(loc.pairwise_distances(gm.ind2xy(np.arange(gm.Nxy)).T, xy_obs.T), f4["distances_to_obs"])
+    assert np.array_equal(loc.taper_for_wells(gm, prod_inds, 40, radius=1.2), f4["taper"])
+
+
 def test_product_obs_helpers_match_reference_fixture(golden):
     """historymatching_amd.obs (host-side inputs of the update) against the fixture captured from
     the reference's own construction (HistoryMatch.py:243-259, 639) and its seed-1 RNG replay (:600-603)."""
