@@ -12,7 +12,7 @@
 
 #include "../../include/hm_abi.h"
 
-#define HM_ABI_VERSION 1
+#define HM_ABI_VERSION 2
 
 void hm_set_error(const char* fmt, ...);
 

@@ -43,6 +43,10 @@ struct hm_upd {
     int overlap = 0;                // hm_upd_run: 1 = small fp64 chain on a second stream beside the big contraction
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // localised plans over several ranks: the per-element solves are column-sharded -- this rank solves the state
+    // elements [col_rank * col_chunk, ...+col_chunk), the rows of Wt are then all-gathered (Wt holds col_world * col_chunk rows)
+    int col_rank = 0, col_world = 1, col_chunk = 0;
+    EvTimer t_comm;                 // collectives issued by hm_upd_all_reduce / hm_upd_run_comm
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -576,6 +580,7 @@ extern "C" void hm_upd_destroy(hm_upd* u) {
                       &u->Wt, &u->Bt, &u->partial, &u->gpart, &u->flags, &u->YD, &u->SD};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     u->t_upd.destroy();
+    u->t_comm.destroy();
     if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
     if (u->ev_join) (void)hipEventDestroy(u->ev_join);
     if (u->stream2) (void)hipStreamDestroy(u->stream2);
@@ -649,6 +654,23 @@ static int upd_phase(hm_upd* u, int phase) {
     // fp32 global analysis on the matrix cores: second-generation kernels in the phased (row-sharded) path as well
     const bool fast2 = std::is_same<T, float>::value && u->use_mfma && !u->localized && M % 4 == 0 && no % 32 == 0 && no <= 256 &&
                        u->SD.p != nullptr;
+    // E_out = E + D Wt^T, the row-local second half of the localised analysis (HistoryMatch.py:792-793)
+    auto apply_localized = [&]() -> int {
+        int r2 = 0, done = -1;
+        if constexpr (std::is_same<T, float>::value)
+            if (u->use_mfma && M % 4 == 0) {
+                if ((r2 = transpose_cast_d2f(s, D, A_T, nl, no))) return r2;
+                if ((r2 = transpose_f2f(s, (const float*)u->Wt.p, (float*)u->Bt.p, M, no))) return r2;
+                done = mfma_apply(s, nl, M, no, E, A_T, (const float*)u->Bt.p, Eo);
+            }
+        if (done > 0) return done;
+        if (done < 0) {
+            hipLaunchKernelGGL((k_cast<double, T>), dim3(gs), dim3(256), 0, s, (const double*)D, A_T, n_small);
+            HM_HIP(hipGetLastError());
+            if ((r2 = gemm<T>(s, nl, M, no, A_T, no, 1, (const T*)u->Wt.p, 1, no, Eo, M, E, M))) return r2;
+        }
+        return 0;
+    };
     int rc = u->t_upd.begin(s);
     if (rc) return rc;
     if (phase == 0) {
@@ -728,35 +750,32 @@ static int upd_phase(hm_upd* u, int phase) {
                 if ((rc = gemm<T>(s, nl, M, no, A_T, no, 1, Gxt, 1, no, Eo, M, E, M))) return rc;
             }
         } else {
-            int la = -1;
+            // per-element solves of this rank's column shard (all of them on a single rank)
+            const int c0 = u->col_world > 1 ? std::min(M, u->col_rank * u->col_chunk) : 0;
+            const int nc = u->col_world > 1 ? std::max(0, std::min(M, c0 + u->col_chunk) - c0) : M;
+            const size_t off = (size_t)c0 * no;
+            int la = nc > 0 ? -1 : 0;
             if constexpr (std::is_same<T, float>::value)
-                if (u->use_mfma && g_use_mfma_inverse)  // fp32 plans: the per-element solves on the matrix cores
-                    la = local_analysis_mfma(s, M, no, u->N_total, u->cutoff, (const float*)u->taper.p, (const double*)G, (const float*)Gxt,
-                                             (float*)u->Wt.p, (int*)u->flags.p);
+                if (nc > 0 && u->use_mfma && g_use_mfma_inverse)  // fp32 plans: the per-element solves on the matrix cores
+                    la = local_analysis_mfma(s, nc, no, u->N_total, u->cutoff, (const float*)u->taper.p + off, (const double*)G,
+                                             (const float*)Gxt + off, (float*)u->Wt.p + off, (int*)u->flags.p);
             if (la > 0) return la;
             if (la < 0) {
                 size_t lds = ((size_t)no * (no + 1) / 2 + 2 * no) * 8 + (size_t)no * 4 + 16;
                 HM_HIP(hipFuncSetAttribute((const void*)k_local_analysis<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_local_analysis<T>, dim3(M), dim3(256), lds, s, M, no, u->N_total, u->cutoff,
-                                   (const T*)u->taper.p, (const double*)G, (const T*)Gxt, (T*)u->Wt.p, (int*)u->flags.p);
+                hipLaunchKernelGGL(k_local_analysis<T>, dim3(nc), dim3(256), lds, s, nc, no, u->N_total, u->cutoff,
+                                   (const T*)u->taper.p + off, (const double*)G, (const T*)Gxt + off, (T*)u->Wt.p + off, (int*)u->flags.p);
                 HM_HIP(hipGetLastError());
             }
-            int done = -1;
-            if constexpr (std::is_same<T, float>::value)
-                if (u->use_mfma && M % 4 == 0) {
-                    if ((rc = transpose_cast_d2f(s, D, A_T, nl, no))) return rc;
-                    if ((rc = transpose_f2f(s, (const float*)u->Wt.p, (float*)u->Bt.p, M, no))) return rc;
-                    done = mfma_apply(s, nl, M, no, E, A_T, (const float*)u->Bt.p, Eo);
-                }
-            if (done > 0) return done;
-            if (done < 0) {
-                hipLaunchKernelGGL((k_cast<double, T>), dim3(gs), dim3(256), 0, s, (const double*)D, A_T, n_small);
-                HM_HIP(hipGetLastError());
-                if ((rc = gemm<T>(s, nl, M, no, A_T, no, 1, (const T*)u->Wt.p, 1, no, Eo, M, E, M))) return rc;
-            }
+            if (u->col_world > 1) return u->t_upd.end(s);  // all-gather of Wt over the ranks, then phase 3
+            if ((rc = apply_localized())) return rc;
         }
+    } else if (phase == 3) {
+        HM_REQUIRE(u->localized && u->col_world > 1, "hm_upd_phase: phase 3 (apply after the all-gather of W) belongs to column-sharded "
+                   "localised plans (hm_upd_set_column_shard)");
+        if ((rc = apply_localized())) return rc;
     } else {
-        hm_set_error("hm_upd_phase: phase must be 0, 1 or 2");
+        hm_set_error("hm_upd_phase: phase must be 0, 1, 2 (or 3 for column-sharded localised plans)");
         return 2;
     }
     return u->t_upd.end(s);
@@ -859,11 +878,75 @@ extern "C" void* hm_upd_reduce_buffer(hm_upd* u, int which, long long* n_elems, 
         case 1: n = u->n_obs; eb = 8; p = u->red1.p; break;
         case 2: n = (long long)u->M * u->n_obs; eb = (int)u->esz; p = u->red2.p; break;
         case 3: n = (long long)u->n_obs * u->n_obs; eb = 8; p = u->red3.p; break;
+        case 4:  // localised plans: the weights W^T (state element major), col_world blocks of col_chunk rows (all-gathered)
+            if (!u->localized) return nullptr;
+            n = (long long)(u->col_world > 1 ? (long long)u->col_world * u->col_chunk : u->M) * u->n_obs; eb = (int)u->esz; p = u->Wt.p; break;
         default: return nullptr;
     }
     if (n_elems) *n_elems = n;
     if (elem_bytes) *elem_bytes = eb;
     return p;
+}
+
+// ---- the analysis step over several ranks (one process per GPU), collectives by RCCL from the library itself ----------------
+// rows of the ensemble stay on their rank; (1) column sums -> all-reduce of M + n_obs values; (2) the Gram pair
+// X^T S, S^T S -> all-reduce of n_obs (M + n_obs) values; (3) localised plans only: the per-element solves are column-sharded and
+// the weights W^T (M x n_obs) all-gathered.  Everything is queued on the context's stream: no host synchronisation in between.
+extern "C" int hm_upd_set_column_shard(hm_upd* u, int rank, int world_size) {
+    HM_REQUIRE(u, "hm_upd_set_column_shard: NULL plan");
+    HM_REQUIRE(u->localized, "hm_upd_set_column_shard: only localised plans have per-element solves to shard");
+    HM_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "hm_upd_set_column_shard: rank %d outside [0,%d)", rank, world_size);
+    HM_HIP(hipSetDevice(u->ctx->device));
+    HM_HIP(hipStreamSynchronize(u->ctx->stream));
+    const int chunk = (u->M + world_size - 1) / world_size;
+    const size_t need = (size_t)world_size * chunk * u->n_obs * u->esz;
+    if (need > u->Wt.bytes) {  // padded to world_size equal blocks: ncclAllGather takes one count for every rank
+        hm_dev_free(u->Wt);
+        int rc = hm_dev_alloc(u->Wt, need);
+        if (rc) return rc;
+    }
+    HM_HIP(hipMemset(u->Wt.p, 0, u->Wt.bytes));
+    u->col_rank = rank; u->col_world = world_size; u->col_chunk = chunk;
+    return 0;
+}
+
+extern "C" int hm_upd_all_reduce(hm_upd* u, hm_comm* c, int after_phase) {
+    HM_REQUIRE(u && c, "hm_upd_all_reduce: NULL argument");
+    HM_REQUIRE(after_phase >= 0 && after_phase <= 2, "hm_upd_all_reduce: after_phase must be 0, 1 or 2");
+    HM_HIP(hipSetDevice(u->ctx->device));
+    hipStream_t s = u->ctx->stream;
+    int rc = u->t_comm.begin(s);
+    if (rc) return rc;
+    if (after_phase == 2) {
+        HM_REQUIRE(u->localized && u->col_world == hm_comm_world_size(c) && u->col_rank == hm_comm_rank(c),
+                   "hm_upd_all_reduce: the plan's column shard (hm_upd_set_column_shard) does not match the communicator");
+        if (u->col_world > 1 && (rc = hm_comm_all_gather(c, u->Wt.p, (long long)u->col_chunk * u->n_obs, u->dtype))) return rc;
+    } else {
+        const int first = after_phase == 0 ? 0 : 2;
+        if ((rc = hm_comm_group_start(c))) return rc;
+        for (int which = first; which < first + 2; ++which) {
+            long long n; int eb;
+            void* p = hm_upd_reduce_buffer(u, which, &n, &eb);
+            if ((rc = hm_comm_all_reduce(c, p, n, eb == 8 ? 64 : 32, HM_COMM_SUM))) { (void)hm_comm_group_end(c); return rc; }
+        }
+        if ((rc = hm_comm_group_end(c))) return rc;
+    }
+    return u->t_comm.end(s);
+}
+
+extern "C" int hm_upd_run_comm(hm_upd* u, hm_comm* c) {
+    HM_REQUIRE(u && c, "hm_upd_run_comm: NULL argument");
+    int rc = 0;
+    const bool shard_cols = u->localized && hm_comm_world_size(c) > 1;
+    if (shard_cols && (u->col_world != hm_comm_world_size(c) || u->col_rank != hm_comm_rank(c)))
+        if ((rc = hm_upd_set_column_shard(u, hm_comm_rank(c), hm_comm_world_size(c)))) return rc;
+    for (int ph = 0; ph < 3; ++ph) {
+        if ((rc = hm_upd_phase(u, ph))) return rc;
+        if (ph < 2 || shard_cols)
+            if ((rc = hm_upd_all_reduce(u, c, ph))) return rc;
+    }
+    if (shard_cols) rc = hm_upd_phase(u, 3);
+    return rc;
 }
 
 extern "C" int hm_upd_sync(hm_upd* u, hm_stats* st) {
@@ -872,8 +955,14 @@ extern "C" int hm_upd_sync(hm_upd* u, hm_stats* st) {
     HM_HIP(hipStreamSynchronize(u->ctx->stream));
     int flag = 0;
     HM_HIP(hipMemcpy(&flag, u->flags.p, 4, hipMemcpyDeviceToHost));
-    if (st) { memset(st, 0, sizeof(*st)); st->ms_update = u->t_upd.total_ms(); st->ms_total = st->ms_update; }
+    if (st) {
+        memset(st, 0, sizeof(*st));
+        st->ms_update = u->t_upd.total_ms();
+        st->ms_comm = u->t_comm.total_ms();
+        st->ms_total = st->ms_update + st->ms_comm;
+    }
     u->t_upd.reset();
+    u->t_comm.reset();
     if (flag) {
         HM_HIP(hipMemset(u->flags.p, 0, 16));
         hm_set_error("ensemble update: non-positive pivot (C = S^T S + (N-1) I must be SPD; NaN/Inf in inputs?)");

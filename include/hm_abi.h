@@ -22,6 +22,7 @@ extern "C" {
 typedef struct hm_ctx hm_ctx;   /* one per process per GPU */
 typedef struct hm_fwd hm_fwd;   /* device-resident ensemble forward-model plan */
 typedef struct hm_upd hm_upd;   /* device-resident ensemble-smoother update plan */
+typedef struct hm_comm hm_comm; /* RCCL communicator of one rank (one process per GPU) */
 
 /* Timing/accounting of the last run (all times from HIP events on the context's stream). */
 typedef struct hm_stats {
@@ -34,6 +35,7 @@ typedef struct hm_stats {
     long long n_saturation_launches;
     long long member_steps; /* N * nTime processed                                              */
     double mean_n_cg;       /* mean CG iterations per member-step (0 when the direct solver ran)   */
+    double ms_comm;         /* update plans: collectives issued through hm_upd_all_reduce / hm_upd_run_comm */
 } hm_stats;
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -43,10 +45,36 @@ const char* hm_last_error(void);
 int         hm_device_name(hm_ctx* ctx, char* buf, int buflen);   /* e.g. "gfx950:..."           */
 int         hm_abi_version(void);
 /* Raw copies between caller host buffers and device pointers handed out by hm_*_device_ptr /
- * hm_upd_reduce_buffer (host-staged fallback of the multi-rank update's all-reduce; with the nccl backend the
- * reduction runs in place on those device buffers, historymatching_amd/dist.py). Synchronous. */
+ * hm_upd_reduce_buffer (host-staged form of the multi-rank update's reductions: CPU-side tests and ranks that share
+ * one GPU; over distinct GPUs the reductions run in place on those device buffers through hm_comm_*). Synchronous. */
 int         hm_copy_to_host(hm_ctx* ctx, void* dst_host, const void* src_device, long long bytes);
 int         hm_copy_to_device(hm_ctx* ctx, void* dst_device, const void* src_host, long long bytes);
+
+/* ---- ranks: replaces the process pool of utils.apply (notebooks/tools/utils.py:201-224) -------------------------
+ * The reference's only parallel layer is an ordered process-pool map over independent members; its workers "don't
+ * communicate back from child processes" (utils.py:226-228).  Here one process drives one GPU, the forward model needs
+ * no exchange at all, and the update's cross-member sums are RCCL collectives issued by the library on
+ * the context's stream, in place on the plan's device buffers (librccl.so.1 is dlopen'ed on first use; no PyTorch).
+ * Rendezvous: rank 0 calls hm_comm_unique_id and hands the HM_COMM_ID_BYTES bytes to the other ranks by any host
+ * channel (historymatching_amd/dist.py: a localhost socket); then every rank calls hm_comm_create.  RCCL does not
+ * accept two ranks of one communicator on the same GPU ("Duplicate GPU detected"). */
+#define HM_COMM_ID_BYTES 128
+#define HM_COMM_SUM 0
+#define HM_COMM_MAX 1
+int  hm_comm_unique_id(char* id_out /* HM_COMM_ID_BYTES */);
+int  hm_comm_create(hm_ctx* ctx, int rank, int world_size, const char* unique_id, hm_comm** out);
+void hm_comm_destroy(hm_comm* c);
+int  hm_comm_rank(hm_comm* c);
+int  hm_comm_world_size(hm_comm* c);
+/* Collectives on DEVICE buffers of the communicator's context, in place, asynchronous on the context's stream.
+ * dtype: 64 double | 32 float | 1 int32 | 8 bytes.  all_gather: rank r's block of n_per_rank elements lies at
+ * buf + r * n_per_rank on entry. */
+int  hm_comm_all_reduce(hm_comm* c, void* buf, long long n, int dtype, int op /* HM_COMM_SUM | HM_COMM_MAX */);
+int  hm_comm_all_gather(hm_comm* c, void* buf, long long n_per_rank, int dtype);
+int  hm_comm_broadcast(hm_comm* c, void* buf, long long n, int dtype, int root);
+int  hm_comm_group_start(hm_comm* c);   /* ncclGroupStart / ncclGroupEnd: one launch for the calls in between */
+int  hm_comm_group_end(hm_comm* c);
+int  hm_comm_sync(hm_comm* c);          /* stream synchronisation + RCCL asynchronous-error check */
 
 /* ---- forward model: replaces utils.apply(comp1, ...) = forward_model --------------------------
  * Reference: forward_model  notebooks/HistoryMatch.py:383-387  (-> utils.apply tools/utils.py:155-242
@@ -147,8 +175,8 @@ int hm_es_update_loc(hm_ctx* ctx, int N, int M, int n_obs, const void* E, const 
                      double cutoff, int dtype, void* E_out, hm_stats* stats);
 
 /* Device-resident / sharded form: rows [row0, row0+N_local) of an N-member ensemble live on this GPU.
- * The cross-rank reductions are exposed as four sum-reduce buffers the host all-reduces (RCCL)
- * between the phases:
+ * The cross-rank reductions are exposed as four sum-reduce buffers, all-reduced between the phases
+ * (hm_upd_all_reduce: RCCL from the library; or host-staged through hm_upd_reduce_buffer + hm_copy_*):
  *   phase 0: local column sums                      -> buffers 0 (E: M values, dtype) and 1 (obs_ens: n_obs, fp64)
  *   phase 1: (after all-reduce of 0,1) S, D, and the local Gram pair
  *                                                   -> buffers 2 (X^T S: M*n_obs, dtype) and 3 (S^T S: n_obs^2, fp64)
@@ -176,13 +204,23 @@ int   hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double ridge, do
 int   hm_upd_set_inputs_device(hm_upd* u, const void* E_dev, int E_dtype, const void* obs_ens_dev, int obs_dtype);
 int   hm_upd_swap(hm_upd* u);
 int   hm_upd_phase(hm_upd* u, int phase);
+/* Localised plans over several ranks: the per-element solves of phase 2 (HistoryMatch.py:783-793; "<-- can multiprocess
+ * this map" :795) are column-sharded -- rank r solves the state elements [r*chunk, (r+1)*chunk), chunk = ceil(M/world) --
+ * and phase 2 stops after them; the weights W^T (reduce buffer 4: world*chunk rows of n_obs) are all-gathered, then
+ * phase 3 applies them to this rank's members. */
+int   hm_upd_set_column_shard(hm_upd* u, int rank, int world_size);
+/* The collective that follows `after_phase` (0: buffers 0,1; 1: buffers 2,3; 2: all-gather of buffer 4), queued on the
+ * context's stream behind the phase, no host synchronisation. */
+int   hm_upd_all_reduce(hm_upd* u, hm_comm* c, int after_phase);
+/* The whole analysis step of a row-sharded plan over the ranks of `c`: phases and collectives in stream order. */
+int   hm_upd_run_comm(hm_upd* u, hm_comm* c);
 /* All three phases of a plan that holds every member (N_local == N_total), no reduction points.  fp32 plans run the
  * second-generation matrix-core kernels here (LDS-staged contractions, fp64 matrix-core products for the N x n_obs
  * quantities, matrix-core inverse of C); option "overlap" = 1 puts the small fp64 chain on a second stream. */
 int   hm_upd_run(hm_upd* u);
 int   hm_upd_set_option(hm_upd* u, const char* name, int value);  /* "use_mfma": 1 (default) | 0 = generic fp32 GEMMs;
                                                                    * "mfma_inverse": 1 | 0; "overlap": 0 | 1        */
-void* hm_upd_reduce_buffer(hm_upd* u, int which /*0..3*/, long long* n_elems, int* elem_bytes); /* device pointer */
+void* hm_upd_reduce_buffer(hm_upd* u, int which /*0..4*/, long long* n_elems, int* elem_bytes); /* device pointer */
 int   hm_upd_sync(hm_upd* u, hm_stats* stats);
 int   hm_upd_get_output(hm_upd* u, void* E_out_local);
 void* hm_upd_device_ptr(hm_upd* u, const char* name);   /* "E","E_out","obs_ens","perturbs" */
