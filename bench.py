@@ -7,11 +7,15 @@ member per step), fp64, nTime=40, wells/fluid/dt of notebooks/HistoryMatch.py:97
 
 A "step" (--steps) is ONE pass of the hot path over the whole batch: all N_e members advanced nTime=40 time
 steps, inputs (permeability, initial saturation) already resident in HBM.  Multi-GPU (--gpus N, launched by
-torch.distributed.run): members are independent, so every rank runs its own N_e members with no data-path
-collective ("weak" scaling); value = total member-steps of all ranks / max-over-ranks time.
+torch.distributed.run, which only provides RANK / LOCAL_RANK / WORLD_SIZE -- no PyTorch is imported here): members are
+independent, so every rank runs its own N_e members with no data-path collective ("weak" scaling); value = total
+member-steps of all ranks / max-over-ranks time, bracketed by a barrier + device synchronisation on both sides.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the library on the launch
 stream) and `cpu_baseline` (the NumPy/SciPy oracle on the host cores, bounded sample, rank 0 at N=1 only).
+Beside `value` (outside its timed region): `es_update` (the analysis step at config 3's shape; 4 ES-MDA passes of config 3;
+at N > 1 the analysis step row-sharded over the ranks with RCCL) and `config4` (BASELINE config 4: N_e = 4096 at
+256 x 256 split over the ranks -- strong scaling -- one ES-MDA pass = forward model + analysis step over RCCL).
 """
 import argparse
 import json
@@ -29,13 +33,19 @@ NX = NY = 128
 N_E = 1000
 NTIME = 40
 DT = 0.025
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, fp64 VALU = 16 lanes / cycle / SIMD, 2.4 GHz; fp64 vector peak = fp64 matrix peak
+HBM_PEAK_GBS = 8000.0
+CLOCK_HZ = 2.4e9
+N_CU = 256
+DP_LANE_RATE = N_CU * 4 * 16 * CLOCK_HZ          # double-precision lane-instructions / s (39.3e12)
+FP64_PEAK_TFLOPS = 2 * DP_LANE_RATE / 1e12        # 78.6: one FMA per lane-slot
+FP32_MATRIX_PEAK_TFLOPS = 157.3
 
 
-def build_model(dtype=64, device=None):
+def build_model(dtype=64, device=None, n=NX):
     from historymatching_amd.ressim import ResSim
 
-    m = ResSim(NX, NY, 2, 1, dtype=dtype, device=device)
+    m = ResSim(n, n, 2, 1, dtype=dtype, device=device)
     near01 = np.array([0.12, 0.87])  # HistoryMatch.py:177-190
     m.prd_xy = [[x, y] for y in m.Ly * near01 for x in m.Lx * near01]
     m.inj_xy = [[m.Lx / 2, m.Ly / 2]]
@@ -61,69 +71,83 @@ def cpu_baseline(members, steps, nproc):
     return members * steps / wall, wall
 
 
+def reference_obs_error(n_obs):
+    """R12 of the reference's observation-error model (HistoryMatch.py:243-259: 1e-2 * toeplitz(exp(-k/2), entries below
+    1e-2 cut) per well, kron I_nPrd, lower Cholesky factor)."""
+    from historymatching_amd.obs import obs_error_model
+
+    return obs_error_model(n_obs // 4, 4)[1]
+
+
 def es_update_timing(device):
     """BASELINE.json's second metric (ES-MDA update wall-time) at config 3's shape: N=1000 members, M=128*128 state
     elements, n_obs=160, fp32 state contractions on the matrix cores, every N x n_obs quantity in fp64.  Device time of
     one analysis step (HIP events inside the library), inputs resident in HBM; flops by SURVEY.md 8d (min-flop order)."""
+    import scipy.linalg as sla
+
     from historymatching_amd.update import UpdatePlan
 
     N, M, n_obs = N_E, NX * NY, 160
     rng = np.random.RandomState(0)
+    R12 = reference_obs_error(n_obs)
     plan = UpdatePlan(N, N, M, n_obs, dtype=32, device=device)
-    plan.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), rng.rand(n_obs), 0.1 * rng.randn(N, n_obs), 3.0 * np.eye(n_obs))
+    plan.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), rng.rand(n_obs), rng.randn(N, n_obs) @ R12.T, sla.inv(R12.T))
     plan.run_local()  # warm-up
-    ms = sorted(plan.run_local()["ms_update"] for _ in range(7))
+    ms = sorted(plan.run_local()["ms_update"] for _ in range(9))
     plan.close()
     flops = 4.0 * N * n_obs * M
-    peak = 157.3  # TF, fp32 matrix peak (MI355X_MICROARCH.md)
-    return {"wall_ms": ms[len(ms) // 2], "best_ms": ms[0], "config": f"N={N}, M={M}, n_obs={n_obs}, fp32 (config 3 shape)",
-            "flops_min_order": flops, "tflops": flops / (ms[len(ms) // 2] * 1e-3) / 1e12, "mfma_peak_tflops": peak,
-            "mfma_frac_of_fp32_peak": flops / (ms[len(ms) // 2] * 1e-3) / 1e12 / peak}
+    med = ms[len(ms) // 2]
+    return {"wall_ms": med, "best_ms": ms[0], "config": f"N={N}, M={M}, n_obs={n_obs}, fp32 (config 3 shape), correlated R of HistoryMatch.py:243-259",
+            "flops_min_order": flops, "tflops": flops / (med * 1e-3) / 1e12, "mfma_peak_tflops": FP32_MATRIX_PEAK_TFLOPS,
+            "mfma_frac_of_fp32_peak": flops / (med * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS}
 
 
-def es_update_sharded_timing(device, world, reps=5):
+def es_update_sharded_timing(device, comm, reps=5):
     """The analysis step row-sharded over the ranks (weak scaling like the forward metric: every rank holds
-    N_e=1000 members of an N_e x world ensemble, M=128*128, n_obs=160, fp32 state): three local phases with two RCCL
-    all-reduces on the library's own device buffers in between (column sums; X^T S and S^T S).  Wall time per update,
-    barrier + device synchronisation on both sides, maximum over ranks.  Called by EVERY rank."""
-    import torch
-    import torch.distributed as td
+    N_e=1000 members of an N_e x world ensemble, M=128*128, n_obs=160, fp32 state): `hm_upd_run_comm` = three local phases with
+    two RCCL all-reduces issued by the library on its own device buffers in between (column sums; X^T S and S^T S), all in stream
+    order.  Wall time per update, barrier + device synchronisation on both sides, maximum over ranks.  Called by EVERY rank."""
+    import scipy.linalg as sla
 
-    from historymatching_amd.dist import Comm, sharded_update
+    from historymatching_amd.dist import sharded_update
     from historymatching_amd.update import UpdatePlan
 
+    world = comm.world_size
     N, M, n_obs = N_E, NX * NY, 160
-    rng = np.random.RandomState(100 + td.get_rank())
+    rng = np.random.RandomState(100 + comm.rank)
+    R12 = reference_obs_error(n_obs)
     plan = UpdatePlan(N * world, N, M, n_obs, dtype=32, device=device)
-    plan.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), np.random.RandomState(7).rand(n_obs), 0.1 * rng.randn(N, n_obs), 3.0 * np.eye(n_obs))
-    comm = Comm()
-    sharded_update(plan, comm, fetch=False)  # warm-up (RCCL communicator set-up included)
-    td.barrier()
-    torch.cuda.synchronize()
+    plan.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), np.random.RandomState(7).rand(n_obs), rng.randn(N, n_obs) @ R12.T, sla.inv(R12.T))
+    sharded_update(plan, comm, fetch=False)  # warm-up
+    comm.barrier()
     t0 = time.perf_counter()
+    dev_ms = comm_ms = 0.0
     for _ in range(reps):
-        sharded_update(plan, comm, fetch=False)
-    td.barrier()
-    torch.cuda.synchronize()
-    t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device="cuda")
-    td.all_reduce(t, op=td.ReduceOp.MAX)
+        st = sharded_update(plan, comm, fetch=False)  # ends with a stream synchronisation
+        dev_ms += st["ms_update"]
+        comm_ms += st.get("ms_comm", 0.0)
+    comm.barrier()
+    wall = comm.all_reduce_max((time.perf_counter() - t0) / reps)
     nbytes = sum(plan.reduce_buffer(w)[1] * np.dtype(plan.reduce_buffer(w)[2]).itemsize for w in (0, 1, 2, 3))
     plan.close()
-    return {"wall_ms": 1e3 * float(t.item()), "n_ranks": world, "members_total": N * world, "members_per_rank": N, "M": M, "n_obs": n_obs,
-            "allreduce_bytes_per_update": int(nbytes), "collective": "RCCL all-reduce in place on the library's device buffers",
+    return {"wall_ms": 1e3 * wall, "device_ms_phases": dev_ms / reps, "device_ms_collectives": comm_ms / reps, "n_ranks": world,
+            "members_total": N * world, "members_per_rank": N, "M": M, "n_obs": n_obs, "allreduce_bytes_per_update": int(nbytes),
+            "collective": ("RCCL all-reduce issued by the library in place on its device buffers (hm_upd_run_comm)" if comm.rccl is not None
+                           else f"host channel (RCCL unavailable: {comm.rccl_error})"),
             "config": "row-sharded global analysis step, fp32 state contractions on the matrix cores, weak scaling"}
 
 
 def es_mda_c3(device, perms, n_iter=4):
     """BASELINE.json config 3: N_e=1000, 128x128, 4 ES-MDA passes (forward model in fp32 mode + fp32 matrix-core analysis), the
-    ensemble resident in HBM throughout (update.es_mda_device).  Observations = member 0's simulated production + noise."""
+    ensemble resident in HBM throughout (update.es_mda_device), observation error as the reference's (correlated in time).
+    Observations = member 0's simulated production + noise."""
     from historymatching_amd.forward import ForwardPlan
     from historymatching_amd.update import es_mda_device
 
     model = build_model(32, device=device)  # config 3 is the fp32 configuration: fp32 saturation sweep (sat128f), fp64 pressure
     n_obs = NTIME * 4
     rng = np.random.RandomState(4)
-    R12 = 0.1 * np.eye(n_obs)  # HistoryMatch.py:243-259 uses a correlated R; the update cost does not depend on it
+    R12 = reference_obs_error(n_obs)
     fwd = ForwardPlan(model, 1, DT, NTIME, keep_history=False, device=device)
     fwd.set_inputs(perms[:1], None, transformed=False)
     fwd.run()
@@ -135,11 +159,52 @@ def es_mda_c3(device, perms, n_iter=4):
     t0 = time.perf_counter()
     post = es_mda_device(model, perms, obs, R12, DT, NTIME, n_iter=n_iter, rng=rng, dtype=32, device=device, stats=st)
     wall = time.perf_counter() - t0
+    # the assimilation must have pulled the ensemble's simulated production towards the observations
     return {"iterations": n_iter, "wall_s": wall, "device_ms_forward": st["ms_forward"], "device_ms_update": st["ms_update"],
             "ensemble_steps_per_s_incl_updates": len(perms) * NTIME * n_iter / wall,
             "posterior_finite": bool(np.isfinite(post).all()),
+            "rms_change_of_log_perm": float(np.sqrt(np.mean((post - perms) ** 2))),
             "config": f"N_e={len(perms)}, {NX}x{NY}, {n_iter} ES-MDA passes, forward model dtype=32 (fp32 saturation sweep, fp64 "
-                      "pressure solve) + fp32 matrix-core analysis, ensemble resident in HBM (config 3)"}
+                      "pressure solve) + fp32 matrix-core analysis, ensemble resident in HBM, correlated R (config 3)"}
+
+
+def config4_sharded(device, comm, n_total=4096, n_grid=256):
+    """BASELINE.json config 4: N_e = 4096 members at 256 x 256, members split over the ranks (4096 / world each: STRONG scaling --
+    the total work is fixed), one ES-MDA pass = forward model of the local members (no communication) + the analysis step over
+    the ranks (two all-reduces on the library's device buffers).  fp64 forward model, fp32 matrix-core analysis.  Called by EVERY rank."""
+    from historymatching_amd.dist import es_mda_sharded, shard_bounds
+    from historymatching_amd.geostat import gaussian_fields_kron
+
+    lo, hi = shard_bounds(n_total, comm.world_size, comm.rank)
+    model = build_model(64, device=device, n=n_grid)
+    n_obs = NTIME * 4
+    R12 = reference_obs_error(n_obs)
+    obs = np.clip(0.2 + R12 @ np.random.RandomState(9).randn(n_obs), 0, 1)
+    # every rank draws only its own members' fields (seeded per member block: the prior does not depend on the world size
+    # up to the block boundaries; statistically the same prior -- this leg is a timing)
+    prior = gaussian_fields_kron(n_grid, n_grid, 2, 1, hi - lo, r=0.8, seed=1000 + lo)
+    st = {}
+    comm.barrier()
+    t0 = time.perf_counter()
+    post = es_mda_sharded(model, prior, obs, R12, DT, NTIME, n_iter=1, seed=3, comm=comm, dtype=32, device=device, stats=st)
+    comm.barrier()
+    wall = comm.all_reduce_max(time.perf_counter() - t0)
+    fwd_ms = comm.all_reduce_max(st["ms_forward"])
+    upd_ms = comm.all_reduce_max(st["ms_update"] + st.get("ms_comm", 0.0))
+    ok = comm.all_reduce_max(0.0 if np.isfinite(post).all() else 1.0) == 0.0
+    return {"members_total": n_total, "members_per_rank": hi - lo, "grid": [n_grid, n_grid], "n_ranks": comm.world_size, "scaling": "strong",
+            "passes": 1, "wall_s": wall, "device_ms_forward_max": fwd_ms, "device_ms_update_max": upd_ms,
+            "ensemble_steps_per_s_forward": n_total * NTIME / (fwd_ms * 1e-3), "ensemble_steps_per_s_incl_update_and_setup": n_total * NTIME / wall,
+            "posterior_finite": bool(ok),
+            "collective": "RCCL (hm_upd_run_comm)" if comm.rccl is not None else ("none (one rank)" if comm.world_size == 1 else f"host channel ({comm.rccl_error})")}
+
+
+def load_profile_json(name):
+    """Newest committed profiles/rNN/<name> (measured separately under rocprofv3 / from the built object), or None."""
+    try:
+        return json.loads(sorted((ROOT / "profiles").glob(f"r*/{name}"))[-1].read_text()), str(sorted((ROOT / "profiles").glob(f"r*/{name}"))[-1].relative_to(ROOT))
+    except Exception:
+        return None, None
 
 
 def main():
@@ -150,29 +215,24 @@ def main():
     ap.add_argument("--members", type=int, default=N_E, help="members per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-esmda", action="store_true", help="skip the 4-pass ES-MDA leg (config 3)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (N_e=4096 at 256x256 over the ranks)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0, help="0 = fastest kernels, 1 = generic kernels")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    td = None
-    if world > 1 or os.environ.get("HM_BENCH_FORCE_DIST") == "1":  # the env switch exercises the N>1 code path with 1 rank
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as td
-
-        torch.cuda.set_device(local_rank)
-        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-
     from historymatching_amd import _lib
+    from historymatching_amd.dist import Comm
     from historymatching_amd.forward import ForwardPlan
     from historymatching_amd.geostat import gaussian_fields_kron
 
+    comm = Comm.from_env()
+    world, rank, local_rank = comm.world_size, comm.rank, comm.local_rank
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
     ctx = _lib.Context.get(local_rank)
+    if world > 1 or os.environ.get("HM_BENCH_FORCE_DIST") == "1":  # the env switch exercises the RCCL path with 1 rank
+        comm.enable_rccl(ctx, force_single=True)
     model = build_model(64, device=local_rank)
     n_e = args.members
     perms = gaussian_fields_kron(NX, NY, 2, 1, n_e, r=0.8, seed=1 + rank)  # synthetic prior, SURVEY.md 8d
@@ -180,43 +240,39 @@ def main():
     plan.set_variant(args.variant, args.variant)
     plan.set_inputs(perms, None, transformed=False)  # inputs resident in HBM before the timed region
 
-    def one_pass():
-        plan.run(0, NTIME)
-
     for _ in range(args.warmup):
-        one_pass()
+        plan.run(0, NTIME)
     plan.sync()
 
-    def fence():
-        if td is not None:
-            import torch
-
-            td.barrier()
-            torch.cuda.synchronize()
-
-    fence()
+    comm.barrier()           # all ranks' devices are idle here: plan.sync() above is a stream synchronisation
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_pass()
-    stats = plan.sync()  # hipStreamSynchronize on the launch stream + event read-out
-    fence()
-    elapsed = time.perf_counter() - t0
-    if td is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
+        plan.run(0, NTIME)
+    stats = plan.sync()      # hipStreamSynchronize on the launch stream + event read-out
+    comm.barrier()
+    elapsed = comm.all_reduce_max(time.perf_counter() - t0)
 
     _, prods, status = plan.outputs(want_wsats=False)
     ok = not status.any() and np.isfinite(prods).all()
+    plan.close()
 
-    upd_sharded = None
-    if td is not None:  # every rank: the analysis step sharded over the ranks (outside the timed region of `value`)
+    def guarded(leg):
+        """Run a leg every rank takes part in; if it fails on any rank, every rank reports the error instead of a result
+        (the legs after the timed region never cost the headline line)."""
+        err, res = None, None
         try:
-            upd_sharded = es_update_sharded_timing(local_rank, world)
+            res = leg()
         except Exception as e:
-            upd_sharded = {"error": str(e)}
+            err = f"rank {rank}: {type(e).__name__}: {e}"
+        msgs = comm.host.all_gather(err) if world > 1 else [err]
+        bad = [m for m in msgs if m]
+        return {"error": "; ".join(bad)} if bad else res
+
+    upd_sharded = c4 = None
+    if world > 1 or comm.rccl is not None:  # every rank: the analysis step sharded over the ranks (outside the timed region of `value`)
+        upd_sharded = guarded(lambda: es_update_sharded_timing(local_rank, comm))
+    if not args.no_config4 and args.members == N_E:
+        c4 = guarded(lambda: config4_sharded(local_rank, comm))
 
     if rank == 0:
         member_steps = n_e * NTIME * args.steps * world
@@ -227,40 +283,47 @@ def main():
         nts = stats["mean_nts"]
         sat_ms = stats["ms_saturation"] / max(1, stats["n_saturation_launches"])
         prs_ms = stats["ms_pressure"] / max(1, stats["n_pressure_launches"])
-        # algorithmic bytes per member-step: saturation = read S,Vx,Vy + write S per explicit
-        # sub-step; pressure = compulsory (K,S in; P out) + factor write + factor read of the direct block solver
-        # (the symmetric factor: 36 of the 64 16x16 tiles of every 128x128 inverse Schur complement)
+        dominant = "saturation" if stats["ms_saturation"] >= stats["ms_pressure"] else "pressure"
+        isa, isa_src = load_profile_json("isa_counts.json")
+        pmc, pmc_src = load_profile_json("pmc_hbm_traffic.json")
+        # saturation sweep (k_sat128): member state register/LDS resident, bound by the CU's double-precision VALU.  Work per
+        # launch = DP VALU instructions of the sub-step loop (counted from the built object: profiles/tools/isa_count.py) x
+        # cells x sub-steps x members, in lane-instructions; the peak is one DP lane-instruction per lane-slot.
+        dp_per_cell = (isa or {}).get("k_sat128", {}).get("dp_valu_per_cell_substep", 41.8)
+        sat_lane_instr = dp_per_cell * nxy * nts * n_e
+        # pressure (k_press128s): fp64 matrix cores; flops = rank-16 updates of the 36 stored tiles x 8 panels x Nx blocks
+        prs_flops = 2.0 * 36 * 16 * 16 * 16 * 8 * NX * n_e
+        if dominant == "saturation":
+            ach = 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12
+            bound, what = "fp64_valu", ("double-precision VALU issue slots: every DP VALU instruction of the sub-step loop counted as one FMA slot "
+                                        "(2 flop) per lane, peak = 256 CUs x 4 SIMDs x 16 DP lanes x 2.4 GHz x 2")
+        else:
+            ach = prs_flops / (prs_ms * 1e-3) / 1e12
+            bound, what = "fp64_mfma", "v_mfma_f64_16x16x4 flops of the block elimination's rank-16 panel updates"
+        traffic = None
+        key = {"saturation": "sat128", "pressure": "press128s"}[dominant]
+        if pmc and args.variant == 0 and key in pmc.get("kernels", {}):
+            traffic = pmc["kernels"][key]["hbm_bytes_per_member_corrected"] * n_e
+        dom_ms = sat_ms if dominant == "saturation" else prs_ms
+        # SURVEY.md 8d accounting kept as a separately named diagnostic: "effective" bytes (read S,Vx,Vy + write S per explicit
+        # sub-step; compulsory + factor write + factor read for the pressure solver) -- NOT a roofline for a register-resident sweep
         sat_bytes = w * nxy * 4 * nts * n_e
         prs_bytes = w * nxy * (4 + 2 * NY * 36 / 64) * n_e
-        dominant = "saturation" if stats["ms_saturation"] >= stats["ms_pressure"] else "pressure"
-        ach = (sat_bytes / (sat_ms * 1e-3) if dominant == "saturation" else prs_bytes / (prs_ms * 1e-3)) / 1e9
-        # measured HBM traffic of the same kernel: PMC passes are taken separately under rocprofv3 (profiles/),
-        # bench.py only scales the per-member figure to this launch size
-        traffic, traffic_src = None, None
-        try:
-            pmc_file = sorted((ROOT / "profiles").glob("r*/pmc_hbm_traffic.json"))[-1]
-            pmc = json.loads(pmc_file.read_text())
-            key = {"saturation": "sat128", "pressure": "press128s"}[dominant]
-            if args.variant == 0 and key in pmc["kernels"]:
-                traffic = pmc["kernels"][key]["hbm_bytes_per_member_corrected"] * n_e
-                traffic_src = str(pmc_file.relative_to(ROOT))
-        except Exception:
-            pass
         roofline = {
-            "bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "bound": bound, "kernel": {"saturation": "k_sat128", "pressure": "k_press128s"}[dominant] if args.variant == 0 else dominant,
+            "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
+            "hbm_frac_of_peak_from_measured_traffic": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "work_counted": what, "dp_valu_per_cell_substep": dp_per_cell, "isa_count_source": isa_src,
             "avg_launch_ms": {"saturation": sat_ms, "pressure": prs_ms},
-            "algorithmic_bytes_per_launch": {"saturation": sat_bytes, "pressure": prs_bytes},
-            "compulsory_floor_bytes_per_member_step": 4 * w * nxy,
-            "mean_nts": nts,
-            "note": "effective GB/s by SURVEY.md 8d accounting; the state is LDS/register-resident so it may exceed HBM peak",
-            # what actually bounds the two kernels: the CU's fp64 pipe.  Saturation: 37 double-precision
-            # VALU instructions per cell and explicit sub-step (sat128.hip ISA), peak = CUs x 4 SIMDs x 16 lanes x clock
-            "compute_view": {
-                "saturation_fp64_valu_frac": (37.0 * nxy * nts * n_e / (sat_ms * 1e-3)) / (256 * 4 * 16 * 2.4e9),
-                "pressure_fp64_mfma_frac": (2.0 * 36 * 16 * 16 * 16 * 8 * NX * n_e / (prs_ms * 1e-3)) / 78.6e12,
-                "assumes": "2.4 GHz, 256 CUs; pressure flops = rank-16 updates of the 36 stored tiles x 8 panels x Nx blocks",
-            },
+            "per_kernel": {"saturation_fp64_valu_frac": 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                           "pressure_fp64_mfma_frac": prs_flops / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+            "effective_bandwidth_diagnostic": {
+                "note": "SURVEY.md 8d 'effective GB/s' (algorithmic bytes / launch time); exceeds the HBM peak by construction for the register-resident sweep",
+                "saturation_GBps": sat_bytes / (sat_ms * 1e-3) / 1e9, "pressure_GBps": prs_bytes / (prs_ms * 1e-3) / 1e9,
+                "algorithmic_bytes_per_launch": {"saturation": sat_bytes, "pressure": prs_bytes},
+                "compulsory_floor_bytes_per_member_step": 4 * w * nxy},
+            "mean_nts": nts, "assumes": "2.4 GHz, 256 CUs (the chip holds a lower clock under this load: profiles/rNN/fp64_roofline.json)",
         }
         upd = None if upd_sharded is None else {"sharded": upd_sharded}
         if world == 1:
@@ -287,15 +350,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"N_e={n_e} per GPU, {NX}x{NY} grid, forward model only (nTime={NTIME}, dt={DT}), fp64",
                        "members_per_gpu": n_e, "grid": [NX, NY], "nTime": NTIME, "device": ctx.name(),
-                       "kernel_variant": args.variant, "results_finite_and_status_ok": bool(ok)},
-            "roofline": roofline, "cpu_baseline": cpu, "es_update": upd,
+                       "kernel_variant": args.variant, "results_finite_and_status_ok": bool(ok),
+                       "ranks": "one process per GPU, host channel for barriers/timing, RCCL from the library for the update's reductions (no PyTorch)"},
+            "roofline": roofline, "cpu_baseline": cpu, "es_update": upd, "config4": c4,
             "device_ms": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
         }
         print(json.dumps(out))
-    plan.close()
-    if td is not None:
-        td.barrier()
-        td.destroy_process_group()
+    comm.barrier()
+    comm.close()
     if not ok:
         sys.exit(3)
 

@@ -31,6 +31,7 @@ class hm_stats(C.Structure):
         ("n_saturation_launches", C.c_longlong),
         ("member_steps", C.c_longlong),
         ("mean_n_cg", C.c_double),
+        ("ms_comm", C.c_double),
     ]
 
     def asdict(self):
@@ -48,6 +49,17 @@ SIGNATURES = {
     "hm_abi_version": (C.c_int, []),
     "hm_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_longlong]),
     "hm_copy_to_device": (C.c_int, [_vp, _vp, _vp, C.c_longlong]),
+    "hm_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "hm_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(_vp)]),
+    "hm_comm_destroy": (None, [_vp]),
+    "hm_comm_rank": (C.c_int, [_vp]),
+    "hm_comm_world_size": (C.c_int, [_vp]),
+    "hm_comm_all_reduce": (C.c_int, [_vp, _vp, C.c_longlong, C.c_int, C.c_int]),
+    "hm_comm_all_gather": (C.c_int, [_vp, _vp, C.c_longlong, C.c_int]),
+    "hm_comm_broadcast": (C.c_int, [_vp, _vp, C.c_longlong, C.c_int, C.c_int]),
+    "hm_comm_group_start": (C.c_int, [_vp]),
+    "hm_comm_group_end": (C.c_int, [_vp]),
+    "hm_comm_sync": (C.c_int, [_vp]),
     "hm_forward_batched": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _vp, C.c_int, _vp,
                                      C.c_int, _ip, _dp, C.c_int, C.c_int, _ip, _dp, C.c_int, C.c_double, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_double, _dp, C.c_int, C.c_int, _vp, _vp,
@@ -80,6 +92,9 @@ SIGNATURES = {
     "hm_upd_set_inputs": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double]),
     "hm_upd_phase": (C.c_int, [_vp, C.c_int]),
     "hm_upd_run": (C.c_int, [_vp]),
+    "hm_upd_set_column_shard": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "hm_upd_all_reduce": (C.c_int, [_vp, _vp, C.c_int]),
+    "hm_upd_run_comm": (C.c_int, [_vp, _vp]),
     "hm_recompose": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "hm_sample_kron": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "hm_upd_set_inputs_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),
@@ -129,34 +144,12 @@ def as_c(a, dtype):
     return None if a is None else np.ascontiguousarray(a, dtype=dtype)
 
 
-def _torch_first():
-    """PyTorch-ROCm wheels carry their own copy of the HIP runtime; libhm_amd.so links the system one.  Both can live in
-    one process only if torch's copy opens the device FIRST (the other order leaves torch with "no GPUs found": RCCL
-    process groups then fail).  So: if torch is already imported, or this is a torch.distributed launch
-    (RANK/WORLD_SIZE set), let torch initialise its runtime before the first hm_create.  Plain single-process use never
-    imports torch."""
-    import sys
-
-    if os.environ.get("HM_AMD_NO_TORCH_PREINIT") == "1":
-        return
-    if "torch" not in sys.modules and "WORLD_SIZE" not in os.environ:
-        return
-    try:
-        import torch
-
-        if torch.cuda.device_count() > 0:
-            torch.cuda.init()
-    except Exception:
-        pass
-
-
 class Context:
     """One HIP context (device + stream).  Reused process-wide per device."""
 
     _cache = {}
 
     def __init__(self, device=0):
-        _torch_first()
         lib = load()
         h = C.c_void_p()
         check(lib.hm_create(int(device), C.byref(h)), "hm_create")

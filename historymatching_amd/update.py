@@ -124,13 +124,24 @@ class UpdatePlan:
 
     REDUCE_AFTER_PHASE = {0: (0, 1), 1: (2, 3)}  # which buffers to sum over ranks after each phase
 
+    def set_column_shard(self, rank, world_size):
+        """Localised plans over several ranks: this rank solves the state elements of block ``rank`` of ``world_size`` in
+        phase 2 (reduce buffer 4 = the weights, all-gathered before phase 3 applies them)."""
+        _lib.check(self.lib.hm_upd_set_column_shard(self.h, int(rank), int(world_size)), "hm_upd_set_column_shard")
+
+    def run_comm(self, comm_handle):
+        """The whole analysis step over the ranks of an RCCL communicator (``dist.Comm.rccl``): phases and collectives
+        queued on the context's stream, no host synchronisation in between (`hm_upd_run_comm`)."""
+        _lib.check(self.lib.hm_upd_run_comm(self.h, comm_handle), "hm_upd_run_comm")
+
     def reduce_buffer(self, which):
         n, eb = C.c_longlong(), C.c_int()
         p = self.lib.hm_upd_reduce_buffer(self.h, int(which), C.byref(n), C.byref(eb))
         return p, n.value, (np.float64 if eb.value == 8 else np.float32)
 
     def get_reduce(self, which):
-        """Host copy of reduce buffer `which` (0: colsum E, 1: colsum obs_ens, 2: X^T S, 3: S^T S)."""
+        """Host copy of reduce buffer `which` (0: colsum E, 1: colsum obs_ens, 2: X^T S, 3: S^T S, 4: the localised
+        analysis' weights W^T, blocks of state elements per rank)."""
         p, n, dt = self.reduce_buffer(which)
         out = np.empty(n, dtype=dt)
         _lib.check(self.lib.hm_copy_to_host(self.ctx.handle, _lib.ptr(out), p, out.nbytes), "hm_copy_to_host")

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Static instruction census of a kernel's hot loop from the built object (no GPU needed).
+
+    python3 profiles/tools/isa_count.py historymatching_amd/csrc/sat128.o k_sat128ILb1
+
+Extracts the gfx950 code object from the fat object (llvm-objdump --offloading), disassembles it, finds the loop with the
+largest body inside the first function whose mangled name contains the given substring (a backward s_cbranch to an earlier
+address) and counts its instructions by class.  For k_sat128 that loop is the explicit sub-step loop: one trip = one sub-step of
+the thread's 8 x 4 cell patch, so `dp_valu / 32` is the double-precision VALU instructions per cell per sub-step that
+bench.py's roofline uses (profiles/rNN/isa_counts.json)."""
+import json
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def disassemble(obj):
+    with tempfile.TemporaryDirectory() as d:
+        local = Path(d) / Path(obj).name
+        shutil.copy(obj, local)
+        subprocess.run([OBJDUMP, "--offloading", local.name], cwd=d, check=True, capture_output=True)
+        co = next(Path(d).glob("*gfx950*"))
+        return subprocess.run([OBJDUMP, "-d", str(co)], check=True, capture_output=True, text=True).stdout
+
+
+def functions(text):
+    out, name, body = {}, None, []
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            if name:
+                out[name] = body
+            name, body = m.group(1), []
+            continue
+        m = re.match(r"^\s+(\S+)\s+(.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+        if m and name:
+            body.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    if name:
+        out[name] = body
+    return out
+
+
+def classify(op):
+    if op.startswith("v_mfma"):
+        return "mfma"
+    if re.match(r"v_.*_f64", op) or op in ("v_rcp_f64_e32", "v_rcp_f64_e64"):
+        return "dp_valu"
+    if op.startswith("v_"):
+        return "other_valu"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+        return "vmem"
+    if op.startswith("s_"):
+        return "salu"
+    return "other"
+
+
+def hot_loop(body):
+    addr_index = {a: i for i, (a, _, _) in enumerate(body)}
+    best = None
+    for i, (a, op, args) in enumerate(body):
+        if not op.startswith("s_cbranch") and op != "s_branch":
+            continue
+        m = re.search(r"<[^>]*\+0x([0-9a-f]+)>", args) or re.search(r"<[^>+]*>", args)
+        # objdump prints the target as  <func+0xOFF>; recover the absolute address from the simm16
+        m16 = re.match(r"(\d+)", args.strip())
+        if not m16:
+            continue
+        off = int(m16.group(1))
+        if off >= 0x8000:
+            off -= 0x10000
+        target = a + 4 + 4 * off
+        if target <= a and target in addr_index:
+            j = addr_index[target]
+            if best is None or (i - j) > (best[1] - best[0]):
+                best = (j, i)
+    return best
+
+
+def main():
+    obj, sub = sys.argv[1], sys.argv[2]
+    per = float(sys.argv[3]) if len(sys.argv) > 3 else 32.0
+    fns = functions(disassemble(obj))
+    name = next(n for n in fns if sub in n)
+    body = fns[name]
+    lo, hi = hot_loop(body)
+    counts = {}
+    divisions = 0
+    for _, op, _ in body[lo:hi + 1]:
+        c = classify(op)
+        counts[c] = counts.get(c, 0) + 1
+        if op.startswith("v_div_fmas_f64"):
+            divisions += 1
+    out = {"object": obj, "kernel": name, "loop_instructions": hi - lo + 1, "counts": counts, "fp64_divisions": divisions,
+           "cells_per_thread_per_trip": per, "dp_valu_per_cell_substep": counts.get("dp_valu", 0) / per,
+           "valu_per_cell_substep": (counts.get("dp_valu", 0) + counts.get("other_valu", 0)) / per}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hm_abi_version() == 1
+    assert lib.hm_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_device(lib):

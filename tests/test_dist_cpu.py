@@ -1,9 +1,11 @@
-"""N>1 path on CPU: world_size-2 `gloo` process groups drive the SAME host logic the GPU ranks use
-(historymatching_amd.dist: member sharding, the two reduction points of the sharded update, ordered gather).
-The per-rank compute is a NumPy test double with the device plan's interface (phases / reduce buffers), built
-from the oracle's formulas -- tests may use the oracle, the product path never does."""
+"""N>1 path on CPU: world_size-2 runs drive the SAME host logic the GPU ranks use (historymatching_amd.dist: member
+sharding, the reduction points of the sharded update incl. the column-sharded localised solves, ordered gather, failure
+agreement) -- once over the product's own host channel (localhost sockets, no PyTorch) and once over a `gloo` process group
+through a test-side adapter with the same methods.  The per-rank compute is a NumPy test double with the device plan's
+interface (phases / reduce buffers), built from the oracle's formulas -- tests may use the oracle, the product path never does."""
 import os
 import socket
+import tempfile
 
 import numpy as np
 import pytest
@@ -20,7 +22,12 @@ class HostShardPlan:
     def __init__(self, N_total, E, obs_ens, obs, perturbs, decorr, taper=None, cutoff=1e-2):
         self.N, self.E, self.obs_ens, self.obs, self.perturbs, self.decorr = N_total, E, obs_ens, obs, perturbs, decorr
         self.taper, self.cutoff = taper, cutoff
+        self.localized = taper is not None
         self.red = {}
+        self.col = (0, 1)  # (rank, world) of the column shard of the localised solves
+
+    def set_column_shard(self, rank, world):
+        self.col = (rank, world)
 
     def phase(self, k):
         N = self.N
@@ -32,21 +39,30 @@ class HostShardPlan:
             self.S = Y @ self.decorr
             self.D = (self.obs - self.obs_ens - self.perturbs) @ self.decorr
             self.red[2], self.red[3] = (X.T @ self.S).ravel(), (self.S.T @ self.S).ravel()
-        else:
+        elif k == 2:
             n_obs = len(self.obs)
             G = self.red[3].reshape(n_obs, n_obs)
             Gxt = self.red[2].reshape(-1, n_obs)
             if self.taper is None:
                 self.out = self.E + (self.D @ np.linalg.inv(G + (N - 1) * np.eye(n_obs))) @ Gxt.T
-            else:
-                Wt = np.zeros_like(Gxt)
-                for i in range(Gxt.shape[0]):
-                    c = np.sqrt(self.taper[i])
-                    jj = c > self.cutoff
-                    if jj.any():
-                        Ci = np.outer(c[jj], c[jj]) * G[np.ix_(jj, jj)] + (N - 1) * np.eye(jj.sum())
-                        Wt[i, jj] = c[jj] * np.linalg.solve(Ci, c[jj] * Gxt[i, jj])
-                self.out = self.E + self.D @ Wt.T
+                return
+            M = Gxt.shape[0]
+            rank, world = self.col
+            chunk = -(-M // world)
+            Wt = np.zeros((world * chunk, n_obs))  # padded to equal blocks like the device buffer
+            for i in range(rank * chunk, min(M, (rank + 1) * chunk)):
+                c = np.sqrt(self.taper[i])
+                jj = c > self.cutoff
+                if jj.any():
+                    Ci = np.outer(c[jj], c[jj]) * G[np.ix_(jj, jj)] + (N - 1) * np.eye(jj.sum())
+                    Wt[i, jj] = c[jj] * np.linalg.solve(Ci, c[jj] * Gxt[i, jj])
+            self.red[4] = Wt.ravel()
+            if world == 1:
+                self.phase(3)
+        else:
+            n_obs = len(self.obs)
+            Wt = self.red[4].reshape(-1, n_obs)[: self.E.shape[1]]
+            self.out = self.E + self.D @ Wt.T
 
     def get_reduce(self, which):
         return self.red[which]
@@ -88,27 +104,78 @@ def _inputs():
     return N, E, obs_ens, obs, perturbs, decorr, taper
 
 
-def _worker(rank, world, port, q):
+class GlooComm:
+    """Test-side adapter: the methods `dist.sharded_update` / `forward_model_sharded` use, over a torch.distributed gloo group."""
+
+    rccl = None
+
+    def __init__(self):
+        import torch.distributed as td
+
+        self.td = td
+        self.rank, self.world_size = td.get_rank(), td.get_world_size()
+
+    def all_reduce_sum(self, arr):
+        import torch
+
+        t = torch.from_numpy(np.array(arr, copy=True))
+        self.td.all_reduce(t)
+        return t.numpy()
+
+    def all_gather_rows(self, arr):
+        out = [None] * self.world_size
+        self.td.all_gather_object(out, np.ascontiguousarray(arr))
+        return np.concatenate(out, axis=0)
+
+
+def _drive(comm, rank, world):
+    assert (comm.rank, comm.world_size) == (rank, world)
+    N, E, obs_ens, obs, perturbs, decorr, taper = _inputs()
+    lo, hi = shard_bounds(N, world, rank)
+    res = {}
+    for name, tp in (("global", None), ("local", taper)):
+        plan = HostShardPlan(N, E[lo:hi], obs_ens[lo:hi], obs, perturbs[lo:hi], decorr, taper=tp)
+        res[name] = comm.all_gather_rows(sharded_update(plan, comm))
+        if tp is not None:
+            assert plan.col == (rank, world)  # the localised solves were column-sharded
+
+    # forward model: member blocks, ordered gather, per-member wsat0 zipped along
+    def local_forward(perms, wsat0s):
+        return [perms[:, None, :] * 2 + wsat0s[:, None, :], perms[:, :3, None] + np.zeros((1, 1, 4))]
+
+    perms = np.arange(N * 5, dtype=float).reshape(N, 5)
+    w, p = forward_model_sharded(local_forward, perms, perms * 0.5, comm=comm)
+    res["w"], res["p"] = w, p
+    return res
+
+
+def _worker_sockets(rank, world, rdzv, q):
+    comm = Comm(rank, world, rdzv)
+    try:
+        res = _drive(comm, rank, world)
+        # host collectives of the product channel
+        assert comm.all_reduce_max(rank * 10) == (world - 1) * 10
+        assert comm.enable_rccl() is False and comm.rccl_error  # no GPU here: every rank stays on the host channel
+        # failure agreement: rank 1 fails, both ranks raise together instead of rank 0 waiting in the next collective
+        try:
+            comm.raise_if_any(RuntimeError("boom") if rank == 1 else None, "step failed")
+            res["agreed"] = False
+        except Exception as e:
+            res["agreed"] = "boom" in str(e)
+        comm.barrier()
+        if rank == 0:
+            q.put(res)
+    finally:
+        comm.close()
+
+
+def _worker_gloo(rank, world, port, q):
     import torch.distributed as td
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        comm = Comm()
-        assert (comm.rank, comm.world_size) == (rank, world)
-        N, E, obs_ens, obs, perturbs, decorr, taper = _inputs()
-        lo, hi = shard_bounds(N, world, rank)
-        res = {}
-        for name, tp in (("global", None), ("local", taper)):
-            plan = HostShardPlan(N, E[lo:hi], obs_ens[lo:hi], obs, perturbs[lo:hi], decorr, taper=tp)
-            res[name] = comm.all_gather_rows(sharded_update(plan, comm))
-        # forward model: member blocks, ordered gather, per-member wsat0 zipped along
-        def local_forward(perms, wsat0s):
-            return [perms[:, None, :] * 2 + wsat0s[:, None, :], perms[:, :3, None] + np.zeros((1, 1, 4))]
-
-        perms = np.arange(N * 5, dtype=float).reshape(N, 5)
-        w, p = forward_model_sharded(local_forward, perms, perms * 0.5, comm=comm)
-        res["w"], res["p"] = w, p
+        res = _drive(GlooComm(), rank, world)
         if rank == 0:
             q.put(res)
     finally:
@@ -116,26 +183,42 @@ def _worker(rank, world, port, q):
         td.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_world_size_2_gloo_sharded_update_and_forward():
-    import torch.multiprocessing as mp
-
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = q.get(timeout=240)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+def _check(res):
     N, E, obs_ens, obs, perturbs, decorr, taper = _inputs()
     assert np.abs(res["global"] - es.ens_update0(E, obs_ens, obs, perturbs, decorr)).max() < 1e-11
     assert np.abs(res["local"] - es.ens_update0_loc(E, obs_ens, obs, perturbs, decorr, taper)).max() < 1e-11
     perms = np.arange(N * 5, dtype=float).reshape(N, 5)
     assert np.array_equal(res["w"], (perms * 2 + perms * 0.5)[:, None, :])
     assert res["p"].shape == (N, 3, 4)
+
+
+def _run(target, world, extra):
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, extra, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_world_size_n_host_channel_sharded_update_and_forward(world):
+    with tempfile.TemporaryDirectory() as d:
+        res = _run(_worker_sockets, world, os.path.join(d, "rdzv"))
+    _check(res)
+    assert res["agreed"] is True
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_gloo_sharded_update_and_forward():
+    _check(_run(_worker_gloo, 2, _free_port()))
 
 
 def test_single_process_comm_is_identity():

@@ -1,9 +1,10 @@
 """Multi-rank ES-MDA with device-resident members (historymatching_amd.dist.es_mda_sharded) on the one GPU of the test box:
-two processes (gloo rendezvous, host-staged all-reduces; both ranks use device 0) against the single-process
-device-resident driver on the whole ensemble.  The RCCL form of the same all-reduces is covered by
-test_update_gpu.py::test_rccl_all_reduce_on_library_buffers."""
+two processes (the product's host channel; both ranks use device 0) against the single-process device-resident driver on
+the whole ensemble.  Both ranks ask for RCCL first: RCCL does not accept two ranks of a communicator on one GPU
+("Duplicate GPU detected"), which the ranks agree on and then run the same reductions host-staged.  The RCCL form itself
+runs in test_update_gpu.py::test_rccl_communicator_runs_the_analysis_step_on_library_buffers."""
 import os
-import socket
+import tempfile
 
 import numpy as np
 import pytest
@@ -28,59 +29,53 @@ def _problem():
     return model, prior, obs, R12, taper
 
 
-def _worker(rank, world, port, q):
-    import torch.distributed as td
+def _worker(rank, world, rdzv, q):
+    from historymatching_amd.dist import Comm, es_mda_sharded, shard_bounds
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    td.init_process_group("gloo", rank=rank, world_size=world)
+    comm = Comm(rank, world, rdzv, local_rank=0)
     try:
-        from historymatching_amd.dist import Comm, es_mda_sharded, shard_bounds
-
-        comm = Comm()
+        got_rccl = comm.enable_rccl()
         model, prior, obs, R12, taper = _problem()
         lo, hi = shard_bounds(N, world, rank)
-        res = {}
+        res = {"rccl": got_rccl, "rccl_error": comm.rccl_error}
         for name, tp in (("global", None), ("local", taper)):
             post = es_mda_sharded(model, prior[lo:hi], obs, R12, DT, NT, n_iter=2, seed=5, comm=comm, dtype=64, taper=tp, device=0)
             res[name] = comm.all_gather_rows(post)
+        comm.barrier()
         if rank == 0:
             q.put(res)
     finally:
-        td.barrier()
-        td.destroy_process_group()
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+        comm.close()
 
 
 @pytest.mark.timeout(600)
 def test_two_rank_es_mda_matches_single_process():
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
 
     from historymatching_amd.dist import es_mda_sharded
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = None
-    for _ in range(500):  # a crashed worker must fail the test at once, not after the queue's timeout
-        try:
-            res = q.get(timeout=1.0)
-            break
-        except Exception:
-            if any(p.exitcode not in (None, 0) for p in procs):
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=_worker, args=(r, 2, os.path.join(d, "rdzv"), q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = None
+        for _ in range(500):  # a crashed worker must fail the test at once, not after the queue's timeout
+            try:
+                res = q.get(timeout=1.0)
                 break
-    for p in procs:
-        p.join(60 if res is not None else 5)
-        if p.is_alive():
-            p.terminate()
+            except Exception:
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    break
+        for p in procs:
+            p.join(60 if res is not None else 5)
+            if p.is_alive():
+                p.terminate()
     assert res is not None and all(p.exitcode == 0 for p in procs)
+    # two ranks on ONE device: RCCL must have been refused on both ranks, with its own diagnosis
+    if not res["rccl"]:
+        assert "rank 0" in res["rccl_error"] and "rank 1" in res["rccl_error"]
     model, prior, obs, R12, taper = _problem()
     for name, tp in (("global", None), ("local", taper)):
         ref = es_mda_sharded(model, prior, obs, R12, DT, NT, n_iter=2, seed=5, dtype=64, taper=tp, device=0)

@@ -277,43 +277,102 @@ def test_matrix_core_spd_inverse(n, golden):
         assert np.abs(W - W.T).max() <= 1e-9 * np.abs(ref).max()  # off-diagonal tiles are mirrored, diagonal tiles swept
 
 
-def test_rccl_all_reduce_on_library_buffers():
-    """The multi-rank update sums its reduce buffers with RCCL directly on the library's device memory
-    (dist.Comm.all_reduce_device, zero-copy through __cuda_array_interface__).  One rank here (one GPU per box): the
-    collective must run on the wrapped pointer and leave the single contribution unchanged; the two-rank arithmetic is
-    covered on CPU (tests/test_dist_cpu.py) and by the two-shard test above."""
-    import os
-    import socket
+def test_rccl_communicator_runs_the_analysis_step_on_library_buffers():
+    """The multi-rank update's collectives are issued by the library itself (hm_comm_* / hm_upd_run_comm: RCCL opened with
+    dlopen, in place on the plan's device buffers, on the context's stream).  One rank here (RCCL refuses two ranks on one
+    GPU and the test box has one): a real RCCL communicator of world size 1 drives (a) MAX / SUM all-reduces and an
+    all-gather on library memory, (b) the whole global analysis step (fp32 matrix-core path and fp64) and (c) the localised
+    one, each equal to the same plan's single-process run.  The two-rank arithmetic is covered on the host channel
+    (tests/test_dist_cpu.py, tests/test_dist_gpu.py)."""
+    import ctypes as C
 
-    import torch
-    import torch.distributed as td
-
-    from historymatching_amd.dist import Comm
+    from historymatching_amd import _lib
+    from historymatching_amd.dist import Comm, sharded_update
     from historymatching_amd.update import UpdatePlan
+    from oracle import es
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    td.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        rng = np.random.RandomState(3)
-        N, M, n_obs = 24, 64, 32
-        p = UpdatePlan(N, N, M, n_obs, dtype=32)
-        p.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), rng.rand(n_obs), 0.1 * rng.randn(N, n_obs), np.eye(n_obs))
-        p.phase(0)
-        p.phase(1)
-        p.sync()
-        comm = Comm()
-        assert comm.backend == "nccl"
-        for which in (2, 3):
-            before = p.get_reduce(which).copy()
-            ptr, n, dt = p.reduce_buffer(which)
-            comm.all_reduce_device(ptr, n, dt, force=True)
-            assert np.array_equal(p.get_reduce(which), before)
-        p.close()
-    finally:
-        td.destroy_process_group()
+    comm = Comm()
+    assert comm.enable_rccl() is False                      # one rank: nothing to create ...
+    assert comm.enable_rccl(force_single=True), comm.rccl_error   # ... unless asked to
+    lib, ctx = comm.ctx.lib, comm.ctx
+    assert lib.hm_comm_world_size(comm.rccl) == 1 and lib.hm_comm_rank(comm.rccl) == 0
+    rng = np.random.RandomState(3)
+    N, M, n_obs = 96, 512, 32
+    E = rng.randn(N, M) + rng.randn(M)
+    obs_ens = 0.3 * E[:, :n_obs] + 0.1 * rng.randn(N, n_obs)
+    _, R12, decorr = es.obs_error_model(n_obs // 4, 4)
+    obs = obs_ens[0] + R12 @ rng.randn(n_obs)
+    perturbs = rng.randn(N, n_obs) @ R12.T
+    taper = es.bump(rng.rand(M, n_obs) * 1.3)
+    # (a) raw collectives on a plan's reduce buffer
+    p = UpdatePlan(N, N, M, n_obs, dtype=32)
+    p.set_inputs(E, obs_ens, obs, perturbs, decorr)
+    p.phase(0)
+    before = p.get_reduce(0).copy()
+    ptr, n, dt = p.reduce_buffer(0)
+    comm.device_all_reduce(ptr, n, dt, "sum")
+    comm.device_all_reduce(ptr, n, dt, "max")
+    _lib.check(lib.hm_comm_all_gather(comm.rccl, C.c_void_p(ptr), n, 32), "hm_comm_all_gather")
+    _lib.check(lib.hm_comm_broadcast(comm.rccl, C.c_void_p(ptr), n, 32, 0), "hm_comm_broadcast")
+    comm.device_sync()
+    assert np.array_equal(p.get_reduce(0), before)
+    p.close()
+    # (b), (c): the analysis step through hm_upd_run_comm
+    for dtype, loc in ((32, False), (64, False), (32, True), (64, True)):
+        outs = []
+        for through_comm in (True, False):
+            p = UpdatePlan(N, N, M, n_obs, dtype=dtype, localized=loc)
+            p.set_inputs(E, obs_ens, obs, perturbs, decorr, taper if loc else None)
+            if through_comm:
+                outs.append(sharded_update(p, comm))
+                assert p.ctx is ctx
+            else:
+                for ph in range(3):
+                    p.phase(ph)
+                p.sync()
+                outs.append(p.output())
+            p.close()
+        assert np.array_equal(outs[0], outs[1])
+        ref = es.ens_update0_loc(E, obs_ens, obs, perturbs, decorr, taper) if loc else es.ens_update0(E, obs_ens, obs, perturbs, decorr)
+        assert np.abs(outs[0] - ref).max() <= (1e-10 if dtype == 64 else 1e-4 * np.abs(ref - E).max())
+    comm.close()
+
+
+def test_column_sharded_localised_solves_match_unsharded():
+    """the per-element solves of the localised analysis sharded by state column over G ranks (here G plans on one
+    GPU, the all-gather of the weights done on the host) reproduce the unsharded plan bit for bit -- M not a multiple of G, so
+    the last block is ragged and the buffer padded."""
+    from historymatching_amd.update import UpdatePlan
+    from oracle import es
+
+    rng = np.random.RandomState(12)
+    N, M, n_obs, G = 64, 1001, 32, 3
+    E = rng.randn(N, M)
+    obs_ens = 0.3 * E[:, :n_obs] + 0.1 * rng.randn(N, n_obs)
+    _, R12, decorr = es.obs_error_model(n_obs // 4, 4)
+    obs = obs_ens[0] + R12 @ rng.randn(n_obs)
+    perturbs = rng.randn(N, n_obs) @ R12.T
+    taper = es.bump(rng.rand(M, n_obs) * 1.3)
+    for dtype in (64, 32):
+        full = UpdatePlan(N, N, M, n_obs, dtype=dtype, localized=True)
+        full.set_inputs(E, obs_ens, obs, perturbs, decorr, taper)
+        ref = (full.run_local(), full.output())[1]
+        full.close()
+        plans = []
+        for r in range(G):  # every "rank" holds all rows here: only the column shard differs
+            p = UpdatePlan(N, N, M, n_obs, dtype=dtype, localized=True)
+            p.set_inputs(E, obs_ens, obs, perturbs, decorr, taper)
+            p.set_column_shard(r, G)
+            for ph in range(3):
+                p.phase(ph)
+            plans.append(p)
+        blocks = [p.get_reduce(4).reshape(G, -1)[r] for r, p in enumerate(plans)]
+        for p in plans:
+            p.set_reduce(4, np.concatenate(blocks))
+            p.phase(3)
+            p.sync()
+            assert np.array_equal(p.output(), ref)
+            p.close()
 
 
 def test_ies_matches_reference_fixtures(golden):
@@ -350,33 +409,3 @@ def test_device_kronecker_prior_sampler_matches_host(nx, ny, N):
     dev = gaussian_fields_kron_device(nx, ny, 2, 1, N, r=0.8, seed=11)
     assert dev.shape == host.shape
     assert np.abs(dev - host).max() <= 1e-12 * max(1.0, np.abs(host).max())
-
-
-def test_torch_kernels_read_and_write_library_buffers():
-    """dist.Comm.all_reduce_device hands RCCL a tensor that aliases a device buffer of the library (two HIP runtime copies
-    live in the process: PyTorch's bundled one and the library's).  A one-rank all-reduce never touches the buffer, so this
-    pins the assumption directly: kernels launched by PyTorch's runtime read and modify the library's reduce buffer."""
-    import torch
-
-    from historymatching_amd.update import UpdatePlan
-
-    N, M, n_obs = 8, 256, 16
-    rng = np.random.RandomState(0)
-    plan = UpdatePlan(N, N, M, n_obs, dtype=32)
-    plan.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), rng.rand(n_obs), 0.1 * rng.randn(N, n_obs), np.eye(n_obs))
-    plan.phase(0)
-    plan.sync()
-    ptr, n, dt = plan.reduce_buffer(0)
-    before = plan.get_reduce(0).copy()
-
-    class _Dev:
-        pass
-
-    d = _Dev()
-    d.__cuda_array_interface__ = {"shape": (int(n),), "typestr": np.dtype(dt).str, "data": (int(ptr), False), "version": 2}
-    t = torch.as_tensor(d, device=torch.device("cuda", 0))
-    assert np.array_equal(t.cpu().numpy(), before)
-    t.mul_(2.0).add_(1.0)
-    torch.cuda.synchronize()
-    assert np.allclose(plan.get_reduce(0), 2 * before + 1)
-    plan.close()
