@@ -102,6 +102,12 @@ SIGNATURES = {
     "hm_debug_spd_inverse": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp]),
     "hm_upd_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "hm_upd_reduce_buffer": (_vp, [_vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
+    "hm_iles_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, C.c_double, _dp, C.POINTER(_vp)]),
+    "hm_iles_destroy": (None, [_vp]),
+    "hm_iles_compose": (C.c_int, [_vp, _vp]),
+    "hm_iles_step": (C.c_int, [_vp, _dp, _dp, C.c_double]),
+    "hm_iles_get_weights": (C.c_int, [_vp, C.c_int, _dp]),
+    "hm_iles_device_ptr": (_vp, [_vp, C.c_char_p]),
     "hm_upd_sync": (C.c_int, [_vp, C.POINTER(hm_stats)]),
     "hm_upd_get_output": (C.c_int, [_vp, _vp]),
     "hm_upd_device_ptr": (_vp, [_vp, C.c_char_p]),

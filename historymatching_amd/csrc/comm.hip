@@ -8,6 +8,7 @@
 // librccl.so.1 is opened lazily with dlopen: single-GPU users never load it.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include "common.h"
 
@@ -106,7 +107,17 @@ extern "C" int hm_comm_create(hm_ctx* ctx, int rank, int world_size, const char*
     memcpy(&id, unique_id, sizeof(id));
     hm_comm* c = new hm_comm();
     c->ctx = ctx; c->rank = rank; c->world = world_size;
+    // RCCL 2.27 prints a version banner with printf to stdout while rank 0 initialises; callers (bench.py) own stdout
+    // (one JSON line): for the duration of the call C stdout is pointed at stderr, flushed, and restored.
+    fflush(stdout);
+    const int saved_out = dup(STDOUT_FILENO);
+    if (saved_out >= 0) (void)dup2(STDERR_FILENO, STDOUT_FILENO);
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, world_size, id, rank);
+    fflush(stdout);
+    if (saved_out >= 0) {
+        (void)dup2(saved_out, STDOUT_FILENO);
+        close(saved_out);
+    }
     if (r != ncclSuccess) {
         const char* more = g_rccl.GetLastError ? g_rccl.GetLastError(nullptr) : "";
         hm_set_error("ncclCommInitRank(rank %d of %d, device %d) failed: %s%s%s", rank, world_size, ctx->device, g_rccl.GetErrorString(r),

@@ -288,11 +288,104 @@ def ies(prior_ens, obs_ens, obs, perturbs, decorr, xStep=1.0, iMax=4, dtype=64, 
     return recompose(W, X0, x0, dtype=dtype, device=device).astype(float), stats
 
 
-def iles(prior_ens, obs_ens, obs, perturbs, decorr, taper, xStep=1.0, iMax=4, cutoff=1e-2):
+class IlesPlan:
+    """Device-resident state of the partitioned localised iterative smoother (``hm_iles_*``): the centred prior, one N x N
+    weight matrix per batch (local domain) of state elements, the composed ensemble."""
+
+    def __init__(self, prior_ens, batches, taper_b, cutoff=1e-2, device=None):
+        prior = _lib.as_c(prior_ens, np.float64)
+        self.N, self.M = prior.shape
+        sizes = np.array([len(b) for b in batches], dtype=np.int64)
+        index = np.concatenate([np.asarray(b, dtype=np.int64).reshape(-1) for b in batches])
+        if len(index) != self.M or not np.array_equal(np.sort(index), np.arange(self.M)):
+            raise ValueError("the batches must partition the state elements 0..M-1")
+        self.B = len(batches)
+        taper_b = _lib.as_c(taper_b, np.float64)
+        self.n_obs = taper_b.shape[1]
+        if taper_b.shape != (self.B, self.n_obs):
+            raise ValueError(f"taper_b must have shape {(self.B, self.n_obs)}")
+        off = np.ascontiguousarray(np.concatenate([[0], np.cumsum(sizes)]), dtype=np.int32)
+        idx = np.ascontiguousarray(index, dtype=np.int32)
+        self.ctx = _lib.Context.get(device)
+        self.lib = self.ctx.lib
+        h = C.c_void_p()
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        _lib.check(self.lib.hm_iles_create(self.ctx.handle, self.N, self.M, self.n_obs, self.B, ip(off), ip(idx), dp(taper_b),
+                                           float(cutoff), dp(prior), C.byref(h)), "hm_iles_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.hm_iles_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def compose(self):
+        """``x0 + W_b X0`` per batch (HistoryMatch.py:1021-1022) -> ``(N, M)``."""
+        E = np.empty((self.N, self.M))
+        _lib.check(self.lib.hm_iles_compose(self.h, _lib.ptr(E)), "hm_iles_compose")
+        return E
+
+    def step(self, S, D, xStep):
+        S, D = _lib.as_c(S, np.float64), _lib.as_c(D, np.float64)
+        if S.shape != (self.N, self.n_obs) or D.shape != S.shape:
+            raise ValueError(f"S and D must have shape {(self.N, self.n_obs)}")
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        _lib.check(self.lib.hm_iles_step(self.h, dp(S), dp(D), float(xStep)), "hm_iles_step")
+
+    def weights(self, batch):
+        W = np.empty((self.N, self.N))
+        _lib.check(self.lib.hm_iles_get_weights(self.h, int(batch), W.ctypes.data_as(C.POINTER(C.c_double))), "hm_iles_get_weights")
+        return W
+
+
+def iles(prior_ens, obs_ens, obs, perturbs, decorr, taper, xStep=1.0, iMax=4, cutoff=1e-2, batches=None, device=None):
     """Localised iterative ensemble smoother, same call surface as the reference's `ILES`
-    (notebooks/HistoryMatch.py:1007-1064): one N x N weight matrix PER STATE ELEMENT, each updated by the Gauss-Newton
-    step of `ies` restricted to the observations whose ``sqrt(taper[i]) > cutoff``, scaled by those taper weights.
+    (notebooks/HistoryMatch.py:1007-1064): one N x N weight matrix per local domain, each updated by the Gauss-Newton
+    step of `ies` restricted to the observations whose ``sqrt(taper) > cutoff``, scaled by those taper weights.
     Returns ``(posterior_ens, stats)``.
+
+    ``batches``: the local domains -- a list of index arrays that partition the state elements (e.g.
+    ``localization.rectangular_partitioning(model.shape, (8, 8))``: the batched form the reference points at,
+    HistoryMatch.py:802-804); the elements of a batch share one weight matrix and the mean of their taper rows.  None = one
+    element per batch: the reference's algorithm itself (its ``M N^2`` weight storage then lives in HBM).
+    The per-domain subspace algebra (a linear solve with W, an n_loc x n_loc Cholesky, three N x N x n_loc products per
+    iterate) and the re-composition of the ensemble run on the GPU in fp64 (`hm_iles_*`); the forward model behind
+    ``obs_ens`` is the caller's (the GPU forward model in the workflow).  Domains without any observation in range keep
+    their prior weights."""
+    prior_ens = np.asarray(prior_ens, dtype=float)
+    taper = np.asarray(taper, dtype=float)
+    N, M = prior_ens.shape
+    if taper.shape[0] != M:
+        raise ValueError(f"taper must have one row per state element ({M}), got {taper.shape}")
+    if batches is None:
+        batches = [np.array([i]) for i in range(M)]
+        taper_b = taper
+    else:
+        taper_b = np.stack([taper[np.asarray(b).reshape(-1)].mean(0) for b in batches])
+    plan = IlesPlan(prior_ens, batches, taper_b, cutoff=cutoff, device=device)
+    stats = {"E": [], "Eo": []}
+    try:
+        for _ in range(int(iMax)):
+            E = plan.compose()
+            Eo = np.asarray(obs_ens(E), dtype=float)
+            stats["E"].append(E)
+            stats["Eo"].append(Eo)
+            Sd = Eo @ decorr
+            Sd = Sd - Sd.mean(0)                                                              # HistoryMatch.py:1031
+            Dd = (np.asarray(obs, float) - Eo - np.asarray(perturbs, float)) @ decorr          # HistoryMatch.py:1032
+            plan.step(Sd, Dd, xStep)
+        post = plan.compose()
+    finally:
+        plan.close()
+    return post, stats
+
+
+def iles_host(prior_ens, obs_ens, obs, perturbs, decorr, taper, xStep=1.0, iMax=4, cutoff=1e-2):
+    """Host-NumPy twin of `iles` with one element per batch (the reference's own evaluation order: pseudo-inverse and SVD per
+    state element), kept as the in-package cross-check of the device path.
 
     The per-element subspace algebra (M pseudo-inverses and SVDs of N x N / N x n_loc matrices per iterate) is host
     NumPy in fp64, like the reference's, and its ``M * N^2`` weight storage limits it to the reference's own problem

@@ -23,6 +23,7 @@ typedef struct hm_ctx hm_ctx;   /* one per process per GPU */
 typedef struct hm_fwd hm_fwd;   /* device-resident ensemble forward-model plan */
 typedef struct hm_upd hm_upd;   /* device-resident ensemble-smoother update plan */
 typedef struct hm_comm hm_comm; /* RCCL communicator of one rank (one process per GPU) */
+typedef struct hm_iles hm_iles; /* localised iterative smoother: one weight matrix per local domain, on the device */
 
 /* Timing/accounting of the last run (all times from HIP events on the context's stream). */
 typedef struct hm_stats {
@@ -224,6 +225,23 @@ void* hm_upd_reduce_buffer(hm_upd* u, int which /*0..4*/, long long* n_elems, in
 int   hm_upd_sync(hm_upd* u, hm_stats* stats);
 int   hm_upd_get_output(hm_upd* u, void* E_out_local);
 void* hm_upd_device_ptr(hm_upd* u, const char* name);   /* "E","E_out","obs_ens","perturbs" */
+
+/* ---- localised iterative ensemble smoother, partitioned: replaces ILES ---------------------------------------------
+ * Reference: ILES  notebooks/HistoryMatch.py:1007-1064 (one N x N weight matrix per state element), in the batched form
+ * the reference points at (HistoryMatch.py:802-804; notebooks/tools/localization.py:95-145 rectangular_partitioning): the
+ * state elements batch_index[batch_offsets[b] .. batch_offsets[b+1]) share one weight matrix W_b and one taper row
+ * taper_b[b] (n_obs).  One element per batch = the reference's algorithm.  fp64.
+ *   hm_iles_create   uploads the prior (N x M), centres it (X0, x0: HistoryMatch.py:1017), sets every W_b = I
+ *   hm_iles_compose  E = x0 + W_b X0 per batch (HistoryMatch.py:1021-1025) -> host buffer (or NULL: stays on the device, "E")
+ *   hm_iles_step     one Gauss-Newton step of every W_b (HistoryMatch.py:1035-1058) from S = center(Eo decorr) and
+ *                    D = (obs - Eo - perturbs) decorr (N x n_obs, formed by the caller: HistoryMatch.py:1031-1032)            */
+int   hm_iles_create(hm_ctx* ctx, int N, int M, int n_obs, int B, const int* batch_offsets /* B+1 */, const int* batch_index /* M */,
+                     const double* taper_b /* B*n_obs */, double cutoff, const double* prior_ens /* N*M */, hm_iles** out);
+void  hm_iles_destroy(hm_iles* p);
+int   hm_iles_compose(hm_iles* p, double* E_out /* N*M or NULL */);
+int   hm_iles_step(hm_iles* p, const double* S, const double* D, double xstep);
+int   hm_iles_get_weights(hm_iles* p, int batch, double* W_out /* N*N */);
+void* hm_iles_device_ptr(hm_iles* p, const char* name /* "E","W","X0" */);
 
 #ifdef __cplusplus
 }

@@ -129,10 +129,10 @@ def test_product_obs_helpers_match_reference_fixture(golden):
 
 
 def test_product_iles_matches_reference_fixture(golden):
-    """historymatching_amd.update.iles (host algebra) against the output of the REAL reference `ILES` on
+    """historymatching_amd.update.iles_host (host algebra; the device path is tested in test_update_gpu.py) against the output of the REAL reference `ILES` on
     the linear-Gaussian bug check (fixture F6 `iles_gg`), which must also reproduce the non-iterative local analysis
     (HistoryMatch.py:1069-1071)."""
-    from historymatching_amd.update import iles
+    from historymatching_amd.update import iles_host as iles
 
     f1, f4, f6 = _load(golden, "f1_rng_replay.npz"), _load(golden, "f4_ens_update0_loc.npz"), _load(golden, "f6_iterative.npz")
     post, stats = iles(f1["gg_E"], lambda x: x, 4 * np.ones(3), f1["gg_perturbs"], 0.5 * np.eye(3), taper=np.eye(3))
