@@ -1,0 +1,48 @@
+"""Analysis step at BASELINE config 3 size (N=1000, M=128*128, n_obs=160, fp32 plan): device time of the fused run (hm_upd_run) in
+its variants -- decorrelated form vs Kalman form (contraction on the centred observations, gain through R), one stream vs the
+small fp64 chain on a second stream -- with the reference's correlated observation error."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+import numpy as np
+import scipy.linalg as sla
+
+from historymatching_amd.obs import obs_error_model
+from historymatching_amd.update import UpdatePlan
+
+N, M, n_obs = 1000, 128 * 128, 160
+rng = np.random.RandomState(0)
+R12 = obs_error_model(40, 4)[1]
+E = rng.randn(N, M)
+obs_ens = rng.rand(N, n_obs)
+obs = rng.rand(n_obs)
+perturbs = rng.randn(N, n_obs) @ R12.T
+decorr = sla.inv(R12.T)
+res = {}
+outs = {}
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+for kal, ov, kc in ((0, 0, 32), (0, 1, 32), (1, 0, 32), (1, 1, 32), (1, 0, 64), (1, 1, 64)):
+    if True:
+        p = UpdatePlan(N, N, M, n_obs, dtype=32)
+        p.set_option("kalman_form", kal)
+        p.set_option("overlap", ov)
+        p.set_option("gxt_chunk", kc)
+        p.set_inputs(E, obs_ens, obs, perturbs, decorr)
+        p.run_local()
+        ts = sorted(p.run_local()["ms_update"] for _ in range(reps))
+        # back to back: 10 analysis steps queued without a host synchronisation in between (as ES-MDA chains them behind the
+        # forward model): no idle gap in front of the first kernel of a step
+        from historymatching_amd import _lib
+        for _ in range(10):
+            _lib.check(p.lib.hm_upd_run(p.h), "hm_upd_run")
+        b2b = p.sync()["ms_update"] / 10
+        outs[(kal, ov, kc)] = p.output()
+        p.close()
+        flops = 4.0 * N * n_obs * M
+        res[f"kalman{kal}_overlap{ov}_chunk{kc}"] = {"ms_median": ts[len(ts) // 2], "ms_best": ts[0], "ms_back_to_back": b2b, "frac_back_to_back": flops / b2b / 1e9 / 157.3, "frac_of_fp32_matrix_peak_median": flops / ts[len(ts) // 2] / 1e9 / 157.3}
+ref = outs[(0, 0, 32)].astype(float)
+inc = np.abs(ref - E).max()
+res["max_diff_between_variants_rel_to_increment"] = max(float(np.abs(o - ref).max() / inc) for o in outs.values())
+print(json.dumps(res, indent=1))

@@ -9,6 +9,8 @@
 // workgroup of 16 waves: waves 0, 4, 8, 12 are service waves (wave 0 sweeps), the other 12 hold SLOTS tiles each
 // (tile t -> wave t % 12, slot t / 12).  ~10 panels x ~5k cycles at n = 160: ~25 us against 129 us for the rank-1
 // register sweeps (k_invert_C_reg).
+#include <algorithm>
+
 #include "common.h"
 #include "sweep16.h"
 
@@ -66,7 +68,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * R + g.lq + 4 * r, col = 16 * C + g.lc;
                 // G may arrive as `nparts` partial Gram matrices (split over row blocks): summed here in fixed order
+                // (nparts == 0: one matrix the caller has already made exactly symmetric -- no transposed read, which is a
+                //  64-line gather per wave instruction through this one CU: ~25 of the kernel's 53 us at n = 160)
                 double gs = 0.0;
+                if (nparts == 0) gs = G[(size_t)row * n + col];
                 for (int z = 0; z < nparts; ++z) {
                     const double* Gz = G + (size_t)z * n * n;
                     gs += 0.5 * (Gz[(size_t)row * n + col] + Gz[(size_t)col * n + row]);
@@ -180,8 +185,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
         __syncthreads();
         cur ^= 1;
     }
-    // acc = -inv: write both triangles
+    // acc = -inv: write both triangles.  The mirrored tile goes through a wave-private 16 x 17 LDS block so that its rows are
+    // stored contiguously too (a direct transposed store is a 64-line scatter per wave instruction through this one CU).
     if (!service) {
+        double (*T)[17] = reinterpret_cast<double (*)[17]>(lds_d) + 16 * w;  // all panel buffers are free after the last barrier
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int R = tR[s], C = tC[s];
@@ -191,7 +198,14 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
                 const int row = 16 * R + g.lq + 4 * r, col = 16 * C + g.lc;
                 const double v = -acc[s][r];
                 Wout[(size_t)row * n + col] = v;
-                if (R != C) Wout[(size_t)col * n + row] = v;
+                T[g.lq + 4 * r][g.lc] = v;
+            }
+            if (R != C) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Wout[(size_t)(16 * C + g.lq + 4 * r) * n + 16 * R + g.lc] = T[g.lc][g.lq + 4 * r];
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
@@ -420,7 +434,8 @@ __global__ __launch_bounds__(1024, 4) void k_local_analysis_mfma(int M, int n_ob
 int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double ridge, double* W, int* flag) {
     if (n % 16 != 0 || n < 16 || n > 256) return -1;
     const int nt = n / 16, ntiles = nt * (nt + 1) / 2;
-    const size_t lds = ((size_t)3 * n * 17 + 2 * 16 * 17) * 8 + 16;
+    // panel buffers U[2][n][17], W[n][17], P, Dg + flag; the final mirrored store wants a 16 x 17 block per wave (16 waves at most)
+    const size_t lds = std::max(((size_t)3 * n * 17 + 2 * 16 * 17) * 8 + 16, (size_t)16 * 16 * 17 * 8);
 #define L(S, NW)                                                                                                              \
     do {                                                                                                                      \
         HM_HIP(hipFuncSetAttribute((const void*)k_spd_inverse<S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \

@@ -23,6 +23,8 @@ int mfma_gxt(hipStream_t s, int N, int M, int n_obs, const float* E, const float
 int mfma_apply(hipStream_t s, int N, int M, int n_obs, const float* E, const float* At, const float* B, float* Eout);
 int transpose_cast_d2f(hipStream_t s, const double* in, float* out, int rows, int cols);
 int transpose_f2f(hipStream_t s, const float* in, float* out, int rows, int cols);
+int transpose_cast_f2d(hipStream_t s, const float* in, double* out, int rows, int cols);
+void mfma_set_gxt_chunk(int kc);
 
 struct hm_upd {
     hm_ctx* ctx = nullptr;
@@ -38,9 +40,13 @@ struct hm_upd {
     // lose 3 digits); only the two contractions over the state dimension M run in `dtype`.
     DevBuf Y, D0, S, D, T1, decorr64, S_T, A_T, Cinv, Wt, Bt, partial, gpart, flags;
     DevBuf YD, SD;  // hm_upd_run: [Y; D0] and [S; D] stacked (2 N_local x n_obs), one matrix-core product for both
+    DevBuf Rm;      // hm_upd_run, "kalman_form": R = (decorr decorr^T)^-1, formed when decorr is set
+    bool rm_ready = false;
+    int kalman_form = 1;            // hm_upd_run: 1 = contraction on the centred observations, gain through R (see there)
     int use_mfma = 1;  // fp32 only: 0 forces the generic VALU GEMMs (tests compare both)
     EvTimer t_upd;
-    int overlap = 0;                // hm_upd_run: 1 = small fp64 chain on a second stream beside the big contraction
+    int overlap = 0;                // hm_upd_run: 1 = small fp64 chain on a second stream beside the big contraction (measured: no gain,
+                                    // the 16-wave inverse does not fit on a CU beside a contraction workgroup and waits for one to finish)
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // localised plans over several ranks: the per-element solves are column-sharded -- this rank solves the state
@@ -218,12 +224,92 @@ __global__ __launch_bounds__(256) void k_gram_partial(const double* __restrict__
     }
 }
 
-__global__ void k_gram_reduce(const double* __restrict__ part, int nparts, int nn, double* __restrict__ G) {
+__global__ void k_gram_reduce(const double* __restrict__ part, int nparts, int nn, double* __restrict__ G,
+                              const double* __restrict__ add = nullptr, double add_scale = 0.0) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nn) return;
     double acc = 0.0;
     for (int p = 0; p < nparts; ++p) acc += part[(size_t)p * nn + e];
+    if (add) acc += add_scale * add[e];
     G[e] = acc;
+}
+
+// B = sym(sum of the partial Gram matrices) + add_scale * add: the exactly symmetric input of the matrix-core inverse
+__global__ void k_gram_reduce_sym(const double* __restrict__ part, int nparts, int n, double* __restrict__ B,
+                                  const double* __restrict__ add, double add_scale) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * n) return;
+    const int r = e / n, c = e - r * n;
+    if (r < c) return;  // one thread per lower-triangle entry writes both (r, c) and (c, r): exactly symmetric
+    const int et = c * n + r;
+    const size_t nn = (size_t)n * n;
+    double a = 0.0, b = 0.0;
+    int p = 0;
+    for (; p + 4 <= nparts; p += 4) {  // four partials of each triangle in flight; the sum order stays p = 0, 1, 2, ...
+        const double a0 = part[p * nn + e], a1 = part[(p + 1) * nn + e], a2 = part[(p + 2) * nn + e], a3 = part[(p + 3) * nn + e];
+        const double b0 = part[p * nn + et], b1 = part[(p + 1) * nn + et], b2 = part[(p + 2) * nn + et], b3 = part[(p + 3) * nn + et];
+        a = (((a + a0) + a1) + a2) + a3;
+        b = (((b + b0) + b1) + b2) + b3;
+    }
+    for (; p < nparts; ++p) { a += part[p * nn + e]; b += part[p * nn + et]; }
+    const double v = 0.5 * (a + b) + add_scale * 0.5 * (add[e] + add[et]);
+    B[e] = v;
+    B[et] = v;
+}
+
+// Centred observations and innovations of the fused analysis step (hm_upd_run), one launch: workgroup = 32 observation
+// columns x all members; column sums in a fixed order (32 row lanes, then a serial sum over the lanes).
+//   Yc = obs_ens - mean (fp64 -> YD rows [0, N), fp32 -> Yc32),  D0 = obs - obs_ens - perturbs (fp64 -> YD rows [N, 2N))
+constexpr int CO_COLS = 8, CO_LANES = 1024 / CO_COLS;  // k_center_obs: columns per workgroup, row lanes
+__global__ __launch_bounds__(1024) void k_center_obs(const float* __restrict__ obs_ens, const float* __restrict__ perturbs,
+                                                     const float* __restrict__ obs, int rows, int n_obs, double* __restrict__ YD,
+                                                     float* __restrict__ Yc32) {
+    // 8 columns x 128 row lanes per workgroup (n_obs / 8 workgroups): at N = 1000 a thread holds its 8 rows in registers, all
+    // loads of the launch are in flight at once, and the code stays small (a 32-rows-per-thread version of this kernel took
+    // 14.5 us, most of it instruction fetch of its unrolled body on a cold CU)
+    __shared__ double part[CO_LANES][CO_COLS + 1];
+    const int c = threadIdx.x & (CO_COLS - 1), g = threadIdx.x / CO_COLS;
+    const int jraw = blockIdx.x * CO_COLS + c, j = min(jraw, n_obs - 1);
+    constexpr int U = 8;
+    float v[U], pv[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+        const int r = min(g + CO_LANES * q, rows - 1);  // clamped, unconditional loads
+        v[q] = obs_ens[(size_t)r * n_obs + j];
+        pv[q] = perturbs[(size_t)r * n_obs + j];
+    }
+    double s0 = 0.0;
+#pragma unroll
+    for (int q = 0; q < U; ++q) s0 += (g + CO_LANES * q < rows) ? (double)v[q] : 0.0;
+    for (int r = g + CO_LANES * U; r < rows; r += CO_LANES) s0 += (double)obs_ens[(size_t)r * n_obs + j];
+    part[g][c] = s0;
+    __syncthreads();
+    for (int st = CO_LANES / 2; st > 0; st >>= 1) {  // fixed-order tree over the row lanes
+        if (g < st) part[g][c] += part[g + st][c];
+        __syncthreads();
+    }
+    const double mean = part[0][c] / (double)rows;
+    if (jraw >= n_obs) return;
+    const double ob = (double)obs[j];
+    const size_t n = (size_t)rows * n_obs;
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+        const int r = g + CO_LANES * q;
+        if (r < rows) {
+            const size_t e = (size_t)r * n_obs + j;
+            const double o = (double)v[q];
+            YD[e] = o - mean;
+            Yc32[e] = (float)(o - mean);
+            YD[n + e] = ob - o - (double)pv[q];
+        }
+    }
+    for (int r = g + CO_LANES * U; r < rows; r += CO_LANES) {
+        const size_t e = (size_t)r * n_obs + j;
+        const double o = (double)obs_ens[e];
+        YD[e] = o - mean;
+        Yc32[e] = (float)(o - mean);
+        YD[n + e] = ob - o - (double)perturbs[e];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,8 +648,8 @@ extern "C" int hm_upd_create(hm_ctx* ctx, int N_total, int N_local, int M, int n
     ALLOC(Cinv, (no * no + no) * 8);
     ALLOC(partial, (size_t)64 * (m + no) * 8); ALLOC(flags, 16);
     if (dtype == 32) ALLOC(Bt, m * no * e);
-    if (dtype == 32) { ALLOC(YD, 2 * nl * no * 8); ALLOC(SD, 2 * nl * no * 8); }
-    ALLOC(gpart, std::max<size_t>((nl + GRB - 1) / GRB, 8) * no * no * 8);
+    if (dtype == 32) { ALLOC(YD, 2 * nl * no * 8); ALLOC(SD, 2 * nl * no * 8); ALLOC(Rm, no * no * 8); }
+    ALLOC(gpart, std::max<size_t>((nl + GRB - 1) / GRB, 16) * no * no * 8);
     if (localized) { ALLOC(taper, m * no * e); ALLOC(Wt, m * no * e); }
 #undef ALLOC
     HM_HIP(hipMemset(u->flags.p, 0, 16));
@@ -577,7 +663,7 @@ extern "C" void hm_upd_destroy(hm_upd* u) {
     (void)hipStreamSynchronize(u->ctx->stream);
     DevBuf* bufs[] = {&u->E, &u->E_out, &u->obs_ens, &u->perturbs, &u->obs, &u->decorr, &u->taper, &u->red0, &u->red1,
                       &u->red2, &u->red3, &u->Y, &u->D0, &u->S, &u->D, &u->T1, &u->decorr64, &u->S_T, &u->A_T, &u->Cinv,
-                      &u->Wt, &u->Bt, &u->partial, &u->gpart, &u->flags, &u->YD, &u->SD};
+                      &u->Wt, &u->Bt, &u->partial, &u->gpart, &u->flags, &u->YD, &u->SD, &u->Rm};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     u->t_upd.destroy();
     u->t_comm.destroy();
@@ -598,7 +684,10 @@ extern "C" int hm_upd_set_inputs(hm_upd* u, const void* E, const void* obs_ens, 
     if (obs_ens) HM_HIP(hipMemcpyAsync(u->obs_ens.p, obs_ens, nl * no * e, hipMemcpyHostToDevice, s));
     if (obs) HM_HIP(hipMemcpyAsync(u->obs.p, obs, no * e, hipMemcpyHostToDevice, s));
     if (perturbs) HM_HIP(hipMemcpyAsync(u->perturbs.p, perturbs, nl * no * e, hipMemcpyHostToDevice, s));
-    if (decorr) HM_HIP(hipMemcpyAsync(u->decorr.p, decorr, no * no * e, hipMemcpyHostToDevice, s));
+    if (decorr) {
+        HM_HIP(hipMemcpyAsync(u->decorr.p, decorr, no * no * e, hipMemcpyHostToDevice, s));
+        u->rm_ready = false;
+    }
     if (taper && u->localized) {
         HM_HIP(hipMemcpyAsync(u->taper.p, taper, m * no * e, hipMemcpyHostToDevice, s));
         u->taper_set = true;
@@ -815,6 +904,51 @@ extern "C" int hm_upd_run(hm_upd* u) {
     //  the 8 dependent kernels are drain/ramp time of the kernels themselves, not launch overhead -- so it is launched eagerly)
     const double inv_n = 1.0 / (double)u->N_total;
     const size_t nsm = (size_t)nl * no;
+    if (u->kalman_form) {
+        // The same update with the decorrelation folded away: with S = Yc decorr, D = D0 decorr, C = S^T S + (N-1) I
+        //     D C^-1 S^T X  =  D0 (Yc^T Yc + (N-1) R)^-1 Yc^T X,      R = (decorr decorr^T)^-1   (= the R of HistoryMatch.py:243-259)
+        // so the big contraction needs only the centred observations (one small launch after the inputs, instead of
+        // column sums -> [Y; D0] -> products with decorr), and the chain Gram -> inverse -> gain has no product with decorr
+        // left in it.  (N-1) R depends on decorr alone and is formed when decorr changes (ES-MDA: once per assimilation).
+        double* YD = (double*)u->YD.p;
+        if (!u->rm_ready) {
+            const unsigned gs = (unsigned)((no * no + 255) / 256);
+            // R^-1 = decorr decorr^T (decorr = R12^-T, HistoryMatch.py:639): with Dt = decorr^T in fp64, R^-1 = Dt^T Dt
+            (void)gs;
+            if ((rc = transpose_cast_f2d(s, (const float*)u->decorr.p, (double*)u->decorr64.p, no, no))) return rc;
+            if ((rc = dgemm_mfma(s, true, no, no, no, (const double*)u->decorr64.p, no, (const double*)u->decorr64.p, no, G, no, 1, nullptr, 0, nullptr))) return rc;
+            rc = spd_inverse_mfma(s, G, 1, no, 0.0, (double*)u->Rm.p, (int*)u->flags.p);
+            if (rc > 0) return rc;
+            if (rc < 0 && (rc = invert_C(s, G, no, 0.0, (double*)u->Rm.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p, false))) return rc;
+            u->rm_ready = true;
+        }
+        hipLaunchKernelGGL(k_center_obs, dim3((no + CO_COLS - 1) / CO_COLS), dim3(1024), 0, s, (const float*)u->obs_ens.p, (const float*)u->perturbs.p,
+                           (const float*)u->obs.p, nl, no, YD, S_T);
+        HM_HIP(hipGetLastError());
+        if (u->overlap) {
+            HM_HIP(hipEventRecord(u->ev_fork, s));
+            HM_HIP(hipStreamWaitEvent(s2, u->ev_fork, 0));
+        }
+        // stream 2: B = Yc^T Yc + (N-1) R (8 row blocks, fixed-order sum), B^-1, gain A' = D0 B^-1 as its fp32 transpose
+        const int nsplit = dgemm_mfma_splits(nl, 16);
+        if ((rc = dgemm_mfma(s2, true, no, no, nl, YD, no, YD, no, (double*)u->gpart.p, no, 16, nullptr, 0, nullptr))) return rc;
+        hipLaunchKernelGGL(k_gram_reduce_sym, dim3((no * no + 255) / 256), dim3(256), 0, s2, (const double*)u->gpart.p, nsplit, no, G,
+                           (const double*)u->Rm.p, (double)(u->N_total - 1));
+        HM_HIP(hipGetLastError());
+        rc = g_use_mfma_inverse ? spd_inverse_mfma(s2, G, 0, no, 0.0, (double*)u->Cinv.p, (int*)u->flags.p) : -1;
+        if (rc > 0) return rc;
+        if (rc < 0 && (rc = invert_C(s2, G, no, 0.0, (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p, true))) return rc;
+        if ((rc = dgemm_mfma(s2, false, nl, no, no, YD + nsm, no, (const double*)u->Cinv.p, no, nullptr, no, 1, nullptr, 0, A_T))) return rc;
+        if (u->overlap) HM_HIP(hipEventRecord(u->ev_join, s2));
+        // stream 1: Gy = Yc^T (E - c), then (after the join) E_out = E + A' Gy
+        if ((rc = mfma_gxt_lds(s, nl, M, no, E, nullptr, inv_n, S_T, (float*)u->Bt.p)) > 0) return rc;
+        HM_REQUIRE(rc == 0, "hm_upd_run: matrix-core kernel not applicable");
+        if (u->overlap) HM_HIP(hipStreamWaitEvent(s, u->ev_join, 0));
+        rc = mfma_apply_lds(s, nl, M, no, E, A_T, (const float*)u->Bt.p, Eo);
+        if (rc > 0) return rc;
+        HM_REQUIRE(rc == 0, "hm_upd_run: matrix-core apply kernel not applicable");
+        return u->t_upd.end(s);
+    }
     S = (double*)u->SD.p;
     D = S + nsm;
     {   // column sums of obs_ens; [Y; D0] (and decorr in fp64); [S; D] = [Y; D0] decorr on the fp64 matrix cores with the
@@ -859,6 +993,8 @@ extern "C" int hm_upd_set_option(hm_upd* u, const char* name, int value) {
     HM_REQUIRE(u && name, "hm_upd_set_option: NULL argument");
     if (std::string(name) == "use_mfma") { u->use_mfma = value; return 0; }
     if (std::string(name) == "overlap") { u->overlap = value; return 0; }  // hm_upd_run: second stream for the small chain
+    if (std::string(name) == "kalman_form") { u->kalman_form = value; return 0; }
+    if (std::string(name) == "gxt_chunk") { mfma_set_gxt_chunk(value); return 0; }  // members per LDS chunk of k_gxt_lds: 32 | 64  // hm_upd_run: 0 = decorrelated form (S, D, C)
     if (std::string(name) == "mfma_inverse") { g_use_mfma_inverse = value; return 0; }  // 0: rank-1 register sweeps
     hm_set_error("hm_upd_set_option: unknown option '%s'", name);
     return 2;

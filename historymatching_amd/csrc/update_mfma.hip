@@ -170,13 +170,13 @@ __global__ __launch_bounds__(256) void k_apply_mfma(int N, int M, int n_obs, con
 //   LDS (40 KB at n_obs = 160: 3 workgroups per CU overlap staging, MFMAs and the E read/modify/write), A operand
 //   fetched 16 k-pairs ahead from L2, the E tile loaded before the MFMA loop.
 // ------------------------------------------------------------------------------------------------------------
-template <int NJ>
-__global__ __launch_bounds__(512, 4) void k_gxt_lds(int N, int M, int n_obs, const float* __restrict__ E,
+template <int NJ, int KC>
+__global__ __launch_bounds__(512, KC == 64 ? 2 : 4) void k_gxt_lds(int N, int M, int n_obs, const float* __restrict__ E,
                                                  const float* __restrict__ colsum, float inv_n,
                                                  const float* __restrict__ S, float* __restrict__ Gx) {
     // 8 waves = 2 state halves x 4 interleaved quarters of the k-pairs (two waves per SIMD: one wave's LDS/barrier
-    // stalls are covered by the other's MFMAs)
-    constexpr int KC = 32, NO = 32 * NJ, NKH = 4, NT = 512;
+    // stalls are covered by the other's MFMAs).  KC members per LDS chunk = per barrier.
+    constexpr int NO = 32 * NJ, NKH = 4, NT = 512;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     // [2][KC][64] E chunks, [2][KC][NO] S chunks; the final reduction buffers alias them
     float* Eb = sm;
@@ -185,7 +185,8 @@ __global__ __launch_bounds__(512, 4) void k_gxt_lds(int N, int M, int n_obs, con
     const int sh = w & 1, kh = w >> 1;
     const int il = lane & 31, kq = lane >> 5;
     const int i0 = blockIdx.x * 64;
-    // staging roles: E chunk = KC rows x 16 float4 (one per thread); S chunk = KC rows x NO/4 float4
+    // staging roles: E chunk = KC rows x 16 float4 (EPT per thread); S chunk = KC rows x NO/4 float4
+    constexpr int EPT = KC * 16 / NT;
     const int er = tid >> 4, ec = (tid & 15) * 4;
     const int ei = min(i0 + ec, M - 4);  // M % 4 == 0 (host-checked); columns past M are never stored
     float4 shift;
@@ -193,13 +194,16 @@ __global__ __launch_bounds__(512, 4) void k_gxt_lds(int N, int M, int n_obs, con
     else shift = *reinterpret_cast<const float4*>(E + ei);
     constexpr int SV = KC * NO / 4;           // float4 per S chunk
     constexpr int SPT = (SV + NT - 1) / NT;   // per thread
-    float4 ereg, sreg[SPT];
+    float4 ereg[EPT], sreg[SPT];
     auto fetch = [&](int k0) {
-        const int k = k0 + er;
-        ereg = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < N) {
-            const float4 v = *reinterpret_cast<const float4*>(E + (size_t)k * M + ei);
-            ereg = make_float4(v.x - shift.x, v.y - shift.y, v.z - shift.z, v.w - shift.w);
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int k = k0 + er + 32 * q;
+            ereg[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < N) {
+                const float4 v = *reinterpret_cast<const float4*>(E + (size_t)k * M + ei);
+                ereg[q] = make_float4(v.x - shift.x, v.y - shift.y, v.z - shift.z, v.w - shift.w);
+            }
         }
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
@@ -210,7 +214,8 @@ __global__ __launch_bounds__(512, 4) void k_gxt_lds(int N, int M, int n_obs, con
         }
     };
     auto stash = [&](int buf) {
-        *reinterpret_cast<float4*>(Eb + (buf * KC + er) * 64 + ec) = ereg;
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) *reinterpret_cast<float4*>(Eb + (buf * KC + er + 32 * q) * 64 + ec) = ereg[q];
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
             const int e = tid + NT * q;
@@ -373,6 +378,13 @@ int transpose_cast_d2f(hipStream_t s, const double* in, float* out, int rows, in
     return 0;
 }
 
+int transpose_cast_f2d(hipStream_t s, const float* in, double* out, int rows, int cols) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
+    hipLaunchKernelGGL((k_transpose<float, double>), grid, block, 0, s, in, out, rows, cols);
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
 int transpose_f2f(hipStream_t s, const float* in, float* out, int rows, int cols) {
     dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
     hipLaunchKernelGGL((k_transpose<float, float>), grid, block, 0, s, in, out, rows, cols);
@@ -381,17 +393,24 @@ int transpose_f2f(hipStream_t s, const float* in, float* out, int rows, int cols
 }
 
 // second-generation kernels (hm_upd_run); Gx is (n_obs x M)
+static int g_gxt_kc = 64;  // 64 members per LDS chunk: half the barriers of 32 (65.6 vs 68.6 us at C3)
+void mfma_set_gxt_chunk(int kc) { g_gxt_kc = kc == 64 ? 64 : 32; }
+
 int mfma_gxt_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const float* colsum, double inv_n, const float* S,
                  float* Gx) {
     if (n_obs % 32 != 0 || n_obs > 256 || M % 4 != 0 || M < 4) return -1;
     const int nj = n_obs / 32;
+    const int kc = g_gxt_kc;
     dim3 grid((M + 63) / 64), block(512);
-    const size_t chunks = (size_t)2 * 32 * (64 + n_obs) * 4, red = (size_t)2 * 2 * nj * 16 * 64 * 4;
+    const size_t chunks = (size_t)2 * kc * (64 + n_obs) * 4, red = (size_t)2 * 2 * nj * 16 * 64 * 4;
     const size_t lds = chunks > red ? chunks : red;
-#define L(NJ) case NJ: HM_HIP(hipFuncSetAttribute((const void*)k_gxt_lds<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                       hipLaunchKernelGGL(k_gxt_lds<NJ>, grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); break
+    if (lds > 160 * 1024) return -1;
+#define L2(NJ, KC) do { HM_HIP(hipFuncSetAttribute((const void*)k_gxt_lds<NJ, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                       hipLaunchKernelGGL((k_gxt_lds<NJ, KC>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); } while (0)
+#define L(NJ) case NJ: if (kc == 64) L2(NJ, 64); else L2(NJ, 32); break
     switch (nj) { L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); default: return -1; }
 #undef L
+#undef L2
     HM_HIP(hipGetLastError());
     return 0;
 }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Static instruction census of a kernel's hot loop from the built object (no GPU needed).
 
-    python3 profiles/tools/isa_count.py historymatching_amd/csrc/sat128.o k_sat128ILb1
+    python3 profiles/tools/isa_count.py historymatching_amd/csrc/sat128.o k_sat128ILb1 32 2
+    (object, substring of the mangled kernel name, cells per thread per loop trip, s_barrier count of the loop wanted)
 
 Extracts the gfx950 code object from the fat object (llvm-objdump --offloading), disassembles it, finds the loop with the
 largest body inside the first function whose mangled name contains the given substring (a backward s_cbranch to an earlier
@@ -61,7 +62,10 @@ def classify(op):
     return "other"
 
 
-def hot_loop(body):
+def hot_loop(body, barriers=None):
+    """Largest backward-branch region [target, branch]; with `barriers` only regions holding exactly that many s_barrier
+    (the compiler places cold blocks at the end of the function that jump BACK into the body: those regions span
+    several loops and are told apart by their barrier count)."""
     addr_index = {a: i for i, (a, _, _) in enumerate(body)}
     best = None
     for i, (a, op, args) in enumerate(body):
@@ -78,6 +82,8 @@ def hot_loop(body):
         target = a + 4 + 4 * off
         if target <= a and target in addr_index:
             j = addr_index[target]
+            if barriers is not None and sum(1 for _, o, _ in body[j:i + 1] if o == "s_barrier") != barriers:
+                continue
             if best is None or (i - j) > (best[1] - best[0]):
                 best = (j, i)
     return best
@@ -86,10 +92,11 @@ def hot_loop(body):
 def main():
     obj, sub = sys.argv[1], sys.argv[2]
     per = float(sys.argv[3]) if len(sys.argv) > 3 else 32.0
+    barriers = int(sys.argv[4]) if len(sys.argv) > 4 else None
     fns = functions(disassemble(obj))
     name = next(n for n in fns if sub in n)
     body = fns[name]
-    lo, hi = hot_loop(body)
+    lo, hi = hot_loop(body, barriers)
     counts = {}
     divisions = 0
     for _, op, _ in body[lo:hi + 1]:
@@ -97,7 +104,7 @@ def main():
         counts[c] = counts.get(c, 0) + 1
         if op.startswith("v_div_fmas_f64"):
             divisions += 1
-    out = {"object": obj, "kernel": name, "loop_instructions": hi - lo + 1, "counts": counts, "fp64_divisions": divisions,
+    out = {"object": obj, "kernel": name, "loop_instructions": hi - lo + 1, "loop_start": hex(body[lo][0]), "loop_end": hex(body[hi][0]), "counts": counts, "fp64_divisions": divisions,
            "cells_per_thread_per_trip": per, "dp_valu_per_cell_substep": counts.get("dp_valu", 0) / per,
            "valu_per_cell_substep": (counts.get("dp_valu", 0) + counts.get("other_valu", 0)) / per}
     print(json.dumps(out, indent=1))
