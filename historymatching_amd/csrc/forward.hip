@@ -8,7 +8,7 @@
 //
 // One workgroup = one ensemble member.  The generic kernels keep the per-member work arrays in HBM/L2
 // scratch and use LDS only for the dense Ny x Ny Schur-complement block; they are the correctness
-// baseline the 128x128 specialisations (press128.hip, sat128.hip) are validated against.
+// baseline the 128x128 specialisations (press128s.hip, sat128.hip) are validated against.
 //
 // This file is compiled with -ffp-contract=off: every product/sum is rounded separately exactly as
 // NumPy does; FMAs appear only where written explicitly (inside the pressure solve, which is not a
@@ -782,8 +782,9 @@ static int launch_pressure(hm_fwd* f, int k) {
     int rc = f->t_press.begin(s);
     if (rc) return rc;
     int done = -1;
-    // press_variant: 1 generic, 2 press128 (VALU rank-1), 3/4/5/8 press128m (full tiles: 8w rank-4, 16w rank-4,
-    // 16w rank-16, 8w rank-16 x 2 workgroups/CU), 6/7 and every other value press128s (symmetric tiles, 8/16 waves)
+    // press_variant: 1 generic (the in-library cross-check), 9 Jacobi-CG, 7 the 16-wave form of press128s, every other value
+    // press128s (symmetric tiles, 8 waves).  (The first three generations of the 128-wide solver -- rank-1 VALU sweeps, full-tile
+    // rank-4 and rank-16 matrix-core panels -- were removed in round 2; their timings are in profiles/README.md.)
     const int pv = f->press_variant;
     if (pv == 9 || p.Ny > 128) {
         if (f->cg_lazy) {  // CG requested on a small grid: the work vectors were not allocated at creation
@@ -796,9 +797,7 @@ static int launch_pressure(hm_fwd* f, int k) {
         }
         if (pv != 9 && f->cg_precond == 0 && pressure_two_level_applies(p)) done = launch_pressure_two_level(f, S, stride, k);
         else done = launch_pressure_pcg(f, S, stride, k);
-    } else if (pv == 2) done = launch_pressure_128(f, S, stride, k);
-    else if (pv == 3 || pv == 4 || pv == 5 || pv == 8) done = launch_pressure_128m(f, S, stride, k);
-    else if (pv != 1) done = launch_pressure_128s(f, S, stride, k);
+    } else if (pv != 1) done = launch_pressure_128s(f, S, stride, k);
     if (done > 0) return done;
     if (done < 0) {
         int T = generic_threads(p.Ny);

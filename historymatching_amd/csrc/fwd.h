@@ -80,9 +80,7 @@ static inline void* fwd_S_ptr(hm_fwd* f, int k, long long* stride) {
 }
 
 // ---- kernels implemented in other translation units ------------------------------------------
-// 128x128 fp64 specialisations (press128.hip / sat128.hip).  Return 0 if launched, -1 if not applicable.
-int launch_pressure_128(hm_fwd* f, const void* S, long long S_stride, int k);   // VALU rank-1 sweeps (variant 2)
-int launch_pressure_128m(hm_fwd* f, const void* S, long long S_stride, int k);  // MFMA panels, full tile storage
+// 128x128 fp64 specialisations (press128s.hip / sat128.hip).  Return 0 if launched, -1 if not applicable.
 int launch_pressure_128s(hm_fwd* f, const void* S, long long S_stride, int k);  // MFMA panels, symmetric tile storage (default)
 int launch_pressure_pcg(hm_fwd* f, const void* S, long long S_stride, int k);   // Jacobi-CG, any grid (press_pcg.hip)
 bool pressure_two_level_applies(const FwdParams& p);

@@ -1,6 +1,6 @@
 // press128s.hip -- Ny = 128 fp64 pressure step, SYMMETRIC tile storage + a SIMD reserved for the pivot chain.
 //
-// Same block elimination as press128m.hip (block-Thomas along ix, every 128x128 Schur complement
+// Block elimination (block-Thomas along ix, every 128x128 Schur complement
 // inverted explicitly by blocked symmetric Gauss-Jordan sweeps with rank-16 panels), re-laid-out around two
 // measured facts of gfx950 (diag/inv16.hip):
 //   * fp64 MFMA and the VALU share the SIMD's double-precision lanes: a wave's VALU instruction waits for every
@@ -553,5 +553,33 @@ int launch_coarse_solve_128(hipStream_t s, const FwdParams& pc, const double* b,
     if (pc.Ny != NB) return -1;
     hipLaunchKernelGGL(k_coarse_solve<8>, dim3(pc.N), dim3(512), 0, s, pc, b, x, skip);
     HM_HIP(hipGetLastError());
+    return 0;
+}
+
+// Self-test hook: D(16x16) = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 with the operand/result lane maps this
+// file assumes.  Host buffers.
+namespace {
+__global__ void k_mfma_f64_probe(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ D) {
+    const int l = threadIdx.x;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+}  // namespace
+
+extern "C" int hm_debug_mfma_f64(hm_ctx* ctx, const double* A, const double* B, double* D) {
+    HM_REQUIRE(ctx && A && B && D, "hm_debug_mfma_f64: NULL argument");
+    HM_HIP(hipSetDevice(ctx->device));
+    double *dA, *dB, *dD;
+    HM_HIP(hipMalloc(&dA, 64 * 8));
+    HM_HIP(hipMalloc(&dB, 64 * 8));
+    HM_HIP(hipMalloc(&dD, 256 * 8));
+    HM_HIP(hipMemcpy(dA, A, 64 * 8, hipMemcpyHostToDevice));
+    HM_HIP(hipMemcpy(dB, B, 64 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_mfma_f64_probe, dim3(1), dim3(64), 0, ctx->stream, dA, dB, dD);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipStreamSynchronize(ctx->stream));
+    HM_HIP(hipMemcpy(D, dD, 256 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
     return 0;
 }

@@ -123,8 +123,7 @@ int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
 int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member);     /* D2H */
 /* Kernel selection (tests and diagnostics; 0/0 = the fastest applicable kernels).
  *   pressure  : 1 generic block elimination in LDS (any Ny <= 128) | at Ny = 128: 0 symmetric-tile MFMA solver (press128s),
- *               7 its 16-wave form, 3/4/5/8 full-tile MFMA solver (press128m: 8w rank-4, 16w rank-4, 16w rank-16, 8w rank-16),
- *               2 rank-1 VALU solver (press128) | 9 Jacobi-CG (any grid; beyond 128 the default is two-level CG where
+ *               7 its 16-wave form | 9 Jacobi-CG (any grid; beyond 128 the default is two-level CG where
  *               Ny = 128 c, Nx = c Nx_c, else Jacobi-CG)
  *   saturation: 1 generic (coefficient + fw images) | 2 streaming | 3 LDS-tiled | 0: at 128 x 128 the register/LDS-resident
  *               sweep (sat128 fp64 / sat128f fp32; needs uniform porosity and at most one well per 8 x 4 cell patch), else the
