@@ -20,6 +20,13 @@
 // allocator spill the whole flux state), so the straight-line code needs no per-cell source terms (x + 0.0 == x).
 // Requires <= 1 well per patch and uniform porosity; otherwise the host falls back to the generic kernel.
 //
+// Dry waves: a wave whose 16 x 128 band holds S == 0 everywhere (and no injector) has fw == 0 there, so its phase A would store
+// the zeros its rows of the LDS image already hold, and while the fw rows just above and below the band are zero as well its phase
+// B adds exact zeros (x + (+-0) == x).  Such a wave skips both phases under a wave-uniform branch -- it only reads its two halo
+// rows and ballots -- and the wet wave that shares its SIMD gets the whole issue rate: the early time steps, when the water has
+// reached 2-4 of the 8 bands, run up to twice as fast.  Once water arrives (a non-zero halo row) the wave runs phase B and is wet
+// for good.  Results are bit-identical (tests/test_forward_gpu.py::test_saturation_step_bitexact_given_fluxes and the rest).
+//
 // Compiled with -ffp-contract=off (no FMA contraction: every product and sum is rounded separately, as NumPy does).
 #include "fwd.h"
 
@@ -227,6 +234,17 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
     // instructions over such perturbations; a guard around phase A as well is worse again).  No effect on results.
     int always = __builtin_amdgcn_readfirstlane(Nts > 0);
     asm volatile("" : "+s"(always));
+    // wave-uniform: every cell of the band is exactly zero and no lane owns an injector (a producer in a dry band sits at S = 0:
+    // its record stays 0 and its fw entry 0 until the band itself becomes wet)
+    auto band_is_dry = [&]() {
+        unsigned long long bits = 0ull;
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+#pragma unroll
+            for (int j = 0; j < PY; ++j) bits |= (unsigned long long)__double_as_longlong(S[i][j]) << 1;  // -0.0 counts as zero
+        return __ballot(bits != 0ull || (has_well && (wq > 0.0 || Sin[wcell] != 0.0))) == 0ull;
+    };
+    int dry = band_is_dry() ? 1 : 0;
     // ---------------- explicit sub-steps
     for (int it = 0; it < Nts; ++it) {
         // The upwind coefficients are pure functions of (Vx, Vy, d): left alone, the compiler hoists all of them
@@ -235,7 +253,8 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
         double dd = d, z = 0.0;
         asm volatile("" : "+v"(dd), "+v"(z));
 
-        // phase A: fractional flow of every own cell -> LDS
+        // phase A: fractional flow of every own cell -> LDS (a dry band's rows already hold its zeros after the first sub-step)
+        if (!(dry && it > 0)) {
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             char* base = lds + (ix0 + i) * 1024 + seg;
@@ -248,6 +267,7 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
             *reinterpret_cast<double2*>(base + ((1 ^ swz) * 16)) = b;
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         {   // well side path, branch-free (threads without a well run it on the dummy record)
             double* rec = reinterpret_cast<double*>(lds + wrec);
             double wf = frac_flow<FD>(p, rec[0]);
@@ -256,7 +276,15 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
         }
         __syncthreads();
 
-        if (always) {
+        int run_b = always;
+        if (dry) {  // the band only changes if a fractional flow just outside it is non-zero: its west / east halo rows
+            const unsigned long long* hw = reinterpret_cast<const unsigned long long*>(lds + ixW * 1024 + seg);
+            const unsigned long long* he = reinterpret_cast<const unsigned long long*>(lds + ixE * 1024 + seg);
+            const unsigned long long o = (hw[0] | hw[1]) | (hw[2] | hw[3]) | (he[0] | he[1]) | (he[2] | he[3]);  // fw >= +0: bit test
+            run_b = __ballot(o != 0ull) != 0ull;
+            dry = !run_b;  // water at the border: the band is wet from now on
+        }
+        if (run_b) {
         // phase B: upwind update row by row
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
