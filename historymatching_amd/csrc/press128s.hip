@@ -156,6 +156,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Roles by wave index: waves 0, 4, ... (one SIMD under round-robin placement) are the service waves.  (Roles by PHYSICAL
+    // SIMD -- the service waves of both workgroups of a CU on SIMD 0, read from HW_REG_HW_ID -- were measured in round 2: the
+    // sweep drops from 4.4 k to 3.3 k cycles, but both workgroups' matrix-core waves then share three SIMDs instead of
+    // spilling onto the other workgroup's service SIMD, and the launch takes 12.5 ms instead of 11.6.)
     const bool service = (w & 3) == 0;
     const bool sweeper = w == 0;
     const int c = service ? 0 : (w >> 2) * 3 + (w & 3) - 1;  // compute wave index
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
         tC[s] = __builtin_amdgcn_readfirstlane(e & 15);
     }
 
+    if (sweeper) __builtin_amdgcn_s_setprio(3);  // the pivot chain outranks whatever else is issued on its SIMD
     PROF_DECL;
     if constexpr (!FACTOR) assemble_transmissibilities<TS>(p, S, Km, P /* scratch for L */, TX, TY, tid, NT);
     const double pin = FACTOR ? p.pin[m] : Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
@@ -344,10 +349,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
             if (!service) {
                 // ---- phase C, pass 1: tiles of the NEXT pivot column/row first, handed over at once
                 if (Cn < 8) {
+                    // the next DIAGONAL tile before anything else: its in-wave sweep on the service SIMD is the critical path
+                    // of the panel (stamps: the sweeper waited 1.9 k cycles per panel for it when it came in slot order)
 #pragma unroll
                     for (int s = 0; s < TPW; ++s) {
                         const int R = tR[s], C = tC[s];
-                        if (R == Cn || C == Cn) {
+                        if (R == Cn && C == Cn) {
+                            __builtin_amdgcn_s_setprio(3);  // ahead of the other waves' rank-16 updates on this SIMD
+                            update_tile(s, Cp, U);
+                            publish_tile(s, Cn, Un, token);
+                            __builtin_amdgcn_s_setprio(0);
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < TPW; ++s) {
+                        const int R = tR[s], C = tC[s];
+                        if ((R == Cn) != (C == Cn)) {
                             if (C != Cp) update_tile(s, Cp, U);
                             publish_tile(s, Cn, Un, token);
                         }

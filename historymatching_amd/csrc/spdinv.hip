@@ -167,7 +167,15 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) {
                     const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
-                    if (R >= 0 && (R == Cn || C == Cn)) {
+                    if (R == Cn && C == Cn) {  // the next diagonal tile first: its sweep is the panel's critical path
+                        update_tile(s, U);
+                        publish_tile(s, Cn, Un, token);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+                    if (R >= 0 && ((R == Cn) != (C == Cn))) {
                         if (C != Cp) update_tile(s, U);
                         publish_tile(s, Cn, Un, token);
                     }
@@ -397,7 +405,15 @@ __global__ __launch_bounds__(1024, 4) void k_local_analysis_mfma(int M, int n_ob
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) {
                     const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
-                    if (R >= 0 && (R == Cn || C == Cn)) {
+                    if (R == Cn && C == Cn) {  // the next diagonal tile first: its sweep is the panel's critical path
+                        update_tile(s, U);
+                        publish_tile(s, Cn, Un, token);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+                    if (R >= 0 && ((R == Cn) != (C == Cn))) {
                         if (C != Cp) update_tile(s, U);
                         publish_tile(s, Cn, Un, token);
                     }
