@@ -832,11 +832,33 @@ static int launch_saturation(hm_fwd* f, int k) {
         if (done < 0) done = launch_saturation_128ft(f, Sin, Sout, stride, k); // fp32 twin
     }
     if (done > 0) return done;
+    if (done == 0 && p.Ny > 128 && f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
+        // The tile-team sweeps spin on their neighbours' edges, which needs every workgroup of a team resident at once; the
+        // launch is sized for an otherwise idle GPU (one workgroup per CU).  If something else held CUs (another process, a
+        // masked device), a team can be partly resident: its workgroups give up after a bounded spin and flag the member
+        // HM_MEMBER_SYNC_TIMEOUT.  Large grids already synchronise with the host every time step (CG convergence), so the
+        // flags are read here and the step is redone for everyone by the single-workgroup tiled sweep, which needs no
+        // co-residency and is bit-identical (S_in is untouched: the sweep writes the other time slot).
+        std::vector<int> st(p.N);
+        HM_HIP(hipStreamSynchronize(s));
+        HM_HIP(hipMemcpy(st.data(), f->status.p, (size_t)p.N * 4, hipMemcpyDeviceToHost));
+        bool timed_out = false;
+        for (int& v : st)
+            if (v & HM_MEMBER_SYNC_TIMEOUT) { timed_out = true; v &= ~HM_MEMBER_SYNC_TIMEOUT; }
+        if (f->sat_variant == 4) timed_out = true;  // test hook: take the retry path although nobody timed out
+        if (timed_out) {
+            HM_HIP(hipMemcpy(f->status.p, st.data(), (size_t)p.N * 4, hipMemcpyHostToDevice));
+            f->team_retries++;
+            done = -1;  // fall through to the tiled kernel below
+        }
+    }
+    const bool retry_tiled = done < 0 && p.Ny > 128 && f->team_retries_seen != f->team_retries;
+    f->team_retries_seen = f->team_retries;
     if (done < 0) {
         // sat_variant 1: generic (coefficient arrays + fw image); 2: streaming; 3: tiled; otherwise (no 128 x 128 specialisation
         // applies: other sizes, porosity field, two wells in one patch) tiled from 64 x 64 cells up (67.9 vs 124 ms per launch at
         // 128 x 128, N = 1000), generic below
-        const bool tiled = f->sat_variant == 3 || (f->sat_variant != 1 && f->sat_variant != 2 && p.Nxy >= 64 * 64);
+        const bool tiled = retry_tiled || f->sat_variant == 3 || (f->sat_variant != 1 && f->sat_variant != 2 && p.Nxy >= 64 * 64);
         const bool stream = f->sat_variant == 2;
         rc = ensure_generic_sat_scratch(f, !(stream || tiled));
         if (rc) return rc;

@@ -65,6 +65,7 @@ struct hm_fwd {
     std::vector<int> well_cells_host;
     DevBuf well_cells;
     DevBuf team_mem;  // synchronisation blocks of the multi-tile saturation sweep (sat128t.hip), allocated on first use
+    long long team_retries = 0, team_retries_seen = 0;  // time steps redone by the tiled sweep after a team gave up waiting
 };
 
 // Pointer to the saturation of (member 0, time index k) and the member stride in elements.

@@ -330,6 +330,9 @@ int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, 
     auto kern = k_sat128ft<FD>;
     const int lds_req = LDS_BYTES;
     HM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_req));
+    int resident = 0;  // the runtime's own answer: can a workgroup of this kernel be resident on a CU at all?
+    HM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, NT, lds_req));
+    if (resident < 1) return -1;  // no: the caller falls back to the single-workgroup tiled sweep
     for (int first = 0; first < p.N; first += max_teams) {
         const int nteams = std::min(max_teams, p.N - first);
         const int used_per_xcd = (nteams + 7) / 8;

@@ -442,6 +442,9 @@ int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, 
     hipStream_t s = f->ctx->stream;
     auto kern = k_sat128t<FD>;
     HM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    int resident = 0;  // the runtime's own answer: can a workgroup of this kernel be resident on a CU at all?
+    HM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, NT, LDS_TOTAL));
+    if (resident < 1) return -1;  // no: the caller falls back to the single-workgroup tiled sweep
     // one launch per round of max_teams members (a member loop inside the kernel costs registers the sweep does not have)
     for (int first = 0; first < p.N; first += max_teams) {
         const int nteams = std::min(max_teams, p.N - first);

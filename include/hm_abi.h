@@ -128,7 +128,9 @@ int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status
  *   saturation: 1 generic (coefficient + fw images) | 2 streaming | 3 LDS-tiled | 0: at 128 x 128 the register/LDS-resident
  *               sweep (sat128 fp64 / sat128f fp32; needs uniform porosity and at most one well per 8 x 4 cell patch), else the
  *               tiled sweep from 64 x 64 cells up, the generic one below; grids of 128 x 128 tiles (256^2, 512^2 ...): teams of
- *               workgroups, one per tile (sat128t / sat128ft) | pressure 11: two-level CG with the additive preconditioner
+ *               workgroups, one per tile (sat128t / sat128ft; a team that gives up waiting for a neighbour -- CUs held by
+ *               someone else -- has its time step redone by the tiled sweep; 4 = take that retry path every step, a test
+ *               hook) | pressure 11: two-level CG with the additive preconditioner
  *               instead of the two-grid cycle */
 int  hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant);
 /* Conjugate-gradient pressure solver (always used when Ny > 128): relative residual target and iteration cap

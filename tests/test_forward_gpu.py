@@ -462,6 +462,28 @@ def test_multi_tile_saturation_teams_bitexact_vs_tiled(nx, ny, N, wells, dtype):
     assert out[0][0][:, -1].max() > 0.5  # the front has left the injector
 
 
+@pytest.mark.parametrize("dtype", [64, 32])
+def test_tile_team_timeout_is_retried_by_the_tiled_sweep(dtype):
+    """A tile team that gives up waiting for a neighbour (its workgroups were not all resident: CUs held by another process)
+    flags the member HM_MEMBER_SYNC_TIMEOUT; the host redoes that time step with the single-workgroup tiled sweep instead of
+    failing the member.  saturation variant 4 takes the retry path on every step: same result as the teams, status clean."""
+    n, N, steps = 256, 3, 2
+    _, gm = make_models(n, n, dtype=dtype)
+    x = perms(n, n, N, seed=37)
+    out = {}
+    for sat_variant in (0, 4):
+        plan = _plan(gm, N, nTime=steps)
+        plan.set_variant(0, sat_variant)
+        plan.set_inputs(x, transformed=False)
+        plan.run()
+        plan.sync()
+        w, p, status = plan.outputs()
+        assert not status.any()
+        out[sat_variant] = (w, p, plan.get_field("nts"))
+        plan.close()
+    assert all(np.array_equal(a, b) for a, b in zip(out[0], out[4]))
+
+
 @pytest.mark.parametrize("nx,ny", [(64, 128), (200, 128), (128, 64)])
 def test_rectangular_grids_mixed_kernels(nx, ny):
     """Ny = 128 with Nx != 128 runs the matrix-core pressure solver (any number of 128-wide blocks) with the generic
