@@ -14,7 +14,7 @@ namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // C_z (M x N) = op(A) B over k in [z*kchunk, min(K, (z+1)*kchunk));  op(A)[i][k] = TA ? A[k*lda + i] : A[i*lda + k]
-template <bool TA>
+template <bool TA, int U = 4>
 __global__ __launch_bounds__(64) void k_dgemm_mfma(int M, int N, int K, const double* __restrict__ A, int lda,
                                                    const double* __restrict__ B, int ldb, double* __restrict__ C, int ldc,
                                                    int kchunk, float* __restrict__ C32, int rows32, float* __restrict__ C32T) {
@@ -32,7 +32,6 @@ __global__ __launch_bounds__(64) void k_dgemm_mfma(int M, int N, int K, const do
         mrow[t] = min(m0 + 16 * t + lc, M - 1);
         ncol[t] = min(n0 + 16 * t + lc, N - 1);
     }
-    constexpr int U = 4;
     for (int k0 = kbeg; k0 < kend; k0 += 4 * U) {
         double a[U][2], b[U][2];
 #pragma unroll
@@ -73,6 +72,48 @@ __global__ __launch_bounds__(64) void k_dgemm_mfma(int M, int N, int K, const do
             }
 }
 
+// Lower triangle of G = A^T A (A: K x n, row-major), 16 x 16 tiles: one workgroup of 4 waves per tile (R >= C), each wave one
+// quarter of the K range, partial tiles added in fixed order through LDS.  No split-K partials in memory, no reduction launch;
+// the matrix-core inverse reads the lower tiles only.  Unsplit, a tile is a chain of K/4 dependent MFMAs (64 cycles each).
+__global__ __launch_bounds__(256) void k_gram_lower(int n, int K, const double* __restrict__ A, int lda, double* __restrict__ G) {
+    __shared__ double part[3][4][64];
+    const int nt = n >> 4;
+    int R = 0, t = blockIdx.x;
+    while ((R + 1) * (R + 2) / 2 <= t) ++R;
+    const int C = t - R * (R + 1) / 2;
+    (void)nt;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lc = l & 15, lq = l >> 4;
+    const int kq = ((K + 3) / 4 + 3) / 4 * 4;  // k range of a wave, a multiple of 4
+    const int kbeg = w * kq, kend = min(K, kbeg + kq);
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    constexpr int U = 8;
+    for (int k0 = kbeg; k0 < kend; k0 += 4 * U) {
+        double a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 4 * u + lq;
+            const double kmask = k < kend ? 1.0 : 0.0;
+            const int kc = min(k, kend - 1);
+            a[u] = A[(size_t)kc * lda + 16 * R + lc];
+            b[u] = A[(size_t)kc * lda + 16 * C + lc] * kmask;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) part[w - 1][g][l] = acc[g];
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const double v = ((acc[g] + part[0][g][l]) + part[1][g][l]) + part[2][g][l];
+            G[(size_t)(16 * R + lq + 4 * g) * n + 16 * C + lc] = v;
+        }
+    }
+}
+
 // Y = obs_ens - mean(obs_ens) (rows 0..N-1), D0 = obs - obs_ens - perturbs (rows N..2N-1)     HistoryMatch.py:582, 584
 template <typename T>
 __global__ void k_obs_prep(const T* __restrict__ obs_ens, const T* __restrict__ perturbs, const T* __restrict__ obs,
@@ -97,10 +138,22 @@ int dgemm_mfma(hipStream_t s, bool transA, int M, int N, int K, const double* A,
                int ldc, int ksplit, float* C32, int rows32, float* C32T) {
     const int kchunk = ksplit > 1 ? (((K + ksplit - 1) / ksplit + 3) / 4) * 4 : K;
     const dim3 grid((N + 31) / 32, (M + 31) / 32, ksplit > 1 ? (K + kchunk - 1) / kchunk : 1), block(64);
-    if (transA) hipLaunchKernelGGL(k_dgemm_mfma<true>, grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, kchunk, C32, rows32, C32T);
-    else hipLaunchKernelGGL(k_dgemm_mfma<false>, grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, kchunk, C32, rows32, C32T);
+    // short K unsplit (the gain D0 B^-1: K = n_obs): 8 k-steps of loads in flight halve the number of dependent round trips
+    const bool deep = ksplit <= 1 && K <= 512;
+    if (transA) hipLaunchKernelGGL((k_dgemm_mfma<true, 4>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, kchunk, C32, rows32, C32T);
+    else if (deep) hipLaunchKernelGGL((k_dgemm_mfma<false, 8>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, kchunk, C32, rows32, C32T);
+    else hipLaunchKernelGGL((k_dgemm_mfma<false, 4>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, kchunk, C32, rows32, C32T);
     HM_HIP(hipGetLastError());
     return (int)grid.z > 0 ? 0 : 0;
+}
+
+// G (n x n, lower 16 x 16 tiles only) = A^T A, A: K x n.  Returns -1 if n is not a multiple of 16.
+int gram_lower_mfma(hipStream_t s, int n, int K, const double* A, int lda, double* G) {
+    if (n % 16 != 0 || K < 1) return -1;
+    const int nt = n / 16;
+    hipLaunchKernelGGL(k_gram_lower, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, n, K, A, lda, G);
+    HM_HIP(hipGetLastError());
+    return 0;
 }
 
 int dgemm_mfma_splits(int K, int ksplit) {

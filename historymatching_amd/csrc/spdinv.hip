@@ -27,7 +27,8 @@ __device__ __forceinline__ int opaque_s(int x) {
 
 template <int SLOTS, int NW>
 __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __restrict__ G, int nparts, int n, double ridge,
-                                                      double* __restrict__ Wout, int* __restrict__ flag) {
+                                                      double* __restrict__ Wout, int* __restrict__ flag,
+                                                      const double* __restrict__ add, double add_scale) {
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     const int nt = n >> 4;
     // LDS: U[2][n][17], W[n][17], P[16][17], Dg[16][17], flag
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
                 // (nparts == 0: one matrix the caller has already made exactly symmetric -- no transposed read, which is a
                 //  64-line gather per wave instruction through this one CU: ~25 of the kernel's 53 us at n = 160)
                 double gs = 0.0;
-                if (nparts == 0) gs = G[(size_t)row * n + col];
+                if (nparts == 0) gs = G[(size_t)row * n + col] + (add ? add_scale * add[(size_t)row * n + col] : 0.0);
                 for (int z = 0; z < nparts; ++z) {
                     const double* Gz = G + (size_t)z * n * n;
                     gs += 0.5 * (Gz[(size_t)row * n + col] + Gz[(size_t)col * n + row]);
@@ -447,7 +448,10 @@ __global__ __launch_bounds__(1024, 4) void k_local_analysis_mfma(int M, int n_ob
 }  // namespace
 
 // W = inv(G + ridge I) for n a multiple of 16, n <= 256.  Returns 0 if launched, -1 if not applicable, >0 on error.
-int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double ridge, double* W, int* flag) {
+// nparts > 0: G is the sum of `nparts` partial matrices, symmetrised while loading; nparts == 0: one matrix of which only the
+// lower 16 x 16 tiles are read, plus add_scale * add (lower tiles of a second matrix) if `add` is given.
+int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double ridge, double* W, int* flag, const double* add,
+                     double add_scale) {
     if (n % 16 != 0 || n < 16 || n > 256) return -1;
     const int nt = n / 16, ntiles = nt * (nt + 1) / 2;
     // panel buffers U[2][n][17], W[n][17], P, Dg + flag; the final mirrored store wants a 16 x 17 block per wave (16 waves at most)
@@ -455,7 +459,7 @@ int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double r
 #define L(S, NW)                                                                                                              \
     do {                                                                                                                      \
         HM_HIP(hipFuncSetAttribute((const void*)k_spd_inverse<S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_spd_inverse<S, NW>), dim3(1), dim3(64 * NW), lds, s, G, nparts, n, ridge, W, flag);                \
+        hipLaunchKernelGGL((k_spd_inverse<S, NW>), dim3(1), dim3(64 * NW), lds, s, G, nparts, n, ridge, W, flag, add, add_scale);  \
     } while (0)
     if (ntiles <= 12) L(2, 8);
     else if (ntiles <= 24) L(2, 16);
@@ -480,7 +484,7 @@ extern "C" int hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double 
     HM_HIP(hipMalloc(&dflag, 4));
     HM_HIP(hipMemset(dflag, 0, 4));
     HM_HIP(hipMemcpy(dG, G, bytes, hipMemcpyHostToDevice));
-    int rc = spd_inverse_mfma(ctx->stream, dG, 1, n, ridge, dW, dflag);
+    int rc = spd_inverse_mfma(ctx->stream, dG, 1, n, ridge, dW, dflag, nullptr, 0.0);
     int flag = 0;
     if (rc == 0 && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(W, dW, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
                     hipMemcpy(&flag, dflag, 4, hipMemcpyDeviceToHost) != hipSuccess)) {

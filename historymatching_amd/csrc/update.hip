@@ -25,6 +25,7 @@ int transpose_cast_d2f(hipStream_t s, const double* in, float* out, int rows, in
 int transpose_f2f(hipStream_t s, const float* in, float* out, int rows, int cols);
 int transpose_cast_f2d(hipStream_t s, const float* in, double* out, int rows, int cols);
 void mfma_set_gxt_chunk(int kc);
+void mfma_set_apply_variant(int v);
 
 struct hm_upd {
     hm_ctx* ctx = nullptr;
@@ -507,7 +508,9 @@ __global__ __launch_bounds__(1024) void k_invert_C_reg(const double* __restrict_
     if (bad) *flag = 1;
 }
 
-int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double ridge, double* W, int* flag);  // spdinv.hip
+int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double ridge, double* W, int* flag, const double* add = nullptr,
+                     double add_scale = 0.0);  // spdinv.hip
+int gram_lower_mfma(hipStream_t s, int n, int K, const double* A, int lda, double* G);  // dgemm_mfma.hip
 // dgemm_mfma.hip
 int dgemm_mfma(hipStream_t s, bool transA, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C,
                int ldc, int ksplit, float* C32, int rows32, float* C32T);
@@ -930,14 +933,22 @@ extern "C" int hm_upd_run(hm_upd* u) {
             HM_HIP(hipStreamWaitEvent(s2, u->ev_fork, 0));
         }
         // stream 2: B = Yc^T Yc + (N-1) R (8 row blocks, fixed-order sum), B^-1, gain A' = D0 B^-1 as its fp32 transpose
-        const int nsplit = dgemm_mfma_splits(nl, 16);
-        if ((rc = dgemm_mfma(s2, true, no, no, nl, YD, no, YD, no, (double*)u->gpart.p, no, 16, nullptr, 0, nullptr))) return rc;
-        hipLaunchKernelGGL(k_gram_reduce_sym, dim3((no * no + 255) / 256), dim3(256), 0, s2, (const double*)u->gpart.p, nsplit, no, G,
-                           (const double*)u->Rm.p, (double)(u->N_total - 1));
-        HM_HIP(hipGetLastError());
-        rc = g_use_mfma_inverse ? spd_inverse_mfma(s2, G, 0, no, 0.0, (double*)u->Cinv.p, (int*)u->flags.p) : -1;
+        // B = Yc^T Yc + (N-1) R: the lower 16 x 16 tiles of the Gram matrix in one launch (4 k-quarters per tile, fixed-order sum),
+        // (N-1) R added by the inverse while it loads its tiles
+        rc = g_use_mfma_inverse ? gram_lower_mfma(s2, no, nl, YD, no, G) : -1;
         if (rc > 0) return rc;
-        if (rc < 0 && (rc = invert_C(s2, G, no, 0.0, (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p, true))) return rc;
+        if (rc == 0) {
+            rc = spd_inverse_mfma(s2, G, 0, no, 0.0, (double*)u->Cinv.p, (int*)u->flags.p, (const double*)u->Rm.p, (double)(u->N_total - 1));
+            if (rc > 0) return rc;
+        }
+        if (rc < 0) {
+            const int nsplit = dgemm_mfma_splits(nl, 16);
+            if ((rc = dgemm_mfma(s2, true, no, no, nl, YD, no, YD, no, (double*)u->gpart.p, no, 16, nullptr, 0, nullptr))) return rc;
+            hipLaunchKernelGGL(k_gram_reduce_sym, dim3((no * no + 255) / 256), dim3(256), 0, s2, (const double*)u->gpart.p, nsplit, no, G,
+                               (const double*)u->Rm.p, (double)(u->N_total - 1));
+            HM_HIP(hipGetLastError());
+            if ((rc = invert_C(s2, G, no, 0.0, (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p, true))) return rc;
+        }
         if ((rc = dgemm_mfma(s2, false, nl, no, no, YD + nsm, no, (const double*)u->Cinv.p, no, nullptr, no, 1, nullptr, 0, A_T))) return rc;
         if (u->overlap) HM_HIP(hipEventRecord(u->ev_join, s2));
         // stream 1: Gy = Yc^T (E - c), then (after the join) E_out = E + A' Gy
@@ -994,7 +1005,8 @@ extern "C" int hm_upd_set_option(hm_upd* u, const char* name, int value) {
     if (std::string(name) == "use_mfma") { u->use_mfma = value; return 0; }
     if (std::string(name) == "overlap") { u->overlap = value; return 0; }  // hm_upd_run: second stream for the small chain
     if (std::string(name) == "kalman_form") { u->kalman_form = value; return 0; }
-    if (std::string(name) == "gxt_chunk") { mfma_set_gxt_chunk(value); return 0; }  // members per LDS chunk of k_gxt_lds: 32 | 64  // hm_upd_run: 0 = decorrelated form (S, D, C)
+    if (std::string(name) == "gxt_chunk") { mfma_set_gxt_chunk(value); return 0; }
+    if (std::string(name) == "apply_variant") { mfma_set_apply_variant(value); return 0; }  // 2: pipelined, 2 workgroups per CU (default) | 1  // members per LDS chunk of k_gxt_lds: 32 | 64  // hm_upd_run: 0 = decorrelated form (S, D, C)
     if (std::string(name) == "mfma_inverse") { g_use_mfma_inverse = value; return 0; }  // 0: rank-1 register sweeps
     hm_set_error("hm_upd_set_option: unknown option '%s'", name);
     return 2;

@@ -346,6 +346,104 @@ __global__ __launch_bounds__(256) void k_apply_lds(int N, int M, int n_obs, cons
     }
 }
 
+// Third generation of the apply: one workgroup = 64 state elements x EVERY NG-th block of 128 members.  The Gx tile is staged
+// once per workgroup (8 / NG times less often than one workgroup per member block), the grid is exactly two workgroups per CU
+// (no partial last round), and the loads of a member block are issued one step ahead of their use: the A operand of the next
+// 16 k-pairs while the current 16 feed the matrix cores, the E tile of the next member block behind the last A batch of the
+// current one (vector-memory waits retire in issue order: an E tile requested in front of A loads would stall them).
+template <int NG>
+__global__ __launch_bounds__(256, 2) void k_apply_lds2(int N, int M, int n_obs, const float* __restrict__ E,
+                                                       const float* __restrict__ At, const float* __restrict__ Gx,
+                                                       float* __restrict__ Eout) {
+    extern __shared__ __attribute__((aligned(16))) float Bs[];  // n_obs x 64
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < n_obs * 16; e += 256) {  // float4 granules
+        const int j = e >> 4, c4 = (e & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + c4 + 3 < M) v = *reinterpret_cast<const float4*>(Gx + (size_t)j * M + i0 + c4);
+        *reinterpret_cast<float4*>(Bs + j * 64 + c4) = v;
+    }
+    const int nl = lane & 31, kh = lane >> 5;
+    const int nblocks = (N + 127) / 128, npairs = (n_obs + 1) / 2;
+    constexpr int UA = 8;
+    float ev[2][16], evn[2][16], av[UA], avn[UA];
+    // rows of a wave: n0 .. n0 + 31 with n0 clamped to N - 32 (host: N >= 32), so the ragged last block needs no per-row clamps --
+    // its last waves recompute rows another wave also computes and store the same values.  M % 64 == 0 (host-checked).
+    // The product is formed TRANSPOSED, (states x k) . (k x members): accumulator column = lane & 31 = member, registers = states
+    // 32 t + 8 g + 4 kh + {0..3} -- four consecutive state elements per register quad, so the E tile moves as 16-byte accesses
+    // (8 loads + 8 stores per thread and member block instead of 32 + 32 dword accesses: the scalar form was issue-bound in the
+    // memory pipeline).  Addresses = wave-uniform pointer (scalar registers) + one 32-bit lane offset.
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    auto wave_row0 = [&](int blk) { return min(blk * 128 + 32 * wu, N - 32); };
+    const int e_off = nl * M + 4 * kh;   // lane part of an E / E_out address (floats): member row nl, state quad kh
+    const int a_off = kh * N + nl;       // lane part of an A-operand address
+    auto load_E = [&](int blk, float (&dst)[2][16]) {
+        const float* base = E + (size_t)wave_row0(blk) * M + i0 + e_off;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 v = *reinterpret_cast<const float4*>(base + 32 * t + 8 * g4);
+                dst[t][4 * g4 + 0] = v.x; dst[t][4 * g4 + 1] = v.y; dst[t][4 * g4 + 2] = v.z; dst[t][4 * g4 + 3] = v.w;
+            }
+    };
+    auto load_A = [&](int blk, int jp0, float (&dst)[UA]) {
+        const float* base = At + wave_row0(blk) + (size_t)(2 * jp0) * N;
+#pragma unroll
+        for (int u = 0; u < UA; ++u) dst[u] = (base + (size_t)(2 * u) * N)[a_off];  // n_obs even: j = 2 (jp0 + u) + kh < n_obs
+    };
+    // (Measured and rejected: an explicit ping-pong of the A-operand registers with the batch loop unrolled by two and the batch's
+    //  LDS reads grouped in front of its MFMAs -- 78 us against 67 us for this form, in which the compiler interleaves one
+    //  ds_read2 per MFMA pair and waits for the A loads issued one batch earlier.)
+    int b = blockIdx.y;
+    if (b < nblocks) {
+        load_A(b, 0, av);
+        load_E(b, ev);
+    }
+    __syncthreads();
+    for (; b < nblocks; b += NG) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        const bool more = b + NG < nblocks;
+        for (int jp0 = 0; jp0 < npairs; jp0 += UA) {  // npairs % UA == 0 (host-checked)
+            if (jp0 + UA < npairs) {
+                load_A(b, jp0 + UA, avn);
+            } else if (more) {
+                load_A(b + NG, 0, avn);
+                load_E(b + NG, evn);
+            }
+            const float* brow = Bs + (2 * jp0 + kh) * 64 + nl;
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(brow[u * 128 + 32 * t], av[u], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < UA; ++u) av[u] = avn[u];
+        }
+        float* obase = Eout + (size_t)wave_row0(b) * M + i0 + e_off;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 v;
+                v.x = ev[t][4 * g4 + 0] + acc[t][4 * g4 + 0];
+                v.y = ev[t][4 * g4 + 1] + acc[t][4 * g4 + 1];
+                v.z = ev[t][4 * g4 + 2] + acc[t][4 * g4 + 2];
+                v.w = ev[t][4 * g4 + 3] + acc[t][4 * g4 + 3];
+                *reinterpret_cast<float4*>(obase + 32 * t + 8 * g4) = v;
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ev[t][r] = evn[t][r];
+    }
+}
+
 // ---- host entry points (return 0 launched, >0 error, -1 not applicable -> caller uses the generic GEMM) ----
 int mfma_gxt(hipStream_t s, int N, int M, int n_obs, const float* E, const float* colsum, double inv_n, const float* S,
              float* Gxt) {
@@ -415,9 +513,19 @@ int mfma_gxt_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const f
     return 0;
 }
 
+static int g_apply_variant = 2;
+void mfma_set_apply_variant(int v) { g_apply_variant = v; }
+
 int mfma_apply_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const float* At, const float* Gx, float* Eout) {
     const size_t lds = (size_t)n_obs * 64 * 4;
     if (lds > 150 * 1024 || M % 4 != 0) return -1;
+    if (g_apply_variant == 2 && lds <= 78 * 1024 && M % 64 == 0 && N >= 32 && n_obs % 16 == 0) {  // two workgroups per CU
+        HM_HIP(hipFuncSetAttribute((const void*)k_apply_lds2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        dim3 grid((M + 63) / 64, 2), block(256);
+        hipLaunchKernelGGL(k_apply_lds2<2>, grid, block, lds, s, N, M, n_obs, E, At, Gx, Eout);
+        HM_HIP(hipGetLastError());
+        return 0;
+    }
     HM_HIP(hipFuncSetAttribute((const void*)k_apply_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((M + 63) / 64, (N + 127) / 128), block(256);
     hipLaunchKernelGGL(k_apply_lds, grid, block, lds, s, N, M, n_obs, E, At, Gx, Eout);
