@@ -447,6 +447,9 @@ __global__ __launch_bounds__(1024, 4) void k_local_analysis_mfma(int M, int n_ob
 
 }  // namespace
 
+static int g_spd_small = 0;
+void spd_inverse_set_small(int v) { g_spd_small = v; }
+
 // W = inv(G + ridge I) for n a multiple of 16, n <= 256.  Returns 0 if launched, -1 if not applicable, >0 on error.
 // nparts > 0: G is the sum of `nparts` partial matrices, symmetrised while loading; nparts == 0: one matrix of which only the
 // lower 16 x 16 tiles are read, plus add_scale * add (lower tiles of a second matrix) if `add` is given.
@@ -463,6 +466,7 @@ int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double r
     } while (0)
     if (ntiles <= 12) L(2, 8);
     else if (ntiles <= 24) L(2, 16);
+    else if (ntiles <= 60 && g_spd_small) L(10, 8);  // 8 waves, <= 128 registers: fits on a CU beside a contraction workgroup
     else if (ntiles <= 60) L(5, 16);
     else if (ntiles <= 96) L(8, 16);
     else L(12, 16);

@@ -26,6 +26,7 @@ int transpose_f2f(hipStream_t s, const float* in, float* out, int rows, int cols
 int transpose_cast_f2d(hipStream_t s, const float* in, double* out, int rows, int cols);
 void mfma_set_gxt_chunk(int kc);
 void mfma_set_apply_variant(int v);
+void spd_inverse_set_small(int v);
 
 struct hm_upd {
     hm_ctx* ctx = nullptr;
@@ -46,8 +47,9 @@ struct hm_upd {
     int kalman_form = 1;            // hm_upd_run: 1 = contraction on the centred observations, gain through R (see there)
     int use_mfma = 1;  // fp32 only: 0 forces the generic VALU GEMMs (tests compare both)
     EvTimer t_upd;
-    int overlap = 0;                // hm_upd_run: 1 = small fp64 chain on a second stream beside the big contraction (measured: no gain,
-                                    // the 16-wave inverse does not fit on a CU beside a contraction workgroup and waits for one to finish)
+    int overlap = 0;                // hm_upd_run: 1 = small fp64 chain on a second stream beside the big contraction.  Measured, no gain:
+                                    // the 16-wave inverse does not fit on a CU beside a contraction workgroup (it waits for one to finish);
+                                    // the 8-wave form that fits ("small_inverse") spills and is as much slower as the overlap hides
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // localised plans over several ranks: the per-element solves are column-sharded -- this rank solves the state
@@ -1006,6 +1008,7 @@ extern "C" int hm_upd_set_option(hm_upd* u, const char* name, int value) {
     if (std::string(name) == "overlap") { u->overlap = value; return 0; }  // hm_upd_run: second stream for the small chain
     if (std::string(name) == "kalman_form") { u->kalman_form = value; return 0; }
     if (std::string(name) == "gxt_chunk") { mfma_set_gxt_chunk(value); return 0; }
+    if (std::string(name) == "small_inverse") { spd_inverse_set_small(value); return 0; }  // 8-wave matrix-core inverse (co-resident form)
     if (std::string(name) == "apply_variant") { mfma_set_apply_variant(value); return 0; }  // 2: pipelined, 2 workgroups per CU (default) | 1  // members per LDS chunk of k_gxt_lds: 32 | 64  // hm_upd_run: 0 = decorrelated form (S, D, C)
     if (std::string(name) == "mfma_inverse") { g_use_mfma_inverse = value; return 0; }  // 0: rank-1 register sweeps
     hm_set_error("hm_upd_set_option: unknown option '%s'", name);
