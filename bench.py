@@ -14,8 +14,9 @@ member-steps of all ranks / max-over-ranks time, bracketed by a barrier + device
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the library on the launch
 stream) and `cpu_baseline` (the NumPy/SciPy oracle on the host cores, bounded sample, rank 0 at N=1 only).
 Beside `value` (outside its timed region): `es_update` (the analysis step at config 3's shape; 4 ES-MDA passes of config 3;
-at N > 1 the analysis step row-sharded over the ranks with RCCL) and `config4` (BASELINE config 4: N_e = 4096 at
-256 x 256 split over the ranks -- strong scaling -- one ES-MDA pass = forward model + analysis step over RCCL).
+at N > 1 the analysis step row-sharded over the ranks with RCCL), `config4` (BASELINE config 4: N_e = 4096 at
+256 x 256 split over the ranks -- strong scaling -- one ES-MDA pass = forward model + analysis step over RCCL) and, from 4 ranks
+up or with --config5, `config5` (N_e = 1000 at 512 x 512, localised analysis with column-sharded solves).
 """
 import argparse
 import json
@@ -206,6 +207,38 @@ def config4_sharded(device, comm, n_total=4096, n_grid=256):
             "collective": "RCCL (hm_upd_run_comm)" if comm.rccl is not None else ("none (one rank)" if comm.world_size == 1 else f"host channel ({comm.rccl_error})")}
 
 
+def config5_sharded(device, comm, n_total=1000, n_grid=512):
+    """BASELINE.json config 5: N_e = 1000 members at 512 x 512, localised update (taper = bump(dist / 1.2) to the 4 producers x
+    40 times, HistoryMatch.py:700-717, 863), fp32 plans, members split over the ranks (strong scaling); one ES-MDA pass = forward
+    model of the local members + the localised analysis over the ranks: two all-reduces, per-element solves sharded by state
+    column, all-gather of the weights.  Called by EVERY rank.  Default only at 4 ranks or more (one rank: ~4 min)."""
+    from historymatching_amd.dist import es_mda_sharded, shard_bounds
+    from historymatching_amd.geostat import gaussian_fields_kron
+    from historymatching_amd.localization import taper_for_wells
+
+    lo, hi = shard_bounds(n_total, comm.world_size, comm.rank)
+    model = build_model(32, device=device, n=n_grid)
+    n_obs = NTIME * 4
+    R12 = reference_obs_error(n_obs)
+    obs = np.clip(0.2 + R12 @ np.random.RandomState(9).randn(n_obs), 0, 1)
+    taper = taper_for_wells(model, model.xy2ind(*model.prd_xy.T), NTIME, radius=1.2)
+    prior = gaussian_fields_kron(n_grid, n_grid, 2, 1, hi - lo, r=0.8, seed=2000 + lo)
+    st = {}
+    comm.barrier()
+    t0 = time.perf_counter()
+    post = es_mda_sharded(model, prior, obs, R12, DT, NTIME, n_iter=1, seed=3, comm=comm, dtype=32, taper=taper, device=device, stats=st)
+    comm.barrier()
+    wall = comm.all_reduce_max(time.perf_counter() - t0)
+    fwd_ms = comm.all_reduce_max(st["ms_forward"])
+    upd_ms = comm.all_reduce_max(st["ms_update"] + st.get("ms_comm", 0.0))
+    ok = comm.all_reduce_max(0.0 if np.isfinite(post).all() else 1.0) == 0.0
+    return {"members_total": n_total, "members_per_rank": hi - lo, "grid": [n_grid, n_grid], "n_ranks": comm.world_size, "scaling": "strong",
+            "passes": 1, "wall_s": wall, "device_ms_forward_max": fwd_ms, "device_ms_localised_update_max": upd_ms,
+            "ensemble_steps_per_s_forward": n_total * NTIME / (fwd_ms * 1e-3), "posterior_finite": bool(ok), "dtype": "f32 saturation sweep + fp64 pressure, fp32 matrix-core analysis",
+            "collective": "RCCL (hm_upd_run_comm: 2 all-reduces + all-gather of the column-sharded weights)" if comm.rccl is not None
+                          else ("none (one rank)" if comm.world_size == 1 else f"host channel ({comm.rccl_error})")}
+
+
 def load_profile_json(name):
     """Newest committed profiles/rNN/<name> (measured separately under rocprofv3 / from the built object), or None."""
     try:
@@ -223,6 +256,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-esmda", action="store_true", help="skip the 4-pass ES-MDA leg (config 3)")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (N_e=4096 at 256x256 over the ranks)")
+    ap.add_argument("--config5", action="store_true", help="run the config-5 leg (N_e=1000 at 512x512, localised) also below 4 ranks")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0, help="0 = fastest kernels, 1 = generic kernels")
     args = ap.parse_args()
@@ -280,6 +314,9 @@ def main():
         upd_sharded = guarded(lambda: es_update_sharded_timing(local_rank, comm))
     if not args.no_config4 and args.members == N_E:
         c4 = guarded(lambda: config4_sharded(local_rank, comm))
+    c5 = None
+    if args.members == N_E and (args.config5 or (world >= 4 and not args.no_config4)):
+        c5 = guarded(lambda: config5_sharded(local_rank, comm))
 
     if rank == 0:
         member_steps = n_e * NTIME * args.steps * world
@@ -359,7 +396,7 @@ def main():
                        "members_per_gpu": n_e, "grid": [NX, NY], "nTime": NTIME, "device": ctx.name(),
                        "kernel_variant": args.variant, "results_finite_and_status_ok": bool(ok),
                        "ranks": "one process per GPU, host channel for barriers/timing, RCCL from the library for the update's reductions (no PyTorch)"},
-            "roofline": roofline, "cpu_baseline": cpu, "es_update": upd, "config4": c4,
+            "roofline": roofline, "cpu_baseline": cpu, "es_update": upd, "config4": c4, "config5": c5,
             "device_ms": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
         }
         print(json.dumps(out))
