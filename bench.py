@@ -334,13 +334,18 @@ def main():
         # launch = DP VALU instructions of the sub-step loop (counted from the built object: profiles/tools/isa_count.py) x
         # cells x sub-steps x members, in lane-instructions; the peak is one DP lane-instruction per lane-slot.
         dp_per_cell = (isa or {}).get("k_sat128", {}).get("dp_valu_per_cell_substep", 39.25)
-        sat_lane_instr = dp_per_cell * nxy * nts * n_e
+        # dry bands are skipped (sat128.hip): the instructions actually executed are fewer than cells x sub-steps x count; the
+        # ratio is measured (SQ_INSTS_VALU over the same workload, profiles/rNN/fp64_roofline.json) -- `frac` uses EXECUTED work
+        f64r, f64r_src = load_profile_json("fp64_roofline.json")
+        executed_ratio = ((f64r or {}).get("kernels", {}).get("k_sat128", {}).get("executed_over_algorithmic", 1.0)) if args.variant == 0 else 1.0
+        sat_lane_instr_algorithmic = dp_per_cell * nxy * nts * n_e
+        sat_lane_instr = sat_lane_instr_algorithmic * executed_ratio
         # pressure (k_press128s): fp64 matrix cores; flops = rank-16 updates of the 36 stored tiles x 8 panels x Nx blocks
         prs_flops = 2.0 * 36 * 16 * 16 * 16 * 8 * NX * n_e
         if dominant == "saturation":
             ach = 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12
-            bound, what = "fp64_valu", ("double-precision VALU issue slots: every DP VALU instruction of the sub-step loop counted as one FMA slot "
-                                        "(2 flop) per lane, peak = 256 CUs x 4 SIMDs x 16 DP lanes x 2.4 GHz x 2")
+            bound, what = "fp64_valu", ("double-precision VALU issue slots actually executed: every DP VALU instruction of the sub-step loop counted as "
+                                        "one FMA slot (2 flop) per lane, dry bands' skipped instructions not counted; peak = 256 CUs x 4 SIMDs x 16 DP lanes x 2.4 GHz x 2")
         else:
             ach = prs_flops / (prs_ms * 1e-3) / 1e12
             bound, what = "fp64_mfma", "v_mfma_f64_16x16x4 flops of the block elimination's rank-16 panel updates"
@@ -359,6 +364,8 @@ def main():
             "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
             "hbm_frac_of_peak_from_measured_traffic": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "work_counted": what, "dp_valu_per_cell_substep": dp_per_cell, "isa_count_source": isa_src,
+            "executed_over_algorithmic_instructions": executed_ratio, "executed_ratio_source": f64r_src,
+            "frac_if_skipped_dry_bands_counted_as_work": 2 * sat_lane_instr_algorithmic / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             "avg_launch_ms": {"saturation": sat_ms, "pressure": prs_ms},
             "per_kernel": {"saturation_fp64_valu_frac": 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                            "pressure_fp64_mfma_frac": prs_flops / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},

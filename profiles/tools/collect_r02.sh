@@ -42,5 +42,5 @@ import json, subprocess
 d = json.loads(subprocess.run(["python3", "profiles/tools/isa_count.py", "historymatching_amd/csrc/sat128.o", "k_sat128ILb1", "32", "2"], capture_output=True, text=True, check=True).stdout)
 print(json.dumps({"k_sat128": d, "how": "profiles/tools/isa_count.py historymatching_amd/csrc/sat128.o k_sat128ILb1 32 2"}, indent=1))
 PY
-python3 profiles/tools/fp64_roofline.py $OUT/pmc_fp64_forward_counter_collection.csv $OUT/kernel_stats_bench.csv $OUT/isa_counts.json > $OUT/fp64_roofline.json
+python3 profiles/tools/fp64_roofline.py $OUT/pmc_fp64_forward_counter_collection.csv $OUT/kernel_stats_bench.csv $OUT/isa_counts.json $OUT/bench_under_rocprof.json > $OUT/fp64_roofline.json
 ls -la $OUT

@@ -2,7 +2,8 @@
 """fp64 roofline of the forward kernels from one rocprofv3 --pmc pass, reproducible from the committed CSVs:
 
     python3 profiles/tools/fp64_roofline.py profiles/r02/pmc_fp64_forward_counter_collection.csv \
-            profiles/r02/kernel_stats_bench.csv profiles/r02/isa_counts.json > profiles/r02/fp64_roofline.json
+            profiles/r02/kernel_stats_bench.csv profiles/r02/isa_counts.json profiles/r02/bench_under_rocprof.json \
+            > profiles/r02/fp64_roofline.json
 
 Counters (own pass, counters only): SQ_INSTS_VALU, SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES,
 GRBM_GUI_ACTIVE.  Per kernel, averaged over its dispatches:
@@ -30,6 +31,12 @@ if len(sys.argv) > 2:
         if m:
             stats.setdefault(m.group(1), float(r["AverageNs"]))
 isa = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else {}
+bench_line = {}
+if len(sys.argv) > 4:  # the JSON line bench.py printed under the kernel trace: measured mean sub-steps per member-step
+    try:
+        bench_line = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+    except Exception:
+        bench_line = {}
 disp = defaultdict(dict)
 for r in rows:
     key = (r["Dispatch_Id"], r["Kernel_Name"])
@@ -61,6 +68,14 @@ for name, cs in sorted(agg.items()):
         e["dp_lane_instr_per_launch"] = lane_instr * share
         e["fp64_valu_frac_of_dp_lane_peak"] = lane_instr * share / (ns * 1e-9) / DP_LANE_RATE
         e["valu_issue_frac_if_every_instr_took_a_dp_slot"] = lane_instr / (ns * 1e-9) / DP_LANE_RATE
+        nts = bench_line.get("roofline", {}).get("mean_nts")
+        if nts:
+            # instructions the sweep would execute if no wave skipped a dry band: (DP + other VALU per thread and sub-step) x 8 waves
+            # x sub-steps x members; the measured count is lower by the dry-band skip
+            algo = (c["dp_valu"] + c["other_valu"]) * 8.0 * nts * e["members_per_launch"]
+            e["algorithmic_valu_wave_instr_per_launch"] = algo
+            e["executed_over_algorithmic"] = avg("SQ_INSTS_VALU") / algo
+            e["fp64_valu_frac_algorithmic_work"] = algo * 64 * share / (ns * 1e-9) / DP_LANE_RATE
     flops = avg("SQ_INSTS_VALU_MFMA_MOPS_F64") * 512
     if flops > 0:
         e["fp64_mfma_flops_per_launch"] = flops
