@@ -69,6 +69,7 @@ SIGNATURES = {
                                 C.c_double, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "hm_fwd_destroy": (None, [_vp]),
     "hm_fwd_set_inputs": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "hm_fwd_set_perm_y": (C.c_int, [_vp, _vp, C.c_int]),
     "hm_fwd_run": (C.c_int, [_vp, C.c_int, C.c_int]),
     "hm_fwd_sync": (C.c_int, [_vp, C.POINTER(hm_stats)]),
     "hm_fwd_get_outputs": (C.c_int, [_vp, _vp, _vp, _ip]),

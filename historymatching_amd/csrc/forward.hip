@@ -66,6 +66,7 @@ __global__ void k_pressure_generic(FwdParams p, const TS* __restrict__ S_base, l
 
     const TS* S = S_base + (long long)m * S_stride;
     const double* Km = p.K + (long long)m * Nxy;
+    const double* Kym = p.Ky ? p.Ky + (long long)m * Nxy : Km;
     double* TX = p.TX + (long long)m * (Nx + 1) * Ny;
     double* TY = p.TY + (long long)m * Nx * (Ny + 1);
     double* G = p.G + (long long)m * Nx * Ny * Ny;
@@ -77,7 +78,7 @@ __global__ void k_pressure_generic(FwdParams p, const TS* __restrict__ S_base, l
     double* L = P;  // temporarily holds L = 1/(Mt*K)
 
     // --- mobility-weighted inverse permeability, harmonic-mean face transmissibilities
-    assemble_transmissibilities<TS>(p, S, Km, L, TX, TY, tid, T);
+    assemble_transmissibilities<TS>(p, S, Km, Kym, L, TX, TY, tid, T);
 
     int bad = 0;
     // --- forward block elimination
@@ -112,7 +113,7 @@ __global__ void k_pressure_generic(FwdParams p, const TS* __restrict__ S_base, l
             double y1 = TY[i * (Ny + 1) + j], y2 = TY[i * (Ny + 1) + j + 1];
             double x1 = TX[i * Ny + j], x2 = TX[(i + 1) * Ny + j];
             double dg = y1 + y2 + x1 + x2;
-            if (i == 0 && j == 0) dg += Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
+            if (i == 0 && j == 0) dg += Km[0] + Kym[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
             A[j * LD + j] += dg;
             if (j + 1 < Ny) {
                 A[j * LD + j + 1] -= y2;
@@ -645,7 +646,7 @@ extern "C" void hm_fwd_destroy(hm_fwd* f) {
     (void)hipStreamSynchronize(f->ctx->stream);
     DevBuf* bufs[] = {&f->K, &f->por, &f->q, &f->prd_ind, &f->TX, &f->TY, &f->G, &f->yv, &f->P, &f->Vx,
                       &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells, &f->cg_r, &f->cg_p, &f->n_cg,
-                      &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->tl_z1, &f->tl_dinv, &f->tl_parts, &f->team_mem};
+                      &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->tl_z1, &f->tl_dinv, &f->tl_parts, &f->team_mem, &f->Ky};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     f->t_total.destroy(); f->t_press.destroy(); f->t_sat.destroy();
     delete f;
@@ -720,6 +721,34 @@ extern "C" int hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transf
     HM_HIP(hipMemsetAsync(f->status.p, 0, (size_t)p.N * 4, s));
     f->cur = 0;
     HM_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+// Anisotropic permeability: the y-component of K per member (the x-component is the `perm` of hm_fwd_set_inputs*).  The reference's
+// set_perm stacks [p, p] (HistoryMatch.py:160-164), so its own runs never need this; the simulator's K is (2, Nx, Ny) all the same
+// (TX from K[0], TY from K[1], the SPD pin K[0,0,0] + K[1,0,0]).  NULL returns the plan to Kx = Ky.
+extern "C" int hm_fwd_set_perm_y(hm_fwd* f, const void* perm_y, int perm_is_transformed) {
+    HM_REQUIRE(f, "hm_fwd_set_perm_y: NULL plan");
+    HM_HIP(hipSetDevice(f->ctx->device));
+    hipStream_t s = f->ctx->stream;
+    if (!perm_y) {
+        f->p.Ky = nullptr;
+        return 0;
+    }
+    const size_t n = (size_t)f->p.N * f->p.Nxy;
+    if (!f->Ky.p) {
+        int rc = hm_dev_alloc(f->Ky, n * 8);
+        if (rc) return rc;
+    }
+    if (perm_is_transformed) {
+        HM_HIP(hipMemcpyAsync(f->Ky.p, perm_y, n * 8, hipMemcpyHostToDevice, s));
+    } else {
+        HM_HIP(hipMemcpyAsync(f->perm_in.p, perm_y, n * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_perm_transform, dim3(2048), dim3(256), 0, s, (const double*)f->perm_in.p, (double*)f->Ky.p, (long long)n);
+        HM_HIP(hipGetLastError());
+    }
+    HM_HIP(hipStreamSynchronize(s));
+    f->p.Ky = (const double*)f->Ky.p;
     return 0;
 }
 

@@ -13,7 +13,8 @@ struct FwdParams {
     double vw, vo, swc, sor;  // fluid
     int fluid_default;        // 1 when vw=vo=1, swc=sor=0: S*=S, Mw=S^2, Mo=(1-S)^2 exactly
     double dt;
-    const double* K;          // N*Nxy permeability (isotropic: Kx=Ky, set_perm HistoryMatch.py:164)
+    const double* K;          // N*Nxy x-permeability (= y-permeability when Ky is null: set_perm HistoryMatch.py:164 sets Kx = Ky)
+    const double* Ky;         // N*Nxy y-permeability or nullptr
     const double* por;        // Nxy porosity or nullptr (=1)
     const double* q;          // q_cols*Nxy source field per time column
     int q_cols;
@@ -51,6 +52,7 @@ struct hm_fwd {
     int press_variant = 0, sat_variant = 0;
     bool cg_lazy = true;  // CG work vectors not allocated yet
     size_t esz = 8;  // bytes per saturation element
+    DevBuf Ky;     // y-permeability of an anisotropic run (hm_fwd_set_perm_y), else unallocated
     DevBuf K, por, q, prd_ind, TX, TY, G, yv, P, Vx, Vy, coef, fw, status, nts, perm_in, cg_r, cg_p, n_cg;
     // two-level CG preconditioner (allocated on first use): coarse transmissibilities, pin, restricted residual, coarse
     // correction, coarse scratch, coarse factor, per-member CG scalars and convergence flags

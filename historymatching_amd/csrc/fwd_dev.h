@@ -20,12 +20,15 @@ __device__ __forceinline__ void rel_perm(const FwdParams& p, T s, T& mw, T& mo) 
     }
 }
 
-// L = (Mt*K)**(-1) per cell, then harmonic-mean face transmissibilities TX (Nx+1,Ny), TY (Nx,Ny+1), zero on the
-// boundary.  All threads of the workgroup must call this; contains barriers.
+// L = (Mt*K)**(-1) per cell, then harmonic-mean face transmissibilities TX (Nx+1,Ny) from the x-permeability, TY (Nx,Ny+1)
+// from the y-permeability, zero on the boundary.  Kym == Km (the reference's case, set_perm HistoryMatch.py:164: Kx = Ky): one
+// pass over L; otherwise L is rebuilt from Ky between the two face loops.  All threads of the workgroup must call this;
+// contains barriers.
 template <typename TS>
 __device__ __forceinline__ void assemble_transmissibilities(const FwdParams& p, const TS* __restrict__ S,
-                                                            const double* __restrict__ Km, double* __restrict__ L,
-                                                            double* __restrict__ TX, double* __restrict__ TY, int tid, int T) {
+                                                            const double* __restrict__ Km, const double* __restrict__ Kym,
+                                                            double* __restrict__ L, double* __restrict__ TX, double* __restrict__ TY,
+                                                            int tid, int T) {
     const int Nx = p.Nx, Ny = p.Ny, Nxy = p.Nxy;
     for (int j = tid; j < Nxy; j += T) {
         double mw, mo;
@@ -37,6 +40,16 @@ __device__ __forceinline__ void assemble_transmissibilities(const FwdParams& p, 
     for (int f = tid; f < (Nx + 1) * Ny; f += T) {
         int ix = f / Ny, iy = f % Ny;
         TX[f] = (ix == 0 || ix == Nx) ? 0.0 : p.cx / (L[(ix - 1) * Ny + iy] + L[ix * Ny + iy]);
+    }
+    if (Kym != Km) {  // anisotropic: uniform over the workgroup
+        __syncthreads();
+        for (int j = tid; j < Nxy; j += T) {
+            double mw, mo;
+            rel_perm<double>(p, (double)S[j], mw, mo);
+            double KM = (mw + mo) * Kym[j];
+            L[j] = 1.0 / KM;
+        }
+        __syncthreads();
     }
     for (int f = tid; f < Nx * (Ny + 1); f += T) {
         int ix = f / (Ny + 1), iy = f % (Ny + 1);

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
 
     const TS* S = S_base + (long long)m * S_stride;
     const double* Km = p.K + (long long)m * Nxy;
+    const double* Kym = (!FACTOR && p.Ky) ? p.Ky + (long long)m * Nxy : Km;
     double* TX = p.TX + (long long)m * (Nx + 1) * NB;
     double* TY = p.TY + (long long)m * Nx * (NB + 1);
     double2* G = reinterpret_cast<double2*>(p.G + (long long)m * Nx * NB * NB);
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
 
     if (sweeper) __builtin_amdgcn_s_setprio(3);  // the pivot chain outranks whatever else is issued on its SIMD
     PROF_DECL;
-    if constexpr (!FACTOR) assemble_transmissibilities<TS>(p, S, Km, P /* scratch for L */, TX, TY, tid, NT);
-    const double pin = FACTOR ? p.pin[m] : Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
+    if constexpr (!FACTOR) assemble_transmissibilities<TS>(p, S, Km, Kym, P /* scratch for L */, TX, TY, tid, NT);
+    const double pin = FACTOR ? p.pin[m] : Km[0] + Kym[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
     if (tid == 0) L.flag = 0;
     __syncthreads();  // TX/TY entries written by other threads are read below
     PROF(5);

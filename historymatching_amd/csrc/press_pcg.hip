@@ -41,6 +41,7 @@ __global__ __launch_bounds__(PT) void k_pressure_pcg(FwdParams p, const TS* __re
     const int Nx = p.Nx, Ny = p.Ny, Nxy = p.Nxy;
     const TS* S = S_base + (long long)m * S_stride;
     const double* Km = p.K + (long long)m * Nxy;
+    const double* Kym = p.Ky ? p.Ky + (long long)m * Nxy : Km;
     double* TX = p.TX + (long long)m * (Nx + 1) * Ny;
     double* TY = p.TY + (long long)m * Nx * (Ny + 1);
     double* x = p.P + (long long)m * Nxy;
@@ -50,9 +51,9 @@ __global__ __launch_bounds__(PT) void k_pressure_pcg(FwdParams p, const TS* __re
     double* Vx = p.Vx + (long long)m * (Nx + 1) * Ny;
     double* Vy = p.Vy + (long long)m * Nx * (Ny + 1);
     const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
-    const double pin = Km[0] + Km[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
+    const double pin = Km[0] + Kym[0];  // SPD pin: A[0,0] += Kx[0,0]+Ky[0,0]
 
-    assemble_transmissibilities<TS>(p, S, Km, Ap /* scratch for L */, TX, TY, tid, PT);
+    assemble_transmissibilities<TS>(p, S, Km, Kym, Ap /* scratch for L */, TX, TY, tid, PT);
     __syncthreads();
 
     auto diag = [&](int j, int ix, int iy) {
@@ -241,13 +242,14 @@ __global__ __launch_bounds__(PT) void k_tl_setup(FwdParams p, TlArgs t, const TS
     const int Nx = p.Nx, Ny = p.Ny, Nxy = p.Nxy, c = t.c, Nxc = t.Nxc;
     const TS* S = S_base + (long long)m * S_stride;
     const double* Km = p.K + (long long)m * Nxy;
+    const double* Kym = p.Ky ? p.Ky + (long long)m * Nxy : Km;
     double* TX = p.TX + (long long)m * (Nx + 1) * Ny;
     double* TY = p.TY + (long long)m * Nx * (Ny + 1);
     double* x = p.P + (long long)m * Nxy;
     double* r = p.cg_r + (long long)m * Nxy;
     double* Ap = p.yv + (long long)m * Nxy;
     const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
-    assemble_transmissibilities<TS>(p, S, Km, Ap /* scratch for L */, TX, TY, tid, PT);
+    assemble_transmissibilities<TS>(p, S, Km, Kym, Ap /* scratch for L */, TX, TY, tid, PT);
     __syncthreads();
     // coarse transmissibilities = sums of the fine ones across the aggregate boundaries
     double* TXc = t.TXc + (long long)m * (Nxc + 1) * 128;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(PT) void k_tl_setup(FwdParams p, TlArgs t, const TS
             for (int a = 0; a < c; ++a) s += TY[(I * c + a) * (Ny + 1) + J * c];
         TYc[f] = s;
     }
-    const FineOp A{TX, TY, Nx, Ny, Km[0] + Km[0]};
+    const FineOp A{TX, TY, Nx, Ny, Km[0] + Kym[0]};
     if (tid == 0) t.pin[m] = A.pin;
     double* dinv = t.dinv + (long long)m * Nxy;
     double rr = 0.0, bb = 0.0;

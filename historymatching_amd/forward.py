@@ -52,7 +52,9 @@ class ForwardPlan:
 
     __del__ = close
 
-    def set_inputs(self, perms, wsat0s=None, transformed=False):
+    def set_inputs(self, perms, wsat0s=None, transformed=False, perms_y=None):
+        """``perms_y``: the y-permeability per member for an anisotropic K (``model.K[1]`` differing from ``model.K[0]``);
+        None = Kx = Ky, the reference's case (set_perm, HistoryMatch.py:160-164)."""
         perms = _lib.as_c(perms, np.float64)
         if perms.shape != (self.N, self.model.Nxy):
             raise ValueError(f"perms must have shape {(self.N, self.model.Nxy)}, got {perms.shape}")
@@ -62,6 +64,11 @@ class ForwardPlan:
                 raise ValueError(f"wsat0s must have shape {perms.shape}, got {wsat0s.shape}")
         _lib.check(self.lib.hm_fwd_set_inputs(self.h, _lib.ptr(perms), int(bool(transformed)), _lib.ptr(wsat0s)),
                    "hm_fwd_set_inputs")
+        if perms_y is not None:
+            perms_y = _lib.as_c(perms_y, np.float64)
+            if perms_y.shape != perms.shape:
+                raise ValueError(f"perms_y must have shape {perms.shape}, got {perms_y.shape}")
+        _lib.check(self.lib.hm_fwd_set_perm_y(self.h, _lib.ptr(perms_y), int(bool(transformed))), "hm_fwd_set_perm_y")
 
     def set_inputs_device(self, perm_ptr, perm_dtype=64, transformed=False):
         """Permeability input from a DEVICE buffer of this context (e.g. ``UpdatePlan.device_ptr("E_out")``); initial

@@ -162,9 +162,27 @@ class ResSim:
 
     def sim(self, dt, nTime, wsat0, pbar=True):
         """``model.sim(dt, nTime, wsat0, pbar=False)`` -> ``(nTime+1, Nxy)``, row 0 = ``wsat0``
-        (HistoryMatch.py:224-225, 362).  Uses ``self.K[0]`` (the reference always sets Kx = Ky)."""
-        if not np.array_equal(self.K[0], self.K[1]):
-            raise NotImplementedError("anisotropic K (Kx != Ky) is not used by the reference and not supported")
-        wsats, _ = self.sim_ensemble(self.K[0].reshape(1, -1), np.asarray(wsat0).reshape(1, -1), dt=dt, nTime=nTime,
-                                     transformed=True, return_history=True)
+        (HistoryMatch.py:224-225, 362).  ``self.K`` is ``(2, Nx, Ny)``: the reference always sets Kx = Ky, an anisotropic K runs
+        through the same kernels with the y-permeability handed over separately."""
+        if np.array_equal(self.K[0], self.K[1]):
+            wsats, _ = self.sim_ensemble(self.K[0].reshape(1, -1), np.asarray(wsat0).reshape(1, -1), dt=dt, nTime=nTime,
+                                         transformed=True, return_history=True)
+            return wsats[0].astype(np.float64, copy=False)
+        # anisotropic K = (Kx, Ky): a batch of one through the device-resident plan, which takes the y-permeability separately
+        from .forward import ForwardPlan
+
+        plan = ForwardPlan(self, 1, dt, nTime, keep_history=True)
+        try:
+            plan.set_inputs(self.K[0].reshape(1, -1), np.asarray(wsat0, dtype=float).reshape(1, -1), transformed=True,
+                            perms_y=self.K[1].reshape(1, -1))
+            plan.run()
+            self.last_stats = plan.sync()
+            wsats, _, status = plan.outputs()
+        finally:
+            plan.close()
+        if status.any():
+            raise _lib.HmError(f"simulation failed (status {int(status[0])})")
+        inj_ind, inj, prd_ind, prd = self._wells(nTime)
+        cols = lambda r: np.broadcast_to(r, (r.shape[0], nTime)).copy()  # noqa: E731
+        self.actual_rates = dict(inj=cols(inj), prd=cols(prd))
         return wsats[0].astype(np.float64, copy=False)

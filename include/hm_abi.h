@@ -114,6 +114,10 @@ int  hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,
                    const double* porosity, int dtype, int keep_history, hm_fwd** out);
 void hm_fwd_destroy(hm_fwd* f);
 int  hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transformed, const void* wsat0); /* H2D */
+/* Anisotropic K: the y-permeability per member (N*Nxy; `perm` above is then the x-permeability).  The simulator's K is
+ * (2, Nx, Ny) (set via model.K, HistoryMatch.py:164, Optimise.py:69,888; the reference itself always stacks Kx = Ky).
+ * Call after hm_fwd_set_inputs (perm_in scratch is shared); NULL = back to Kx = Ky. */
+int  hm_fwd_set_perm_y(hm_fwd* f, const void* perm_y, int perm_is_transformed);
 /* Device-resident chaining (forward -> update -> forward without PCIe): permeability input from a device buffer
  * (fp64 or fp32), initial saturation zero.  Asynchronous on the context's stream. */
 int  hm_fwd_set_inputs_device(hm_fwd* f, const void* perm_dev, int perm_dtype, int perm_is_transformed);

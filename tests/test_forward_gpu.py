@@ -462,6 +462,57 @@ def test_multi_tile_saturation_teams_bitexact_vs_tiled(nx, ny, N, wells, dtype):
     assert out[0][0][:, -1].max() > 0.5  # the front has left the injector
 
 
+@pytest.mark.parametrize("n", [20, 128, 256])
+def test_anisotropic_permeability(n):
+    """K = (Kx, Ky) with Kx != Ky (the simulator's K is (2, Nx, Ny), HistoryMatch.py:164; the reference itself stacks Kx = Ky):
+    TX from Kx, TY from Ky, the SPD pin Kx[0,0] + Ky[0,0].  `model.sim` with an anisotropic K against the oracle
+    within its solver noise (generic kernels at 20 x 20, matrix-core solver at 128 x 128, two-level CG at 256 x 256), assembly
+    bit-exact, and the ensemble form (`ForwardPlan.set_inputs(..., perms_y=)`) equal to the single-member runs."""
+    import oracle.ressim as orc
+    from scipy.sparse.linalg import spsolve
+
+    steps = 3 if n <= 128 else 2
+    om, gm = make_models(n, n)
+    x = perms(n, n, 4, seed=71)
+    Kx = 0.1 + np.exp(5 * x[:2])
+    Ky = 0.1 + np.exp(5 * (0.6 * x[2:] - 0.3))
+    outs = []
+    for m in range(2):
+        K = np.stack([Kx[m].reshape(n, n), Ky[m].reshape(n, n)])
+        om.K = K
+        gm.K = K
+        ref = om.sim(DT, steps, np.zeros(n * n))
+        orig = orc.spsolve
+        orc.spsolve = lambda A, b: spsolve(A.tocsc(), b, permc_spec="NATURAL" if n <= 128 else "MMD_AT_PLUS_A")
+        try:
+            noise = float(np.abs(om.sim(DT, steps, np.zeros(n * n)) - ref).max())
+        finally:
+            orc.spsolve = orig
+        out = gm.sim(DT, steps, np.zeros(n * n))
+        err = np.abs(out - ref).max()
+        assert err <= 10 * noise + 1e-9, (m, err, noise)
+        outs.append(out)
+    # different from the isotropic run with Kx alone (the y-permeability matters)
+    gm.K = Kx[0].reshape(n, n)
+    assert np.abs(gm.sim(DT, steps, np.zeros(n * n)) - outs[0]).max() > 1e-3
+    plan = _plan(gm, 2, nTime=steps)
+    plan.set_inputs(Kx, None, transformed=True, perms_y=Ky)
+    plan.pressure_only(0)
+    TX, TY = plan.get_field("TX"), plan.get_field("TY")
+    hx, hy = gm.Lx / n, gm.Ly / n
+    for m in range(2):  # S = 0: Mt = 1, L = 1/K
+        Lx, Ly = 1.0 / Kx[m].reshape(n, n), 1.0 / Ky[m].reshape(n, n)
+        assert np.array_equal(TX[m][1:-1, :], 2 * hy / hx / (Lx[:-1, :] + Lx[1:, :]))
+        assert np.array_equal(TY[m][:, 1:-1], 2 * hx / hy / (Ly[:, :-1] + Ly[:, 1:]))
+    plan.run()
+    plan.sync()
+    w, _, status = plan.outputs()
+    plan.close()
+    assert not status.any()
+    for m in range(2):
+        assert np.array_equal(w[m], outs[m])
+
+
 @pytest.mark.parametrize("dtype", [64, 32])
 def test_tile_team_timeout_is_retried_by_the_tiled_sweep(dtype):
     """A tile team that gives up waiting for a neighbour (its workgroups were not all resident: CUs held by another process)
