@@ -170,24 +170,25 @@ __global__ __launch_bounds__(256) void k_apply_mfma(int N, int M, int n_obs, con
 //   LDS (40 KB at n_obs = 160: 3 workgroups per CU overlap staging, MFMAs and the E read/modify/write), A operand
 //   fetched 16 k-pairs ahead from L2, the E tile loaded before the MFMA loop.
 // ------------------------------------------------------------------------------------------------------------
-template <int NJ, int KC>
-__global__ __launch_bounds__(512, KC == 64 ? 2 : 4) void k_gxt_lds(int N, int M, int n_obs, const float* __restrict__ E,
+template <int NJ, int KC, int SH = 2>
+__global__ __launch_bounds__(256 * SH, (KC == 64 || SH == 1) ? 2 : 4) void k_gxt_lds(int N, int M, int n_obs, const float* __restrict__ E,
                                                  const float* __restrict__ colsum, float inv_n,
                                                  const float* __restrict__ S, float* __restrict__ Gx) {
-    // 8 waves = 2 state halves x 4 interleaved quarters of the k-pairs (two waves per SIMD: one wave's LDS/barrier
-    // stalls are covered by the other's MFMAs).  KC members per LDS chunk = per barrier.
-    constexpr int NO = 32 * NJ, NKH = 4, NT = 512;
+    // 4 SH waves = SH state halves (32 state elements each) x 4 interleaved quarters of the k-pairs.  SH = 2: one 8-wave
+    // workgroup per CU (two waves per SIMD: one wave's LDS/barrier stalls are covered by the other's MFMAs); SH = 1: two
+    // unsynchronised 4-wave workgroups per CU.  KC members per LDS chunk = per barrier.
+    constexpr int NO = 32 * NJ, NKH = 4, NT = 256 * SH, SW = 32 * SH;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    // [2][KC][64] E chunks, [2][KC][NO] S chunks; the final reduction buffers alias them
+    // [2][KC][SW] E chunks, [2][KC][NO] S chunks; the final reduction buffers alias them
     float* Eb = sm;
-    float* Sb = sm + 2 * KC * 64;
+    float* Sb = sm + 2 * KC * SW;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int sh = w & 1, kh = w >> 1;
+    const int sh = SH == 2 ? (w & 1) : 0, kh = SH == 2 ? (w >> 1) : w;
     const int il = lane & 31, kq = lane >> 5;
-    const int i0 = blockIdx.x * 64;
-    // staging roles: E chunk = KC rows x 16 float4 (EPT per thread); S chunk = KC rows x NO/4 float4
-    constexpr int EPT = KC * 16 / NT;
-    const int er = tid >> 4, ec = (tid & 15) * 4;
+    const int i0 = blockIdx.x * SW;
+    // staging roles: E chunk = KC rows x SW/4 float4 (EPT per thread); S chunk = KC rows x NO/4 float4
+    constexpr int EPT = KC * (SW / 4) / NT, ERS = NT / (SW / 4);  // = KC / 32 float4 per thread; rows covered per pass = 32
+    const int er = tid / (SW / 4), ec = (tid % (SW / 4)) * 4;
     const int ei = min(i0 + ec, M - 4);  // M % 4 == 0 (host-checked); columns past M are never stored
     float4 shift;
     if (colsum) shift = make_float4(colsum[ei] * inv_n, colsum[ei + 1] * inv_n, colsum[ei + 2] * inv_n, colsum[ei + 3] * inv_n);
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(512, KC == 64 ? 2 : 4) void k_gxt_lds(int N, int M,
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
-            const int k = k0 + er + 32 * q;
+            const int k = k0 + er + ERS * q;
             ereg[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < N) {
                 const float4 v = *reinterpret_cast<const float4*>(E + (size_t)k * M + ei);
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(512, KC == 64 ? 2 : 4) void k_gxt_lds(int N, int M,
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < EPT; ++q) *reinterpret_cast<float4*>(Eb + (buf * KC + er + 32 * q) * 64 + ec) = ereg[q];
+        for (int q = 0; q < EPT; ++q) *reinterpret_cast<float4*>(Eb + (buf * KC + er + ERS * q) * SW + ec) = ereg[q];
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
             const int e = tid + NT * q;
@@ -234,13 +235,13 @@ __global__ __launch_bounds__(512, KC == 64 ? 2 : 4) void k_gxt_lds(int N, int M,
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) fetch((c + 1) * KC);
-        const float* eb = Eb + buf * KC * 64 + 32 * sh + il;
+        const float* eb = Eb + buf * KC * SW + 32 * sh + il;
         const float* sb = Sb + buf * KC * NO + il;
         // this wave's k-pairs of the chunk: pair p = NKH q + kh  (rows 2p, 2p+1)
 #pragma unroll
         for (int q = 0; q < KC / 2 / NKH; ++q) {
             const int row = 2 * (NKH * q + kh) + kq;
-            const float b = eb[row * 64];
+            const float b = eb[row * SW];
 #pragma unroll
             for (int t = 0; t < NJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sb[row * NO + 32 * t], b, acc[t], 0, 0, 0);
         }
@@ -248,9 +249,9 @@ __global__ __launch_bounds__(512, KC == 64 ? 2 : 4) void k_gxt_lds(int N, int M,
         __syncthreads();
     }
     // fixed-order tree over the 4 k-quarters through LDS: (0 + 1) and (2 + 3), then (0+1) + (2+3); buffers
-    // [2 publishers][2 sh][NJ][16][64] alias the chunks
+    // [2 publishers][SH][NJ][16][64] alias the chunks
     float* red = sm;
-    auto slot = [&](int pub, int t, int r) { return red + (((pub * 2 + sh) * NJ + t) * 16 + r) * 64 + lane; };
+    auto slot = [&](int pub, int t, int r) { return red + (((pub * SH + sh) * NJ + t) * 16 + r) * 64 + lane; };
     if (kh & 1) {
 #pragma unroll
         for (int t = 0; t < NJ; ++t)
@@ -494,21 +495,24 @@ int transpose_f2f(hipStream_t s, const float* in, float* out, int rows, int cols
 static int g_gxt_kc = 64;  // 64 members per LDS chunk: half the barriers of 32 (65.6 vs 68.6 us at C3)
 void mfma_set_gxt_chunk(int kc) { g_gxt_kc = kc == 64 ? 64 : 32; }
 
+static int g_gxt_sh = 2;
+void mfma_set_gxt_halves(int sh) { g_gxt_sh = sh == 1 ? 1 : 2; }
+
 int mfma_gxt_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const float* colsum, double inv_n, const float* S,
                  float* Gx) {
     if (n_obs % 32 != 0 || n_obs > 256 || M % 4 != 0 || M < 4) return -1;
     const int nj = n_obs / 32;
-    const int kc = g_gxt_kc;
-    dim3 grid((M + 63) / 64), block(512);
-    const size_t chunks = (size_t)2 * kc * (64 + n_obs) * 4, red = (size_t)2 * 2 * nj * 16 * 64 * 4;
+    const int sh = g_gxt_sh, kc = sh == 1 ? 32 : g_gxt_kc, sw = 32 * sh;
+    dim3 grid((M + sw - 1) / sw), block(256 * sh);
+    const size_t chunks = (size_t)2 * kc * (sw + n_obs) * 4, red = (size_t)2 * sh * nj * 16 * 64 * 4;
     const size_t lds = chunks > red ? chunks : red;
     if (lds > 160 * 1024) return -1;
-#define L2(NJ, KC) do { HM_HIP(hipFuncSetAttribute((const void*)k_gxt_lds<NJ, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                       hipLaunchKernelGGL((k_gxt_lds<NJ, KC>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); } while (0)
-#define L(NJ) case NJ: if (kc == 64) L2(NJ, 64); else L2(NJ, 32); break
+#define L3(NJ, KC, SH) do { HM_HIP(hipFuncSetAttribute((const void*)k_gxt_lds<NJ, KC, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                           hipLaunchKernelGGL((k_gxt_lds<NJ, KC, SH>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); } while (0)
+#define L(NJ) case NJ: if (sh == 1) L3(NJ, 32, 1); else if (kc == 64) L3(NJ, 64, 2); else L3(NJ, 32, 2); break
     switch (nj) { L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); default: return -1; }
 #undef L
-#undef L2
+#undef L3
     HM_HIP(hipGetLastError());
     return 0;
 }

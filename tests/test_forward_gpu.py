@@ -510,7 +510,10 @@ def test_anisotropic_permeability(n):
     plan.close()
     assert not status.any()
     for m in range(2):
-        assert np.array_equal(w[m], outs[m])
+        if n <= 128:
+            assert np.array_equal(w[m], outs[m])
+        else:  # the CG passes of a member are split over a member-count-dependent number of workgroups: rounding-level differences
+            assert np.abs(w[m] - outs[m]).max() < 1e-6
 
 
 @pytest.mark.parametrize("dtype", [64, 32])
