@@ -280,6 +280,19 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
 
     int always = __builtin_amdgcn_readfirstlane(Nts > 0);
     asm volatile("" : "+s"(always));
+    // Dry bands (as in sat128.hip): a wave whose 16 x 128 band of the tile holds S == 0 everywhere and owns no injector skips
+    // phase A after the first sub-step (its rows of the fw image already hold its zeros; the hand-off publishes them from there)
+    // and phase B while every fractional flow around the band is zero: the rows above and below it (the west / east halo rows
+    // of the tile included) and, for the lanes on the tile's south / north border, the column halo.  Bit-identical.
+    int dry;
+    {
+        unsigned long long bits = 0ull;
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+#pragma unroll
+            for (int j = 0; j < PY; ++j) bits |= (unsigned long long)__double_as_longlong(S[i][j]) << 1;  // -0.0 counts as zero
+        dry = __ballot(bits != 0ull || (has_well && (wq > 0.0 || Sin[wcell] != 0.0))) == 0ull;
+    }
 #ifdef HM_SAT_PROF
     unsigned long long prof_a = 0, prof_h = 0, prof_b = 0, prof_t;
 #define STAMP(acc) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); acc += t_ - prof_t; prof_t = t_; } while (0)
@@ -292,6 +305,7 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
         double dd = d, z = 0.0;
         asm volatile("" : "+v"(dd), "+v"(z));
         // phase A: fractional flow of every own cell -> LDS
+        if (!(dry && it > 0)) {
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             char* base = lds + (ix0 + i) * 1024 + seg;
@@ -303,6 +317,7 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
             *reinterpret_cast<double2*>(base + (swz * 16)) = a;
             *reinterpret_cast<double2*>(base + ((1 ^ swz) * 16)) = b;
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         {   // well side path, branch-free (threads without a well run it on the dummy record)
             double* rec = reinterpret_cast<double*>(lds + wrec);
@@ -331,7 +346,19 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
         __syncthreads();
         STAMP(prof_h);
 
-        if (always) {
+        int run_b = always;
+        if (dry) {
+            const unsigned long long* hw = reinterpret_cast<const unsigned long long*>(lds + ixW * 1024 + seg);
+            const unsigned long long* he = reinterpret_cast<const unsigned long long*>(lds + ixE * 1024 + seg);
+            unsigned long long o = (hw[0] | hw[1]) | (hw[2] | hw[3]) | (he[0] | he[1]) | (he[2] | he[3]);  // fw >= +0: bit test
+            unsigned long long oc = 0ull;  // column halo {fw, Vy north}: the fw entries of this patch's 8 rows
+#pragma unroll
+            for (int i = 0; i < PX; ++i) oc |= *reinterpret_cast<const unsigned long long*>(edge_row0 + i * 16);
+            if (isS || isN) o |= oc;
+            run_b = __ballot(o != 0ull) != 0ull;
+            dry = !run_b;  // water at the border: the band is wet from now on
+        }
+        if (run_b) {
         // phase B: upwind update row by row
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
