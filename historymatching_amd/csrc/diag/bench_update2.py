@@ -23,7 +23,7 @@ decorr = sla.inv(R12.T)
 res = {}
 outs = {}
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 9
-for kal, ov, kc, av, sm, gh in ((0, 0, 32, 1, 0, 2), (1, 0, 64, 2, 0, 2), (1, 0, 32, 2, 0, 1)):
+for kal, ov, kc, av, sm, gh, gd, dma in ((0, 0, 32, 1, 0, 2, 1, 0), (1, 0, 64, 3, 0, 2, 1, 1), (1, 0, 64, 3, 0, 2, 1, 2)):
     if True:
         p = UpdatePlan(N, N, M, n_obs, dtype=32)
         p.set_option("kalman_form", kal)
@@ -32,6 +32,8 @@ for kal, ov, kc, av, sm, gh in ((0, 0, 32, 1, 0, 2), (1, 0, 64, 2, 0, 2), (1, 0,
         p.set_option("apply_variant", av)
         p.set_option("small_inverse", sm)
         p.set_option("gxt_halves", gh)
+        p.set_option("gxt_depth", gd)
+        p.set_option("gxt_dma", dma)
         p.set_inputs(E, obs_ens, obs, perturbs, decorr)
         p.run_local()
         ts = sorted(p.run_local()["ms_update"] for _ in range(reps))
@@ -41,11 +43,11 @@ for kal, ov, kc, av, sm, gh in ((0, 0, 32, 1, 0, 2), (1, 0, 64, 2, 0, 2), (1, 0,
         for _ in range(10):
             _lib.check(p.lib.hm_upd_run(p.h), "hm_upd_run")
         b2b = p.sync()["ms_update"] / 10
-        outs[(kal, ov, kc, av, sm, gh)] = p.output()
+        outs[(kal, ov, kc, av, sm, gh, gd, dma)] = p.output()
         p.close()
         flops = 4.0 * N * n_obs * M
-        res[f"kalman{kal}_overlap{ov}_chunk{kc}_apply{av}_small{sm}_halves{gh}"] = {"ms_median": ts[len(ts) // 2], "ms_best": ts[0], "ms_back_to_back": b2b, "frac_back_to_back": flops / b2b / 1e9 / 157.3, "frac_of_fp32_matrix_peak_median": flops / ts[len(ts) // 2] / 1e9 / 157.3}
-ref = outs[(0, 0, 32, 1, 0, 2)].astype(float)
+        res[f"kalman{kal}_overlap{ov}_chunk{kc}_apply{av}_small{sm}_halves{gh}_depth{gd}_dma{dma}"] = {"ms_median": ts[len(ts) // 2], "ms_best": ts[0], "ms_back_to_back": b2b, "frac_back_to_back": flops / b2b / 1e9 / 157.3, "frac_of_fp32_matrix_peak_median": flops / ts[len(ts) // 2] / 1e9 / 157.3}
+ref = outs[(0, 0, 32, 1, 0, 2, 1, 0)].astype(float)
 inc = np.abs(ref - E).max()
 res["max_diff_between_variants_rel_to_increment"] = max(float(np.abs(o - ref).max() / inc) for o in outs.values())
 print(json.dumps(res, indent=1))

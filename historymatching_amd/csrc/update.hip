@@ -27,6 +27,9 @@ int transpose_cast_f2d(hipStream_t s, const float* in, double* out, int rows, in
 void mfma_set_gxt_chunk(int kc);
 void mfma_set_apply_variant(int v);
 void mfma_set_gxt_halves(int sh);
+void mfma_set_gxt_depth(int d);
+void mfma_set_gxt_debug(int d);
+void mfma_set_gxt_dma(int d);
 void spd_inverse_set_small(int v);
 
 struct hm_upd {
@@ -1010,6 +1013,9 @@ extern "C" int hm_upd_set_option(hm_upd* u, const char* name, int value) {
     if (std::string(name) == "kalman_form") { u->kalman_form = value; return 0; }
     if (std::string(name) == "gxt_chunk") { mfma_set_gxt_chunk(value); return 0; }
     if (std::string(name) == "small_inverse") { spd_inverse_set_small(value); return 0; }  // 8-wave matrix-core inverse (co-resident form)
+    if (std::string(name) == "gxt_dma") { mfma_set_gxt_dma(value); return 0; }  // 1: LDS-DMA staging (k_gxt_dma) | 0: register staging (k_gxt_lds)
+    if (std::string(name) == "gxt_debug") { mfma_set_gxt_debug(value); return 0; }  // diagnostic: matrix loop without staging (wrong results)
+    if (std::string(name) == "gxt_depth") { mfma_set_gxt_depth(value); return 0; }  // global loads 1 | 2 chunks ahead of the MFMAs
     if (std::string(name) == "gxt_halves") { mfma_set_gxt_halves(value); return 0; }  // 2: one 8-wave workgroup per CU | 1: two 4-wave ones
     if (std::string(name) == "apply_variant") { mfma_set_apply_variant(value); return 0; }  // 2: pipelined, 2 workgroups per CU (default) | 1  // members per LDS chunk of k_gxt_lds: 32 | 64  // hm_upd_run: 0 = decorrelated form (S, D, C)
     if (std::string(name) == "mfma_inverse") { g_use_mfma_inverse = value; return 0; }  // 0: rank-1 register sweeps

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_apply_mfma(int N, int M, int n_obs, con
 //   LDS (40 KB at n_obs = 160: 3 workgroups per CU overlap staging, MFMAs and the E read/modify/write), A operand
 //   fetched 16 k-pairs ahead from L2, the E tile loaded before the MFMA loop.
 // ------------------------------------------------------------------------------------------------------------
-template <int NJ, int KC, int SH = 2>
+template <int NJ, int KC, int SH = 2, int DEPTH = 1>
 __global__ __launch_bounds__(256 * SH, (KC == 64 || SH == 1) ? 2 : 4) void k_gxt_lds(int N, int M, int n_obs, const float* __restrict__ E,
                                                  const float* __restrict__ colsum, float inv_n,
                                                  const float* __restrict__ S, float* __restrict__ Gx) {
@@ -195,8 +195,10 @@ __global__ __launch_bounds__(256 * SH, (KC == 64 || SH == 1) ? 2 : 4) void k_gxt
     else shift = *reinterpret_cast<const float4*>(E + ei);
     constexpr int SV = KC * NO / 4;           // float4 per S chunk
     constexpr int SPT = (SV + NT - 1) / NT;   // per thread
-    float4 ereg[EPT], sreg[SPT];
-    auto fetch = [&](int k0) {
+    // DEPTH = 2: the global loads run TWO chunks ahead of the MFMAs (a second register set; one chunk = 2.1 us of matrix work at
+    // KC = 64, about the latency of an HBM miss under load)
+    float4 ereg[EPT], sreg[SPT], ereg2[DEPTH == 2 ? EPT : 1], sreg2[DEPTH == 2 ? SPT : 1];
+    auto fetch_into = [&](int k0, float4* ereg, float4* sreg) {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int k = k0 + er + ERS * q;
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(256 * SH, (KC == 64 || SH == 1) ? 2 : 4) void k_gxt
             if (e < SV && k0 + r < N) sreg[q] = *reinterpret_cast<const float4*>(S + (size_t)(k0 + r) * n_obs + c4);
         }
     };
+    auto fetch = [&](int k0) { fetch_into(k0, ereg, sreg); };
     auto stash = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) *reinterpret_cast<float4*>(Eb + (buf * KC + er + ERS * q) * SW + ec) = ereg[q];
@@ -229,24 +232,55 @@ __global__ __launch_bounds__(256 * SH, (KC == 64 || SH == 1) ? 2 : 4) void k_gxt
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const int nchunks = (N + KC - 1) / KC;
+    const bool dbg_nostage = inv_n < 0.0f;  // diagnostic (wrong results): every chunk re-uses the first one, no loads, no stash
     fetch(0);
     stash(0);
+    if (DEPTH == 2 && nchunks > 1) fetch(KC);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) fetch((c + 1) * KC);
+        const int buf = dbg_nostage ? 0 : (c & 1);
+        if (DEPTH == 2) {
+            if (c + 2 < nchunks) fetch_into((c + 2) * KC, ereg2, sreg2);
+        } else if (c + 1 < nchunks && !dbg_nostage) fetch((c + 1) * KC);
         const float* eb = Eb + buf * KC * SW + 32 * sh + il;
         const float* sb = Sb + buf * KC * NO + il;
-        // this wave's k-pairs of the chunk: pair p = NKH q + kh  (rows 2p, 2p+1)
+        // this wave's k-pairs of the chunk: pair p = NKH q + kh  (rows 2p, 2p+1).  The LDS operands of pair q + 1 are requested
+        // BEFORE the MFMAs of pair q are issued (left to itself the compiler emits read -> wait -> two MFMAs -> read ...: every
+        // MFMA pair then waits out the LDS latency of its own operands and the matrix pipe idles half the time).
+        constexpr int NQ = KC / 2 / NKH;
+        float a_cur[NJ], a_nxt[NJ], b_cur, b_nxt;
+        {
+            const int row = 2 * kh + kq;
+            b_cur = eb[row * SW];
 #pragma unroll
-        for (int q = 0; q < KC / 2 / NKH; ++q) {
-            const int row = 2 * (NKH * q + kh) + kq;
-            const float b = eb[row * SW];
-#pragma unroll
-            for (int t = 0; t < NJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sb[row * NO + 32 * t], b, acc[t], 0, 0, 0);
+            for (int t = 0; t < NJ; ++t) a_cur[t] = sb[row * NO + 32 * t];
         }
-        if (c + 1 < nchunks) stash(buf ^ 1);
-        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + 1 < NQ) {
+                const int row = 2 * (NKH * (q + 1) + kh) + kq;
+                b_nxt = eb[row * SW];
+#pragma unroll
+                for (int t = 0; t < NJ; ++t) a_nxt[t] = sb[row * NO + 32 * t];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b_cur, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < NQ) {
+                b_cur = b_nxt;
+#pragma unroll
+                for (int t = 0; t < NJ; ++t) a_cur[t] = a_nxt[t];
+            }
+        }
+        if (c + 1 < nchunks && !dbg_nostage) stash(buf ^ 1);
+        if (!dbg_nostage) __syncthreads();
+        if (DEPTH == 2) {
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) ereg[q] = ereg2[q];
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) sreg[q] = sreg2[q];
+        }
     }
     // fixed-order tree over the 4 k-quarters through LDS: (0 + 1) and (2 + 3), then (0+1) + (2+3); buffers
     // [2 publishers][SH][NJ][16][64] alias the chunks
@@ -347,6 +381,241 @@ __global__ __launch_bounds__(256) void k_apply_lds(int N, int M, int n_obs, cons
     }
 }
 
+// k_gxt_dma: the first contraction with the chunks staged by LDS-DMA (global_load_lds_dwordx4: memory -> LDS without passing
+// through registers, asynchronous, retired by the issuing wave's vmcnt).  Measured on k_gxt_lds: the matrix loop alone takes 48 us,
+// register staging (global load -> VGPR -> ds_write_b128) + the barrier of every chunk another 20 us.  Same tiling (64 state
+// elements x all observations per workgroup, 8 waves = 2 state halves x 4 k-quarters, KC members per chunk, double-buffered);
+// one DMA piece = one wave instruction = 1 KB: 4 rows of the E chunk (256 B each) or 256 consecutive floats of the S chunk.
+// The shift c (first member / exact mean) is subtracted when the E operand is read from LDS (one v_sub per 5 MFMAs).  Rows past
+// N in the last chunk: sources clamped, the S rows zeroed in LDS before use.  Requires M % 64 == 0.
+template <int NJ, int KC>
+__global__ __launch_bounds__(512, 2) void k_gxt_dma(int N, int M, int n_obs, const float* __restrict__ E,
+                                                    const float* __restrict__ colsum, float inv_n,
+                                                    const float* __restrict__ S, float* __restrict__ Gx) {
+    constexpr int NO = 32 * NJ, NKH = 4, SW = 64, NQ = KC / 2 / NKH;
+    constexpr int EP = KC / 4, SP = KC * NO / 256, NP = EP + SP;  // DMA pieces per chunk
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Eb = sm;                  // [2][KC][64]
+    float* Sb = sm + 2 * KC * SW;    // [2][KC][NO]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sh = w & 1, kh = w >> 1;
+    const int il = lane & 31, kq = lane >> 5;
+    const int i0 = blockIdx.x * SW;
+    const int istate = i0 + 32 * sh + il;
+    const float shift = colsum ? colsum[istate] * inv_n : E[istate];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    auto stage = [&](int c, int buf) {
+        const int k0 = c * KC;
+#pragma unroll
+        for (int q = 0; q < (NP + 7) / 8; ++q) {
+            const int piece = w + 8 * q;  // wave-uniform
+            if (piece < EP) {
+                const int row = min(k0 + 4 * piece + (lane >> 4), N - 1);
+                const float* src = E + (size_t)row * M + i0 + (lane & 15) * 4;
+                float* dst = Eb + (buf * KC + 4 * piece) * SW;
+                __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 0);
+            } else if (piece < NP) {
+                const int sp = piece - EP;
+                const size_t e = min((size_t)k0 * NO + (size_t)sp * 256 + lane * 4, (size_t)N * NO - 4);
+                float* dst = Sb + buf * KC * NO + sp * 256;
+                __builtin_amdgcn_global_load_lds((glb_ptr)(S + e), (lds_ptr)dst, 16, 0, 0);
+            }
+        }
+    };
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int nchunks = (N + KC - 1) / KC;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
+        if (c + 1 == nchunks && N % KC != 0) {  // rows past N: their S operands must be zero (the E rows are clamped copies)
+            const int nvalid = N - c * KC;
+            for (int e = tid; e < (KC - nvalid) * NO; e += 512) Sb[buf * KC * NO + nvalid * NO + e] = 0.0f;
+            __syncthreads();
+        }
+        const float* eb = Eb + buf * KC * SW + 32 * sh + il;
+        const float* sb = Sb + buf * KC * NO + il;
+        float a_cur[NJ], a_nxt[NJ], b_cur, b_nxt;
+        {
+            const int row = 2 * kh + kq;
+            b_cur = eb[row * SW];
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) a_cur[t] = sb[row * NO + 32 * t];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + 1 < NQ) {
+                const int row = 2 * (NKH * (q + 1) + kh) + kq;
+                b_nxt = eb[row * SW];
+#pragma unroll
+                for (int t = 0; t < NJ; ++t) a_nxt[t] = sb[row * NO + 32 * t];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float bs = b_cur - shift;
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], bs, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < NQ) {
+                b_cur = b_nxt;
+#pragma unroll
+                for (int t = 0; t < NJ; ++t) a_cur[t] = a_nxt[t];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next chunk have landed
+        __syncthreads();                                   // ... and everybody else's; the current buffer is free
+    }
+    // fixed-order tree over the 4 k-quarters through LDS (as k_gxt_lds)
+    float* red = sm;
+    auto slot = [&](int pub, int t, int r) { return red + (((pub * 2 + sh) * NJ + t) * 16 + r) * 64 + lane; };
+    if (kh & 1) {
+#pragma unroll
+        for (int t = 0; t < NJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) *slot(kh >> 1, t, r) = acc[t][r];
+    }
+    __syncthreads();
+    if (!(kh & 1)) {
+#pragma unroll
+        for (int t = 0; t < NJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += *slot(kh >> 1, t, r);
+    }
+    __syncthreads();
+    if (kh == 2) {
+#pragma unroll
+        for (int t = 0; t < NJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) *slot(0, t, r) = acc[t][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int t = 0; t < NJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kq;  // accumulator row = observation
+                Gx[(size_t)j * M + istate] = acc[t][r] + *slot(0, t, r);
+            }
+    }
+}
+
+// k_gxt_dma2: as k_gxt_dma, but WITHOUT a workgroup barrier in the main loop.  4 waves per workgroup (one per SIMD), wave kh owns
+// the members [16 kh, 16 kh + 16) of every 64-member chunk and BOTH state halves (64 state elements x all observations: 2 NJ
+// accumulator tiles), and stages exactly the rows it consumes -- 16 rows of E (4 KB) and 16 rows of S (contiguous, 10 KB at
+// n_obs = 160) -- by LDS-DMA into its own double buffer; it waits only on its own vmcnt.  The four partial sums are added in
+// fixed order through LDS at the end.  Requires M % 64 == 0.
+template <int NJ>
+__global__ __launch_bounds__(256, 1) void k_gxt_dma2(int N, int M, int n_obs, const float* __restrict__ E,
+                                                     const float* __restrict__ colsum, float inv_n,
+                                                     const float* __restrict__ S, float* __restrict__ Gx) {
+    constexpr int NO = 32 * NJ, KC = 64, KW = KC / 4, SW = 64, RW = SW + NO;  // rows per wave and chunk; floats per staged row pair
+    constexpr int EP = KW * SW / 256, SP = KW * NO / 256;                      // DMA pieces per wave and chunk (4 + 10)
+    static_assert(KW * NO % 256 == 0, "S slab of a wave must be whole 1 KB pieces");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, kh = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* Ew = sm + kh * (2 * KW * RW);   // [2][KW][64] then [2][KW][NO] of this wave
+    float* Sw = Ew + 2 * KW * SW;
+    const int il = lane & 31, kq = lane >> 5;
+    const int i0 = blockIdx.x * SW;
+    float shift[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) shift[h] = colsum ? colsum[i0 + 32 * h + il] * inv_n : E[i0 + 32 * h + il];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    auto stage = [&](int c, int buf) {
+        const int k0 = c * KC + kh * KW;
+#pragma unroll
+        for (int pc = 0; pc < EP; ++pc) {
+            const int row = min(k0 + 4 * pc + (lane >> 4), N - 1);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(E + (size_t)row * M + i0 + (lane & 15) * 4), (lds_ptr)(Ew + (buf * KW + 4 * pc) * SW), 16, 0, 0);
+        }
+#pragma unroll
+        for (int pc = 0; pc < SP; ++pc) {
+            const size_t e = min((size_t)k0 * NO + (size_t)pc * 256 + lane * 4, (size_t)N * NO - 4);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(S + e), (lds_ptr)(Sw + buf * KW * NO + pc * 256), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < NJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[h][t][r] = 0.0f;
+    const int nchunks = (N + KC - 1) / KC;
+    stage(0, 0);
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c (issued one chunk ago) have landed
+        if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
+        const int nvalid = N - (c * KC + kh * KW);          // rows of this wave's slab that exist (wave-uniform)
+        if (nvalid < KW) {                                  // last chunk: rows past N must not contribute -> zero their S rows
+            const int first = max(nvalid, 0);
+            for (int e = lane; e < (KW - first) * NO; e += 64) Sw[buf * KW * NO + first * NO + e] = 0.0f;
+        }
+        const float* eb = Ew + buf * KW * SW + il;
+        const float* sb = Sw + buf * KW * NO + il;
+        float a_cur[NJ], a_nxt[NJ], b_cur[2], b_nxt[2];
+        b_cur[0] = eb[kq * SW]; b_cur[1] = eb[kq * SW + 32];
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) a_cur[t] = sb[kq * NO + 32 * t];
+#pragma unroll
+        for (int q = 0; q < KW / 2; ++q) {
+            if (q + 1 < KW / 2) {
+                const int row = 2 * (q + 1) + kq;
+                b_nxt[0] = eb[row * SW]; b_nxt[1] = eb[row * SW + 32];
+#pragma unroll
+                for (int t = 0; t < NJ; ++t) a_nxt[t] = sb[row * NO + 32 * t];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float bs0 = b_cur[0] - shift[0], bs1 = b_cur[1] - shift[1];
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], bs0, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], bs1, acc[1][t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < KW / 2) {
+                b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
+#pragma unroll
+                for (int t = 0; t < NJ; ++t) a_cur[t] = a_nxt[t];
+            }
+        }
+    }
+    // fixed-order sum over the 4 waves through LDS: ((0 + 1) + 2) + 3; buffers [3][2][NJ][16][64] alias the chunk buffers
+    __syncthreads();
+    float* red = sm;
+    auto slot = [&](int pub, int h, int t, int r) { return red + ((((pub * 2 + h) * NJ + t) * 16 + r) * 64) + lane; };
+    if (kh > 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < NJ; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *slot(kh - 1, h, t, r) = acc[h][t][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < NJ; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kq;  // accumulator row = observation
+                    const float v = ((acc[h][t][r] + *slot(0, h, t, r)) + *slot(1, h, t, r)) + *slot(2, h, t, r);
+                    Gx[(size_t)j * M + i0 + 32 * h + il] = v;
+                }
+    }
+}
+
 // Third generation of the apply: one workgroup = 64 state elements x EVERY NG-th block of 128 members.  The Gx tile is staged
 // once per workgroup (8 / NG times less often than one workgroup per member block), the grid is exactly two workgroups per CU
 // (no partial last round), and the loads of a member block are issued one step ahead of their use: the A operand of the next
@@ -417,11 +686,22 @@ __global__ __launch_bounds__(256, 2) void k_apply_lds2(int N, int M, int n_obs, 
                 load_A(b + NG, 0, avn);
                 load_E(b + NG, evn);
             }
+            // the LDS operands of k-pair u + 2 are requested before the MFMAs of pair u are issued (two pairs = 256 cycles of
+            // matrix work ahead: the LDS latency; see k_gxt_lds)
             const float* brow = Bs + (2 * jp0 + kh) * 64 + nl;
+            float bq[UA + 2][2];
+            bq[0][0] = brow[0]; bq[0][1] = brow[32];
+            bq[1][0] = brow[128]; bq[1][1] = brow[128 + 32];
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(brow[u * 128 + 32 * t], av[u], acc[t], 0, 0, 0);
+                if (u + 2 < UA) {
+                    bq[u + 2][0] = brow[(u + 2) * 128];
+                    bq[u + 2][1] = brow[(u + 2) * 128 + 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[u][0], av[u], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[u][1], av[u], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int u = 0; u < UA; ++u) av[u] = avn[u];
@@ -442,6 +722,96 @@ __global__ __launch_bounds__(256, 2) void k_apply_lds2(int N, int M, int n_obs, 
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) ev[t][r] = evn[t][r];
+    }
+}
+
+// k_apply_dma: the apply with its A operand (the gain, n_obs x N) staged by LDS-DMA into WAVE-PRIVATE double buffers: every wave
+// streams the 32 member columns it needs in chunks of 16 k-pairs (4 KB = four 1 KB pieces of 8 rows x 128 B) and waits only on
+// its own vmcnt -- no workgroup barrier in the main loop.  Everything else as k_apply_lds2 (Gx tile in LDS once per workgroup,
+// transposed product, 16-byte E accesses, two workgroups per CU, every second block of 128 members per workgroup).  The member
+// rows of a block start at min(128 b, N - 128): the ragged last block overlaps its predecessor and stores the same values again.
+// Requires M % 64 == 0, N >= 128, N % 4 == 0, n_obs % 32 == 0.
+template <int NG>
+__global__ __launch_bounds__(256, 2) void k_apply_dma(int N, int M, int n_obs, const float* __restrict__ E,
+                                                      const float* __restrict__ At, const float* __restrict__ Gx,
+                                                      float* __restrict__ Eout) {
+    extern __shared__ __attribute__((aligned(16))) float Bs[];  // [n_obs][64] Gx tile, then [4 waves][2][32][32] A chunks
+    constexpr int UA = 16, AROWS = 2 * UA;                       // k-pairs / observation rows per chunk
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i0 = blockIdx.x * 64;
+    float* Ab = Bs + n_obs * 64 + w * (2 * AROWS * 32);
+    for (int e = threadIdx.x; e < n_obs * 16; e += 256) {  // float4 granules
+        const int j = e >> 4, c4 = (e & 15) * 4;
+        *reinterpret_cast<float4*>(Bs + j * 64 + c4) = *reinterpret_cast<const float4*>(Gx + (size_t)j * M + i0 + c4);
+    }
+    const int nl = lane & 31, kh = lane >> 5;
+    const int nblocks = (N + 127) / 128, nchunk = n_obs / AROWS;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    auto row0 = [&](int blk) { return min(blk * 128, N - 128) + 32 * w; };  // this wave's first member row of block blk
+    auto stage_A = [&](int blk, int ch, int buf) {  // rows [AROWS ch, +AROWS) of the gain, member columns row0 .. row0 + 31
+        const float* base = At + (size_t)(AROWS * ch) * N + row0(blk);
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const float* src = base + (size_t)(8 * pc + (lane >> 3)) * N + (lane & 7) * 4;
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(Ab + (buf * AROWS + 8 * pc) * 32), 16, 0, 0);
+        }
+    };
+    const int e_off = nl * M + 4 * kh;
+    float ev[2][16];
+    auto load_E = [&](int blk, float (&dst)[2][16]) {
+        const float* base = E + (size_t)row0(blk) * M + i0 + e_off;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 v = *reinterpret_cast<const float4*>(base + 32 * t + 8 * g4);
+                dst[t][4 * g4 + 0] = v.x; dst[t][4 * g4 + 1] = v.y; dst[t][4 * g4 + 2] = v.z; dst[t][4 * g4 + 3] = v.w;
+            }
+    };
+    int b = blockIdx.y, buf = 0;
+    if (b < nblocks) stage_A(b, 0, 0);
+    __syncthreads();  // Gx tile
+    bool first = true;
+    for (; b < nblocks; b += NG) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        const bool more = b + NG < nblocks;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            // Wait for THIS chunk's four pieces, issued one chunk ago.  Vector-memory operations retire in issue order, so what was
+            // issued after them may stay in flight: at chunk 0 the 8 epilogue stores of the previous block, at chunk 1 the 8 loads of
+            // this block's E tile (requested at chunk 0, consumed by the epilogue four chunks later).
+            if ((ch == 0 && !first) || ch == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ch + 1 < nchunk) stage_A(b, ch + 1, buf ^ 1);
+            else if (more) stage_A(b + NG, 0, buf ^ 1);
+            if (ch == 0) load_E(b, ev);
+            const float* arow = Ab + (buf * AROWS + kh) * 32 + nl;       // A'^T[j = AROWS ch + 2 u + kh][member nl]
+            const float* brow = Bs + (AROWS * ch + kh) * 64 + nl;        // Gx[j][state nl (+32)]
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const float a = arow[u * 64];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(brow[u * 128], a, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(brow[u * 128 + 32], a, acc[1], 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+        first = false;
+        float* obase = Eout + (size_t)row0(b) * M + i0 + e_off;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 v;
+                v.x = ev[t][4 * g4 + 0] + acc[t][4 * g4 + 0];
+                v.y = ev[t][4 * g4 + 1] + acc[t][4 * g4 + 1];
+                v.z = ev[t][4 * g4 + 2] + acc[t][4 * g4 + 2];
+                v.w = ev[t][4 * g4 + 3] + acc[t][4 * g4 + 3];
+                *reinterpret_cast<float4*>(obase + 32 * t + 8 * g4) = v;
+            }
     }
 }
 
@@ -495,6 +865,12 @@ int transpose_f2f(hipStream_t s, const float* in, float* out, int rows, int cols
 static int g_gxt_kc = 64;  // 64 members per LDS chunk: half the barriers of 32 (65.6 vs 68.6 us at C3)
 void mfma_set_gxt_chunk(int kc) { g_gxt_kc = kc == 64 ? 64 : 32; }
 
+static int g_gxt_dma = 1;  // chunks staged by LDS-DMA (k_gxt_dma) where it applies
+void mfma_set_gxt_dma(int d) { g_gxt_dma = d; }
+static int g_gxt_debug = 0;
+void mfma_set_gxt_debug(int d) { g_gxt_debug = d; }
+static int g_gxt_depth = 1;
+void mfma_set_gxt_depth(int d) { g_gxt_depth = d == 2 ? 2 : 1; }
 static int g_gxt_sh = 2;
 void mfma_set_gxt_halves(int sh) { g_gxt_sh = sh == 1 ? 1 : 2; }
 
@@ -502,28 +878,66 @@ int mfma_gxt_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const f
                  float* Gx) {
     if (n_obs % 32 != 0 || n_obs > 256 || M % 4 != 0 || M < 4) return -1;
     const int nj = n_obs / 32;
+    if (g_gxt_dma == 2 && M % 64 == 0 && N >= 4 && nj <= 5 && (16 * n_obs) % 256 == 0) {
+        dim3 grid(M / 64), block(256);
+        const size_t chunks = (size_t)4 * 2 * 16 * (64 + n_obs) * 4, red = (size_t)3 * 2 * nj * 16 * 64 * 4;
+        const size_t lds = chunks > red ? chunks : red;
+        if (lds <= 160 * 1024) {
+#define LD2(NJ) case NJ: HM_HIP(hipFuncSetAttribute((const void*)k_gxt_dma2<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                         hipLaunchKernelGGL((k_gxt_dma2<NJ>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); break
+            switch (nj) { LD2(1); LD2(2); LD2(3); LD2(4); LD2(5); default: goto no_dma; }
+#undef LD2
+            HM_HIP(hipGetLastError());
+            return 0;
+        }
+    }
+    if (g_gxt_dma && M % 64 == 0 && N >= 4) {
+        constexpr int KC = 64;
+        dim3 grid(M / 64), block(512);
+        const size_t lds = (size_t)2 * KC * (64 + n_obs) * 4;
+        if (lds <= 160 * 1024) {
+#define LD(NJ) case NJ: HM_HIP(hipFuncSetAttribute((const void*)k_gxt_dma<NJ, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                        hipLaunchKernelGGL((k_gxt_dma<NJ, KC>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); break
+            switch (nj) { LD(1); LD(2); LD(3); LD(4); LD(5); default: goto no_dma; }
+#undef LD
+            HM_HIP(hipGetLastError());
+            return 0;
+        }
+    }
+no_dma:
     const int sh = g_gxt_sh, kc = sh == 1 ? 32 : g_gxt_kc, sw = 32 * sh;
     dim3 grid((M + sw - 1) / sw), block(256 * sh);
     const size_t chunks = (size_t)2 * kc * (sw + n_obs) * 4, red = (size_t)2 * sh * nj * 16 * 64 * 4;
     const size_t lds = chunks > red ? chunks : red;
     if (lds > 160 * 1024) return -1;
 #define L3(NJ, KC, SH) do { HM_HIP(hipFuncSetAttribute((const void*)k_gxt_lds<NJ, KC, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                           hipLaunchKernelGGL((k_gxt_lds<NJ, KC, SH>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); } while (0)
-#define L(NJ) case NJ: if (sh == 1) L3(NJ, 32, 1); else if (kc == 64) L3(NJ, 64, 2); else L3(NJ, 32, 2); break
+                           hipLaunchKernelGGL((k_gxt_lds<NJ, KC, SH>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)(g_gxt_debug ? -inv_n : inv_n), S, Gx); } while (0)
+#define L4(NJ, KC) do { HM_HIP(hipFuncSetAttribute((const void*)k_gxt_lds<NJ, KC, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                        hipLaunchKernelGGL((k_gxt_lds<NJ, KC, 2, 2>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); } while (0)
+#define L(NJ) case NJ: if (sh == 1) L3(NJ, 32, 1); else if (g_gxt_depth == 2 && kc == 64) L4(NJ, 64); else if (kc == 64) L3(NJ, 64, 2); else L3(NJ, 32, 2); break
     switch (nj) { L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); default: return -1; }
 #undef L
+#undef L4
 #undef L3
     HM_HIP(hipGetLastError());
     return 0;
 }
 
-static int g_apply_variant = 2;
+static int g_apply_variant = 3;  // 3: k_apply_dma | 2: k_apply_lds2 | 1: k_apply_lds
 void mfma_set_apply_variant(int v) { g_apply_variant = v; }
 
 int mfma_apply_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const float* At, const float* Gx, float* Eout) {
     const size_t lds = (size_t)n_obs * 64 * 4;
     if (lds > 150 * 1024 || M % 4 != 0) return -1;
-    if (g_apply_variant == 2 && lds <= 78 * 1024 && M % 64 == 0 && N >= 32 && n_obs % 16 == 0) {  // two workgroups per CU
+    if (g_apply_variant == 3 && lds + 32 * 1024 <= 80 * 1024 && M % 64 == 0 && N >= 128 && N % 4 == 0 && n_obs % 32 == 0) {
+        const size_t lds3 = lds + (size_t)4 * 2 * 32 * 32 * 4;  // + wave-private A chunks
+        HM_HIP(hipFuncSetAttribute((const void*)k_apply_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        dim3 grid(M / 64, 2), block(256);
+        hipLaunchKernelGGL(k_apply_dma<2>, grid, block, lds3, s, N, M, n_obs, E, At, Gx, Eout);
+        HM_HIP(hipGetLastError());
+        return 0;
+    }
+    if (g_apply_variant >= 2 && lds <= 78 * 1024 && M % 64 == 0 && N >= 32 && n_obs % 16 == 0) {  // two workgroups per CU
         HM_HIP(hipFuncSetAttribute((const void*)k_apply_lds2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         dim3 grid((M + 63) / 64, 2), block(256);
         hipLaunchKernelGGL(k_apply_lds2<2>, grid, block, lds, s, N, M, n_obs, E, At, Gx, Eout);
