@@ -81,33 +81,45 @@ def reference_obs_error(n_obs):
 
 
 def es_update_timing(device):
-    """BASELINE.json's second metric (ES-MDA update wall-time) at config 3's shape: N=1000 members, M=128*128 state
-    elements, n_obs=160, fp32 state contractions on the matrix cores, every N x n_obs quantity in fp64.  Device time of
-    one analysis step (HIP events inside the library), inputs resident in HBM; flops by SURVEY.md 8d (min-flop order)."""
+    """BASELINE.json's second metric (ES-MDA update wall-time): device time of one analysis step (HIP events inside the library),
+    inputs resident in HBM, fp32 state contractions on the matrix cores, every N x n_obs quantity in fp64, the reference's
+    correlated observation error; flops by SURVEY.md 8d (min-flop order).  Headline = config 3's shape (N=1000 members, M=128*128
+    state elements, n_obs=160); the same step at config 4's and config 5's ensemble/state sizes beside it (`by_shape`)."""
     import scipy.linalg as sla
 
+    from historymatching_amd import _lib
     from historymatching_amd.update import UpdatePlan
 
-    N, M, n_obs = N_E, NX * NY, 160
-    rng = np.random.RandomState(0)
+    n_obs = 160
     R12 = reference_obs_error(n_obs)
-    plan = UpdatePlan(N, N, M, n_obs, dtype=32, device=device)
-    plan.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), rng.rand(n_obs), rng.randn(N, n_obs) @ R12.T, sla.inv(R12.T))
-    from historymatching_amd import _lib
-
-    plan.run_local()  # warm-up (also forms R from decorr: done once per decorr, i.e. once per ES-MDA assimilation)
-    ms = sorted(plan.run_local()["ms_update"] for _ in range(9))   # one step at a time, host synchronisation after each
-    reps = 10                                                      # steps queued back to back, as ES-MDA chains them behind the
-    for _ in range(reps):                                          # forward model: no idle gap in front of a step's first kernel
-        _lib.check(plan.lib.hm_upd_run(plan.h), "hm_upd_run")
-    med = plan.sync()["ms_update"] / reps
-    plan.close()
-    flops = 4.0 * N * n_obs * M
-    return {"wall_ms": med, "isolated_step_median_ms": ms[len(ms) // 2], "best_ms": ms[0],
-            "timing": "device time (HIP events) per analysis step, 10 steps queued back to back",
-            "config": f"N={N}, M={M}, n_obs={n_obs}, fp32 (config 3 shape), correlated R of HistoryMatch.py:243-259",
-            "flops_min_order": flops, "tflops": flops / (med * 1e-3) / 1e12, "mfma_peak_tflops": FP32_MATRIX_PEAK_TFLOPS,
-            "mfma_frac_of_fp32_peak": flops / (med * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS}
+    decorr = sla.inv(R12.T)
+    rng = np.random.default_rng(0)
+    shapes = [(N_E, NX * NY, "config 3: N_e=1000, 128x128"), (4096, 256 * 256, "config 4: N_e=4096, 256x256 (whole ensemble on one GPU)"),
+              (1000, 512 * 512, "config 5: N_e=1000, 512x512 (global analysis)")]
+    out, by_shape = None, []
+    for N, M, label in shapes:
+        plan = UpdatePlan(N, N, M, n_obs, dtype=32, device=device)
+        plan.set_inputs(rng.standard_normal((N, M), dtype=np.float32), rng.random((N, n_obs)), rng.random(n_obs),
+                        rng.standard_normal((N, n_obs)) @ R12.T, decorr)
+        plan.run_local()  # warm-up (also forms R from decorr: done once per decorr, i.e. once per ES-MDA assimilation)
+        ms = sorted(plan.run_local()["ms_update"] for _ in range(5))   # one step at a time, host synchronisation after each
+        reps = 10                                                      # steps queued back to back, as ES-MDA chains them behind the
+        for _ in range(reps):                                          # forward model: no idle gap in front of a step's first kernel
+            _lib.check(plan.lib.hm_upd_run(plan.h), "hm_upd_run")
+        med = plan.sync()["ms_update"] / reps
+        plan.close()
+        flops = 4.0 * N * n_obs * M
+        entry = {"shape": label, "N": N, "M": M, "n_obs": n_obs, "wall_ms": med, "isolated_step_median_ms": ms[len(ms) // 2],
+                 "tflops": flops / (med * 1e-3) / 1e12, "mfma_frac_of_fp32_peak": flops / (med * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS}
+        by_shape.append(entry)
+        if out is None:
+            out = {"wall_ms": med, "isolated_step_median_ms": ms[len(ms) // 2], "best_ms": ms[0],
+                   "timing": "device time (HIP events) per analysis step, 10 steps queued back to back",
+                   "config": f"N={N}, M={M}, n_obs={n_obs}, fp32 (config 3 shape), correlated R of HistoryMatch.py:243-259",
+                   "flops_min_order": flops, "tflops": entry["tflops"], "mfma_peak_tflops": FP32_MATRIX_PEAK_TFLOPS,
+                   "mfma_frac_of_fp32_peak": entry["mfma_frac_of_fp32_peak"]}
+    out["by_shape"] = by_shape
+    return out
 
 
 def es_update_sharded_timing(device, comm, reps=5):
