@@ -388,11 +388,11 @@ __global__ __launch_bounds__(256) void k_apply_lds(int N, int M, int n_obs, cons
 // one DMA piece = one wave instruction = 1 KB: 4 rows of the E chunk (256 B each) or 256 consecutive floats of the S chunk.
 // The shift c (first member / exact mean) is subtracted when the E operand is read from LDS (one v_sub per 5 MFMAs).  Rows past
 // N in the last chunk: sources clamped, the S rows zeroed in LDS before use.  Requires M % 64 == 0.
-template <int NJ, int KC>
-__global__ __launch_bounds__(512, 2) void k_gxt_dma(int N, int M, int n_obs, const float* __restrict__ E,
+template <int NJ, int KC, int NKH = 4>
+__global__ __launch_bounds__(128 * NKH, NKH / 2) void k_gxt_dma(int N, int M, int n_obs, const float* __restrict__ E,
                                                     const float* __restrict__ colsum, float inv_n,
                                                     const float* __restrict__ S, float* __restrict__ Gx) {
-    constexpr int NO = 32 * NJ, NKH = 4, SW = 64, NQ = KC / 2 / NKH;
+    constexpr int NO = 32 * NJ, SW = 64, NQ = KC / 2 / NKH, NWV = 2 * NKH, NT = 64 * NWV;  // NKH k-parts x 2 state halves
     constexpr int EP = KC / 4, SP = KC * NO / 256, NP = EP + SP;  // DMA pieces per chunk
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Eb = sm;                  // [2][KC][64]
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(512, 2) void k_gxt_dma(int N, int M, int n_obs, con
     auto stage = [&](int c, int buf) {
         const int k0 = c * KC;
 #pragma unroll
-        for (int q = 0; q < (NP + 7) / 8; ++q) {
-            const int piece = w + 8 * q;  // wave-uniform
+        for (int q = 0; q < (NP + NWV - 1) / NWV; ++q) {
+            const int piece = w + NWV * q;  // wave-uniform
             if (piece < EP) {
                 const int row = min(k0 + 4 * piece + (lane >> 4), N - 1);
                 const float* src = E + (size_t)row * M + i0 + (lane & 15) * 4;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void k_gxt_dma(int N, int M, int n_obs, con
         if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
         if (c + 1 == nchunks && N % KC != 0) {  // rows past N: their S operands must be zero (the E rows are clamped copies)
             const int nvalid = N - c * KC;
-            for (int e = tid; e < (KC - nvalid) * NO; e += 512) Sb[buf * KC * NO + nvalid * NO + e] = 0.0f;
+            for (int e = tid; e < (KC - nvalid) * NO; e += NT) Sb[buf * KC * NO + nvalid * NO + e] = 0.0f;
             __syncthreads();
         }
         const float* eb = Eb + buf * KC * SW + 32 * sh + il;
@@ -471,30 +471,34 @@ __global__ __launch_bounds__(512, 2) void k_gxt_dma(int N, int M, int n_obs, con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next chunk have landed
         __syncthreads();                                   // ... and everybody else's; the current buffer is free
     }
-    // fixed-order tree over the 4 k-quarters through LDS (as k_gxt_lds)
+    // fixed-order tree over the NKH k-parts through LDS: step s = 1, 2, 4: part kh (kh % 2s == s) is added to part kh - s.
+    // Two publisher slots (82 KB at n_obs = 160) alias the chunk buffers; a step with more than two publishers runs in rounds.
     float* red = sm;
     auto slot = [&](int pub, int t, int r) { return red + (((pub * 2 + sh) * NJ + t) * 16 + r) * 64 + lane; };
-    if (kh & 1) {
-#pragma unroll
-        for (int t = 0; t < NJ; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) *slot(kh >> 1, t, r) = acc[t][r];
-    }
     __syncthreads();
-    if (!(kh & 1)) {
 #pragma unroll
-        for (int t = 0; t < NJ; ++t)
+    for (int st = 1; st < NKH; st *= 2) {
+        const int npub = NKH / (2 * st);                 // publishers of this step: kh = st, 3 st, 5 st, ...
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] += *slot(kh >> 1, t, r);
+        for (int round = 0; round < (npub + 1) / 2; ++round) {
+            const int pidx = (kh / (2 * st));            // index of this wave's pair within the step
+            const bool in_round = pidx / 2 == round;
+            if (in_round && kh % (2 * st) == st) {
+#pragma unroll
+                for (int t = 0; t < NJ; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) *slot(pidx & 1, t, r) = acc[t][r];
+            }
+            __syncthreads();
+            if (in_round && kh % (2 * st) == 0 && st * 2 < NKH) {
+#pragma unroll
+                for (int t = 0; t < NJ; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += *slot(pidx & 1, t, r);
+            }
+            if (st * 2 < NKH) __syncthreads();
+        }
     }
-    __syncthreads();
-    if (kh == 2) {
-#pragma unroll
-        for (int t = 0; t < NJ; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) *slot(0, t, r) = acc[t][r];
-    }
-    __syncthreads();
     if (kh == 0) {
 #pragma unroll
         for (int t = 0; t < NJ; ++t)
@@ -896,8 +900,10 @@ int mfma_gxt_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const f
         dim3 grid(M / 64), block(512);
         const size_t lds = (size_t)2 * KC * (64 + n_obs) * 4;
         if (lds <= 160 * 1024) {
-#define LD(NJ) case NJ: HM_HIP(hipFuncSetAttribute((const void*)k_gxt_dma<NJ, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                        hipLaunchKernelGGL((k_gxt_dma<NJ, KC>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); break
+#define LD(NJ) case NJ: if (g_gxt_dma == 3) { HM_HIP(hipFuncSetAttribute((const void*)k_gxt_dma<NJ, KC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                        hipLaunchKernelGGL((k_gxt_dma<NJ, KC, 8>), grid, dim3(1024), lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); } else { \
+                        HM_HIP(hipFuncSetAttribute((const void*)k_gxt_dma<NJ, KC, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                        hipLaunchKernelGGL((k_gxt_dma<NJ, KC, 4>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); } break
             switch (nj) { LD(1); LD(2); LD(3); LD(4); LD(5); default: goto no_dma; }
 #undef LD
             HM_HIP(hipGetLastError());
