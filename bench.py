@@ -280,6 +280,8 @@ def main():
 
     comm = Comm.from_env()
     world, rank, local_rank = comm.world_size, comm.rank, comm.local_rank
+    if os.environ.get("HM_BENCH_ALL_ON_DEVICE0") == "1":  # functional check of the N > 1 path on a one-GPU box: every rank on device 0
+        local_rank = comm.local_rank = 0                   # (RCCL refuses that; the reductions then run over the host channel)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -320,6 +322,40 @@ def main():
         msgs = comm.host.all_gather(err) if world > 1 else [err]
         bad = [m for m in msgs if m]
         return {"error": "; ".join(bad)} if bad else res
+
+    # The same workload as two member blocks on two HIP streams (members are independent; the partial last round of one kernel --
+    # 1000 members are 3.9 rounds of 256 CUs -- is filled by the other block's kernels).  Reported beside `value`, which stays the
+    # one-stream figure its per-kernel roofline refers to.
+    two_streams = None
+    if world == 1 and args.variant == 0:
+        try:
+            ctx2 = _lib.Context(local_rank)
+            halves = []
+            for c, lo, hi in ((ctx, 0, n_e // 2), (ctx2, n_e // 2, n_e)):
+                hp = ForwardPlan(model, hi - lo, DT, NTIME, keep_history=True, ctx=c)
+                hp.set_inputs(perms[lo:hi], None, transformed=False)
+                halves.append(hp)
+
+            def both(reps):
+                for _ in range(reps):
+                    for k in range(NTIME):
+                        for hp in halves:
+                            hp.run(k, 1)
+                for hp in halves:
+                    hp.sync()
+
+            both(1)
+            t1 = time.perf_counter()
+            both(2)
+            wall2 = (time.perf_counter() - t1) / 2
+            p2 = np.concatenate([hp.outputs(want_wsats=False)[1] for hp in halves])
+            two_streams = {"value": n_e * NTIME / wall2, "unit": "ensemble-steps/s", "ms_per_pass": 1e3 * wall2,
+                           "producer_series_identical_to_one_stream": bool(np.array_equal(p2, prods)),
+                           "how": "two plans of N_e/2 members on two streams of one GPU, launches interleaved step by step"}
+            for hp in halves:
+                hp.close()
+        except Exception as e:
+            two_streams = {"error": str(e)}
 
     upd_sharded = c4 = None
     if world > 1 or comm.rccl is not None:  # every rank: the analysis step sharded over the ranks (outside the timed region of `value`)
@@ -415,7 +451,7 @@ def main():
                        "members_per_gpu": n_e, "grid": [NX, NY], "nTime": NTIME, "device": ctx.name(),
                        "kernel_variant": args.variant, "results_finite_and_status_ok": bool(ok),
                        "ranks": "one process per GPU, host channel for barriers/timing, RCCL from the library for the update's reductions (no PyTorch)"},
-            "roofline": roofline, "cpu_baseline": cpu, "es_update": upd, "config4": c4, "config5": c5,
+            "roofline": roofline, "cpu_baseline": cpu, "two_streams": two_streams, "es_update": upd, "config4": c4, "config5": c5,
             "device_ms": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
         }
         print(json.dumps(out))

@@ -28,10 +28,12 @@ class ForwardPlan:
     iterative smoothers) can chain forward runs and updates without host round trips.
     """
 
-    def __init__(self, model: ResSim, N, dt, nTime, keep_history=True, device=None):
+    def __init__(self, model: ResSim, N, dt, nTime, keep_history=True, device=None, ctx=None):
+        """``ctx``: an own ``_lib.Context`` (= an own HIP stream on the device) instead of the process-wide one of ``device``:
+        plans on different contexts run concurrently (member blocks are independent)."""
         self.model, self.N, self.dt, self.nTime = model, int(N), float(dt), int(nTime)
         self.keep_history = bool(keep_history)
-        self.ctx = _lib.Context.get(model.device if device is None else device)
+        self.ctx = ctx if ctx is not None else _lib.Context.get(model.device if device is None else device)
         self.lib = self.ctx.lib
         self.ft = np.float64 if model.dtype == 64 else np.float32
         inj_ind, inj, prd_ind, prd = model._wells(self.nTime)
