@@ -59,7 +59,10 @@ class HostChannel:
                 fh.write(f"{listener.address[1]} {key.hex()}\n")
             os.replace(tmp, rdzv_file)
             try:
-                listener._listener._socket.settimeout(timeout)
+                try:  # bound the wait for peers that never show up (private attribute of the stdlib Listener: best effort)
+                    listener._listener._socket.settimeout(timeout)
+                except AttributeError:
+                    pass
                 while len(self.peers) < self.world_size - 1:
                     conn = listener.accept()
                     self.peers[int(conn.recv())] = conn
