@@ -28,7 +28,7 @@
 // for good.  Results are bit-identical (tests/test_forward_gpu.py::test_saturation_step_bitexact_given_fluxes and the rest).
 //
 // Compiled with -ffp-contract=off (no FMA contraction: every product and sum is rounded separately, as NumPy does).
-#include "fwd.h"
+#include "fracflow.h"
 
 namespace {
 
@@ -62,23 +62,6 @@ __device__ __forceinline__ double from_prev_lane(double v) {
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);  // wave_shr:1
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
-}
-
-template <bool FD>
-__device__ __forceinline__ double frac_flow(const FwdParams& p, double s) {
-    double mw, mo;
-    if (FD) {
-        mw = s * s;
-        double o = 1.0 - s;
-        mo = o * o;
-    } else {
-        double den = (1.0 - p.swc) - p.sor;
-        double S = (s - p.swc) / den;
-        mw = (S * S) / p.vw;
-        double o = 1.0 - S;
-        mo = (o * o) / p.vo;
-    }
-    return mw / (mw + mo);
 }
 
 template <bool FD>
