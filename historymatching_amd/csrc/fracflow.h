@@ -17,6 +17,8 @@
 // 1e-191, 0), so values of the second kind sit along the whole front all the time: a form that branched to the compiler's division
 // for them was slower than no change at all.  Non-finite or absurd |S| >= 2^500 is outside the claim (such members are flagged).
 // The general fluid keeps the compiler's division (four quotients with arbitrary operand ranges).
+// fp32 sweeps (dtype = 32 plans): the same in single precision -- the compiler's sequence there is v_rcp_f32, ONE Newton step and
+// two residual corrections; scaling is an identity for S^2 >= 2^-103, and 1 - S, S^2 + 1 round to exactly 1.0f for |S| < 2^-25.
 #pragma once
 #include "fwd.h"
 
@@ -55,5 +57,43 @@ __device__ __forceinline__ double frac_flow(const FwdParams& p, double s) {
     const double mw = s * s;
     const double o = 1.0 - s;
     const double mo = o * o;
+    return div_unscaled(mw, mw + mo);
+}
+
+// ---------------------------------------------------------------- single precision (dtype = 32 plans)
+template <bool FD>
+__device__ __forceinline__ float frac_flow_ieee(const FwdParams& p, float s) {
+    float mw, mo;
+    if (FD) {
+        mw = s * s;
+        const float o = 1.0f - s;
+        mo = o * o;
+    } else {
+        const float den = (float)((1.0 - p.swc) - p.sor);
+        const float S = (s - (float)p.swc) / den;
+        mw = (S * S) / (float)p.vw;
+        const float o = 1.0f - S;
+        mo = (o * o) / (float)p.vo;
+    }
+    return mw / (mw + mo);
+}
+
+__device__ __forceinline__ float div_unscaled(float n, float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = n * r;
+    e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+
+template <bool FD>
+__device__ __forceinline__ float frac_flow(const FwdParams& p, float s) {
+    if (!FD) return frac_flow_ieee<false>(p, s);
+    const float mw = s * s;
+    const float o = 1.0f - s;
+    const float mo = o * o;
     return div_unscaled(mw, mw + mo);
 }

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
         return __ballot(bits != 0ull || (has_well && (wq > 0.0 || Sin[wcell] != 0.0))) == 0ull;
     };
     int dry = band_is_dry() ? 1 : 0;
+    const int wave_well = __builtin_amdgcn_readfirstlane(__ballot(has_well) != 0ull);
     // ---------------- explicit sub-steps
     for (int it = 0; it < Nts; ++it) {
         // The upwind coefficients are pure functions of (Vx, Vy, d): left alone, the compiler hoists all of them
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
             __builtin_amdgcn_sched_barrier(0);
         }
         }
-        {   // well side path, branch-free (threads without a well run it on the dummy record)
+        if (wave_well) {  // well side path: lane-branch-free (lanes without a well run it on the dummy record), skipped by waves without wells
             double* rec = reinterpret_cast<double*>(lds + wrec);
             double wf = frac_flow<FD>(p, rec[0]);
             rec[7] = wf;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
             __builtin_amdgcn_sched_barrier(0);
         }
         }
-        {
+        if (wave_well) {
             double* rec = reinterpret_cast<double*>(lds + wrec);
             double acc = rec[1] * *reinterpret_cast<const double*>(lds + well_addr(1, 0));
             acc = acc + rec[2] * *reinterpret_cast<const double*>(lds + well_addr(0, 1));

@@ -10,7 +10,7 @@
 // conflict-free without swizzling), the iy halo through DPP wave shifts.  Per cell and sub-step: fw (one fp32 division),
 // 5 multiplies, 5 adds.  Wells: branch-free side path on a small LDS record, as in sat128.hip.
 // Summation order = CSR row order of the reference's matrix form (E, N, C, S, W), compiled with -ffp-contract=off.
-#include "fwd.h"
+#include "fracflow.h"
 
 namespace {
 
@@ -28,23 +28,6 @@ __device__ __forceinline__ float next_lane(float v) {  // value of lane+1 (0 pas
 }
 __device__ __forceinline__ float prev_lane(float v) {  // value of lane-1
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
-}
-
-template <bool FD>
-__device__ __forceinline__ float frac_flow(const FwdParams& p, float s) {
-    float mw, mo;
-    if (FD) {
-        mw = s * s;
-        const float o = 1.0f - s;
-        mo = o * o;
-    } else {
-        const float den = (float)((1.0 - p.swc) - p.sor);
-        const float S = (s - (float)p.swc) / den;
-        mw = (S * S) / (float)p.vw;
-        const float o = 1.0f - S;
-        mo = (o * o) / (float)p.vo;
-    }
-    return mw / (mw + mo);
 }
 
 template <bool FD>

@@ -7,6 +7,7 @@
 // tiles' workgroups once per sub-step: one granule per value (a float is the 32-bit payload of one granule).
 // Bit-identical to k_saturation_generic<float> / k_saturation_tiled<float>.  Compiled with -ffp-contract=off.
 #include "sat_team.h"
+#include "fracflow.h"
 
 namespace {
 
@@ -29,23 +30,6 @@ __device__ __forceinline__ float next_lane(float v) {  // value of lane+1 (0 pas
 }
 __device__ __forceinline__ float prev_lane(float v) {  // value of lane-1
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
-}
-
-template <bool FD>
-__device__ __forceinline__ float frac_flow(const FwdParams& p, float s) {
-    float mw, mo;
-    if (FD) {
-        mw = s * s;
-        const float o = 1.0f - s;
-        mo = o * o;
-    } else {
-        const float den = (float)((1.0 - p.swc) - p.sor);
-        const float S = (s - (float)p.swc) / den;
-        mw = (S * S) / (float)p.vw;
-        const float o = 1.0f - S;
-        mo = (o * o) / (float)p.vo;
-    }
-    return mw / (mw + mo);
 }
 
 // float index of fw at tile-local (lix, liy), lix/liy in [-1, 128]: outside the tile -> the halo

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
             for (int j = 0; j < PY; ++j) bits |= (unsigned long long)__double_as_longlong(S[i][j]) << 1;  // -0.0 counts as zero
         dry = __ballot(bits != 0ull || (has_well && (wq > 0.0 || Sin[wcell] != 0.0))) == 0ull;
     }
+    const int wave_well = __builtin_amdgcn_readfirstlane(__ballot(has_well) != 0ull);
 #ifdef HM_SAT_PROF
     unsigned long long prof_a = 0, prof_h = 0, prof_b = 0, prof_t;
 #define STAMP(acc) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); acc += t_ - prof_t; prof_t = t_; } while (0)
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
             __builtin_amdgcn_sched_barrier(0);
         }
         }
-        {   // well side path, branch-free (threads without a well run it on the dummy record)
+        if (wave_well) {  // well side path: lane-branch-free (lanes without a well run it on the dummy record), skipped by waves without wells
             double* rec = reinterpret_cast<double*>(lds + wrec);
             double wf = frac_flow<FD>(p, rec[0]);
             rec[7] = wf;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
             __builtin_amdgcn_sched_barrier(0);
         }
         }
-        {
+        if (wave_well) {
             double* rec = reinterpret_cast<double*>(lds + wrec);
             double acc = rec[1] * *reinterpret_cast<const double*>(lds + well_addr(1, 0));
             acc = acc + rec[2] * *reinterpret_cast<const double*>(lds + well_addr(0, 1));

@@ -11,9 +11,11 @@ from historymatching_amd.geostat import gaussian_fields_kron  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 model = bench.build_model(32, device=0)
 plan = ForwardPlan(model, N, bench.DT, bench.NTIME, keep_history=False, device=0)
-plan.set_inputs(gaussian_fields_kron(128, 128, 2, 1, N, r=0.8, seed=1), None, transformed=False)
+x = gaussian_fields_kron(128, 128, 2, 1, N, r=0.8, seed=1)
+plan.set_inputs(x, None, transformed=False)
 plan.run()
 plan.sync()
+plan.set_inputs(x, None, transformed=False)
 plan.run()
 st = plan.sync()
 _, _, status = plan.outputs(want_wsats=False)
