@@ -855,8 +855,7 @@ static int launch_saturation(hm_fwd* f, int k) {
     if (rc) return rc;
     int done = -1;
     if (f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
-        done = f->sat_variant == 5 ? launch_saturation_128e(f, Sin, Sout, stride, k)  // fp64, edge-exchange form (sat128e.hip)
-                                   : launch_saturation_128(f, Sin, Sout, stride, k);  // fp64, register/LDS resident
+        done = launch_saturation_128(f, Sin, Sout, stride, k);                  // fp64, register/LDS resident
         if (done < 0) done = launch_saturation_128f(f, Sin, Sout, stride, k);  // fp32 twin
         if (done < 0) done = launch_saturation_128t(f, Sin, Sout, stride, k);  // fp64, grids of 128 x 128 tiles (workgroup teams)
         if (done < 0) done = launch_saturation_128ft(f, Sin, Sout, stride, k); // fp32 twin

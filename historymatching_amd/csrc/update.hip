@@ -896,7 +896,9 @@ extern "C" int hm_upd_run(hm_upd* u) {
         return 0;
     }
     if (!u->stream2) {
-        HM_HIP(hipStreamCreateWithFlags(&u->stream2, hipStreamNonBlocking));
+        int prio_lo = 0, prio_hi = 0;  // the small chain is the critical path when it shares CUs with the big contraction
+        HM_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HM_HIP(hipStreamCreateWithPriority(&u->stream2, hipStreamNonBlocking, prio_hi));
         HM_HIP(hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming));
         HM_HIP(hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming));
     }

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_apply_lds(int N, int M, int n_obs, cons
 // one DMA piece = one wave instruction = 1 KB: 4 rows of the E chunk (256 B each) or 256 consecutive floats of the S chunk.
 // The shift c (first member / exact mean) is subtracted when the E operand is read from LDS (one v_sub per 5 MFMAs).  Rows past
 // N in the last chunk: sources clamped, the S rows zeroed in LDS before use.  Requires M % 64 == 0.
-template <int NJ, int KC, int NKH = 4>
+template <int NJ, int KC, int NKH, int NS = 2>
 __global__ __launch_bounds__(128 * NKH, NKH / 2) void k_gxt_dma(int N, int M, int n_obs, const float* __restrict__ E,
                                                     const float* __restrict__ colsum, float inv_n,
                                                     const float* __restrict__ S, float* __restrict__ Gx) {
@@ -480,21 +480,21 @@ __global__ __launch_bounds__(128 * NKH, NKH / 2) void k_gxt_dma(int N, int M, in
     for (int st = 1; st < NKH; st *= 2) {
         const int npub = NKH / (2 * st);                 // publishers of this step: kh = st, 3 st, 5 st, ...
 #pragma unroll
-        for (int round = 0; round < (npub + 1) / 2; ++round) {
+        for (int round = 0; round < (npub + NS - 1) / NS; ++round) {
             const int pidx = (kh / (2 * st));            // index of this wave's pair within the step
-            const bool in_round = pidx / 2 == round;
+            const bool in_round = pidx / NS == round;
             if (in_round && kh % (2 * st) == st) {
 #pragma unroll
                 for (int t = 0; t < NJ; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) *slot(pidx & 1, t, r) = acc[t][r];
+                    for (int r = 0; r < 16; ++r) *slot(pidx % NS, t, r) = acc[t][r];
             }
             __syncthreads();
             if (in_round && kh % (2 * st) == 0 && st * 2 < NKH) {
 #pragma unroll
                 for (int t = 0; t < NJ; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][r] += *slot(pidx & 1, t, r);
+                    for (int r = 0; r < 16; ++r) acc[t][r] += *slot(pidx % NS, t, r);
             }
             if (st * 2 < NKH) __syncthreads();
         }
@@ -894,6 +894,20 @@ int mfma_gxt_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const f
             HM_HIP(hipGetLastError());
             return 0;
         }
+    }
+    if (g_gxt_dma && g_gxt_kc == 32 && M % 64 == 0 && N >= 4) {
+        // 32-member chunks and ONE publisher slot in the final sum: 56 KB of LDS at n_obs = 160 instead of 112 -- a few percent slower
+        // alone, but a second workgroup (the fp64 chain of hm_upd_run on its own stream) fits on the CU beside it
+        constexpr int KC = 32;
+        dim3 grid(M / 64), block(512);
+        const size_t chunks = (size_t)2 * KC * (64 + n_obs) * 4, red = (size_t)2 * (n_obs / 32) * 16 * 64 * 4;
+        const size_t lds = chunks > red ? chunks : red;
+#define LD(NJ) case NJ: HM_HIP(hipFuncSetAttribute((const void*)k_gxt_dma<NJ, KC, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                        hipLaunchKernelGGL((k_gxt_dma<NJ, KC, 4, 1>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); break
+        switch (nj) { LD(1); LD(2); LD(3); LD(4); LD(5); default: goto no_dma; }
+#undef LD
+        HM_HIP(hipGetLastError());
+        return 0;
     }
     if (g_gxt_dma && M % 64 == 0 && N >= 4) {
         constexpr int KC = 64;

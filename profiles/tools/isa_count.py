@@ -102,7 +102,7 @@ def main():
     for _, op, _ in body[lo:hi + 1]:
         c = classify(op)
         counts[c] = counts.get(c, 0) + 1
-        if op.startswith("v_div_fmas_f64"):
+        if op.startswith("v_rcp_f64"):  # one reciprocal per division (compiler's IEEE sequence or fracflow.h's unscaled form)
             divisions += 1
     out = {"object": obj, "kernel": name, "loop_instructions": hi - lo + 1, "loop_start": hex(body[lo][0]), "loop_end": hex(body[hi][0]), "counts": counts, "fp64_divisions": divisions,
            "cells_per_thread_per_trip": per, "dp_valu_per_cell_substep": counts.get("dp_valu", 0) / per,

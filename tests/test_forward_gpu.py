@@ -123,7 +123,7 @@ def test_assembly_bitexact_and_pressure_within_solver_noise(n, variant):
     plan.close()
 
 
-@pytest.mark.parametrize("n,variant", [(20, 1), (20, 0), (128, 1), (128, 0), (128, 5)])
+@pytest.mark.parametrize("n,variant", [(20, 1), (20, 0), (128, 1), (128, 0)])
 def test_saturation_step_bitexact_given_fluxes(n, variant):
     """Same V in, same S out, to the last bit, including the CFL sub-step count."""
     from oracle.ressim import perm_transf, set_perm
@@ -281,7 +281,7 @@ def test_cg_solver_reports_non_convergence():
     plan.close()
 
 
-@pytest.mark.parametrize("n,variant", [(20, 1), (128, 1), (128, 0), (128, 5)])
+@pytest.mark.parametrize("n,variant", [(20, 1), (128, 1), (128, 0)])
 def test_general_fluid_parameters_bitexact(n, variant):
     """vw, vo, swc, sor away from the upstream defaults exercise the general RelPerm path (three extra divisions):
     assembly and saturation sweep stay bit-exact, the pressure solve stays within solver noise."""
