@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-esmda", action="store_true", help="skip the 4-pass ES-MDA leg (config 3)")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (N_e=4096 at 256x256 over the ranks)")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the two-stream leg (profiling runs: one kernel shape per name)")
     ap.add_argument("--config5", action="store_true", help="run the config-5 leg (N_e=1000 at 512x512, localised) also below 4 ranks")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0, help="0 = fastest kernels, 1 = generic kernels")
@@ -327,7 +328,7 @@ def main():
     # 1000 members are 3.9 rounds of 256 CUs -- is filled by the other block's kernels).  Reported beside `value`, which stays the
     # one-stream figure its per-kernel roofline refers to.
     two_streams = None
-    if world == 1 and args.variant == 0:
+    if world == 1 and args.variant == 0 and not args.no_two_streams:
         try:
             ctx2 = _lib.Context(local_rank)
             halves = []

@@ -11,10 +11,10 @@ OUT=gpurun_out/profiles/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 W=/tmp/hmprof; rm -rf $W; mkdir -p $W
-BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-esmda --no-config4"
+BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-esmda --no-config4 --no-two-streams"
 rocprofv3 --kernel-trace --stats --output-format csv -d $W/ks -o ks -- python3 $BENCH > $OUT/bench_under_rocprof.json 2> $W/ks.err
 cp "$(find $W/ks -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_bench.csv
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $W/f64 -o f64 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-esmda --no-config4 > /dev/null 2> $W/f64.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $W/f64 -o f64 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-esmda --no-config4 --no-two-streams > /dev/null 2> $W/f64.err
 f=$(find $W/f64 -name '*counter_collection.csv' | head -1)
 if [ -n "$f" ]; then
   (head -1 $f; grep -E "k_press|k_sat" $f) > $OUT/pmc_fp64_forward_counter_collection.csv
@@ -22,7 +22,7 @@ else
   tail -5 $W/f64.err
 fi
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $W/$C -o pmc -- python3 bench.py --members 256 --steps 1 --warmup 0 --no-cpu-baseline --no-esmda --no-config4 > /dev/null 2> $W/$C.err
+  rocprofv3 --pmc $C --output-format csv -d $W/$C -o pmc -- python3 bench.py --members 256 --steps 1 --warmup 0 --no-cpu-baseline --no-esmda --no-config4 --no-two-streams > /dev/null 2> $W/$C.err
   f=$(find $W/$C -name '*counter_collection.csv' | head -1)
   (head -1 $f; grep -E "k_press|k_sat|k_perm|k_pressure|k_saturation" $f) > $OUT/pmc_${C}_counter_collection.csv
 done
