@@ -155,6 +155,96 @@ def test_saturation_step_bitexact_given_fluxes(n, variant):
     plan.close()
 
 
+def _adversarial_saturations(n, dtype, seed):
+    """Saturation fields made of the values the division of the fractional flow treats specially (csrc/fracflow.h): exact and
+    negative zero, denormals, tiny normals on both sides of the thresholds of the compiler's operand scaling (S^2 around 2^-970 /
+    2^-103), values whose square underflows, the ends of [0, 1] and a little outside, next to ordinary saturations."""
+    rng = np.random.RandomState(seed)
+    ft = np.float64 if dtype == 64 else np.float32
+    fi = np.finfo(ft)
+    emin = fi.minexp  # -1022 / -126
+    special = [0.0, -0.0, fi.smallest_subnormal, 3 * fi.smallest_subnormal, fi.tiny, fi.tiny * (1 + fi.eps), 1.0, 1.0 - fi.epsneg,
+               1.0 + fi.eps, 0.5, 1.2, -fi.tiny, -1e-17 if dtype == 64 else -1e-8, 1e-30, 1e-3]
+    S = rng.rand(n * n).astype(ft)
+    k = rng.rand(n * n)
+    # a third of the cells: mantissa x 2^e with e spread over the whole tiny range, denser around the thresholds
+    e_all = rng.randint(emin - 40, -2, n * n)
+    e_thr = np.array([emin // 2 - 27, emin // 2 - 1, emin // 2, emin // 2 + 1, -485, -484, -481, -480, -479, -52, -51, -27, -26, -25, -24])
+    e_near = e_thr[rng.randint(0, len(e_thr), n * n)] + rng.randint(-1, 2, n * n)
+    tiny = np.ldexp(1.0 + rng.rand(n * n), np.where(rng.rand(n * n) < 0.5, e_all, e_near)).astype(ft)
+    S = np.where(k < 0.35, tiny, S)
+    S = np.where((k >= 0.35) & (k < 0.5), np.array(special, dtype=ft)[rng.randint(0, len(special), n * n)], S)
+    S = np.where((k >= 0.5) & (k < 0.55), -tiny, S)
+    return S.astype(ft)
+
+
+def test_fractional_flow_division_bitexact_on_adversarial_saturations():
+    """The sweeps divide without the compiler's operand scaling and fix-up instructions (csrc/fracflow.h).  One time step from
+    saturation fields built of the values where those instructions act -- zeros, denormals, squares that underflow, tiny normals
+    around the scaling thresholds, the ends of [0, 1] -- equals the NumPy restatement to the last bit, and the generic kernel
+    (compiler's division)."""
+    from oracle.ressim import perm_transf, set_perm
+
+    n, N = 128, 4
+    om, gm = make_models(n, n)
+    x = perms(n, n, N, seed=77)
+    S_in, Vxs, Vys, S_ref = [], [], [], []
+    for m in range(N):
+        S_real, q = _oracle_state(om, x[m], 1)
+        set_perm(om, x[m])
+        _, Vx, Vy = om.pressure_step(S_real, q)
+        S = _adversarial_saturations(n, 64, 100 + m)
+        if m == 3:
+            S[: n * n // 2] = 0.0  # dry bands next to adversarial ones
+        S_in.append(S), Vxs.append(Vx), Vys.append(Vy)
+        with np.errstate(all="ignore"):
+            S_ref.append(om.saturation_step_upwind(S, q, Vx, Vy, DT))
+    out = {}
+    for variant in (0, 1):
+        plan = _plan(gm, N, nTime=2)
+        plan.set_variant(variant, variant)
+        plan.set_inputs(perm_transf(x), transformed=True)
+        plan.set_field("S", np.array(S_in))
+        plan.set_field("Vx", np.array(Vxs))
+        plan.set_field("Vy", np.array(Vys))
+        plan.saturation_only(0)
+        out[variant] = plan.get_field("S").reshape(N, -1)
+        plan.close()
+    for m in range(N):
+        assert np.array_equal(out[0][m], S_ref[m]), (m, np.abs(out[0][m] - S_ref[m]).max())
+        assert np.array_equal(out[1][m], S_ref[m])
+        assert np.array_equal(np.signbit(out[0][m]), np.signbit(out[1][m]))
+
+
+def test_fractional_flow_division_fp32_bitexact_on_adversarial_saturations():
+    """The same for dtype=32 plans: the register-resident fp32 sweep (unscaled single-precision division) against the generic fp32
+    kernel (compiler's division) on adversarial fp32 saturations, same fluxes."""
+    n, N = 128, 3
+    om, gm = make_models(n, n, dtype=32)
+    x = perms(n, n, N, seed=78)
+    out = {}
+    S_in = np.array([_adversarial_saturations(n, 32, 200 + m) for m in range(N)])
+    Vx = Vy = None
+    for variant in (1, 0):
+        plan = _plan(gm, N, nTime=2)
+        plan.set_variant(1, variant)
+        plan.set_inputs(x, transformed=False)
+        if Vx is None:
+            plan.run(0, 1)  # a realistic flux field (one step from S = 0), reused for both kernels
+            plan.sync()
+            Vx, Vy = plan.get_field("Vx"), plan.get_field("Vy")
+            plan.set_inputs(x, transformed=False)
+        plan.set_field("S", S_in)
+        plan.set_field("Vx", Vx)
+        plan.set_field("Vy", Vy)
+        plan.saturation_only(0)
+        out[variant] = (plan.get_field("S").copy(), plan.get_field("nts")[:, 0].copy())
+        plan.close()
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][0].view(np.uint32) & 0x7FFFFFFF, out[1][0].view(np.uint32) & 0x7FFFFFFF) or np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][0], out[1][0])
+
+
 def test_full_sim_20x20_matches_oracle():
     """C1-shaped case (reference default grid, HistoryMatch.py:97,219-221): 40 steps, whole history."""
     from oracle.ressim import forward_model as oracle_forward
