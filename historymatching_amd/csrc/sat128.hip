@@ -277,6 +277,8 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
             load_row(ix, fc);
             const char* rowW = lds + (i > 0 ? ix - 1 : ixW) * 1024 + seg;
             const char* rowE = lds + (i + 1 < PX ? ix + 1 : ixE) * 1024 + seg;
+            // (these two values also sit in the image; reading them from LDS instead of the neighbour lane's registers removes 32 DPP
+            //  moves per sub-step from the VALU and was slower: 14.26 against 13.85 ms)
             const double fS = from_prev_lane(fc[PY - 1]);  // f(ix, iy0-1): its coefficient is 0 on the boundary
             const double fN = from_next_lane(fc[0]);       // f(ix, iy0+PY)
             double2 vx8a = make_double2(0, 0), vx8b = vx8a, vy7a = vx8a;
