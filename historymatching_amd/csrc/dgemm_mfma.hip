@@ -114,6 +114,109 @@ __global__ __launch_bounds__(256) void k_gram_lower(int n, int K, const double* 
     }
 }
 
+// Centring of the observations AND the Gram matrix of the fused analysis step (hm_upd_run) in ONE launch: the two do not depend on
+// each other once the Gram matrix is formed from shifted instead of centred observations,
+//     Yc^T Yc = sum_k (y_k - y_0)(y_k - y_0)^T - N (ybar - y_0)(ybar - y_0)^T          (exact; y_0 = the first member's row)
+// -- the rank-one term is subtracted by the inverse while it loads its tiles (spdinv.hip), like (N-1) R.  The shift by a member keeps
+// the cancellation relative to the ensemble's spread (a collapsed ensemble late in an ES-MDA loses nothing), not to the magnitude
+// of the observations.  Workgroups [0, ncb): 8 observation columns x 128 row lanes each -- column means in a fixed order (per-lane
+// partial sums, then a tree), Yc in fp64 and fp32, the innovations D0 = obs - obs_ens - perturbs (HistoryMatch.py:582-584), and
+// dmean = ybar - y_0.  Workgroups [ncb, ncb + tiles): one lower 16 x 16 tile each, 16 waves = 16 parts of the member range, partial
+// tiles added in fixed order through LDS.
+constexpr int CG_COLS = 8, CG_LANES = 1024 / CG_COLS;
+__global__ __launch_bounds__(1024) void k_center_gram(const float* __restrict__ obs_ens, const float* __restrict__ perturbs,
+                                                      const float* __restrict__ obs, int rows, int n_obs, int ncb,
+                                                      double* __restrict__ YD, float* __restrict__ Yc32, double* __restrict__ dmean,
+                                                      double* __restrict__ G) {
+    __shared__ double sh[15 * 4 * 64];  // centring: [128][9] partial sums; Gram: [15][4][64] partial tiles
+    if ((int)blockIdx.x < ncb) {
+        double (*part)[CG_COLS + 1] = reinterpret_cast<double (*)[CG_COLS + 1]>(sh);
+        const int c = threadIdx.x & (CG_COLS - 1), g = threadIdx.x / CG_COLS;
+        const int jraw = blockIdx.x * CG_COLS + c, j = min(jraw, n_obs - 1);
+        constexpr int U = 8;
+        float v[U], pv[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int r = min(g + CG_LANES * q, rows - 1);  // clamped, unconditional loads
+            v[q] = obs_ens[(size_t)r * n_obs + j];
+            pv[q] = perturbs[(size_t)r * n_obs + j];
+        }
+        double s0 = 0.0;
+#pragma unroll
+        for (int q = 0; q < U; ++q) s0 += (g + CG_LANES * q < rows) ? (double)v[q] : 0.0;
+        for (int r = g + CG_LANES * U; r < rows; r += CG_LANES) s0 += (double)obs_ens[(size_t)r * n_obs + j];
+        part[g][c] = s0;
+        __syncthreads();
+        for (int st = CG_LANES / 2; st > 0; st >>= 1) {  // fixed-order tree over the row lanes
+            if (g < st) part[g][c] += part[g + st][c];
+            __syncthreads();
+        }
+        const double mean = part[0][c] / (double)rows;
+        if (jraw >= n_obs) return;
+        if (g == 0) dmean[j] = mean - (double)obs_ens[j];
+        const double ob = (double)obs[j];
+        const size_t n = (size_t)rows * n_obs;
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int r = g + CG_LANES * q;
+            if (r < rows) {
+                const size_t e = (size_t)r * n_obs + j;
+                const double o = (double)v[q];
+                YD[e] = o - mean;
+                Yc32[e] = (float)(o - mean);
+                YD[n + e] = ob - o - (double)pv[q];
+            }
+        }
+        for (int r = g + CG_LANES * U; r < rows; r += CG_LANES) {
+            const size_t e = (size_t)r * n_obs + j;
+            const double o = (double)obs_ens[e];
+            YD[e] = o - mean;
+            Yc32[e] = (float)(o - mean);
+            YD[n + e] = ob - o - (double)perturbs[e];
+        }
+        return;
+    }
+    double (*part)[4][64] = reinterpret_cast<double (*)[4][64]>(sh);
+    int R = 0;
+    const int t = blockIdx.x - ncb;
+    while ((R + 1) * (R + 2) / 2 <= t) ++R;
+    const int C = t - R * (R + 1) / 2;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lc = l & 15, lq = l >> 4;
+    const int kq = ((rows + 15) / 16 + 3) / 4 * 4;  // member range of a wave, a multiple of 4
+    const int kbeg = w * kq, kend = min(rows, kbeg + kq);
+    const double a0 = (double)obs_ens[16 * R + lc], b0 = (double)obs_ens[16 * C + lc];  // the shift: member 0
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    constexpr int U = 8;
+    for (int k0 = kbeg; k0 < kend; k0 += 4 * U) {
+        float a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kc = min(k0 + 4 * u + lq, kend - 1);
+            a[u] = obs_ens[(size_t)kc * n_obs + 16 * R + lc];
+            b[u] = obs_ens[(size_t)kc * n_obs + 16 * C + lc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double kmask = k0 + 4 * u + lq < kend ? 1.0 : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[u] - a0, ((double)b[u] - b0) * kmask, acc, 0, 0, 0);
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) part[w - 1][g][l] = acc[g];
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            double v = acc[g];
+#pragma unroll
+            for (int z = 0; z < 15; ++z) v += part[z][g][l];
+            G[(size_t)(16 * R + lq + 4 * g) * n_obs + 16 * C + lc] = v;
+        }
+    }
+}
+
 // Y = obs_ens - mean(obs_ens) (rows 0..N-1), D0 = obs - obs_ens - perturbs (rows N..2N-1)     HistoryMatch.py:582, 584
 template <typename T>
 __global__ void k_obs_prep(const T* __restrict__ obs_ens, const T* __restrict__ perturbs, const T* __restrict__ obs,
@@ -152,6 +255,18 @@ int gram_lower_mfma(hipStream_t s, int n, int K, const double* A, int lda, doubl
     if (n % 16 != 0 || K < 1) return -1;
     const int nt = n / 16;
     hipLaunchKernelGGL(k_gram_lower, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, n, K, A, lda, G);
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+// One launch: centred observations (YD rows [0, rows): Yc fp64, rows [rows, 2 rows): innovations D0; Yc32: Yc in fp32), dmean = column
+// mean minus the first member's row, and the lower 16 x 16 tiles of sum_k (y_k - y_0)(y_k - y_0)^T.  Returns -1 if n_obs % 16 != 0.
+int center_gram_mfma(hipStream_t s, const float* obs_ens, const float* perturbs, const float* obs, int rows, int n_obs, double* YD,
+                     float* Yc32, double* dmean, double* G) {
+    if (n_obs % 16 != 0 || rows < 1) return -1;
+    const int nt = n_obs / 16, ncb = (n_obs + CG_COLS - 1) / CG_COLS;
+    hipLaunchKernelGGL(k_center_gram, dim3(ncb + nt * (nt + 1) / 2), dim3(1024), 0, s, obs_ens, perturbs, obs, rows, n_obs, ncb, YD, Yc32,
+                       dmean, G);
     HM_HIP(hipGetLastError());
     return 0;
 }

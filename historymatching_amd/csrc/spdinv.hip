@@ -28,7 +28,8 @@ __device__ __forceinline__ int opaque_s(int x) {
 template <int SLOTS, int NW>
 __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __restrict__ G, int nparts, int n, double ridge,
                                                       double* __restrict__ Wout, int* __restrict__ flag,
-                                                      const double* __restrict__ add, double add_scale) {
+                                                      const double* __restrict__ add, double add_scale,
+                                                      const double* __restrict__ rank1, double rank1_scale) {
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     const int nt = n >> 4;
     // LDS: U[2][n][17], W[n][17], P[16][17], Dg[16][17], flag
@@ -83,6 +84,18 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
     }
     if (tid == 0) *lflag = 0;
     int bad = 0, cur = 0;
+    if (rank1) {  // Gram matrix of shifted columns -> of centred ones: the vector goes through LDS (W's buffer, not in use yet); read
+                  // element by element from global memory beside the tile loads it cost this one CU 6.7 us
+        double* r1 = reinterpret_cast<double*>(Wp);
+        if (tid < n) r1[tid] = rank1[tid];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (tR[s] >= 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[s][r] -= rank1_scale * (r1[16 * tR[s] + g.lq + 4 * r] * r1[16 * tC[s] + g.lc]);
+            }
+    }
 
     auto publish_tile = [&](int s, int Cn, double (*Un)[17], int token) {
         const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
@@ -453,8 +466,10 @@ void spd_inverse_set_small(int v) { g_spd_small = v; }
 // W = inv(G + ridge I) for n a multiple of 16, n <= 256.  Returns 0 if launched, -1 if not applicable, >0 on error.
 // nparts > 0: G is the sum of `nparts` partial matrices, symmetrised while loading; nparts == 0: one matrix of which only the
 // lower 16 x 16 tiles are read, plus add_scale * add (lower tiles of a second matrix) if `add` is given.
+// rank1 (n values) with rank1_scale: G - rank1_scale * rank1 rank1^T is inverted (the Gram matrix of shifted columns turned into
+// the Gram matrix of centred ones while loading; nparts == 0 only).
 int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double ridge, double* W, int* flag, const double* add,
-                     double add_scale) {
+                     double add_scale, const double* rank1, double rank1_scale) {
     if (n % 16 != 0 || n < 16 || n > 256) return -1;
     const int nt = n / 16, ntiles = nt * (nt + 1) / 2;
     // panel buffers U[2][n][17], W[n][17], P, Dg + flag; the final mirrored store wants a 16 x 17 block per wave (16 waves at most)
@@ -462,7 +477,7 @@ int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double r
 #define L(S, NW)                                                                                                              \
     do {                                                                                                                      \
         HM_HIP(hipFuncSetAttribute((const void*)k_spd_inverse<S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_spd_inverse<S, NW>), dim3(1), dim3(64 * NW), lds, s, G, nparts, n, ridge, W, flag, add, add_scale);  \
+        hipLaunchKernelGGL((k_spd_inverse<S, NW>), dim3(1), dim3(64 * NW), lds, s, G, nparts, n, ridge, W, flag, add, add_scale, rank1, rank1_scale);  \
     } while (0)
     if (ntiles <= 12) L(2, 8);
     else if (ntiles <= 24) L(2, 16);
@@ -488,7 +503,7 @@ extern "C" int hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double 
     HM_HIP(hipMalloc(&dflag, 4));
     HM_HIP(hipMemset(dflag, 0, 4));
     HM_HIP(hipMemcpy(dG, G, bytes, hipMemcpyHostToDevice));
-    int rc = spd_inverse_mfma(ctx->stream, dG, 1, n, ridge, dW, dflag, nullptr, 0.0);
+    int rc = spd_inverse_mfma(ctx->stream, dG, 1, n, ridge, dW, dflag, nullptr, 0.0, nullptr, 0.0);
     int flag = 0;
     if (rc == 0 && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(W, dW, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
                     hipMemcpy(&flag, dflag, 4, hipMemcpyDeviceToHost) != hipSuccess)) {

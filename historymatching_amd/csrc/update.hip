@@ -51,6 +51,7 @@ struct hm_upd {
     int kalman_form = 1;            // hm_upd_run: 1 = contraction on the centred observations, gain through R (see there)
     int use_mfma = 1;  // fp32 only: 0 forces the generic VALU GEMMs (tests compare both)
     EvTimer t_upd;
+    int fused_front = 1;            // hm_upd_run: centring and Gram matrix (of shifted observations) in one launch
     int overlap = 0;                // hm_upd_run: 1 = small fp64 chain on a second stream beside the big contraction.  Measured, no gain:
                                     // the 16-wave inverse does not fit on a CU beside a contraction workgroup (it waits for one to finish);
                                     // the 8-wave form that fits ("small_inverse") spills and is as much slower as the overlap hides
@@ -515,8 +516,10 @@ __global__ __launch_bounds__(1024) void k_invert_C_reg(const double* __restrict_
 }
 
 int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double ridge, double* W, int* flag, const double* add = nullptr,
-                     double add_scale = 0.0);  // spdinv.hip
+                     double add_scale = 0.0, const double* rank1 = nullptr, double rank1_scale = 0.0);  // spdinv.hip
 int gram_lower_mfma(hipStream_t s, int n, int K, const double* A, int lda, double* G);  // dgemm_mfma.hip
+int center_gram_mfma(hipStream_t s, const float* obs_ens, const float* perturbs, const float* obs, int rows, int n_obs, double* YD,
+                     float* Yc32, double* dmean, double* G);  // dgemm_mfma.hip
 // dgemm_mfma.hip
 int dgemm_mfma(hipStream_t s, bool transA, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C,
                int ldc, int ksplit, float* C32, int rows32, float* C32T);
@@ -933,20 +936,29 @@ extern "C" int hm_upd_run(hm_upd* u) {
             if (rc < 0 && (rc = invert_C(s, G, no, 0.0, (double*)u->Rm.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p, false))) return rc;
             u->rm_ready = true;
         }
-        hipLaunchKernelGGL(k_center_obs, dim3((no + CO_COLS - 1) / CO_COLS), dim3(1024), 0, s, (const float*)u->obs_ens.p, (const float*)u->perturbs.p,
-                           (const float*)u->obs.p, nl, no, YD, S_T);
-        HM_HIP(hipGetLastError());
+        // one launch: centred observations + innovations, and beside them the lower tiles of the Gram matrix of the observations
+        // shifted by the first member (the inverse subtracts the rank-one difference to the centred Gram matrix while loading);
+        // where that does not apply (n_obs not a multiple of 16): the centring kernel, then the split-K product below
+        double* dmean = sumY;  // red1: n_obs doubles
+        rc = (g_use_mfma_inverse && !u->overlap && u->fused_front) ? center_gram_mfma(s, (const float*)u->obs_ens.p, (const float*)u->perturbs.p, (const float*)u->obs.p, nl, no, YD,
+                                                                      S_T, dmean, G) : -1;
+        if (rc > 0) return rc;
+        const bool fused_front = rc == 0;
+        if (!fused_front) {
+            hipLaunchKernelGGL(k_center_obs, dim3((no + CO_COLS - 1) / CO_COLS), dim3(1024), 0, s, (const float*)u->obs_ens.p, (const float*)u->perturbs.p,
+                               (const float*)u->obs.p, nl, no, YD, S_T);
+            HM_HIP(hipGetLastError());
+        }
         if (u->overlap) {
             HM_HIP(hipEventRecord(u->ev_fork, s));
             HM_HIP(hipStreamWaitEvent(s2, u->ev_fork, 0));
         }
-        // stream 2: B = Yc^T Yc + (N-1) R (8 row blocks, fixed-order sum), B^-1, gain A' = D0 B^-1 as its fp32 transpose
-        // B = Yc^T Yc + (N-1) R: the lower 16 x 16 tiles of the Gram matrix in one launch (4 k-quarters per tile, fixed-order sum),
-        // (N-1) R added by the inverse while it loads its tiles
-        rc = g_use_mfma_inverse ? gram_lower_mfma(s2, no, nl, YD, no, G) : -1;
+        // B = Yc^T Yc + (N-1) R, B^-1, gain A' = D0 B^-1 as its fp32 transpose ((N-1) R is added by the inverse while it loads its tiles)
+        if (!fused_front) rc = g_use_mfma_inverse ? gram_lower_mfma(s2, no, nl, YD, no, G) : -1;
         if (rc > 0) return rc;
         if (rc == 0) {
-            rc = spd_inverse_mfma(s2, G, 0, no, 0.0, (double*)u->Cinv.p, (int*)u->flags.p, (const double*)u->Rm.p, (double)(u->N_total - 1));
+            rc = spd_inverse_mfma(s2, G, 0, no, 0.0, (double*)u->Cinv.p, (int*)u->flags.p, (const double*)u->Rm.p, (double)(u->N_total - 1),
+                                  fused_front ? dmean : nullptr, (double)nl);
             if (rc > 0) return rc;
         }
         if (rc < 0) {
@@ -1011,6 +1023,7 @@ extern "C" int hm_upd_run(hm_upd* u) {
 extern "C" int hm_upd_set_option(hm_upd* u, const char* name, int value) {
     HM_REQUIRE(u && name, "hm_upd_set_option: NULL argument");
     if (std::string(name) == "use_mfma") { u->use_mfma = value; return 0; }
+    if (std::string(name) == "fused_front") { u->fused_front = value; return 0; }
     if (std::string(name) == "overlap") { u->overlap = value; return 0; }  // hm_upd_run: second stream for the small chain
     if (std::string(name) == "kalman_form") { u->kalman_form = value; return 0; }
     if (std::string(name) == "gxt_chunk") { mfma_set_gxt_chunk(value); return 0; }
