@@ -101,6 +101,7 @@ SIGNATURES = {
     "hm_upd_set_inputs_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),
     "hm_upd_swap": (C.c_int, [_vp]),
     "hm_debug_spd_inverse": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp]),
+    "hm_debug_ldl_gain": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_double, _dp, C.POINTER(C.c_float)]),
     "hm_upd_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "hm_upd_reduce_buffer": (_vp, [_vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "hm_iles_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, C.c_double, _dp, C.POINTER(_vp)]),

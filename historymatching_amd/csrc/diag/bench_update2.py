@@ -23,7 +23,7 @@ decorr = sla.inv(R12.T)
 res = {}
 outs = {}
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 9
-for kal, ov, kc, av, sm, gh, gd, dma in ((0, 0, 32, 1, 0, 2, 1, 0), (1, 0, 64, 3, 0, 2, 1, 1), (1, 1, 32, 3, 0, 2, 1, 1)):
+for kal, ov, kc, av, sm, gh, gd, dma in ((0, 0, 32, 1, 0, 2, 1, 0), (1, 0, 64, 3, 0, 2, 1, 1), (1, 0, 64, 3, 0, 2, 1, 4)):
     if True:
         p = UpdatePlan(N, N, M, n_obs, dtype=32)
         p.set_option("kalman_form", kal)
@@ -33,7 +33,8 @@ for kal, ov, kc, av, sm, gh, gd, dma in ((0, 0, 32, 1, 0, 2, 1, 0), (1, 0, 64, 3
         p.set_option("small_inverse", sm)
         p.set_option("gxt_halves", gh)
         p.set_option("gxt_depth", gd)
-        p.set_option("gxt_dma", dma)
+        p.set_option("gxt_dma", 1 if dma == 4 else dma)
+        p.set_option("ldl_gain", 0 if dma == 4 else 1)  # dma 4: the explicit-inverse chain for comparison
         p.set_inputs(E, obs_ens, obs, perturbs, decorr)
         p.run_local()
         ts = sorted(p.run_local()["ms_update"] for _ in range(reps))

@@ -10,6 +10,7 @@
 // (tile t -> wave t % 12, slot t / 12).  ~10 panels x ~5k cycles at n = 160: ~25 us against 129 us for the rank-1
 // register sweeps (k_invert_C_reg).
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 #include "sweep16.h"
@@ -84,6 +85,13 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
     }
     if (tid == 0) *lflag = 0;
     int bad = 0, cur = 0;
+#ifdef HM_INV_PROF
+    unsigned long long pt, pa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ISTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); pa[k] += t_ - pt; pt = t_; } while (0)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt) :: "memory");
+#else
+#define ISTAMP(k)
+#endif
     if (rank1) {  // Gram matrix of shifted columns -> of centred ones: the vector goes through LDS (W's buffer, not in use yet); read
                   // element by element from global memory beside the tile loads it cost this one CU 6.7 us
         double* r1 = reinterpret_cast<double*>(Wp);
@@ -134,6 +142,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
     };
 
     __syncthreads();
+    ISTAMP(0);
     // panel 0: column 0 and the first diagonal tile
     if (!service) {
 #pragma unroll
@@ -143,6 +152,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
         sweep_published(1);
     }
     __syncthreads();
+    ISTAMP(1);
     for (int Cp = 0; Cp < nt; ++Cp) {
         double (*U)[17] = cur ? U1 : U0;
         double (*Un)[17] = cur ? U0 : U1;
@@ -175,7 +185,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
                 }
             }
         }
+        ISTAMP(2);
         __syncthreads();  // W visible; P and Dg free
+        ISTAMP(3);
         if (!service) {
             if (Cn < nt) {
 #pragma unroll
@@ -204,7 +216,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
         } else if (sweeper && Cn < nt) {
             sweep_published(token);
         }
+        ISTAMP(4);
         __syncthreads();
+        ISTAMP(5);
         cur ^= 1;
     }
     // acc = -inv: write both triangles.  The mirrored tile goes through a wave-private 16 x 17 LDS block so that its rows are
@@ -231,7 +245,299 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
             }
         }
     }
+    ISTAMP(6);
+#ifdef HM_INV_PROF
+    if (g.lane == 0 && (w == 0 || w == 1 || w == 5 || w == 15))
+        printf("spd_inverse wave %d: load %llu, panel0 %llu, phaseB %llu, barrier1 %llu, phaseC/sweep %llu, barrier2 %llu, store %llu cycles (n = %d)\n", w, pa[0], pa[1], pa[2], pa[3], pa[4], pa[5], pa[6], n);
+#endif
     if (bad && g.lane == 0) atomicOr(flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Block L D L^T factorisation instead of the explicit inverse, for the fused analysis step (hm_upd_run), which only needs the
+// gain A' = D0 B^-1:   B = Lt Dt Lt^T,  Lt unit block-lower-triangular (16 x 16 blocks), Dt = diag(S_0 .. S_{nt-1}) the Schur pivots.
+// Panel j:  P_j = S_j^-1 (the same in-wave sweep),  Lt_ij = A_ij P_j  (i > j),  A_ik -= Lt_ij A_kj^T  for i >= k > j -- the panel
+// machinery of k_spd_inverse restricted to the TRAILING tiles: 210 tile products instead of 650, and per panel only the chain
+// pivot sweep -> W = U P -> next diagonal tile is serial.  Output F (n x n, row-major): Lt_ij in the blocks below the diagonal, P_j in
+// the diagonal blocks (the blocks above the diagonal are not written).
+template <int SLOTS, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_ldl_factor(const double* __restrict__ G, int n, double* __restrict__ F, int* __restrict__ flag,
+                                                           const double* __restrict__ add, double add_scale,
+                                                           const double* __restrict__ rank1, double rank1_scale) {
+    extern __shared__ __attribute__((aligned(16))) double lds_d[];
+    const int nt = n >> 4;
+    double (*U0)[17] = reinterpret_cast<double (*)[17]>(lds_d);
+    double (*U1)[17] = U0 + n;
+    double (*Wp)[17] = U1 + n;
+    double (*P)[17] = Wp + n;
+    double (*Dg)[17] = P + 16;
+    int* lflag = reinterpret_cast<int*>(Dg + 16);
+
+    const int tid = threadIdx.x;
+    IGeo g;
+    g.lane = tid & 63;
+    g.lc = g.lane & 15;
+    g.lq = g.lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool service = (w & 3) == 0, sweeper = w == 0;
+    constexpr int NC = NW - NW / 4;
+    const int c = service ? 0 : (w >> 2) * 3 + (w & 3) - 1;
+    const int ntiles = nt * (nt + 1) / 2;
+
+    int tR[SLOTS], tC[SLOTS];
+    d4 acc[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int t = s * NC + c;
+        int R = -1, C = -1;
+        if (!service && t < ntiles) {
+            R = 0;
+            while ((R + 1) * (R + 2) / 2 <= t) ++R;
+            C = t - R * (R + 1) / 2;
+        }
+        tR[s] = __builtin_amdgcn_readfirstlane(R);
+        tC[s] = __builtin_amdgcn_readfirstlane(C);
+        acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+        if (R >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * R + g.lq + 4 * r, col = 16 * C + g.lc;
+                acc[s][r] = G[(size_t)row * n + col] + (add ? add_scale * add[(size_t)row * n + col] : 0.0);
+            }
+        }
+    }
+    if (tid == 0) *lflag = 0;
+    int bad = 0, cur = 0;
+    if (rank1) {  // Gram matrix of shifted columns -> of centred ones (the vector goes through LDS: W's buffer, not in use yet)
+        double* r1 = reinterpret_cast<double*>(Wp);
+        if (tid < n) r1[tid] = rank1[tid];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (tR[s] >= 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[s][r] -= rank1_scale * (r1[16 * tR[s] + g.lq + 4 * r] * r1[16 * tC[s] + g.lc]);
+            }
+    }
+    auto publish_tile = [&](int s, int Cn, double (*Un)[17], int token) {  // tiles of column Cn only
+        const int R = opaque_s(tR[s]);
+        if (R == Cn) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Dg[g.lq + 4 * r][g.lc] = acc[s][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (g.lane == 0) __hip_atomic_store(lflag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Un[16 * R + g.lq + 4 * r][g.lc] = acc[s][r];
+        }
+    };
+    auto sweep_published = [&](int token) {
+        for (int spins = 0; __hip_atomic_load(lflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token; ++spins) {
+            if (spins > (1 << 24)) { bad = 1; break; }  // a defect: flag it and go on rather than hang (the barriers below still match)
+            __builtin_amdgcn_s_sleep(1);
+        }
+        d4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = Dg[g.lq + 4 * r][g.lc];
+        sweep16_inwave(t, g, bad);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[g.lq + 4 * r][g.lc] = -t[r];  // t = -inv(tile)
+    };
+    auto update_tile = [&](int s, double (*U)[17]) {
+        const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wp[16 * R + g.lc][4 * kk + g.lq], U[16 * C + g.lc][4 * kk + g.lq], acc[s], 0, 0, 0);
+    };
+
+#ifdef HM_INV_PROF
+    unsigned long long pt, pa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define LSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); pa[k] += t_ - pt; pt = t_; } while (0)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt) :: "memory");
+#else
+#define LSTAMP(k)
+#endif
+    __syncthreads();
+    if (!service) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (tC[s] == 0) publish_tile(s, 0, U0, 1);
+    } else if (sweeper) {
+        sweep_published(1);
+    }
+    __syncthreads();
+    LSTAMP(0);
+    for (int Cp = 0; Cp < nt; ++Cp) {
+        double (*U)[17] = cur ? U1 : U0;
+        double (*Un)[17] = cur ? U0 : U1;
+        const int Cn = Cp + 1, token = Cn + 1;
+        if (!service) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+                if (C != Cp) continue;
+                if (R == Cp) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[s][r] = P[g.lq + 4 * r][g.lc];  // final: P_j
+                } else {  // Lt_R = U_R P: final, and the panel's W operand
+                    d4 wv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        wv = __builtin_amdgcn_mfma_f64_16x16x4f64(U[16 * R + g.lc][4 * kk + g.lq], P[4 * kk + g.lq][g.lc], wv, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Wp[16 * R + g.lq + 4 * r][g.lc] = wv[r];
+                    acc[s] = wv;
+                }
+            }
+        }
+        LSTAMP(1);
+        __syncthreads();  // W visible; P and Dg free
+        LSTAMP(2);
+        if (!service) {
+            if (Cn < nt) {
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+                    if (R == Cn && C == Cn) {  // the next pivot tile first: its sweep is the panel's critical path
+                        update_tile(s, U);
+                        publish_tile(s, Cn, Un, token);
+                    }
+                }
+                LSTAMP(3);
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+                    if (C == Cn && R > Cn) {  // then the next panel's column
+                        update_tile(s, U);
+                        publish_tile(s, Cn, Un, token);
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int C = opaque_s(tC[s]);
+                if (C > Cn) update_tile(s, U);  // the rest of the trailing matrix (R >= C)
+            }
+        } else if (sweeper && Cn < nt) {
+            sweep_published(token);
+        }
+        LSTAMP(4);
+        __syncthreads();
+        LSTAMP(5);
+        cur ^= 1;
+    }
+    if (!service) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int R = tR[s], C = tC[s];
+            if (R < 0) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) F[(size_t)(16 * R + g.lq + 4 * r) * n + 16 * C + g.lc] = acc[s][r];
+        }
+    }
+    LSTAMP(6);
+#ifdef HM_INV_PROF
+    if (g.lane == 0 && (w == 0 || w == 1 || w == 5 || w == 15))
+        printf("ldl_factor wave %d: setup+panel0 %llu, phaseB %llu, barrier1 %llu, diag tile %llu, phaseC/sweep %llu, barrier2 %llu, store %llu cycles (n = %d)\n", w, pa[0], pa[1], pa[2], pa[3], pa[4], pa[5], pa[6], n);
+#endif
+    if (bad && g.lane == 0) atomicOr(flag, 1);
+}
+
+// Gain of the fused analysis step from the block L D L^T factors:  A' = X B^-1 = X Lt^-T Dt^-1 Lt^-1  (X = D0: N x n innovations),
+// written as its fp32 transpose A_T (n x N) -- the operand layout of the apply kernel.  Transposed, every step is a 16 x 16 tile
+// product on the fp64 matrix cores with BOTH the running tile and the result in accumulator layout (a tile in accumulator layout is
+// the B operand of v_mfma_f64_16x16x4 as it stands: register kk <-> rows 4 kk + lq).  One workgroup of 4 waves = 16 members: the nt
+// tiles T_j = (X^T)_j are dealt to the waves (tile j -> wave j mod 4) and the solve runs right-looking,
+//     forward   T_j -= Lt_jk T_k   (k < j),      scaling   T_j = P_j T_j,      backward   T_j -= Lt_kj^T T_k   (k > j),
+// the owner of T_k handing it to the others through LDS at every step (18 workgroup barriers at n = 160; one wave running all 100
+// tile products of its members in sequence took 22 us, the products of a step spread over four waves take 9).  The factor's tiles
+// are A operands from LDS (the whole lower triangle, 2 KB per tile, staged once per workgroup).  No triangular solves inside tiles.
+template <int NT>
+__global__ __launch_bounds__(256) void k_ldl_gain(const double* __restrict__ F, int n, const double* __restrict__ X, int N,
+                                                  float* __restrict__ A_T) {
+    extern __shared__ __attribute__((aligned(16))) double lds_d[];
+    constexpr int NTILES = NT * (NT + 1) / 2, NS = (NT + 3) / 4;  // tiles of the factor; tiles of T per wave
+    double (*Ft)[16][17] = reinterpret_cast<double (*)[16][17]>(lds_d);  // tile (R, C), R >= C, at index R (R + 1) / 2 + C
+    double (*Tk)[4][64] = reinterpret_cast<double (*)[4][64]>(lds_d + (size_t)NTILES * 16 * 17);  // [2][4][64]: the step's T_k
+    const int tid = threadIdx.x, lane = tid & 63, lc = lane & 15, lq = lane >> 4, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {   // stage the lower tiles: every load of a tile row of the factor in flight before the first LDS write of that row
+        const double* Fl = F + (size_t)(tid >> 4) * n + (tid & 15);
+#pragma unroll
+        for (int R = 0; R < NT; ++R) {
+            double v[NT];
+#pragma unroll
+            for (int C = 0; C <= R; ++C) v[C] = Fl[(size_t)16 * R * n + 16 * C];
+#pragma unroll
+            for (int C = 0; C <= R; ++C) Ft[R * (R + 1) / 2 + C][tid >> 4][tid & 15] = v[C];
+        }
+    }
+    const int m0 = blockIdx.x * 16, m = min(m0 + lc, N - 1);
+    d4 T[NS];  // slot s <-> tile j = 4 s + w
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[s][r] = 4 * s + w < NT ? X[(size_t)m * n + 16 * (4 * s + w) + lq + 4 * r] : 0.0;
+    auto tile = [&](int R, int C) -> double (*)[17] { return Ft[R * (R + 1) / 2 + C]; };
+    // hand-over of T_k: its owner writes the four registers, everybody reads them back after the barrier (two buffers: a step's
+    // readers may still be reading while the next owner writes)
+    auto hand_over = [&](int k, int step, d4& tk) {
+        if ((k & 3) == w) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tk[step & 1][r][lane] = T[k >> 2][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tk[r] = Tk[step & 1][r][lane];
+    };
+    __syncthreads();
+    int step = 0;
+    // forward: Lt T = X^T (unit diagonal blocks)
+#pragma unroll
+    for (int k = 0; k + 1 < NT; ++k, ++step) {
+        d4 tk;
+        hand_over(k, step, tk);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int j = 4 * s + w;  // wave-uniform
+                if (j > k && j < NT) T[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tile(j, k)[lc][4 * kk + lq], tk[kk], T[s], 0, 0, 0);
+            }
+    }
+    // scaling by the inverse pivots (symmetric tiles)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int j = 4 * s + w;
+        if (j < NT) {
+            d4 z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) z = __builtin_amdgcn_mfma_f64_16x16x4f64(tile(j, j)[lc][4 * kk + lq], T[s][kk], z, 0, 0, 0);
+            T[s] = z;
+        }
+    }
+    // backward: Lt^T A'^T = T
+#pragma unroll
+    for (int k = NT - 1; k > 0; --k, ++step) {
+        d4 tk;
+        hand_over(k, step, tk);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int j = 4 * s + w;
+                if (j < k) T[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tile(k, j)[4 * kk + lq][lc], tk[kk], T[s], 0, 0, 0);
+            }
+    }
+    if (m0 + lc < N) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int j = 4 * s + w;
+            if (j < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A_T[(size_t)(16 * j + lq + 4 * r) * N + m0 + lc] = (float)T[s][r];
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -491,6 +797,73 @@ int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double r
 }
 
 // Self-test hook (host buffers): W = inv(G + ridge I) through k_spd_inverse.
+// F = block L D L^T factors of G - rank1_scale rank1 rank1^T + add_scale add (lower tiles of G and add are read).  Returns 0 if
+// launched, -1 if not applicable (n not a multiple of 16, or the factor does not fit the gain kernel's LDS), > 0 on error.
+int ldl_factor_mfma(hipStream_t s, const double* G, int n, double* F, int* flag, const double* add, double add_scale,
+                    const double* rank1, double rank1_scale) {
+    if (n % 16 != 0 || n < 16 || n > 176) return -1;
+    const int nt = n / 16, ntiles = nt * (nt + 1) / 2;
+    const size_t lds = ((size_t)3 * n * 17 + 2 * 16 * 17) * 8 + 16;
+#define L(S, NW)                                                                                                             \
+    do {                                                                                                                     \
+        HM_HIP(hipFuncSetAttribute((const void*)k_ldl_factor<S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_ldl_factor<S, NW>), dim3(1), dim3(64 * NW), lds, s, G, n, F, flag, add, add_scale, rank1, rank1_scale); \
+    } while (0)
+    if (ntiles <= 12) L(2, 8);
+    else if (ntiles <= 24) L(2, 16);
+    else if (ntiles <= 60) L(5, 16);
+    else L(6, 16);
+#undef L
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+// A_T (n x N, fp32) = (X B^-1)^T from the factors F of B.  X: N x n (fp64, row-major).
+int ldl_gain_mfma(hipStream_t s, const double* F, int n, const double* X, int N, float* A_T) {
+    if (n % 16 != 0 || n < 16 || n > 176 || N < 1) return -1;
+    const int nt = n / 16;
+    const size_t lds = (size_t)(nt * (nt + 1) / 2) * 16 * 17 * 8 + 2 * 4 * 64 * 8;
+    const dim3 grid((N + 15) / 16), block(256);
+#define L(NT) case NT: HM_HIP(hipFuncSetAttribute((const void*)k_ldl_gain<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                       hipLaunchKernelGGL(k_ldl_gain<NT>, grid, block, lds, s, F, n, X, N, A_T); break
+    switch (nt) { L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); L(9); L(10); L(11); default: return -1; }
+#undef L
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+// test hook: A_T = (X inv(G + ridge I))^T through the factorisation
+extern "C" int hm_debug_ldl_gain(hm_ctx* ctx, int n, int N, const double* G, double ridge, const double* X, float* A_T) {
+    HM_REQUIRE(ctx && G && X && A_T, "hm_debug_ldl_gain: NULL argument");
+    HM_REQUIRE(n % 16 == 0 && n >= 16 && n <= 176 && N >= 1, "hm_debug_ldl_gain: n must be a multiple of 16 in [16, 176]");
+    HM_HIP(hipSetDevice(ctx->device));
+    std::vector<double> Gr(G, G + (size_t)n * n);
+    for (int i = 0; i < n; ++i) Gr[(size_t)i * n + i] += ridge;
+    double *dG, *dF, *dX;
+    float* dA;
+    int* dflag;
+    HM_HIP(hipMalloc(&dG, (size_t)n * n * 8));
+    HM_HIP(hipMalloc(&dF, (size_t)n * n * 8));
+    HM_HIP(hipMalloc(&dX, (size_t)N * n * 8));
+    HM_HIP(hipMalloc(&dA, (size_t)N * n * 4));
+    HM_HIP(hipMalloc(&dflag, 4));
+    HM_HIP(hipMemset(dflag, 0, 4));
+    HM_HIP(hipMemcpy(dG, Gr.data(), (size_t)n * n * 8, hipMemcpyHostToDevice));
+    HM_HIP(hipMemcpy(dX, X, (size_t)N * n * 8, hipMemcpyHostToDevice));
+    int rc = ldl_factor_mfma(ctx->stream, dG, n, dF, dflag, nullptr, 0.0, nullptr, 0.0);
+    if (rc == 0) rc = ldl_gain_mfma(ctx->stream, dF, n, dX, N, dA);
+    int flag = 0;
+    if (rc == 0 && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(A_T, dA, (size_t)N * n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(&flag, dflag, 4, hipMemcpyDeviceToHost) != hipSuccess)) {
+        hm_set_error("hm_debug_ldl_gain: device error");
+        rc = 1;
+    }
+    (void)hipFree(dG); (void)hipFree(dF); (void)hipFree(dX); (void)hipFree(dA); (void)hipFree(dflag);
+    if (rc < 0) { hm_set_error("hm_debug_ldl_gain: not applicable"); rc = 2; }
+    if (!rc && flag) { hm_set_error("hm_debug_ldl_gain: non-positive pivot"); rc = 4; }
+    return rc;
+}
+
 extern "C" int hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double ridge, double* W) {
     HM_REQUIRE(ctx && G && W, "hm_debug_spd_inverse: NULL argument");
     HM_REQUIRE(n % 16 == 0 && n >= 16 && n <= 256, "hm_debug_spd_inverse: n must be a multiple of 16 in [16, 256]");

@@ -51,6 +51,7 @@ struct hm_upd {
     int kalman_form = 1;            // hm_upd_run: 1 = contraction on the centred observations, gain through R (see there)
     int use_mfma = 1;  // fp32 only: 0 forces the generic VALU GEMMs (tests compare both)
     EvTimer t_upd;
+    int ldl_gain = 1;               // hm_upd_run: gain from a block L D L^T factorisation instead of the explicit inverse
     int fused_front = 1;            // hm_upd_run: centring and Gram matrix (of shifted observations) in one launch
     int overlap = 0;                // hm_upd_run: 1 = small fp64 chain on a second stream beside the big contraction.  Measured, no gain:
                                     // the 16-wave inverse does not fit on a CU beside a contraction workgroup (it waits for one to finish);
@@ -518,6 +519,9 @@ __global__ __launch_bounds__(1024) void k_invert_C_reg(const double* __restrict_
 int spd_inverse_mfma(hipStream_t s, const double* G, int nparts, int n, double ridge, double* W, int* flag, const double* add = nullptr,
                      double add_scale = 0.0, const double* rank1 = nullptr, double rank1_scale = 0.0);  // spdinv.hip
 int gram_lower_mfma(hipStream_t s, int n, int K, const double* A, int lda, double* G);  // dgemm_mfma.hip
+int ldl_factor_mfma(hipStream_t s, const double* G, int n, double* F, int* flag, const double* add, double add_scale, const double* rank1,
+                    double rank1_scale);                                                  // spdinv.hip
+int ldl_gain_mfma(hipStream_t s, const double* F, int n, const double* X, int N, float* A_T);  // spdinv.hip
 int center_gram_mfma(hipStream_t s, const float* obs_ens, const float* perturbs, const float* obs, int rows, int n_obs, double* YD,
                      float* Yc32, double* dmean, double* G);  // dgemm_mfma.hip
 // dgemm_mfma.hip
@@ -956,7 +960,19 @@ extern "C" int hm_upd_run(hm_upd* u) {
         // B = Yc^T Yc + (N-1) R, B^-1, gain A' = D0 B^-1 as its fp32 transpose ((N-1) R is added by the inverse while it loads its tiles)
         if (!fused_front) rc = g_use_mfma_inverse ? gram_lower_mfma(s2, no, nl, YD, no, G) : -1;
         if (rc > 0) return rc;
-        if (rc == 0) {
+        bool gain_done = false;
+        if (rc == 0 && u->ldl_gain) {
+            // gain straight from the block L D L^T factors of B: a third of the inverse's matrix work and no explicit inverse
+            int r2 = ldl_factor_mfma(s2, G, no, (double*)u->Cinv.p, (int*)u->flags.p, (const double*)u->Rm.p, (double)(u->N_total - 1),
+                                     fused_front ? dmean : nullptr, (double)nl);
+            if (r2 > 0) return r2;
+            if (r2 == 0) {
+                if ((r2 = ldl_gain_mfma(s2, (const double*)u->Cinv.p, no, YD + nsm, nl, A_T)) > 0) return r2;
+                HM_REQUIRE(r2 == 0, "hm_upd_run: gain kernel not applicable after its factorisation was");
+                gain_done = true;
+            }
+        }
+        if (rc == 0 && !gain_done) {
             rc = spd_inverse_mfma(s2, G, 0, no, 0.0, (double*)u->Cinv.p, (int*)u->flags.p, (const double*)u->Rm.p, (double)(u->N_total - 1),
                                   fused_front ? dmean : nullptr, (double)nl);
             if (rc > 0) return rc;
@@ -969,7 +985,7 @@ extern "C" int hm_upd_run(hm_upd* u) {
             HM_HIP(hipGetLastError());
             if ((rc = invert_C(s2, G, no, 0.0, (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p, true))) return rc;
         }
-        if ((rc = dgemm_mfma(s2, false, nl, no, no, YD + nsm, no, (const double*)u->Cinv.p, no, nullptr, no, 1, nullptr, 0, A_T))) return rc;
+        if (!gain_done && (rc = dgemm_mfma(s2, false, nl, no, no, YD + nsm, no, (const double*)u->Cinv.p, no, nullptr, no, 1, nullptr, 0, A_T))) return rc;
         if (u->overlap) HM_HIP(hipEventRecord(u->ev_join, s2));
         // stream 1: Gy = Yc^T (E - c), then (after the join) E_out = E + A' Gy
         if ((rc = mfma_gxt_lds(s, nl, M, no, E, nullptr, inv_n, S_T, (float*)u->Bt.p)) > 0) return rc;
@@ -1024,6 +1040,7 @@ extern "C" int hm_upd_set_option(hm_upd* u, const char* name, int value) {
     HM_REQUIRE(u && name, "hm_upd_set_option: NULL argument");
     if (std::string(name) == "use_mfma") { u->use_mfma = value; return 0; }
     if (std::string(name) == "fused_front") { u->fused_front = value; return 0; }
+    if (std::string(name) == "ldl_gain") { u->ldl_gain = value; return 0; }
     if (std::string(name) == "overlap") { u->overlap = value; return 0; }  // hm_upd_run: second stream for the small chain
     if (std::string(name) == "kalman_form") { u->kalman_form = value; return 0; }
     if (std::string(name) == "gxt_chunk") { mfma_set_gxt_chunk(value); return 0; }

@@ -205,6 +205,9 @@ int   hm_sample_kron(hm_ctx* ctx, int N, int Nx, int Ny, const double* Ux /* Nx*
 /* Self-test hook: W = inv(G + ridge I) for one SPD matrix of order n (multiple of 16, <= 256) through the matrix-core
  * inverse used for C = S^T S + (N-1) I (HistoryMatch.py:585-586).  Host buffers. */
 int   hm_debug_spd_inverse(hm_ctx* ctx, int n, const double* G, double ridge, double* W);
+/* Self-test hook: A_T (n x N, fp32) = (X inv(G + ridge I))^T through the block L D L^T factorisation and the gain kernel the
+ * fused analysis step uses for its gain D0 B^-1 (n a multiple of 16, <= 176; X: N x n).  Host buffers. */
+int   hm_debug_ldl_gain(hm_ctx* ctx, int n, int N, const double* G, double ridge, const double* X, float* A_T);
 /* Device-resident chaining: ensemble and/or simulated observations from device buffers (NULL = keep); hm_upd_swap makes
  * the last posterior the next prior (ES-MDA / iterative smoothers, HistoryMatch.py:906-959). */
 int   hm_upd_set_inputs_device(hm_upd* u, const void* E_dev, int E_dtype, const void* obs_ens_dev, int obs_dtype);

@@ -277,6 +277,33 @@ def test_matrix_core_spd_inverse(n, golden):
         assert np.abs(W - W.T).max() <= 1e-9 * np.abs(ref).max()  # off-diagonal tiles are mirrored, diagonal tiles swept
 
 
+@pytest.mark.parametrize("n,N", [(16, 5), (48, 64), (160, 1000), (176, 130)])
+def test_ldl_gain_matches_numpy(golden, n, N):
+    """The gain of the fused analysis step, D0 B^-1, comes from a block L D L^T factorisation of B and tile products with its
+    factors (spdinv.hip: k_ldl_factor, k_ldl_gain) instead of an explicit inverse: against NumPy in fp64, on a random SPD matrix and
+    (n = 160) on the reference's own C = S^T S + (N-1) I; the result is stored in fp32."""
+    import ctypes as C
+
+    from historymatching_amd import _lib
+
+    ctx, lib = _lib.Context.get(0), _lib.load()
+    rng = np.random.RandomState(n + N)
+    cases = [(rng.randn(40, n), 39.0)]
+    if n == 160:
+        _, f3, _, kw = _hm(golden)
+        Y = kw["obs_ens"] - kw["obs_ens"].mean(0)
+        cases.append((Y @ kw["decorr"], float(Y.shape[0] - 1)))
+    for S, ridge in cases:
+        G = np.ascontiguousarray(S.T @ S)
+        X = np.ascontiguousarray(rng.randn(N, n))
+        A_T = np.empty((n, N), dtype=np.float32)
+        dp = C.POINTER(C.c_double)
+        _lib.check(lib.hm_debug_ldl_gain(ctx.handle, n, N, G.ctypes.data_as(dp), ridge, X.ctypes.data_as(dp),
+                                         A_T.ctypes.data_as(C.POINTER(C.c_float))), "hm_debug_ldl_gain")
+        ref = X @ np.linalg.inv(G + ridge * np.eye(n))
+        assert np.abs(A_T.T - ref).max() <= 2e-7 * np.abs(ref).max()  # fp32 storage of an fp64 result
+
+
 def test_rccl_communicator_runs_the_analysis_step_on_library_buffers():
     """The multi-rank update's collectives are issued by the library itself (hm_comm_* / hm_upd_run_comm: RCCL opened with
     dlopen, in place on the plan's device buffers, on the context's stream).  One rank here (RCCL refuses two ranks on one
