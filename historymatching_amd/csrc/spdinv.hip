@@ -264,22 +264,29 @@ template <int SLOTS, int NW>
 __global__ __launch_bounds__(64 * NW, 4) void k_ldl_factor(const double* __restrict__ G, int n, double* __restrict__ F, int* __restrict__ flag,
                                                            const double* __restrict__ add, double add_scale,
                                                            const double* __restrict__ rank1, double rank1_scale) {
+    // Synchronisation: the chain  pivot sweep -> W^T = P U^T and update of the next pivot tile -> next sweep  is all that is serial
+    // per panel, so the sweeper (wave 0, alone on SIMD 0: waves 4, 8, 12 only fix the wave placement and leave at once) and the
+    // owner of the next pivot tile talk through two LDS flags and never meet the others at a barrier; the twelve tile waves
+    // synchronise among themselves with an LDS counter (a workgroup barrier would make them wait for the sweeper, and it for them).
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool service = (w & 3) == 0, sweeper = w == 0;
+    if (service && !sweeper) return;
     const int nt = n >> 4;
     double (*U0)[17] = reinterpret_cast<double (*)[17]>(lds_d);
     double (*U1)[17] = U0 + n;
     double (*Wp)[17] = U1 + n;
-    double (*P)[17] = Wp + n;
-    double (*Dg)[17] = P + 16;
-    int* lflag = reinterpret_cast<int*>(Dg + 16);
+    double (*P0)[17] = Wp + n;   // P of even panels, then P of odd panels
+    double (*Dg)[17] = P0 + 32;
+    int* fDg = reinterpret_cast<int*>(Dg + 16);  // token: pivot tile j is in Dg        (value j + 1)
+    int* fP = fDg + 1;                           // token: P_j = S_j^-1 is in P[j & 1]   (value j + 1)
+    int* bar = fDg + 2;                          // arrivals of the tile waves at their barriers
 
-    const int tid = threadIdx.x;
     IGeo g;
     g.lane = tid & 63;
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool service = (w & 3) == 0, sweeper = w == 0;
     constexpr int NC = NW - NW / 4;
     const int c = service ? 0 : (w >> 2) * 3 + (w & 3) - 1;
     const int ntiles = nt * (nt + 1) / 2;
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_ldl_factor(const double* __restr
             }
         }
     }
-    if (tid == 0) *lflag = 0;
+    if (tid == 0) { *fDg = 0; *fP = 0; *bar = 0; }
     int bad = 0, cur = 0;
     if (rank1) {  // Gram matrix of shifted columns -> of centred ones (the vector goes through LDS: W's buffer, not in use yet)
         double* r1 = reinterpret_cast<double*>(Wp);
@@ -319,29 +326,64 @@ __global__ __launch_bounds__(64 * NW, 4) void k_ldl_factor(const double* __restr
                 for (int r = 0; r < 4; ++r) acc[s][r] -= rank1_scale * (r1[16 * tR[s] + g.lq + 4 * r] * r1[16 * tC[s] + g.lc]);
             }
     }
-    auto publish_tile = [&](int s, int Cn, double (*Un)[17], int token) {  // tiles of column Cn only
-        const int R = opaque_s(tR[s]);
-        if (R == Cn) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Dg[g.lq + 4 * r][g.lc] = acc[s][r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (g.lane == 0) __hip_atomic_store(lflag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Un[16 * R + g.lq + 4 * r][g.lc] = acc[s][r];
-        }
-    };
-    auto sweep_published = [&](int token) {
-        for (int spins = 0; __hip_atomic_load(lflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token; ++spins) {
-            if (spins > (1 << 24)) { bad = 1; break; }  // a defect: flag it and go on rather than hang (the barriers below still match)
+    __syncthreads();  // flags zeroed, r1 consumed: from here on no workgroup barrier
+
+    auto wait_for = [&](int* f, int token) {
+        for (int spins = 0; __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < token; ++spins) {
+            if (spins > (1 << 24)) { bad = 1; break; }  // a defect: flag it and go on rather than hang the GPU
             __builtin_amdgcn_s_sleep(1);
         }
-        d4 t;
+    };
+    auto post = [&](int* f, int token) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (g.lane == 0) __hip_atomic_store(f, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    if (sweeper) {
+#ifdef HM_INV_PROF
+        unsigned long long pt, pa[3] = {0, 0, 0};
+#define LSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); pa[k] += t_ - pt; pt = t_; } while (0)
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt) :: "memory");
+#else
+#define LSTAMP(k)
+#endif
+        for (int j = 0; j < nt; ++j) {
+            wait_for(fDg, j + 1);
+            LSTAMP(0);
+            d4 t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = Dg[g.lq + 4 * r][g.lc];
-        sweep16_inwave(t, g, bad);
+            for (int r = 0; r < 4; ++r) t[r] = Dg[g.lq + 4 * r][g.lc];
+            sweep16_inwave(t, g, bad);  // t = -inv(tile)
+            LSTAMP(1);
+            double (*P)[17] = P0 + 16 * (j & 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) P[g.lq + 4 * r][g.lc] = -t[r];  // t = -inv(tile)
+            for (int r = 0; r < 4; ++r) P[g.lq + 4 * r][g.lc] = -t[r];
+            post(fP, j + 1);
+            LSTAMP(2);
+        }
+#ifdef HM_INV_PROF
+        if (g.lane == 0) printf("ldl_factor sweeper: waiting for pivot tiles %llu, sweeps %llu, posting %llu cycles (%d panels)\n", pa[0], pa[1], pa[2], nt);
+#endif
+        if (bad && g.lane == 0) atomicOr(flag, 1);
+        return;
+    }
+
+    int gen = 0;
+    auto tile_barrier = [&]() {  // the NC tile waves only
+        ++gen;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (g.lane == 0) __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        wait_for(bar, NC * gen);
+    };
+    auto publish_column = [&](int s, double (*Un)[17]) {  // a tile of the next panel's column, below the pivot tile
+        const int R = opaque_s(tR[s]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Un[16 * R + g.lq + 4 * r][g.lc] = acc[s][r];
+    };
+    auto publish_pivot = [&](int s, int token) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dg[g.lq + 4 * r][g.lc] = acc[s][r];
+        post(fDg, token);
     };
     auto update_tile = [&](int s, double (*U)[17]) {
         const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
@@ -350,96 +392,80 @@ __global__ __launch_bounds__(64 * NW, 4) void k_ldl_factor(const double* __restr
             acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wp[16 * R + g.lc][4 * kk + g.lq], U[16 * C + g.lc][4 * kk + g.lq], acc[s], 0, 0, 0);
     };
 
-#ifdef HM_INV_PROF
-    unsigned long long pt, pa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define LSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); pa[k] += t_ - pt; pt = t_; } while (0)
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt) :: "memory");
-#else
-#define LSTAMP(k)
-#endif
-    __syncthreads();
-    if (!service) {
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s)
-            if (tC[s] == 0) publish_tile(s, 0, U0, 1);
-    } else if (sweeper) {
-        sweep_published(1);
+    for (int s = 0; s < SLOTS; ++s) {
+        if (tC[s] != 0) continue;
+        if (tR[s] == 0) publish_pivot(s, 1);
+        else publish_column(s, U0);
     }
-    __syncthreads();
-    LSTAMP(0);
+    tile_barrier();
     for (int Cp = 0; Cp < nt; ++Cp) {
         double (*U)[17] = cur ? U1 : U0;
         double (*Un)[17] = cur ? U0 : U1;
-        const int Cn = Cp + 1, token = Cn + 1;
-        if (!service) {
+        double (*P)[17] = P0 + 16 * (Cp & 1);
+        const int Cn = Cp + 1;
+        wait_for(fP, Cp + 1);
+        if (Cn < nt) {
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
-                if (C != Cp) continue;
-                if (R == Cp) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[s][r] = P[g.lq + 4 * r][g.lc];  // final: P_j
-                } else {  // Lt_R = U_R P: final, and the panel's W operand
-                    d4 wv = {0.0, 0.0, 0.0, 0.0};
+                if (R == Cn && C == Cn) {
+                    // the serial chain: W^T = P U^T of the next pivot tile's row block straight into the B-operand layout (a tile in
+                    // accumulator layout is one), the tile's update A -= U W^T, hand-over to the sweeper
+                    d4 wt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
-                        wv = __builtin_amdgcn_mfma_f64_16x16x4f64(U[16 * R + g.lc][4 * kk + g.lq], P[4 * kk + g.lq][g.lc], wv, 0, 0, 0);
+                        wt = __builtin_amdgcn_mfma_f64_16x16x4f64(P[g.lc][4 * kk + g.lq], U[16 * Cn + g.lc][4 * kk + g.lq], wt, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Wp[16 * R + g.lq + 4 * r][g.lc] = wv[r];
-                    acc[s] = wv;
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[16 * Cn + g.lc][4 * kk + g.lq], wt[kk], acc[s], 0, 0, 0);
+                    publish_pivot(s, Cn + 1);
                 }
             }
         }
-        LSTAMP(1);
-        __syncthreads();  // W visible; P and Dg free
-        LSTAMP(2);
-        if (!service) {
-            if (Cn < nt) {
-#pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
-                    const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
-                    if (R == Cn && C == Cn) {  // the next pivot tile first: its sweep is the panel's critical path
-                        update_tile(s, U);
-                        publish_tile(s, Cn, Un, token);
-                    }
-                }
-                LSTAMP(3);
-#pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
-                    const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
-                    if (C == Cn && R > Cn) {  // then the next panel's column
-                        update_tile(s, U);
-                        publish_tile(s, Cn, Un, token);
-                    }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const int C = opaque_s(tC[s]);
-                if (C > Cn) update_tile(s, U);  // the rest of the trailing matrix (R >= C)
-            }
-        } else if (sweeper && Cn < nt) {
-            sweep_published(token);
-        }
-        LSTAMP(4);
-        __syncthreads();
-        LSTAMP(5);
-        cur ^= 1;
-    }
-    if (!service) {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int R = tR[s], C = tC[s];
-            if (R < 0) continue;
+            const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+            if (C != Cp) continue;
+            if (R == Cp) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) F[(size_t)(16 * R + g.lq + 4 * r) * n + 16 * C + g.lc] = acc[s][r];
+                for (int r = 0; r < 4; ++r) acc[s][r] = P[g.lq + 4 * r][g.lc];  // final: P_j
+            } else {  // Lt_R = U_R P: final, and the panel's W operand
+                d4 wv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    wv = __builtin_amdgcn_mfma_f64_16x16x4f64(U[16 * R + g.lc][4 * kk + g.lq], P[4 * kk + g.lq][g.lc], wv, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Wp[16 * R + g.lq + 4 * r][g.lc] = wv[r];
+                acc[s] = wv;
+            }
         }
+        tile_barrier();  // W visible
+        if (Cn < nt) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+                if (C == Cn && R > Cn) {  // the next panel's column first
+                    update_tile(s, U);
+                    publish_column(s, Un);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int C = opaque_s(tC[s]);
+            if (C > Cn) update_tile(s, U);  // the rest of the trailing matrix (the next pivot tile is already done)
+        }
+        tile_barrier();  // next column visible; U, W free
+        cur ^= 1;
     }
-    LSTAMP(6);
-#ifdef HM_INV_PROF
-    if (g.lane == 0 && (w == 0 || w == 1 || w == 5 || w == 15))
-        printf("ldl_factor wave %d: setup+panel0 %llu, phaseB %llu, barrier1 %llu, diag tile %llu, phaseC/sweep %llu, barrier2 %llu, store %llu cycles (n = %d)\n", w, pa[0], pa[1], pa[2], pa[3], pa[4], pa[5], pa[6], n);
-#endif
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int R = tR[s], C = tC[s];
+        if (R < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) F[(size_t)(16 * R + g.lq + 4 * r) * n + 16 * C + g.lc] = acc[s][r];
+    }
     if (bad && g.lane == 0) atomicOr(flag, 1);
 }
 
@@ -803,7 +829,7 @@ int ldl_factor_mfma(hipStream_t s, const double* G, int n, double* F, int* flag,
                     const double* rank1, double rank1_scale) {
     if (n % 16 != 0 || n < 16 || n > 176) return -1;
     const int nt = n / 16, ntiles = nt * (nt + 1) / 2;
-    const size_t lds = ((size_t)3 * n * 17 + 2 * 16 * 17) * 8 + 16;
+    const size_t lds = ((size_t)3 * n * 17 + 3 * 16 * 17) * 8 + 16;
 #define L(S, NW)                                                                                                             \
     do {                                                                                                                     \
         HM_HIP(hipFuncSetAttribute((const void*)k_ldl_factor<S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \

@@ -11,7 +11,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // step is written for instruction count (diag/inv16.hip: 156 cycles per pivot against 296 with the pivot column
 // staged through LDS):
 //   * pivot column to the lanes of each row:   v_mov_b64_dpp row_newbcast:K                     (4 instructions)
-//   * pivot row to the 4 lane-rows:            ds_bpermute (the only cross-row move; symmetric tile)
+//   * pivot row to the 4 lane-rows:            ds_bpermute (the only cross-row move; symmetric tile).  Tried instead: one
+//     v_mfma_f64_16x16x4 with a row selector as A and the tile's register as B (accumulator layout is the B layout) -- no LDS
+//     round trip, but the wave's next VALU instruction waits out the matrix instruction: +1.2 k cycles per tile (spdinv.hip)
 //   * pivot value:                             v_readlane -> SGPR, reciprocal by rcp + cubic Newton step
 //   * deferred column scaling: the textbook sweep multiplies column K by 1/d_K at pivot K, which costs a select per
 //     entry per pivot.  Every later sweep is linear in that factor, so the lanes of column K simply skip pivot K
