@@ -330,8 +330,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_ldl_factor(const double* __restr
 
     auto wait_for = [&](int* f, int token) {
         for (int spins = 0; __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < token; ++spins) {
-            if (spins > (1 << 24)) { bad = 1; break; }  // a defect: flag it and go on rather than hang the GPU
-            __builtin_amdgcn_s_sleep(1);
+            if (spins > (1 << 26)) { bad = 1; break; }  // a defect: flag it and go on rather than hang the GPU
         }
     };
     auto post = [&](int* f, int token) {
