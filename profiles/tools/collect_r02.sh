@@ -32,7 +32,7 @@ cp "$(find $W/upd -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_update
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $W/mf -o mf -- python3 historymatching_amd/csrc/diag/bench_update.py > /dev/null 2> $W/mf.err
 f=$(find $W/mf -name '*counter_collection.csv' | head -1)
 if [ -n "$f" ]; then
-  (head -1 $f; grep -E "gxt|apply|dgemm|spd_inverse|k_upd" $f) > $OUT/pmc_mfma_update_counter_collection.csv
+  (head -1 $f; grep -E "gxt|apply|dgemm|spd_inverse|ldl_|center_gram|k_upd" $f) > $OUT/pmc_mfma_update_counter_collection.csv
   python3 profiles/tools/mfma_util.py $OUT/pmc_mfma_update_counter_collection.csv > $OUT/mfma_utilisation_update.json
 else
   tail -5 $W/mf.err
