@@ -127,8 +127,9 @@ constexpr int CG_COLS = 8, CG_LANES = 1024 / CG_COLS;
 __global__ __launch_bounds__(1024) void k_center_gram(const float* __restrict__ obs_ens, const float* __restrict__ perturbs,
                                                       const float* __restrict__ obs, int rows, int n_obs, int ncb,
                                                       double* __restrict__ YD, float* __restrict__ Yc32, double* __restrict__ dmean,
-                                                      double* __restrict__ G) {
+                                                      double* __restrict__ G, int* __restrict__ zero_me) {
     __shared__ double sh[15 * 4 * 64];  // centring: [128][9] partial sums; Gram: [15][4][64] partial tiles
+    if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;  // the column counter of the factorisation launched next
     if ((int)blockIdx.x < ncb) {
         double (*part)[CG_COLS + 1] = reinterpret_cast<double (*)[CG_COLS + 1]>(sh);
         const int c = threadIdx.x & (CG_COLS - 1), g = threadIdx.x / CG_COLS;
@@ -260,13 +261,14 @@ int gram_lower_mfma(hipStream_t s, int n, int K, const double* A, int lda, doubl
 }
 
 // One launch: centred observations (YD rows [0, rows): Yc fp64, rows [rows, 2 rows): innovations D0; Yc32: Yc in fp32), dmean = column
-// mean minus the first member's row, and the lower 16 x 16 tiles of sum_k (y_k - y_0)(y_k - y_0)^T.  Returns -1 if n_obs % 16 != 0.
+// mean minus the first member's row, and the lower 16 x 16 tiles of sum_k (y_k - y_0)(y_k - y_0)^T; *zero_me = 0 if given.  Returns -1 if
+// n_obs % 16 != 0.
 int center_gram_mfma(hipStream_t s, const float* obs_ens, const float* perturbs, const float* obs, int rows, int n_obs, double* YD,
-                     float* Yc32, double* dmean, double* G) {
+                     float* Yc32, double* dmean, double* G, int* zero_me) {
     if (n_obs % 16 != 0 || rows < 1) return -1;
     const int nt = n_obs / 16, ncb = (n_obs + CG_COLS - 1) / CG_COLS;
     hipLaunchKernelGGL(k_center_gram, dim3(ncb + nt * (nt + 1) / 2), dim3(1024), 0, s, obs_ens, perturbs, obs, rows, n_obs, ncb, YD, Yc32,
-                       dmean, G);
+                       dmean, G, zero_me);
     HM_HIP(hipGetLastError());
     return 0;
 }

@@ -260,10 +260,12 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
 // machinery of k_spd_inverse restricted to the TRAILING tiles: 210 tile products instead of 650, and per panel only the chain
 // pivot sweep -> W = U P -> next diagonal tile is serial.  Output F (n x n, row-major): Lt_ij in the blocks below the diagonal, P_j in
 // the diagonal blocks (the blocks above the diagonal are not written).
+// colflag (may be NULL): a word in global memory that counts the finished columns of F (value j + 1: block column j -- the tiles
+// Lt_ij, i > j, and P_j -- is in memory and visible to the device), for consumers that run beside the factorisation (k_ldl_chain).
 template <int SLOTS, int NW>
-__global__ __launch_bounds__(64 * NW, 4) void k_ldl_factor(const double* __restrict__ G, int n, double* __restrict__ F, int* __restrict__ flag,
-                                                           const double* __restrict__ add, double add_scale,
-                                                           const double* __restrict__ rank1, double rank1_scale) {
+__device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, int n, double* __restrict__ F, int* __restrict__ flag,
+                                                const double* __restrict__ add, double add_scale,
+                                                const double* __restrict__ rank1, double rank1_scale, int* __restrict__ colflag) {
     // Synchronisation: the chain  pivot sweep -> W^T = P U^T and update of the next pivot tile -> next sweep  is all that is serial
     // per panel, so the sweeper (wave 0, alone on SIMD 0: waves 4, 8, 12 only fix the wave placement and leave at once) and the
     // owner of the next pivot tile talk through two LDS flags and never meet the others at a barrier; the twelve tile waves
@@ -438,6 +440,15 @@ __global__ __launch_bounds__(64 * NW, 4) void k_ldl_factor(const double* __restr
                 for (int r = 0; r < 4; ++r) Wp[16 * R + g.lq + 4 * r][g.lc] = wv[r];
                 acc[s] = wv;
             }
+            // final: out it goes -- write-through (sc1) when another XCD's workgroups read it while this kernel runs: every XCD has an
+            // L2 of its own, and an agent-scope release fence (a write-back of this L2) cost 1.4 us per panel
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* dst = F + (size_t)(16 * R + g.lq + 4 * r) * n + 16 * C + g.lc;
+                if (colflag) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(acc[s][r]),
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *dst = acc[s][r];
+            }
         }
         tile_barrier();  // W visible
         if (Cn < nt) {
@@ -455,17 +466,19 @@ __global__ __launch_bounds__(64 * NW, 4) void k_ldl_factor(const double* __restr
             const int C = opaque_s(tC[s]);
             if (C > Cn) update_tile(s, U);  // the rest of the trailing matrix (the next pivot tile is already done)
         }
+        if (colflag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores of column Cp are out
         tile_barrier();  // next column visible; U, W free
+        if (colflag && c == 0 && g.lane == 0) __hip_atomic_store(colflag, Cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cur ^= 1;
     }
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int R = tR[s], C = tC[s];
-        if (R < 0) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) F[(size_t)(16 * R + g.lq + 4 * r) * n + 16 * C + g.lc] = acc[s][r];
-    }
     if (bad && g.lane == 0) atomicOr(flag, 1);
+}
+
+template <int SLOTS, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_ldl_factor(const double* __restrict__ G, int n, double* __restrict__ F, int* __restrict__ flag,
+                                                           const double* __restrict__ add, double add_scale,
+                                                           const double* __restrict__ rank1, double rank1_scale) {
+    ldl_factor_body<SLOTS, NW>(G, n, F, flag, add, add_scale, rank1, rank1_scale, nullptr);
 }
 
 // Gain of the fused analysis step from the block L D L^T factors:  A' = X B^-1 = X Lt^-T Dt^-1 Lt^-1  (X = D0: N x n innovations),
@@ -477,16 +490,19 @@ __global__ __launch_bounds__(64 * NW, 4) void k_ldl_factor(const double* __restr
 // the owner of T_k handing it to the others through LDS at every step (18 workgroup barriers at n = 160; one wave running all 100
 // tile products of its members in sequence took 22 us, the products of a step spread over four waves take 9).  The factor's tiles
 // are A operands from LDS (the whole lower triangle, 2 KB per tile, staged once per workgroup).  No triangular solves inside tiles.
+// colflag != NULL: the factorisation runs beside this workgroup (k_ldl_chain) -- block column k of F is staged when the counter says
+// it is there, right before forward step k, so that only the last forward step, the scaling and the backward sweep are left when the
+// factorisation ends.
 template <int NT>
-__global__ __launch_bounds__(256) void k_ldl_gain(const double* __restrict__ F, int n, const double* __restrict__ X, int N,
-                                                  float* __restrict__ A_T) {
+__device__ __forceinline__ void ldl_gain_body(const double* __restrict__ F, int n, const double* __restrict__ X, int N,
+                                              float* __restrict__ A_T, int wg, const int* __restrict__ colflag, int* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     constexpr int NTILES = NT * (NT + 1) / 2, NS = (NT + 3) / 4;  // tiles of the factor; tiles of T per wave
     double (*Ft)[16][17] = reinterpret_cast<double (*)[16][17]>(lds_d);  // tile (R, C), R >= C, at index R (R + 1) / 2 + C
     double (*Tk)[4][64] = reinterpret_cast<double (*)[4][64]>(lds_d + (size_t)NTILES * 16 * 17);  // [2][4][64]: the step's T_k
     const int tid = threadIdx.x, lane = tid & 63, lc = lane & 15, lq = lane >> 4, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    {   // stage the lower tiles: every load of a tile row of the factor in flight before the first LDS write of that row
-        const double* Fl = F + (size_t)(tid >> 4) * n + (tid & 15);
+    const double* Fl = F + (size_t)(tid >> 4) * n + (tid & 15);
+    if (!colflag) {  // stage the lower tiles: every load of a tile row of the factor in flight before the first LDS write of that row
 #pragma unroll
         for (int R = 0; R < NT; ++R) {
             double v[NT];
@@ -496,7 +512,28 @@ __global__ __launch_bounds__(256) void k_ldl_gain(const double* __restrict__ F, 
             for (int C = 0; C <= R; ++C) Ft[R * (R + 1) / 2 + C][tid >> 4][tid & 15] = v[C];
         }
     }
-    const int m0 = blockIdx.x * 16, m = min(m0 + lc, N - 1);
+    int stalled = 0;
+    auto stage_column = [&](int k) {  // block column k of F (tiles (R, k), R >= k) once the factorisation has published it
+        // ONE wave of the workgroup polls, at a leisurely rate: the counter lives in one L2 channel, and 250 waves asking for it every
+        // few hundred cycles slowed the factorisation itself down to less than half its speed
+        if (w == 0) {
+            for (int spins = 0; __hip_atomic_load(colflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k + 1; ++spins) {
+                if (spins > (1 << 20)) { stalled = 1; break; }  // the factorisation never got there (a defect): flag it, do not hang
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        __syncthreads();
+        double v[NT];  // sc1 loads: past this XCD's caches, where the factorising workgroup's write-through stores went
+#pragma unroll
+        for (int R = 0; R < NT; ++R)
+            if (R >= k)
+                v[R] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(Fl + (size_t)16 * R * n + 16 * k),
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+        for (int R = 0; R < NT; ++R)
+            if (R >= k) Ft[R * (R + 1) / 2 + k][tid >> 4][tid & 15] = v[R];
+    };
+    const int m0 = wg * 16, m = min(m0 + lc, N - 1);
     d4 T[NS];  // slot s <-> tile j = 4 s + w
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -505,7 +542,8 @@ __global__ __launch_bounds__(256) void k_ldl_gain(const double* __restrict__ F, 
     auto tile = [&](int R, int C) -> double (*)[17] { return Ft[R * (R + 1) / 2 + C]; };
     // hand-over of T_k: its owner writes the four registers, everybody reads them back after the barrier (two buffers: a step's
     // readers may still be reading while the next owner writes)
-    auto hand_over = [&](int k, int step, d4& tk) {
+    auto hand_over = [&](int k, int step, d4& tk, bool forward) {
+        if (colflag && forward) stage_column(k);
         if ((k & 3) == w) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) Tk[step & 1][r][lane] = T[k >> 2][r];
@@ -520,7 +558,7 @@ __global__ __launch_bounds__(256) void k_ldl_gain(const double* __restrict__ F, 
 #pragma unroll
     for (int k = 0; k + 1 < NT; ++k, ++step) {
         d4 tk;
-        hand_over(k, step, tk);
+        hand_over(k, step, tk, true);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -528,6 +566,10 @@ __global__ __launch_bounds__(256) void k_ldl_gain(const double* __restrict__ F, 
                 const int j = 4 * s + w;  // wave-uniform
                 if (j > k && j < NT) T[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tile(j, k)[lc][4 * kk + lq], tk[kk], T[s], 0, 0, 0);
             }
+    }
+    if (colflag) {  // the last block column is the last pivot's inverse alone
+        stage_column(NT - 1);
+        __syncthreads();
     }
     // scaling by the inverse pivots (symmetric tiles)
 #pragma unroll
@@ -544,7 +586,7 @@ __global__ __launch_bounds__(256) void k_ldl_gain(const double* __restrict__ F, 
 #pragma unroll
     for (int k = NT - 1; k > 0; --k, ++step) {
         d4 tk;
-        hand_over(k, step, tk);
+        hand_over(k, step, tk, false);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -562,6 +604,30 @@ __global__ __launch_bounds__(256) void k_ldl_gain(const double* __restrict__ F, 
                 for (int r = 0; r < 4; ++r) A_T[(size_t)(16 * j + lq + 4 * r) * N + m0 + lc] = (float)T[s][r];
             }
         }
+    }
+    if (stalled && lane == 0) atomicOr(flag, 2);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_ldl_gain(const double* __restrict__ F, int n, const double* __restrict__ X, int N,
+                                                  float* __restrict__ A_T) {
+    ldl_gain_body<NT>(F, n, X, N, A_T, blockIdx.x, nullptr, nullptr);
+}
+
+// Factorisation and gain in ONE launch: workgroup 0 factorises, workgroups 1.. (four of their sixteen waves) run the gain of 16
+// members each and take the factor's block columns as they are published -- the forward sweep runs behind the factorisation,
+// the launch boundary, the staging of the factor and the loads of the innovations are off the serial path.  Workgroup 0 is
+// dispatched first and waits for nobody, so the others' waits cannot deadlock; they are bounded all the same.
+template <int SLOTS, int NW, int NT>
+__global__ __launch_bounds__(64 * NW, 4) void k_ldl_chain(const double* __restrict__ G, int n, double* __restrict__ F, int* __restrict__ flag,
+                                                          const double* __restrict__ add, double add_scale,
+                                                          const double* __restrict__ rank1, double rank1_scale, int* __restrict__ colflag,
+                                                          const double* __restrict__ X, int N, float* __restrict__ A_T) {
+    if (blockIdx.x == 0) {
+        ldl_factor_body<SLOTS, NW>(G, n, F, flag, add, add_scale, rank1, rank1_scale, colflag);
+    } else {
+        if (threadIdx.x >= 256) return;
+        ldl_gain_body<NT>(F, n, X, N, A_T, blockIdx.x - 1, colflag, flag);
     }
 }
 
@@ -852,6 +918,26 @@ int ldl_gain_mfma(hipStream_t s, const double* F, int n, const double* X, int N,
 #define L(NT) case NT: HM_HIP(hipFuncSetAttribute((const void*)k_ldl_gain<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                        hipLaunchKernelGGL(k_ldl_gain<NT>, grid, block, lds, s, F, n, X, N, A_T); break
     switch (nt) { L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); L(9); L(10); L(11); default: return -1; }
+#undef L
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+// Both in one launch (k_ldl_chain).  colflag: one int of device memory that is ZERO when the kernel starts (the caller resets it on the
+// same stream).  Returns -1 where the pair above applies but this form does not (n = 16 nt with nt outside [2, 11]).
+int ldl_chain_mfma(hipStream_t s, const double* G, int n, double* F, int* flag, const double* add, double add_scale, const double* rank1,
+                   double rank1_scale, int* colflag, const double* X, int N, float* A_T) {
+    if (n % 16 != 0 || n < 32 || n > 176 || N < 1) return -1;
+    const int nt = n / 16, ntiles = nt * (nt + 1) / 2;
+    const size_t lds_f = ((size_t)3 * n * 17 + 3 * 16 * 17) * 8 + 16, lds_g = (size_t)ntiles * 16 * 17 * 8 + 2 * 4 * 64 * 8;
+    const size_t lds = std::max(lds_f, lds_g);
+    const dim3 grid(1 + (N + 15) / 16), block(1024);
+#define L(S, NT)                                                                                                                  \
+    case NT:                                                                                                                      \
+        HM_HIP(hipFuncSetAttribute((const void*)k_ldl_chain<S, 16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
+        hipLaunchKernelGGL((k_ldl_chain<S, 16, NT>), grid, block, lds, s, G, n, F, flag, add, add_scale, rank1, rank1_scale, colflag, X, N, A_T); \
+        break
+    switch (nt) { L(2, 2); L(2, 3); L(2, 4); L(2, 5); L(2, 6); L(5, 7); L(5, 8); L(5, 9); L(5, 10); L(6, 11); default: return -1; }
 #undef L
     HM_HIP(hipGetLastError());
     return 0;

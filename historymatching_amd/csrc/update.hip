@@ -523,7 +523,9 @@ int ldl_factor_mfma(hipStream_t s, const double* G, int n, double* F, int* flag,
                     double rank1_scale);                                                  // spdinv.hip
 int ldl_gain_mfma(hipStream_t s, const double* F, int n, const double* X, int N, float* A_T);  // spdinv.hip
 int center_gram_mfma(hipStream_t s, const float* obs_ens, const float* perturbs, const float* obs, int rows, int n_obs, double* YD,
-                     float* Yc32, double* dmean, double* G);  // dgemm_mfma.hip
+                     float* Yc32, double* dmean, double* G, int* zero_me);  // dgemm_mfma.hip
+int ldl_chain_mfma(hipStream_t s, const double* G, int n, double* F, int* flag, const double* add, double add_scale, const double* rank1,
+                   double rank1_scale, int* colflag, const double* X, int N, float* A_T);  // spdinv.hip
 // dgemm_mfma.hip
 int dgemm_mfma(hipStream_t s, bool transA, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C,
                int ldc, int ksplit, float* C32, int rows32, float* C32T);
@@ -945,7 +947,7 @@ extern "C" int hm_upd_run(hm_upd* u) {
         // where that does not apply (n_obs not a multiple of 16): the centring kernel, then the split-K product below
         double* dmean = sumY;  // red1: n_obs doubles
         rc = (g_use_mfma_inverse && !u->overlap && u->fused_front) ? center_gram_mfma(s, (const float*)u->obs_ens.p, (const float*)u->perturbs.p, (const float*)u->obs.p, nl, no, YD,
-                                                                      S_T, dmean, G) : -1;
+                                                                      S_T, dmean, G, (int*)u->flags.p + 2) : -1;
         if (rc > 0) return rc;
         const bool fused_front = rc == 0;
         if (!fused_front) {
@@ -963,10 +965,17 @@ extern "C" int hm_upd_run(hm_upd* u) {
         bool gain_done = false;
         if (rc == 0 && u->ldl_gain) {
             // gain straight from the block L D L^T factors of B: a third of the inverse's matrix work and no explicit inverse
-            int r2 = ldl_factor_mfma(s2, G, no, (double*)u->Cinv.p, (int*)u->flags.p, (const double*)u->Rm.p, (double)(u->N_total - 1),
-                                     fused_front ? dmean : nullptr, (double)nl);
+            // ... both in one launch where the front kernel has reset the column counter (flags[2])
+            int r2 = (fused_front && u->ldl_gain == 1)
+                         ? ldl_chain_mfma(s2, G, no, (double*)u->Cinv.p, (int*)u->flags.p, (const double*)u->Rm.p, (double)(u->N_total - 1), dmean,
+                                          (double)nl, (int*)u->flags.p + 2, YD + nsm, nl, A_T)
+                         : -1;
             if (r2 > 0) return r2;
-            if (r2 == 0) {
+            if (r2 == 0) gain_done = true;
+            if (!gain_done) r2 = ldl_factor_mfma(s2, G, no, (double*)u->Cinv.p, (int*)u->flags.p, (const double*)u->Rm.p, (double)(u->N_total - 1),
+                                                 fused_front ? dmean : nullptr, (double)nl);
+            if (r2 > 0) return r2;
+            if (r2 == 0 && !gain_done) {
                 if ((r2 = ldl_gain_mfma(s2, (const double*)u->Cinv.p, no, YD + nsm, nl, A_T)) > 0) return r2;
                 HM_REQUIRE(r2 == 0, "hm_upd_run: gain kernel not applicable after its factorisation was");
                 gain_done = true;
