@@ -306,20 +306,31 @@ __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, in
         }
         tR[s] = __builtin_amdgcn_readfirstlane(R);
         tC[s] = __builtin_amdgcn_readfirstlane(C);
-        acc[s] = d4{0.0, 0.0, 0.0, 0.0};
-        if (R >= 0) {
+    }
+    // Every load of the wave's tiles in ONE basic block (an empty slot loads tile (0, 0) and drops it): behind a branch per slot the
+    // loads of slot s + 1 were issued after those of slot s had returned -- five round trips to memory (the producer ran on other
+    // XCDs: nothing of G is in this L2), 8.5 us before the first pivot tile instead of 5
+    const double r1v = rank1 ? rank1[min(tid, n - 1)] : 0.0;  // in flight together with the tiles
+    {
+        double gv[SLOTS][4], av[SLOTS][4];
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * R + g.lq + 4 * r, col = 16 * C + g.lc;
-                acc[s][r] = G[(size_t)row * n + col] + (add ? add_scale * add[(size_t)row * n + col] : 0.0);
+                const size_t e = (size_t)(16 * max(tR[s], 0) + g.lq + 4 * r) * n + 16 * max(tC[s], 0) + g.lc;
+                gv[s][r] = G[e];
+                av[s][r] = add ? add[e] : 0.0;
             }
-        }
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[s][r] = tR[s] >= 0 ? gv[s][r] + add_scale * av[s][r] : 0.0;
     }
     if (tid == 0) { *fDg = 0; *fP = 0; *bar = 0; }
     int bad = 0, cur = 0;
     if (rank1) {  // Gram matrix of shifted columns -> of centred ones (the vector goes through LDS: W's buffer, not in use yet)
         double* r1 = reinterpret_cast<double*>(Wp);
-        if (tid < n) r1[tid] = rank1[tid];
+        if (tid < n) r1[tid] = r1v;
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s)
