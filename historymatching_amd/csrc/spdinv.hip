@@ -273,17 +273,21 @@ __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, in
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool service = (w & 3) == 0, sweeper = w == 0;
-    if (service && !sweeper) return;
+    const bool service = (w & 3) == 0, sweeper = w == 0, pivot_wave = w == 4;
+    if (service && !sweeper && !pivot_wave) return;
     const int nt = n >> 4;
     double (*U0)[17] = reinterpret_cast<double (*)[17]>(lds_d);
     double (*U1)[17] = U0 + n;
-    double (*Wp)[17] = U1 + n;
-    double (*P0)[17] = Wp + n;   // P of even panels, then P of odd panels
+    double (*Wp0)[17] = U1 + n;  // W of even panels, then W of odd panels
+    double (*P0)[17] = Wp0 + 2 * n;  // P of even panels, then P of odd panels
     double (*Dg)[17] = P0 + 32;
-    int* fDg = reinterpret_cast<int*>(Dg + 16);  // token: pivot tile j is in Dg        (value j + 1)
+    double (*Dp0)[17] = Dg + 16;                 // the next pivot tile before its last update: tile j in Dp[j & 1]
+    int* fDg = reinterpret_cast<int*>(Dp0 + 32); // token: pivot tile j is in Dg        (value j + 1)
     int* fP = fDg + 1;                           // token: P_j = S_j^-1 is in P[j & 1]   (value j + 1)
     int* bar = fDg + 2;                          // arrivals of the tile waves at their barriers
+    int* colcnt = fDg + 3;                       // tile waves whose stores of the finished columns have been acknowledged
+    int* fDp = fDg + 4;                          // token: tile j with the updates of panels 0 .. j-2 is in Dp[j & 1]   (value j + 1)
+    int* fU = fDg + 5;                           // token: tile (j + 1, j) of block column j is in its U buffer          (value j + 1)
 
     IGeo g;
     g.lane = tid & 63;
@@ -326,10 +330,10 @@ __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, in
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[s][r] = tR[s] >= 0 ? gv[s][r] + add_scale * av[s][r] : 0.0;
     }
-    if (tid == 0) { *fDg = 0; *fP = 0; *bar = 0; }
+    if (tid == 0) { *fDg = 0; *fP = 0; *bar = 0; *colcnt = 0; *fDp = 0; *fU = 0; }
     int bad = 0, cur = 0;
     if (rank1) {  // Gram matrix of shifted columns -> of centred ones (the vector goes through LDS: W's buffer, not in use yet)
-        double* r1 = reinterpret_cast<double*>(Wp);
+        double* r1 = reinterpret_cast<double*>(Wp0);
         if (tid < n) r1[tid] = r1v;
         __syncthreads();
 #pragma unroll
@@ -346,6 +350,12 @@ __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, in
             if (spins > (1 << 26)) { bad = 1; break; }  // a defect: flag it and go on rather than hang the GPU
         }
     };
+    auto wait_quietly = [&](int* f, int token) {  // sweeper and pivot wave share a SIMD: the one that waits must not take issue slots
+        for (int spins = 0; __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < token; ++spins) {
+            if (spins > (1 << 24)) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
     auto post = [&](int* f, int token) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (g.lane == 0) __hip_atomic_store(f, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -360,7 +370,7 @@ __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, in
 #define LSTAMP(k)
 #endif
         for (int j = 0; j < nt; ++j) {
-            wait_for(fDg, j + 1);
+            wait_quietly(fDg, j + 1);
             LSTAMP(0);
             d4 t;
 #pragma unroll
@@ -379,13 +389,65 @@ __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, in
         if (bad && g.lane == 0) atomicOr(flag, 1);
         return;
     }
+    if (pivot_wave) {
+        // The serial chain's other half, on a wave with nothing else to do (it shares SIMD 0 with the sweeper; one of the two is
+        // always waiting for the other): the next pivot tile arrives from its owner with every update but the current panel's,
+        // W^T = P U^T of its row block goes straight into the B-operand layout (a tile in accumulator layout is one), the tile's
+        // last update A -= U W^T, and on to the sweeper.  As part of the tile waves' panel loop the same work waited for their
+        // trailing updates and barriers: 3.1 k cycles per panel between two sweeps instead of 1.5 k.
+#ifdef HM_INV_PROF
+        unsigned long long qt, qa[4] = {0, 0, 0, 0};
+#define QSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); qa[k] += t_ - qt; qt = t_; } while (0)
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(qt) :: "memory");
+#else
+#define QSTAMP(k)
+#endif
+        for (int Cp = 0; Cp + 1 < nt; ++Cp) {
+            const int Cn = Cp + 1;
+            double (*U)[17] = (Cp & 1) ? U1 : U0;
+            double (*P)[17] = P0 + 16 * (Cp & 1);
+            double (*Dp)[17] = Dp0 + 16 * (Cn & 1);
+            wait_quietly(fU, Cp + 1);  // the row block of column Cp this tile needs is in U (not the whole column: that is the tile waves' barrier)
+            QSTAMP(0);
+            wait_quietly(fDp, Cn + 1);
+            d4 t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = Dp[g.lq + 4 * r][g.lc];
+            QSTAMP(1);
+            wait_quietly(fP, Cp + 1);
+            QSTAMP(2);
+            d4 wt = {0.0, 0.0, 0.0, 0.0}, wz = wt, tz = wt;
+            double un[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) un[kk] = U[16 * Cn + g.lc][4 * kk + g.lq];
+            wt = __builtin_amdgcn_mfma_f64_16x16x4f64(P[g.lc][g.lq], un[0], wt, 0, 0, 0);
+            wz = __builtin_amdgcn_mfma_f64_16x16x4f64(P[g.lc][4 + g.lq], un[1], wz, 0, 0, 0);
+            wt = __builtin_amdgcn_mfma_f64_16x16x4f64(P[g.lc][8 + g.lq], un[2], wt, 0, 0, 0);
+            wz = __builtin_amdgcn_mfma_f64_16x16x4f64(P[g.lc][12 + g.lq], un[3], wz, 0, 0, 0);
+            wt += wz;
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64(-un[0], wt[0], t, 0, 0, 0);
+            tz = __builtin_amdgcn_mfma_f64_16x16x4f64(-un[1], wt[1], tz, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64(-un[2], wt[2], t, 0, 0, 0);
+            tz = __builtin_amdgcn_mfma_f64_16x16x4f64(-un[3], wt[3], tz, 0, 0, 0);
+            t += tz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Dg[g.lq + 4 * r][g.lc] = t[r];
+            post(fDg, Cn + 1);
+            QSTAMP(3);
+        }
+#ifdef HM_INV_PROF
+        if (g.lane == 0) printf("ldl_factor pivot wave: waiting for U row block %llu, for the pre-pivot tile %llu, for P %llu, W^T + update + post %llu cycles\n", qa[0], qa[1], qa[2], qa[3]);
+#endif
+        if (bad && g.lane == 0) atomicOr(flag, 1);
+        return;
+    }
 
     int gen = 0;
     auto tile_barrier = [&]() {  // the NC tile waves only
         ++gen;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (g.lane == 0) __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        wait_for(bar, NC * gen);
+        wait_quietly(bar, NC * gen);
     };
     auto publish_column = [&](int s, double (*Un)[17]) {  // a tile of the next panel's column, below the pivot tile
         const int R = opaque_s(tR[s]);
@@ -397,44 +459,60 @@ __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, in
         for (int r = 0; r < 4; ++r) Dg[g.lq + 4 * r][g.lc] = acc[s][r];
         post(fDg, token);
     };
-    auto update_tile = [&](int s, double (*U)[17]) {
+    // A tile product is four matrix instructions on one accumulator, each waiting for the one before (~100 cycles); two accumulators
+    // of two instructions each and one addition halve the chain -- these chains, not the matrix pipe, are what the panel loop waits for.
+    auto update_tile = [&](int s, double (*U)[17], double (*Wp)[17]) {
         const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wp[16 * R + g.lc][4 * kk + g.lq], U[16 * C + g.lc][4 * kk + g.lq], acc[s], 0, 0, 0);
+        d4 z = {0.0, 0.0, 0.0, 0.0};
+        acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wp[16 * R + g.lc][g.lq], U[16 * C + g.lc][g.lq], acc[s], 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wp[16 * R + g.lc][4 + g.lq], U[16 * C + g.lc][4 + g.lq], z, 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wp[16 * R + g.lc][8 + g.lq], U[16 * C + g.lc][8 + g.lq], acc[s], 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wp[16 * R + g.lc][12 + g.lq], U[16 * C + g.lc][12 + g.lq], z, 0, 0, 0);
+        acc[s] += z;
     };
 
+    // Telling the other workgroups that block columns 0 .. ncols-1 of F are in memory: every tile wave waits for the acknowledgements
+    // of its own write-through stores (issued a panel ago: no stall) and counts itself in; the last one in publishes the count.  Kept off the tile waves' barriers: waiting there put the store latency into every panel.
+    auto publish_columns = [&](int ncols) {
+        if (!colflag || ncols < 1) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (g.lane == 0 && __hip_atomic_fetch_add(colcnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == NC * ncols - 1)
+            __hip_atomic_store(colflag, ncols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the last one in tells the others
+    };
+    auto publish_prepivot = [&](int s, int j) {  // tile (j, j) with every update but panel j-1's, for the pivot wave
+        double (*Dp)[17] = Dp0 + 16 * (j & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dp[g.lq + 4 * r][g.lc] = acc[s][r];
+        post(fDp, j + 1);
+    };
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
+        if (tR[s] == 1 && tC[s] == 1) publish_prepivot(s, 1);
         if (tC[s] != 0) continue;
         if (tR[s] == 0) publish_pivot(s, 1);
-        else publish_column(s, U0);
+        else {
+            publish_column(s, U0);
+            if (tR[s] == 1) post(fU, 1);
+        }
     }
     tile_barrier();
+#ifdef HM_INV_PROF
+    unsigned long long tt, ta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ta[k] += t_ - tt; tt = t_; } while (0)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+#else
+#define TSTAMP(k)
+#endif
     for (int Cp = 0; Cp < nt; ++Cp) {
         double (*U)[17] = cur ? U1 : U0;
         double (*Un)[17] = cur ? U0 : U1;
         double (*P)[17] = P0 + 16 * (Cp & 1);
+        double (*Wp)[17] = Wp0 + n * (Cp & 1);
         const int Cn = Cp + 1;
-        wait_for(fP, Cp + 1);
-        if (Cn < nt) {
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
-                if (R == Cn && C == Cn) {
-                    // the serial chain: W^T = P U^T of the next pivot tile's row block straight into the B-operand layout (a tile in
-                    // accumulator layout is one), the tile's update A -= U W^T, hand-over to the sweeper
-                    d4 wt = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        wt = __builtin_amdgcn_mfma_f64_16x16x4f64(P[g.lc][4 * kk + g.lq], U[16 * Cn + g.lc][4 * kk + g.lq], wt, 0, 0, 0);
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[16 * Cn + g.lc][4 * kk + g.lq], wt[kk], acc[s], 0, 0, 0);
-                    publish_pivot(s, Cn + 1);
-                }
-            }
-        }
+        wait_quietly(fP, Cp + 1);
+        TSTAMP(0);
+        publish_columns(Cp);
+        TSTAMP(1);  // columns 0 .. Cp-1 (stored during the previous panels)
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
@@ -443,10 +521,12 @@ __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, in
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[s][r] = P[g.lq + 4 * r][g.lc];  // final: P_j
             } else {  // Lt_R = U_R P: final, and the panel's W operand
-                d4 wv = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    wv = __builtin_amdgcn_mfma_f64_16x16x4f64(U[16 * R + g.lc][4 * kk + g.lq], P[4 * kk + g.lq][g.lc], wv, 0, 0, 0);
+                d4 wv = {0.0, 0.0, 0.0, 0.0}, wz = wv;
+                wv = __builtin_amdgcn_mfma_f64_16x16x4f64(U[16 * R + g.lc][g.lq], P[g.lq][g.lc], wv, 0, 0, 0);
+                wz = __builtin_amdgcn_mfma_f64_16x16x4f64(U[16 * R + g.lc][4 + g.lq], P[4 + g.lq][g.lc], wz, 0, 0, 0);
+                wv = __builtin_amdgcn_mfma_f64_16x16x4f64(U[16 * R + g.lc][8 + g.lq], P[8 + g.lq][g.lc], wv, 0, 0, 0);
+                wz = __builtin_amdgcn_mfma_f64_16x16x4f64(U[16 * R + g.lc][12 + g.lq], P[12 + g.lq][g.lc], wz, 0, 0, 0);
+                wv += wz;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Wp[16 * R + g.lq + 4 * r][g.lc] = wv[r];
                 acc[s] = wv;
@@ -461,27 +541,43 @@ __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, in
                 else *dst = acc[s][r];
             }
         }
+        TSTAMP(2);
         tile_barrier();  // W visible
+        TSTAMP(3);
         if (Cn < nt) {
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
                 if (C == Cn && R > Cn) {  // the next panel's column first
-                    update_tile(s, U);
+                    update_tile(s, U, Wp);
                     publish_column(s, Un);
+                    if (R == Cn + 1) post(fU, Cn + 1);
                 }
+            }
+        }
+        TSTAMP(4);
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {  // the pivot tile after the next: the pivot wave wants it before the next sweep ends
+            const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+            if (R == Cn + 1 && C == Cn + 1) {
+                update_tile(s, U, Wp);
+                publish_prepivot(s, Cn + 1);
             }
         }
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int C = opaque_s(tC[s]);
-            if (C > Cn) update_tile(s, U);  // the rest of the trailing matrix (the next pivot tile is already done)
+            const int R = opaque_s(tR[s]), C = opaque_s(tC[s]);
+            if (C > Cn && !(R == Cn + 1 && C == Cn + 1)) update_tile(s, U, Wp);  // the rest of the trailing matrix (the next pivot tile is the pivot wave's)
         }
-        if (colflag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores of column Cp are out
-        tile_barrier();  // next column visible; U, W free
-        if (colflag && c == 0 && g.lane == 0) __hip_atomic_store(colflag, Cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        TSTAMP(5);
+        // No second barrier: phase B of the next panel reads only what this wave published itself (its own tiles of the next
+        // column) and P; W has a buffer per panel parity; everything else of the next column is read after the next barrier.
         cur ^= 1;
     }
+#ifdef HM_INV_PROF
+    if (g.lane == 0 && (c == 0 || c == 5 || c == 11)) printf("ldl_factor tile wave %d: waiting for P %llu, publishing columns %llu, phase B %llu, barrier %llu, next column %llu, rest of phase C %llu, barrier %llu cycles\n", c, ta[0], ta[1], ta[2], ta[3], ta[4], ta[5], ta[6]);
+#endif
+    publish_columns(nt);
     if (bad && g.lane == 0) atomicOr(flag, 1);
 }
 
@@ -905,7 +1001,7 @@ int ldl_factor_mfma(hipStream_t s, const double* G, int n, double* F, int* flag,
                     const double* rank1, double rank1_scale) {
     if (n % 16 != 0 || n < 16 || n > 176) return -1;
     const int nt = n / 16, ntiles = nt * (nt + 1) / 2;
-    const size_t lds = ((size_t)3 * n * 17 + 3 * 16 * 17) * 8 + 16;
+    const size_t lds = ((size_t)4 * n * 17 + 5 * 16 * 17) * 8 + 32;
 #define L(S, NW)                                                                                                             \
     do {                                                                                                                     \
         HM_HIP(hipFuncSetAttribute((const void*)k_ldl_factor<S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -940,7 +1036,7 @@ int ldl_chain_mfma(hipStream_t s, const double* G, int n, double* F, int* flag, 
                    double rank1_scale, int* colflag, const double* X, int N, float* A_T) {
     if (n % 16 != 0 || n < 32 || n > 176 || N < 1) return -1;
     const int nt = n / 16, ntiles = nt * (nt + 1) / 2;
-    const size_t lds_f = ((size_t)3 * n * 17 + 3 * 16 * 17) * 8 + 16, lds_g = (size_t)ntiles * 16 * 17 * 8 + 2 * 4 * 64 * 8;
+    const size_t lds_f = ((size_t)4 * n * 17 + 5 * 16 * 17) * 8 + 32, lds_g = (size_t)ntiles * 16 * 17 * 8 + 2 * 4 * 64 * 8;
     const size_t lds = std::max(lds_f, lds_g);
     const dim3 grid(1 + (N + 15) / 16), block(1024);
 #define L(S, NT)                                                                                                                  \
