@@ -23,7 +23,7 @@ decorr = sla.inv(R12.T)
 res = {}
 outs = {}
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 9
-for kal, ov, kc, av, sm, gh, gd, dma in ((0, 0, 32, 1, 0, 2, 1, 0), (1, 0, 64, 3, 0, 2, 1, 1), (1, 0, 64, 3, 0, 2, 1, 4)):
+for kal, ov, kc, av, sm, gh, gd, dma in ((0, 0, 32, 1, 0, 2, 1, 0), (1, 0, 64, 3, 0, 2, 1, 1), (1, 0, 64, 3, 0, 2, 1, 4), (1, 0, 64, 3, 0, 2, 1, 3), (1, 0, 64, 3, 0, 2, 1, 2), (1, 0, 32, 3, 0, 2, 1, 1)):
     if True:
         p = UpdatePlan(N, N, M, n_obs, dtype=32)
         p.set_option("kalman_form", kal)

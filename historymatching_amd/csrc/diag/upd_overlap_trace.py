@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
 if len(sys.argv) > 2 and sys.argv[1] == "--report":
     f = glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    last = [i for i, r in enumerate(rows) if "k_center_obs" in r["Kernel_Name"] or "k_center_gram" in r["Kernel_Name"]][-1]
+    last = [i for i, r in enumerate(rows) if "k_center_obs" in r["Kernel_Name"] or "k_center_gram" in r["Kernel_Name"] or "k_front_chain" in r["Kernel_Name"]][-1]
     t0 = int(rows[last]["Start_Timestamp"])
     for r in rows[last:last + 8]:
         print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} .. {(int(r['End_Timestamp']) - t0) / 1e3:8.1f} us  queue {r.get('Queue_Id', '?'):>3}  "
