@@ -222,10 +222,12 @@ def test_es_mda_device_resident_matches_host_driver(dtype, tol):
 
 
 @pytest.mark.parametrize("N,M,n_obs,localized", [(1000, 4096, 160, False), (999, 4100, 160, False), (130, 1024, 64, True),
-                                                  (64, 512, 48, False)])
+                                                  (64, 512, 48, False), (200, 2048, 32, False), (300, 1024, 96, False),
+                                                  (257, 1536, 128, False)])
 def test_fp32_matrix_core_path_matches_generic_and_oracle(N, M, n_obs, localized):
     """fp32 update: v_mfma_f32_32x32x2 kernels (default) vs the generic VALU GEMMs (use_mfma=0) vs the fp64 oracle.
-    Shapes cover exact tiles, ragged N / M, and an n_obs that is not a multiple of 32 (falls back)."""
+    Shapes cover exact tiles, ragged N / M, an n_obs that is not a multiple of 32 (falls back), and 2, 6, 8 and 10 block columns
+    in the factorisation + gain launch of the fused run (spdinv.hip: k_ldl_chain)."""
     from historymatching_amd.update import UpdatePlan
     from oracle import es
 
@@ -250,6 +252,36 @@ def test_fp32_matrix_core_path_matches_generic_and_oracle(N, M, n_obs, localized
     assert np.abs(outs[0] - ref).max() <= 1e-4 * inc
     assert np.abs(outs[1] - ref).max() <= 1e-4 * inc
     assert np.abs(outs[0].astype(np.float64) - outs[1]).max() <= 2e-5 * inc
+
+
+def test_gain_chain_variants_agree():
+    """The fused run's chain in front of the apply in its forms -- explicit inverse + product (ldl_gain 0), factorisation and gain as
+    two kernels (2), both in one launch with the gain's forward sweep running behind the factorisation (1, default) -- on the same
+    inputs: the same update to fp32 rounding of the gain."""
+    from historymatching_amd.update import UpdatePlan
+    from oracle import es
+
+    N, M, n_obs = 500, 2048, 160
+    rng = np.random.RandomState(7)
+    E = rng.randn(N, M) + rng.randn(M)
+    obs_ens = E[:, :n_obs] * 0.3 + rng.randn(N, n_obs) * 0.1
+    _, R12, decorr = es.obs_error_model(n_obs // 4, 4)
+    obs = obs_ens[0] + R12 @ rng.randn(n_obs)
+    perturbs = rng.randn(N, n_obs) @ R12.T
+    ref = es.ens_update0(E, obs_ens, obs, perturbs, decorr)
+    inc = np.abs(ref - E).max()
+    outs = {}
+    for variant in (0, 2, 1):
+        p = UpdatePlan(N, N, M, n_obs, dtype=32)
+        p.set_option("ldl_gain", variant)
+        p.set_inputs(E, obs_ens, obs, perturbs, decorr)
+        for _ in range(3):  # the one-launch form keeps device counters across runs of a plan
+            p.run_local()
+        outs[variant] = p.output().astype(np.float64)
+        p.close()
+        assert np.abs(outs[variant] - ref).max() <= 1e-4 * inc
+    assert np.abs(outs[1] - outs[0]).max() <= 2e-6 * inc
+    assert np.array_equal(outs[1], outs[2])  # same factors, same tile products: the launch structure does not change a bit
 
 
 @pytest.mark.parametrize("n", [16, 48, 160, 256])
