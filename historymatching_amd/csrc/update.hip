@@ -1165,7 +1165,8 @@ extern "C" int hm_upd_sync(hm_upd* u, hm_stats* st) {
     u->t_comm.reset();
     if (flag) {
         HM_HIP(hipMemset(u->flags.p, 0, 16));
-        hm_set_error("ensemble update: non-positive pivot (C = S^T S + (N-1) I must be SPD; NaN/Inf in inputs?)");
+        if (flag & 2) hm_set_error("ensemble update: the gain's workgroups gave up waiting for the factorisation (kernel defect or a hung device)");
+        else hm_set_error("ensemble update: non-positive pivot (C = S^T S + (N-1) I must be SPD; NaN/Inf in inputs?)");
         return 4;
     }
     return 0;
