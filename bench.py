@@ -104,17 +104,17 @@ def es_update_timing(device):
         plan.run_local()  # warm-up (also forms R from decorr: done once per decorr, i.e. once per ES-MDA assimilation)
         ms = sorted(plan.run_local()["ms_update"] for _ in range(5))   # one step at a time, host synchronisation after each
         # Steps queued back to back, as ES-MDA chains them behind the forward model (no idle gap in front of a step's first kernel):
-        # 0.1 s of untimed batches (clocks back up after the host-synchronised steps above), then five batches of ten, the median
-        # batch.  In THIS process -- seconds of fp64 forward model on the device just before -- the step takes ~6 % longer than in a
-        # process that runs nothing but analysis steps (0.168 against 0.158 ms at config 3's shape:
-        # historymatching_amd/csrc/diag/upd_ramp.py, upd_ab.py); the figure reported is the one behind the forward model.
+        # 0.1 s of untimed batches, then fifteen batches of ten, the median batch.  After an idle spell (the host-synchronised steps
+        # above, the set-up of the inputs) the device needs 15-20 ms of work -- on some boxes of this pool several times that -- to
+        # get back to the clocks it holds behind a forward pass: first batches 0.171 ms, settled 0.158 ms at config 3's shape
+        # (historymatching_amd/csrc/diag/upd_ramp.py, upd_after_forward.py).
         reps, batches = 10, []
         t_warm = time.perf_counter()
         while time.perf_counter() - t_warm < 0.1:
             for _ in range(reps):
                 _lib.check(plan.lib.hm_upd_run(plan.h), "hm_upd_run")
             plan.sync()
-        for _ in range(5):
+        for _ in range(int(os.environ.get("HM_BENCH_UPD_BATCHES", "15"))):
             for _ in range(reps):
                 _lib.check(plan.lib.hm_upd_run(plan.h), "hm_upd_run")
             batches.append(plan.sync()["ms_update"] / reps)
@@ -126,7 +126,7 @@ def es_update_timing(device):
         by_shape.append(entry)
         if out is None:
             out = {"wall_ms": med, "isolated_step_median_ms": ms[len(ms) // 2], "best_ms": ms[0],
-                   "timing": "device time (HIP events) per analysis step, 10 steps queued back to back; median of 5 such batches behind 0.1 s of untimed batches (the clocks of a busy device)",
+                   "timing": "device time (HIP events) per analysis step, 10 steps queued back to back; median of 15 such batches behind 0.1 s of untimed batches (the clocks of a busy device)",
                    "batches_ms": batches,
                    "config": f"N={N}, M={M}, n_obs={n_obs}, fp32 (config 3 shape), correlated R of HistoryMatch.py:243-259",
                    "flops_min_order": flops, "tflops": entry["tflops"], "mfma_peak_tflops": FP32_MATRIX_PEAK_TFLOPS,
