@@ -224,11 +224,16 @@ int   hm_upd_all_reduce(hm_upd* u, hm_comm* c, int after_phase);
 /* The whole analysis step of a row-sharded plan over the ranks of `c`: phases and collectives in stream order. */
 int   hm_upd_run_comm(hm_upd* u, hm_comm* c);
 /* All three phases of a plan that holds every member (N_local == N_total), no reduction points.  fp32 plans run the
- * second-generation matrix-core kernels here (LDS-staged contractions, fp64 matrix-core products for the N x n_obs
- * quantities, matrix-core inverse of C); option "overlap" = 1 puts the small fp64 chain on a second stream. */
+ * second-generation matrix-core kernels here: the Kalman form D0 (Yc^T Yc + (N-1) R)^-1 Yc^T X of the same update
+ * (HistoryMatch.py:578-586 with R = (decorr decorr^T)^-1), LDS-DMA-staged contractions over the state, and for the N x n_obs
+ * quantities one launch for centring + Gram matrix and one for the block L D L^T factorisation of the n_obs x n_obs matrix
+ * with the gain D0 B^-1 computed beside it (n_obs a multiple of 16 up to 176; otherwise matrix-core inverse + product). */
 int   hm_upd_run(hm_upd* u);
-int   hm_upd_set_option(hm_upd* u, const char* name, int value);  /* "use_mfma": 1 (default) | 0 = generic fp32 GEMMs;
-                                                                   * "mfma_inverse": 1 | 0; "overlap": 0 | 1        */
+/* Tuning / test switches (defaults in brackets): "use_mfma" [1] | 0 = generic fp32 GEMMs; "kalman_form" [1] | 0 = decorrelated
+ * form; "ldl_gain" [1] = factorisation + gain in one launch | 2 = as two kernels | 0 = explicit inverse + product;
+ * "fused_front" [1] | 0 = centring and Gram matrix as two kernels; "mfma_inverse" [1] | 0; "overlap" [0] | 1 = the fp64 chain
+ * on a second stream (measured slower); kernel-variant selectors "gxt_dma", "gxt_chunk", "apply_variant", "small_inverse", ... */
+int   hm_upd_set_option(hm_upd* u, const char* name, int value);
 void* hm_upd_reduce_buffer(hm_upd* u, int which /*0..4*/, long long* n_elems, int* elem_bytes); /* device pointer */
 int   hm_upd_sync(hm_upd* u, hm_stats* stats);
 int   hm_upd_get_output(hm_upd* u, void* E_out_local);
