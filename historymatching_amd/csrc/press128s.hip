@@ -160,6 +160,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
     // SIMD -- the service waves of both workgroups of a CU on SIMD 0, read from HW_REG_HW_ID -- were measured in round 2: the
     // sweep drops from 4.4 k to 3.3 k cycles, but both workgroups' matrix-core waves then share three SIMDs instead of
     // spilling onto the other workgroup's service SIMD, and the launch takes 12.5 ms instead of 11.6.)
+    // (Also measured, end of round 2: the next pivot tile's last update on the second service wave -- W^T = P U^T straight into the
+    // B-operand layout, before the panel's first barrier instead of after it, as in spdinv.hip's factorisation -- with the two
+    // workgroup barriers per panel kept: 12.4 ms instead of 11.45.  The barriers tie the sweeper to the tile waves either way;
+    // taking them apart needs the flag / counter synchronisation of spdinv.hip in this kernel too.)
     const bool service = (w & 3) == 0;
     const bool sweeper = w == 0;
     const int c = service ? 0 : (w >> 2) * 3 + (w & 3) - 1;  // compute wave index
