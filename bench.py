@@ -428,6 +428,9 @@ def main():
             "work_counted": what, "dp_valu_per_cell_substep": dp_per_cell, "isa_count_source": isa_src,
             "executed_over_algorithmic_instructions": executed_ratio, "executed_ratio_source": f64r_src,
             "frac_if_skipped_dry_bands_counted_as_work": 2 * sat_lane_instr_algorithmic / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            "measured_issue_ceiling": {"frac_of_peak": 0.74, "note": "at this kernel's two waves per SIMD a SIMD issues one simple DP instruction per "
+                                       "5.4 cycles, not 4 (v_rcp_f64: 16.4; an FMA with three distinct register operands: 6.9) -- "
+                                       "historymatching_amd/csrc/diag/valu_rate.hip, profiles/README.md"},
             "avg_launch_ms": {"saturation": sat_ms, "pressure": prs_ms},
             "per_kernel": {"saturation_fp64_valu_frac": 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                            "pressure_fp64_mfma_frac": prs_flops / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
