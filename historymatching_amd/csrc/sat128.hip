@@ -29,6 +29,9 @@
 // The same skip per patch row (a wet-row mask, phase A for wet rows, phase B for wet rows and their neighbours, frontier rows tested
 // for water afterwards) is bit-identical too and executes fewer instructions, but the branch per row makes the register allocator
 // spill three times as much (76 instead of 21 registers, 32 scratch reloads per sub-step): 19.8 ms instead of 13.85.
+// Neighbour flags in LDS instead of the two workgroup barriers per sub-step (a wave exchanges fw only with the bands above and
+// below its own) are bit-identical as well and slower: 14.3 ms, with or without s_sleep in the polls -- a wave at s_barrier takes
+// no issue slots from the wave it shares its SIMD with, a polling one does.
 //
 // Compiled with -ffp-contract=off (no FMA contraction: every product and sum is rounded separately, as NumPy does).
 #include "fracflow.h"
