@@ -254,6 +254,26 @@ def test_fp32_matrix_core_path_matches_generic_and_oracle(N, M, n_obs, localized
     assert np.abs(outs[0].astype(np.float64) - outs[1]).max() <= 2e-5 * inc
 
 
+def test_fused_run_is_bit_reproducible():
+    """The chain in front of the apply hands tiles from wave to wave and from workgroup to workgroup through flags (spdinv.hip:
+    sweeper, pivot wave, tile waves; the gain's workgroups taking block columns as they are published): every sum has a fixed
+    order, so repeated runs of one plan give the same bits (300 repeats at three shapes: csrc/diag/upd_repeat.py)."""
+    from historymatching_amd.update import UpdatePlan
+    from oracle import es
+
+    N, M, n_obs = 600, 4096, 160
+    rng = np.random.RandomState(11)
+    _, R12, decorr = es.obs_error_model(n_obs // 4, 4)
+    p = UpdatePlan(N, N, M, n_obs, dtype=32)
+    p.set_inputs(rng.randn(N, M), rng.rand(N, n_obs), rng.rand(n_obs), rng.randn(N, n_obs) @ R12.T, decorr)
+    p.run_local()
+    ref = p.output().copy()
+    for _ in range(25):
+        p.run_local()
+        assert np.array_equal(p.output(), ref)
+    p.close()
+
+
 def test_gain_chain_variants_agree():
     """The fused run's chain in front of the apply in its forms -- explicit inverse + product (ldl_gain 0), factorisation and gain as
     two kernels (2), both in one launch with the gain's forward sweep running behind the factorisation (1, default) -- on the same
