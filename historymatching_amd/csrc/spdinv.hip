@@ -827,8 +827,8 @@ __global__ __launch_bounds__(1024, 4) void k_local_analysis_mfma(int M, int n_ob
                 if (R < nt) {
                     const int row = 16 * R + lrow;
                     if (row < nloc && col < nloc) {
-                        const int a = jj[row], b = jj[col];
-                        v = cv[row] * (0.5 * (G[(size_t)a * n_obs + b] + G[(size_t)b * n_obs + a])) * cv[col];
+                        const int a = jj[row], b = jj[col];  // row >= col of a lower tile and the selection keeps the order: a >= b
+                        v = cv[row] * G[(size_t)max(a, b) * n_obs + min(a, b)] * cv[col];  // the lower triangle of the Gram matrix only
                     }
                     if (row == col) v += ridge;
                 } else if (lrow == 0 && C < nt && col < nloc) {
