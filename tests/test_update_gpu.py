@@ -223,7 +223,7 @@ def test_es_mda_device_resident_matches_host_driver(dtype, tol):
 
 @pytest.mark.parametrize("N,M,n_obs,localized", [(1000, 4096, 160, False), (999, 4100, 160, False), (130, 1024, 64, True),
                                                   (64, 512, 48, False), (200, 2048, 32, False), (300, 1024, 96, False),
-                                                  (257, 1536, 128, False)])
+                                                  (257, 1536, 128, False), (5, 256, 32, False), (17, 320, 160, False)])
 def test_fp32_matrix_core_path_matches_generic_and_oracle(N, M, n_obs, localized):
     """fp32 update: v_mfma_f32_32x32x2 kernels (default) vs the generic VALU GEMMs (use_mfma=0) vs the fp64 oracle.
     Shapes cover exact tiles, ragged N / M, an n_obs that is not a multiple of 32 (falls back), and 2, 6, 8 and 10 block columns
