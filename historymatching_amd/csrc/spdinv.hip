@@ -265,7 +265,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_spd_inverse(const double* __rest
 template <int SLOTS, int NW>
 __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, int n, double* __restrict__ F, int* __restrict__ flag,
                                                 const double* __restrict__ add, double add_scale,
-                                                const double* __restrict__ rank1, double rank1_scale, int* __restrict__ colflag) {
+                                                const double* __restrict__ rank1, double rank1_scale, int* __restrict__ colflag,
+                                                double ridge = 0.0) {
     // Synchronisation: the chain  pivot sweep -> W^T = P U^T and update of the next pivot tile -> next sweep  is all that is serial
     // per panel, so the sweeper (wave 0, alone on SIMD 0: waves 4, 8, 12 only fix the wave placement and leave at once) and the
     // owner of the next pivot tile talk through two LDS flags and never meet the others at a barrier; the twelve tile waves
@@ -328,7 +329,8 @@ __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, in
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[s][r] = tR[s] >= 0 ? gv[s][r] + add_scale * av[s][r] : 0.0;
+            for (int r = 0; r < 4; ++r)
+                acc[s][r] = tR[s] >= 0 ? gv[s][r] + add_scale * av[s][r] + (tR[s] == tC[s] && g.lq + 4 * r == g.lc ? ridge : 0.0) : 0.0;
     }
     if (tid == 0) { *fDg = 0; *fP = 0; *bar = 0; *colcnt = 0; *fDp = 0; *fU = 0; }
     int bad = 0, cur = 0;
@@ -729,9 +731,9 @@ template <int SLOTS, int NW, int NT>
 __global__ __launch_bounds__(64 * NW, 4) void k_ldl_chain(const double* __restrict__ G, int n, double* __restrict__ F, int* __restrict__ flag,
                                                           const double* __restrict__ add, double add_scale,
                                                           const double* __restrict__ rank1, double rank1_scale, int* __restrict__ colflag,
-                                                          const double* __restrict__ X, int N, float* __restrict__ A_T) {
+                                                          const double* __restrict__ X, int N, float* __restrict__ A_T, double ridge) {
     if (blockIdx.x == 0) {
-        ldl_factor_body<SLOTS, NW>(G, n, F, flag, add, add_scale, rank1, rank1_scale, colflag);
+        ldl_factor_body<SLOTS, NW>(G, n, F, flag, add, add_scale, rank1, rank1_scale, colflag, ridge);
     } else {
         if (threadIdx.x >= 256) return;
         ldl_gain_body<NT>(F, n, X, N, A_T, blockIdx.x - 1, colflag, flag);
@@ -1030,10 +1032,10 @@ int ldl_gain_mfma(hipStream_t s, const double* F, int n, const double* X, int N,
     return 0;
 }
 
-// Both in one launch (k_ldl_chain).  colflag: one int of device memory that is ZERO when the kernel starts (the caller resets it on the
-// same stream).  Returns -1 where the pair above applies but this form does not (n = 16 nt with nt outside [2, 11]).
+// Both in one launch (k_ldl_chain), of G - rank1_scale rank1 rank1^T + add_scale add + ridge I.  colflag: one int of device memory that is
+// ZERO when the kernel starts (the caller resets it on the same stream).  Returns -1 where the pair above applies but this form does not (n = 16 nt with nt outside [2, 11]).
 int ldl_chain_mfma(hipStream_t s, const double* G, int n, double* F, int* flag, const double* add, double add_scale, const double* rank1,
-                   double rank1_scale, int* colflag, const double* X, int N, float* A_T) {
+                   double rank1_scale, int* colflag, const double* X, int N, float* A_T, double ridge) {
     if (n % 16 != 0 || n < 32 || n > 176 || N < 1) return -1;
     const int nt = n / 16, ntiles = nt * (nt + 1) / 2;
     const size_t lds_f = ((size_t)4 * n * 17 + 5 * 16 * 17) * 8 + 32, lds_g = (size_t)ntiles * 16 * 17 * 8 + 2 * 4 * 64 * 8;
@@ -1042,7 +1044,7 @@ int ldl_chain_mfma(hipStream_t s, const double* G, int n, double* F, int* flag, 
 #define L(S, NT)                                                                                                                  \
     case NT:                                                                                                                      \
         HM_HIP(hipFuncSetAttribute((const void*)k_ldl_chain<S, 16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
-        hipLaunchKernelGGL((k_ldl_chain<S, 16, NT>), grid, block, lds, s, G, n, F, flag, add, add_scale, rank1, rank1_scale, colflag, X, N, A_T); \
+        hipLaunchKernelGGL((k_ldl_chain<S, 16, NT>), grid, block, lds, s, G, n, F, flag, add, add_scale, rank1, rank1_scale, colflag, X, N, A_T, ridge); \
         break
     switch (nt) { L(2, 2); L(2, 3); L(2, 4); L(2, 5); L(2, 6); L(5, 7); L(5, 8); L(5, 9); L(5, 10); L(6, 11); default: return -1; }
 #undef L

@@ -525,7 +525,7 @@ int ldl_gain_mfma(hipStream_t s, const double* F, int n, const double* X, int N,
 int center_gram_mfma(hipStream_t s, const float* obs_ens, const float* perturbs, const float* obs, int rows, int n_obs, double* YD,
                      float* Yc32, double* dmean, double* G, int* zero_me);  // dgemm_mfma.hip
 int ldl_chain_mfma(hipStream_t s, const double* G, int n, double* F, int* flag, const double* add, double add_scale, const double* rank1,
-                   double rank1_scale, int* colflag, const double* X, int N, float* A_T);  // spdinv.hip
+                   double rank1_scale, int* colflag, const double* X, int N, float* A_T, double ridge = 0.0);  // spdinv.hip
 // dgemm_mfma.hip
 int dgemm_mfma(hipStream_t s, bool transA, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C,
                int ldc, int ksplit, float* C32, int rows32, float* C32T);
@@ -829,8 +829,19 @@ static int upd_phase(hm_upd* u, int phase) {
         if constexpr (std::is_same<T, float>::value) {
             if (fast2) {
                 const double* Dd = (const double*)u->SD.p + n_small;
-                if ((rc = invert_C(s, G, no, (double)(u->N_total - 1), (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p, true))) return rc;
-                if ((rc = dgemm_mfma(s, false, nl, no, no, Dd, no, (const double*)u->Cinv.p, no, nullptr, no, 1, nullptr, 0, A_T))) return rc;
+                // T1 = D C^-1 with C = G + (N-1) I: factorisation and gain in one launch (as in hm_upd_run; every rank factorises
+                // the all-reduced G itself and solves for its own members), or inverse + product where that does not apply
+                int r2 = -1;
+                if (g_use_mfma_inverse && u->ldl_gain) {
+                    HM_HIP(hipMemsetAsync((int*)u->flags.p + 2, 0, 4, s));
+                    r2 = ldl_chain_mfma(s, G, no, (double*)u->Cinv.p, (int*)u->flags.p, nullptr, 0.0, nullptr, 0.0, (int*)u->flags.p + 2, Dd, nl, A_T,
+                                        (double)(u->N_total - 1));
+                    if (r2 > 0) return r2;
+                }
+                if (r2 < 0) {
+                    if ((rc = invert_C(s, G, no, (double)(u->N_total - 1), (double*)u->Cinv.p, (double*)u->Cinv.p + (size_t)no * no, (int*)u->flags.p, true))) return rc;
+                    if ((rc = dgemm_mfma(s, false, nl, no, no, Dd, no, (const double*)u->Cinv.p, no, nullptr, no, 1, nullptr, 0, A_T))) return rc;
+                }
                 if ((rc = mfma_apply_lds(s, nl, M, no, E, A_T, Gxt, Eo)) != 0) return rc > 0 ? rc : 2;
                 return u->t_upd.end(s);
             }
