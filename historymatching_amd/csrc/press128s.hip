@@ -164,6 +164,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
     // B-operand layout, before the panel's first barrier instead of after it, as in spdinv.hip's factorisation -- with the two
     // workgroup barriers per panel kept: 12.4 ms instead of 11.45.  The barriers tie the sweeper to the tile waves either way;
     // taking them apart needs the flag / counter synchronisation of spdinv.hip in this kernel too.)
+    // (Round 2, later, both measured with tests/tools/press_time_only.py at 1000 members, 11.45 ms as it stands:
+    //   * the flag / counter synchronisation itself -- sweeper and a pivot wave coupled by LDS flags, the six tile waves on a counter
+    //     barrier of their own, P double buffered, the pre-pivot tile handed over through the free P slot: correct, 13.1 ms.  With two
+    //     workgroups per CU the matrix pipes of SIMDs 1..3 are 86 % busy as it is; off the barriers the tile waves (5.9 k busy cycles per
+    //     panel + 2.4 k at their own barrier) become the chain instead of the sweep (3.5 k) + pivot update (0.8 k).
+    //   * the forward substitution's mat-vec G_{i-1} y_{i-1} moved off the chain, onto the second service wave, from the G_{i-1} the
+    //     tile waves stored (one tile row or five tiles per panel; sums as LDS adds without return; tiles prefetched a panel ahead):
+    //     correct, 12.3-13.2 ms in four forms, 10.8 ms with the wave's work compiled out -- every form made the wave the last at the
+    //     panel's barriers (LDS round trips of ~300 cycles under the operand traffic, L2 latency of 1-2 us under the launch's stores).)
     const bool service = (w & 3) == 0;
     const bool sweeper = w == 0;
     const int c = service ? 0 : (w >> 2) * 3 + (w & 3) - 1;  // compute wave index
