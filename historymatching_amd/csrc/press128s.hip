@@ -69,16 +69,11 @@ struct __attribute__((aligned(16))) SLds {
     double W[NB][17];     // U P
     double P[16][17];     // inverse of the diagonal tile
     double Dg[16][17];    // diagonal tile handed to the sweeper
-    // the block's vectors as they lie in memory (written by LDS-DMA one block ahead): coupling to block i-1 = TX row i, coupling to
-    // block i+1 = TX row i+1, TY row i (NB+1 faces), the right-hand side
-    __attribute__((aligned(16))) double ev[NB];
-    __attribute__((aligned(16))) double evn[NB];
-    __attribute__((aligned(16))) double tyv[NB + 8];
-    __attribute__((aligned(16))) double qv[NB];
-    double yprev[NB], ycur[NB];
+    double ev[NB], dgv[NB], tyv[NB + 8], yprev[NB], ycur[NB];
     int flag;             // token of the diagonal tile currently in Dg
     int pad[3];
     // mat-vec scratch aliases the panel buffers (idle during the substitution mat-vecs)
+    __device__ double* transpose_buf(int c) { return &U[0][0][0] + c * (16 * 17); }  // [NC][16][17]
     __device__ double* partial(int c) { return &W[0][0] + c * NB; }                  // [NC][NB]
 };
 
@@ -102,64 +97,34 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Sum of x over the four lanes of one lc (lanes lc, lc + 16, lc + 32, lc + 48), in all four, without LDS: the two row-swap
-// instructions of gfx950 put rows (0,2 | 1,3) and halves (lower | upper) side by side in two registers.
-__device__ __forceinline__ double sum_over_lq(double x) {
-    {
-        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
-        x = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-    }
-    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-
-// p[r], r = 0..3: a lane's terms of four different sums over the 16 lanes of its row.  Returns, in the lanes with lc & 3 == r, the
-// sum of p[r] over the row: two exchange steps that halve the number of registers in flight (each lane keeps the half its lc bit
-// selects and hands the other half to its partner), then two rotations by 4 and 8 lanes.  21 register-to-register instructions
-// against 48 for four separate butterflies.
-__device__ __forceinline__ double row_sums4(const double (&p)[4], int lc) {
-    const bool b0 = lc & 1, b1 = lc & 2;
-    double k0 = b0 ? p[1] : p[0], s0 = b0 ? p[0] : p[1];
-    double k1 = b0 ? p[3] : p[2], s1 = b0 ? p[2] : p[3];
-    k0 += __builtin_amdgcn_update_dpp(0.0, s0, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
-    k1 += __builtin_amdgcn_update_dpp(0.0, s1, 0xB1, 0xf, 0xf, true);
-    double u = b1 ? k1 : k0;
-    const double s = b1 ? k0 : k1;
-    u += __builtin_amdgcn_update_dpp(0.0, s, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-    u += __builtin_amdgcn_update_dpp(0.0, u, 0x124, 0xf, 0xf, true);  // row_ror:4
-    u += __builtin_amdgcn_update_dpp(0.0, u, 0x128, 0xf, 0xf, true);  // row_ror:8
-    return u;
-}
-
 // Partial products of t = A v for the tiles of one compute wave (A symmetric, lower tiles stored):
-//   tile (R, C) gives t[16C + j] += sum_i tile[i][j] v[16R + i]      (a lane's four rows, then the four lanes of one column)
-//   and, if R != C,  t[16R + i] += sum_j tile[i][j] v[16C + j]      (the 16 lanes of a row)
-// Both sums are finished in registers and leave the wave as one LDS add without return into its private vector, which the
-// service threads sum over the compute waves after a barrier.  (Until round 2 the second sum went through a transposed copy of
-// the tile in LDS and both through 4-way colliding LDS adds: three LDS round trips of ~300 cycles per tile under the other
-// waves' operand traffic, 7 k cycles per block in the forward substitution.)
+//   tile (R, C) gives t[16C + j] += sum_i tile[i][j] v[16R + i]      (column-wise: no cross-lane reduction)
+//   and, if R != C,  t[16R + i] += sum_j tile[i][j] v[16C + j]      (the same on the tile transposed through LDS)
+// Lanes differing in lq hold partial sums of the same output: they are combined by LDS atomic adds into the wave's
+// private vector, which the service threads sum over the compute waves after a barrier.
 template <int TPW>
 __device__ __forceinline__ void matvec_partial(const d4 (&acc)[TPW], const int (&tR)[TPW], const int (&tC)[TPW],
-                                               const double* __restrict__ v, double* __restrict__ tw, const SGeo& g) {
+                                               const double* __restrict__ v, double* __restrict__ tw, double* __restrict__ tb,
+                                               const SGeo& g) {
     tw[g.lane] = 0.0;
     tw[64 + g.lane] = 0.0;
+    wave_lds_fence();
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
         const int R = opaque(tR[s]), C = opaque(tC[s]);
         double sc = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc = fma(acc[s][r], v[16 * R + g.lq + 4 * r], sc);
-        sc = sum_over_lq(sc);
-        if (g.lq == 0) atomicAdd(&tw[16 * C + g.lc], sc);
+        atomicAdd(&tw[16 * C + g.lc], sc);
         if (R != C) {
-            const double vc = v[16 * C + g.lc];
-            double pr[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pr[r] = acc[s][r] * vc;
-            const double sr = row_sums4(pr, g.lc);
-            if (g.lc < 4) atomicAdd(&tw[16 * R + g.lq + 4 * g.lc], sr);
+            for (int r = 0; r < 4; ++r) tb[(g.lq + 4 * r) * 17 + g.lc] = acc[s][r];
+            wave_lds_fence();
+            double sr = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sr = fma(tb[g.lc * 17 + g.lq + 4 * r], v[16 * C + g.lq + 4 * r], sr);
+            atomicAdd(&tw[16 * R + g.lc], sr);
+            wave_lds_fence();
         }
     }
 }
@@ -207,7 +172,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
     //   * the forward substitution's mat-vec G_{i-1} y_{i-1} moved off the chain, onto the second service wave, from the G_{i-1} the
     //     tile waves stored (one tile row or five tiles per panel; sums as LDS adds without return; tiles prefetched a panel ahead):
     //     correct, 12.3-13.2 ms in four forms, 10.8 ms with the wave's work compiled out -- every form made the wave the last at the
-    //     panel's barriers (LDS round trips of ~300 cycles under the operand traffic, L2 latency of 1-2 us under the launch's stores).)
+    //     panel's barriers (LDS round trips of ~300 cycles under the operand traffic, L2 latency of 1-2 us under the launch's stores).
+    //   * the block prologue on its own: the mat-vec's two cross-lane sums finished in registers (v_permlane16/32_swap over lq, a
+    //     register-halving DPP exchange over lc) instead of through a transposed LDS copy and colliding LDS adds: correct, 11.67 ms;
+    //     the next block's vectors brought by LDS-DMA during the panel loop instead of by the service threads' register prefetch
+    //     (which the register allocator spills, waiting for the loads where they are issued): correct, 11.53 ms.  With two workgroups
+    //     per CU one workgroup's prologue runs under the other's panels; neither change moves the launch.)
     const bool service = (w & 3) == 0;
     const bool sweeper = w == 0;
     const int c = service ? 0 : (w >> 2) * 3 + (w & 3) - 1;  // compute wave index
@@ -245,39 +215,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
 
     d4 acc[TPW];
     int bad = 0, cur = 0;
-    // The vectors of block i+1 come by LDS-DMA while block i's panels run, issued by the second service wave once block i's last
-    // reader of the four arrays has passed.  (Until round 2 the service threads fetched them into registers one block ahead; the
-    // registers did not survive the panel loop's pressure, and the spill code waited for the loads right where they were issued --
-    // an HBM round trip per block with every tile wave at the prologue's barrier behind it.)
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    // (One block of inline assembly: between DMAs issued through the builtin the compiler waits for vmcnt(0) -- an LDS write it cannot
-    // tell apart from the next one's -- and again before the next workgroup barrier, and between separate statements it reloads spilled
-    // pointers with a full wait as well: HBM round trips in the wave's first slot of the block, and a late arrival at the panel's
-    // barrier.  The wave waits for its DMAs itself, at the top of the next block.)
-    auto fetch_vectors = [&](int in) {  // one wave; lane l brings bytes 16 l .. 16 l + 15 of each row
-        const double* p_ev = TX + in * NB + 2 * g.lane;
-        const double* p_evn = TX + (in + 1) * NB + 2 * g.lane;
-        const double* p_ty = TY + in * (NB + 1) + 2 * g.lane;
-        const float* p_tyl = (const float*)(TY + in * (NB + 1) + NB) + (g.lane & 1);  // face NB of the row: a dword each from lanes 0, 1
-        const double* p_q = FACTOR ? p_ev : q + in * NB + 2 * g.lane;
-        const unsigned a_ev = (unsigned)(size_t)(lds_ptr)L.ev, a_evn = (unsigned)(size_t)(lds_ptr)L.evn;
-        const unsigned a_ty = (unsigned)(size_t)(lds_ptr)L.tyv, a_tyl = (unsigned)(size_t)(lds_ptr)(L.tyv + NB);
-        const unsigned a_q = (unsigned)(size_t)(lds_ptr)L.qv;
-        unsigned long long saved_exec;
-        asm volatile(
-            "s_mov_b32 m0, %[a_ev]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[p_ev], off\n\t"
-            "s_mov_b32 m0, %[a_evn]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[p_evn], off\n\t"
-            "s_mov_b32 m0, %[a_ty]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[p_ty], off\n\t"
-            "s_mov_b32 m0, %[a_q]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[p_q], off\n\t"
-            "s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 m0, %[a_tyl]\n\ts_nop 0\n\t"
-            "global_load_lds_dword %[p_tyl], off\n\ts_mov_b64 exec, %[sv]"
-            : [sv] "=&s"(saved_exec)
-            : [a_ev] "s"(a_ev), [a_evn] "s"(a_evn), [a_ty] "s"(a_ty), [a_q] "s"(a_q), [a_tyl] "s"(a_tyl), [p_ev] "v"(p_ev),
-              [p_evn] "v"(p_evn), [p_ty] "v"(p_ty), [p_q] "v"(p_q), [p_tyl] "v"(p_tyl)
-            : "memory");
-    };
-    double q_cur = 0.0;
-    if (w == 4) fetch_vectors(0);
+    // vectors of block i+1 are fetched by the service threads one block ahead
+    double pf_y1 = 0.0, pf_y2 = 0.0, pf_x1 = 0.0, pf_x2 = 0.0, pf_q = 0.0, q_cur = 0.0;
+    if (j < NB) {
+        pf_y1 = TY[j]; pf_y2 = TY[j + 1]; pf_x1 = TX[j]; pf_x2 = TX[NB + j]; pf_q = FACTOR ? 0.0 : q[j];
+    }
 
     // ---- one rank-16 panel --------------------------------------------------------------------------------------
     auto update_tile = [&](int s, int Cp, double (*U)[17]) {
@@ -321,13 +263,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
     };
 
     for (int i = 0; i < Nx; ++i) {
-        if (w == 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this block's vectors have landed
+        if (j < NB) {
+            double dg = pf_y1 + pf_y2 + pf_x1 + pf_x2;
+            if (i == 0 && j == 0) dg += pin;
+            L.dgv[j] = dg;
+            L.tyv[j] = pf_y1;
+            if (j == NB - 1) L.tyv[NB] = pf_y2;
+            L.ev[j] = pf_x1;
+            q_cur = pf_q;
+        }
         __syncthreads();
-        if (!FACTOR && j < NB) q_cur = L.qv[j];
         PROF(6);
         if (i > 0) {
             if constexpr (!FACTOR) {
-                if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), g);
+                if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
                 __syncthreads();
                 if (j < NB) L.ycur[j] = q_cur + L.ev[j] * matvec_total<NC>(L, j);
             }
@@ -345,6 +294,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
 #pragma unroll
             for (int s = 0; s < TPW; ++s) acc[s] = d4{0.0, 0.0, 0.0, 0.0};
         }
+        if (j < NB && i + 1 < Nx) {  // next block's vectors
+            const int in = i + 1;
+            pf_y1 = TY[in * (NB + 1) + j]; pf_y2 = TY[in * (NB + 1) + j + 1];
+            pf_x1 = TX[in * NB + j]; pf_x2 = TX[(in + 1) * NB + j];
+            pf_q = FACTOR ? 0.0 : q[in * NB + j];
+        }
         __syncthreads();  // the mat-vec scratch (aliases U, W) is free again
         PROF(7);
         if (!service) {
@@ -358,10 +313,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
                     for (int r = 0; r < 4; ++r) {
                         const int lrow = g.lq + 4 * r, row = 16 * R + lrow, col = 16 * C + g.lc;
                         double add = 0.0;
-                        if (g.lc == lrow) {
-                            add = L.tyv[row] + L.tyv[row + 1] + L.ev[row] + L.evn[row];
-                            if (i == 0 && row == 0) add += pin;
-                        }
+                        if (g.lc == lrow) add = L.dgv[row];
                         else if (g.lc == lrow + 1) add = -L.tyv[col];
                         else if (lrow == g.lc + 1) add = -L.tyv[row];
                         acc[s][r] += add;
@@ -375,8 +327,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
             sweep_published(8 * i + 1);
         }
         PROF(8);
-        __syncthreads();  // U_0, P_0 visible; the block's vectors have been read for the last time
-        if (w == 4 && i + 1 < Nx) fetch_vectors(i + 1);
+        __syncthreads();  // U_0, P_0 visible
         PROF(9);
         for (int Cp = 0; Cp < 8; ++Cp) {
             double (*U)[17] = L.U[cur];
@@ -499,7 +450,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_press128s(FwdParam
             L.yprev[j] = v;
         }
         __syncthreads();
-        if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), g);
+        if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
         __syncthreads();
         if (j < NB) {
             const double t = matvec_total<NC>(L, j);
@@ -579,7 +530,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_coarse_solve(FwdParams p, const 
     for (int i = 1; i < Nx; ++i) {
         if (!service) load_G(i - 1);
         __syncthreads();
-        if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), g);
+        if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
         __syncthreads();
         if (j < NB) {
             const double v = b[i * NB + j] + TX[i * NB + j] * matvec_total<NC>(L, j);
@@ -591,7 +542,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_coarse_solve(FwdParams p, const 
         if (!service) load_G(i);
         if (j < NB && i < Nx - 1) L.yprev[j] = yv[i * NB + j] + TX[(i + 1) * NB + j] * L.ycur[j];
         __syncthreads();
-        if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), g);
+        if (!service) matvec_partial<TPW>(acc, tR, tC, L.yprev, L.partial(c), L.transpose_buf(c), g);
         __syncthreads();
         if (j < NB) {
             const double t = matvec_total<NC>(L, j);
