@@ -41,11 +41,19 @@ struct hm_ctx {
     // two pinned staging buffers + events of hm_d2h_large (allocated on first use)
     void* pin[2] = {nullptr, nullptr};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    // copy stream + event of hm_d2h_rows (results leaving the device while the launch stream computes on)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_after = nullptr;
 };
 
 // Device -> pageable host copy of a large buffer: chunks go to pinned staging buffers at PCIe rate while worker threads
 // move the previous chunk into the destination (first-touch page faults included) in parallel.  Synchronous.
 int hm_d2h_large(hm_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
+
+// The same for `rows` pieces of `width` bytes at a pitch (one time index of every member's history), on the context's COPY
+// stream: the copy starts once everything enqueued on the launch stream so far has finished and runs beside whatever is enqueued
+// there afterwards.  Synchronous for the host.
+int hm_d2h_rows(hm_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_device, size_t src_pitch, size_t width, size_t rows);
 
 // RAII-less device buffer bookkeeping (plans free what they allocate).
 struct DevBuf {

@@ -41,6 +41,8 @@ extern "C" void hm_destroy(hm_ctx* ctx) {
         if (ctx->pin[b]) (void)hipHostFree(ctx->pin[b]);
         if (ctx->pin_ev[b]) (void)hipEventDestroy(ctx->pin_ev[b]);
     }
+    if (ctx->copy_after) (void)hipEventDestroy(ctx->copy_after);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -130,6 +132,46 @@ int hm_d2h_large(hm_ctx* ctx, void* dst_host, const void* src_device, size_t byt
         for (int t = 0; t < NTHREADS; ++t) {
             const size_t a = std::min(len, (size_t)t * slice), e = std::min(len, a + slice);
             workers[t] = std::thread([=]() { if (e > a) memcpy(dst + a, src + a, e - a); });
+        }
+        for (auto& wkr : workers) wkr.join();
+    }
+    return 0;
+}
+
+int hm_d2h_rows(hm_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_device, size_t src_pitch, size_t width, size_t rows) {
+    constexpr size_t CHUNK = (size_t)64 << 20;
+    constexpr int NTHREADS = 8;
+    if (!rows || !width) return 0;
+    HM_REQUIRE(width <= CHUNK, "hm_d2h_rows: a row of %zu bytes does not fit the staging buffer", width);
+    for (int b = 0; b < 2; ++b) {
+        if (!ctx->pin[b]) HM_HIP(hipHostMalloc(&ctx->pin[b], CHUNK, hipHostMallocDefault));
+        if (!ctx->pin_ev[b]) HM_HIP(hipEventCreateWithFlags(&ctx->pin_ev[b], hipEventDisableTiming));
+    }
+    if (!ctx->copy_stream) HM_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->copy_after) HM_HIP(hipEventCreateWithFlags(&ctx->copy_after, hipEventDisableTiming));
+    HM_HIP(hipEventRecord(ctx->copy_after, ctx->stream));
+    HM_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_after, 0));
+    const size_t per = CHUNK / width, nchunks = (rows + per - 1) / per;
+    auto issue = [&](size_t k) -> int {
+        const size_t r0 = k * per, nr = std::min(per, rows - r0);
+        HM_HIP(hipMemcpy2DAsync(ctx->pin[k & 1], width, (const char*)src_device + r0 * src_pitch, src_pitch, width, nr,
+                                hipMemcpyDeviceToHost, ctx->copy_stream));
+        HM_HIP(hipEventRecord(ctx->pin_ev[k & 1], ctx->copy_stream));
+        return 0;
+    };
+    int rc = issue(0);
+    if (rc) return rc;
+    for (size_t k = 0; k < nchunks; ++k) {
+        HM_HIP(hipEventSynchronize(ctx->pin_ev[k & 1]));
+        if (k + 1 < nchunks && (rc = issue(k + 1))) return rc;
+        const size_t r0 = k * per, nr = std::min(per, rows - r0);
+        const char* src = (const char*)ctx->pin[k & 1];
+        char* dst = (char*)dst_host + r0 * dst_pitch;
+        std::thread workers[NTHREADS];
+        const size_t slice = (nr + NTHREADS - 1) / NTHREADS;
+        for (int t = 0; t < NTHREADS; ++t) {
+            const size_t a = std::min(nr, (size_t)t * slice), e = std::min(nr, a + slice);
+            workers[t] = std::thread([=]() { for (size_t r = a; r < e; ++r) memcpy(dst + r * dst_pitch, src + r * width, width); });
         }
         for (auto& wkr : workers) wkr.join();
     }

@@ -352,6 +352,7 @@ __device__ __forceinline__ void ldl_factor_body(const double* __restrict__ G, in
             if (spins > (1 << 26)) { bad = 1; break; }  // a defect: flag it and go on rather than hang the GPU
         }
     };
+    (void)wait_for;  // (not every instantiation has a busy-waiting role)
     auto wait_quietly = [&](int* f, int token) {  // sweeper and pivot wave share a SIMD: the one that waits must not take issue slots
         for (int spins = 0; __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < token; ++spins) {
             if (spins > (1 << 24)) { bad = 1; break; }
