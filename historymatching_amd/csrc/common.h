@@ -52,8 +52,10 @@ int hm_d2h_large(hm_ctx* ctx, void* dst_host, const void* src_device, size_t byt
 
 // The same for `rows` pieces of `width` bytes at a pitch (one time index of every member's history), on the context's COPY
 // stream: the copy starts once everything enqueued on the launch stream so far has finished and runs beside whatever is enqueued
-// there afterwards.  Synchronous for the host.
-int hm_d2h_rows(hm_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_device, size_t src_pitch, size_t width, size_t rows);
+// there afterwards.  Synchronous for the host.  "So far" is the moment of the call, or of an earlier hm_copy_mark (marked = true).
+int hm_copy_mark(hm_ctx* ctx);
+int hm_d2h_rows(hm_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_device, size_t src_pitch, size_t width, size_t rows,
+                bool marked = false);
 
 // RAII-less device buffer bookkeeping (plans free what they allocate).
 struct DevBuf {

@@ -138,7 +138,15 @@ int hm_d2h_large(hm_ctx* ctx, void* dst_host, const void* src_device, size_t byt
     return 0;
 }
 
-int hm_d2h_rows(hm_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_device, size_t src_pitch, size_t width, size_t rows) {
+int hm_copy_mark(hm_ctx* ctx) {
+    if (!ctx->copy_stream) HM_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->copy_after) HM_HIP(hipEventCreateWithFlags(&ctx->copy_after, hipEventDisableTiming));
+    HM_HIP(hipEventRecord(ctx->copy_after, ctx->stream));
+    return 0;
+}
+
+int hm_d2h_rows(hm_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_device, size_t src_pitch, size_t width, size_t rows,
+                bool marked) {
     constexpr size_t CHUNK = (size_t)64 << 20;
     constexpr int NTHREADS = 8;
     if (!rows || !width) return 0;
@@ -147,9 +155,8 @@ int hm_d2h_rows(hm_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_d
         if (!ctx->pin[b]) HM_HIP(hipHostMalloc(&ctx->pin[b], CHUNK, hipHostMallocDefault));
         if (!ctx->pin_ev[b]) HM_HIP(hipEventCreateWithFlags(&ctx->pin_ev[b], hipEventDisableTiming));
     }
-    if (!ctx->copy_stream) HM_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    if (!ctx->copy_after) HM_HIP(hipEventCreateWithFlags(&ctx->copy_after, hipEventDisableTiming));
-    HM_HIP(hipEventRecord(ctx->copy_after, ctx->stream));
+    int rc = marked ? 0 : hm_copy_mark(ctx);
+    if (rc) return rc;
     HM_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_after, 0));
     const size_t per = CHUNK / width, nchunks = (rows + per - 1) / per;
     auto issue = [&](size_t k) -> int {
@@ -159,8 +166,7 @@ int hm_d2h_rows(hm_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_d
         HM_HIP(hipEventRecord(ctx->pin_ev[k & 1], ctx->copy_stream));
         return 0;
     };
-    int rc = issue(0);
-    if (rc) return rc;
+    if ((rc = issue(0))) return rc;
     for (size_t k = 0; k < nchunks; ++k) {
         HM_HIP(hipEventSynchronize(ctx->pin_ev[k & 1]));
         if (k + 1 < nchunks && (rc = issue(k + 1))) return rc;

@@ -14,6 +14,7 @@
 // NumPy does; FMAs appear only where written explicitly (inside the pressure solve, which is not a
 // bit-exact path).
 #include "fwd_dev.h"
+#include <chrono>
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -1057,6 +1058,44 @@ extern "C" void* hm_fwd_device_ptr(hm_fwd* f, const char* name) {
     return r.p;
 }
 
+extern "C" int hm_fwd_run_to_host(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member, hm_stats* stats) {
+    HM_REQUIRE(f, "hm_fwd_run_to_host: NULL plan");
+    const FwdParams& p = f->p;
+    // A large saturation history leaves the device as it is produced: time index k of every member is copied out on the copy
+    // stream while step k (which only reads it) runs on the launch stream.  At config 2 the 5.4 GB of history cost 0.13 s after
+    // the last step; 131 MB per step hide under the step's 25 ms.
+    const size_t row = (size_t)p.Nxy * f->esz;
+    const bool stream_out = f->keep_history && wsats_out && (size_t)p.N * (p.nTime + 1) * row >= ((size_t)256 << 20) && row <= ((size_t)64 << 20);
+    const bool trace = getenv("HM_TRACE_RUN_TO_HOST") != nullptr;  // phase times of this call on stderr
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const double t = now();
+        fprintf(stderr, "hm_fwd_run_to_host: %-28s %8.2f ms\n", what, t - t_prev);
+        t_prev = t;
+    };
+    int rc = 0;
+    if (stream_out) {
+        for (int k = 0; k <= p.nTime && !rc; ++k) {
+            long long stride;
+            const void* Sk = fwd_S_ptr(f, k, &stride);
+            rc = hm_copy_mark(f->ctx);  // time index k is complete here; step k, enqueued next, runs beside its copy
+            if (!rc && k < p.nTime) rc = hm_fwd_run(f, k, 1);
+            if (!rc) rc = hm_d2h_rows(f->ctx, (char*)wsats_out + (size_t)k * row, (size_t)(p.nTime + 1) * row, Sk, (size_t)stride * f->esz, row, (size_t)p.N, true);
+            if (trace && (k < 2 || k + 2 > p.nTime)) lap(k < p.nTime ? "step enqueued + a row out" : "last row out");
+        }
+        lap("steps + rows");
+    } else {
+        rc = hm_fwd_run(f, 0, p.nTime);
+    }
+    if (!rc) rc = hm_fwd_sync(f, stats);
+    lap("sync + statistics");
+    if (!rc) rc = hm_fwd_get_outputs(f, stream_out ? nullptr : wsats_out, prods_out, status_per_member);
+    lap("outputs");
+    return rc;
+}
+
 extern "C" int hm_forward_batched(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly, const void* perm,
                                   int perm_is_transformed, const void* wsat0, int nInj, const int* inj_ind,
                                   const double* inj_rates, int inj_rate_cols, int nPrd, const int* prd_ind,
@@ -1069,23 +1108,7 @@ extern "C" int hm_forward_batched(hm_ctx* ctx, int N, int Nx, int Ny, double Lx,
                            prd_rate_cols, dt, nTime, vw, vo, swc, sor, porosity, dtype, return_history, &f);
     if (rc) return rc;
     rc = hm_fwd_set_inputs(f, perm, perm_is_transformed, wsat0);
-    // A large saturation history leaves the device as it is produced: time index k of every member is copied out on the copy
-    // stream while step k (which only reads it) runs on the launch stream.  At config 2 the 5.4 GB of history cost 0.13 s after
-    // the last step; 131 MB per step hide under the step's 25 ms.
-    const size_t row = (size_t)Nx * Ny * (dtype == 64 ? 8 : 4);
-    const bool stream_out = return_history && wsats_out && !rc && (size_t)N * (nTime + 1) * row >= ((size_t)256 << 20) && row <= ((size_t)64 << 20);
-    if (stream_out) {
-        for (int k = 0; k <= nTime && !rc; ++k) {
-            long long stride;
-            const void* Sk = fwd_S_ptr(f, k, &stride);
-            if (k < nTime) rc = hm_fwd_run(f, k, 1);
-            if (!rc) rc = hm_d2h_rows(ctx, (char*)wsats_out + (size_t)k * row, (size_t)(nTime + 1) * row, Sk, (size_t)stride * f->esz, row, (size_t)N);
-        }
-    } else if (!rc) {
-        rc = hm_fwd_run(f, 0, nTime);
-    }
-    if (!rc) rc = hm_fwd_sync(f, stats);
-    if (!rc) rc = hm_fwd_get_outputs(f, stream_out ? nullptr : wsats_out, prods_out, status_per_member);
+    if (!rc) rc = hm_fwd_run_to_host(f, wsats_out, prods_out, status_per_member, stats);
     hm_fwd_destroy(f);
     return rc;
 }

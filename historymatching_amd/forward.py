@@ -103,6 +103,18 @@ class ForwardPlan:
         _lib.check(self.lib.hm_fwd_sync(self.h, C.byref(st)), "hm_fwd_sync")
         return st.asdict()
 
+    def run_to_host(self):
+        """All steps, then ``(wsats, prods, status, stats)`` on the host; a large saturation history is copied out time index
+        by time index while the later steps run (hm_fwd_run_to_host)."""
+        m = self.model
+        wsats = np.empty((self.N, self.nTime + 1, m.Nxy) if self.keep_history else (self.N, m.Nxy), dtype=self.ft)
+        prods = np.empty((self.N, self.nTime, m.nPrd), dtype=self.ft)
+        status = np.zeros(self.N, dtype=np.int32)
+        st = _lib.hm_stats()
+        _lib.check(self.lib.hm_fwd_run_to_host(self.h, _lib.ptr(wsats), _lib.ptr(prods), status.ctypes.data_as(C.POINTER(C.c_int)),
+                                               C.byref(st)), "hm_fwd_run_to_host")
+        return wsats, prods, status, st.asdict()
+
     def outputs(self, want_wsats=True):
         m = self.model
         wsats = None
@@ -182,9 +194,7 @@ def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True
             cache["sig"] = sig
         plan = cache["plan"]
         plan.set_inputs(perms, wsat0s, transformed=False)
-        plan.run()
-        model.last_stats = plan.sync()
-        wsats, prods, status = plan.outputs()
+        wsats, prods, status, model.last_stats = plan.run_to_host()
         if status.any():
             bad = np.flatnonzero(status)
             raise _lib.HmError(f"forward model failed for members {bad[:8].tolist()} (status {status[bad[:8]].tolist()}): "

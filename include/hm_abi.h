@@ -125,6 +125,10 @@ int  hm_fwd_run(hm_fwd* f, int first_step, int n_steps);           /* steps [fir
                                                                      * (grids beyond poll CG convergence on the host)        */
 int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
 int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member);     /* D2H */
+/* All nTime steps from the inputs set, then sync + outputs in one call -- what forward_model(perms) -> [wsats, prods]
+ * (HistoryMatch.py:383-387) needs.  From 256 MB of saturation history on, time index k of every member is copied to
+ * `wsats_out` on a copy stream while step k runs, so the PCIe transfer of the history hides under the run. */
+int  hm_fwd_run_to_host(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member, hm_stats* stats);
 /* Kernel selection (tests and diagnostics; 0/0 = the fastest applicable kernels).
  *   pressure  : 1 generic block elimination in LDS (any Ny <= 128) | at Ny = 128: 0 symmetric-tile MFMA solver (press128s),
  *               7 its 16-wave form | 9 Jacobi-CG (any grid; beyond 128 the default is two-level CG where
