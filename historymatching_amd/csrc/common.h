@@ -49,6 +49,7 @@ struct hm_ctx {
 // Device -> pageable host copy of a large buffer: chunks go to pinned staging buffers at PCIe rate while worker threads
 // move the previous chunk into the destination (first-touch page faults included) in parallel.  Synchronous.
 int hm_d2h_large(hm_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
+int hm_h2d_large(hm_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);  // the other way; ordered on the launch stream
 
 // The same for `rows` pieces of `width` bytes at a pitch (one time index of every member's history), on the context's COPY
 // stream: the copy starts once everything enqueued on the launch stream so far has finished and runs beside whatever is enqueued

@@ -102,16 +102,18 @@ void EvTimer::destroy() {
 }
 
 int hm_d2h_large(hm_ctx* ctx, void* dst_host, const void* src_device, size_t bytes) {
-    constexpr size_t CHUNK = (size_t)64 << 20;
+    constexpr size_t PIN = (size_t)64 << 20;
     constexpr int NTHREADS = 8;
-    if (bytes < 4 * CHUNK) {
+    if (bytes < ((size_t)32 << 20)) {
         HM_HIP(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
         return 0;
     }
     for (int b = 0; b < 2; ++b) {
-        if (!ctx->pin[b]) HM_HIP(hipHostMalloc(&ctx->pin[b], CHUNK, hipHostMallocDefault));
+        if (!ctx->pin[b]) HM_HIP(hipHostMalloc(&ctx->pin[b], PIN, hipHostMallocDefault));
         if (!ctx->pin_ev[b]) HM_HIP(hipEventCreateWithFlags(&ctx->pin_ev[b], hipEventDisableTiming));
     }
+    // pieces of an eighth of the buffer (4 .. 64 MB): a 131 MB ensemble is pipelined as well as a 5 GB history
+    const size_t CHUNK = std::min(PIN, std::max((size_t)4 << 20, ((bytes / 8) + 0xFFFFF) & ~(size_t)0xFFFFF));
     const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
     auto issue = [&](size_t k) -> int {
         const size_t off = k * CHUNK, len = std::min(CHUNK, bytes - off);
@@ -135,6 +137,41 @@ int hm_d2h_large(hm_ctx* ctx, void* dst_host, const void* src_device, size_t byt
         }
         for (auto& wkr : workers) wkr.join();
     }
+    return 0;
+}
+
+// Pageable host -> device copy of a large buffer, the mirror image of hm_d2h_large: worker threads fill one pinned buffer
+// while the other goes over PCIe.  Returns when the last piece has been enqueued and the staging buffers are free again;
+// ordered on the context's launch stream like the hipMemcpyAsync it replaces.
+int hm_h2d_large(hm_ctx* ctx, void* dst_device, const void* src_host, size_t bytes) {
+    constexpr size_t PIN = (size_t)64 << 20;
+    constexpr int NTHREADS = 8;
+    if (bytes < ((size_t)32 << 20)) {
+        HM_HIP(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+    }
+    for (int b = 0; b < 2; ++b) {
+        if (!ctx->pin[b]) HM_HIP(hipHostMalloc(&ctx->pin[b], PIN, hipHostMallocDefault));
+        if (!ctx->pin_ev[b]) HM_HIP(hipEventCreateWithFlags(&ctx->pin_ev[b], hipEventDisableTiming));
+    }
+    const size_t CHUNK = std::min(PIN, std::max((size_t)4 << 20, ((bytes / 8) + 0xFFFFF) & ~(size_t)0xFFFFF));
+    const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
+    for (size_t k = 0; k < nchunks; ++k) {
+        const size_t off = k * CHUNK, len = std::min(CHUNK, bytes - off);
+        if (k >= 2) HM_HIP(hipEventSynchronize(ctx->pin_ev[k & 1]));  // the piece that used this buffer has left it
+        char* pin = (char*)ctx->pin[k & 1];
+        const char* src = (const char*)src_host + off;
+        std::thread workers[NTHREADS];
+        const size_t slice = ((len / NTHREADS) + 4095) & ~(size_t)4095;
+        for (int t = 0; t < NTHREADS; ++t) {
+            const size_t a = std::min(len, (size_t)t * slice), e = std::min(len, a + slice);
+            workers[t] = std::thread([=]() { if (e > a) memcpy(pin + a, src + a, e - a); });
+        }
+        for (auto& wkr : workers) wkr.join();
+        HM_HIP(hipMemcpyAsync((char*)dst_device + off, pin, len, hipMemcpyHostToDevice, ctx->stream));
+        HM_HIP(hipEventRecord(ctx->pin_ev[k & 1], ctx->stream));
+    }
+    for (int b = 0; b < 2; ++b) HM_HIP(hipEventSynchronize(ctx->pin_ev[b]));
     return 0;
 }
 

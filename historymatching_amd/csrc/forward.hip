@@ -698,9 +698,11 @@ extern "C" int hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transf
     const FwdParams& p = f->p;
     size_t n = (size_t)p.N * p.Nxy;
     if (perm_is_transformed) {
-        HM_HIP(hipMemcpyAsync(f->K.p, perm, n * 8, hipMemcpyHostToDevice, s));
+        int rc = hm_h2d_large(f->ctx, f->K.p, perm, n * 8);
+        if (rc) return rc;
     } else {
-        HM_HIP(hipMemcpyAsync(f->perm_in.p, perm, n * 8, hipMemcpyHostToDevice, s));
+        int rc = hm_h2d_large(f->ctx, f->perm_in.p, perm, n * 8);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_perm_transform, dim3(2048), dim3(256), 0, s, (const double*)f->perm_in.p, (double*)f->K.p, (long long)n);
         HM_HIP(hipGetLastError());
     }
@@ -983,7 +985,8 @@ extern "C" int hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, i
         } else {
             long long stride;
             void* S = fwd_S_ptr(f, f->cur, &stride);
-            HM_HIP(hipMemcpy(wsats_out, S, (size_t)p.N * p.Nxy * f->esz, hipMemcpyDeviceToHost));
+            int rc = hm_d2h_large(f->ctx, wsats_out, S, (size_t)p.N * p.Nxy * f->esz);
+            if (rc) return rc;
         }
     }
     if (prods_out) HM_HIP(hipMemcpy(prods_out, f->prods.p, (size_t)p.N * p.nTime * p.nPrd * f->esz, hipMemcpyDeviceToHost));

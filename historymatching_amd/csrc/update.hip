@@ -698,7 +698,7 @@ extern "C" int hm_upd_set_inputs(hm_upd* u, const void* E, const void* obs_ens, 
     HM_HIP(hipSetDevice(u->ctx->device));
     hipStream_t s = u->ctx->stream;
     size_t e = u->esz, nl = u->N_local, no = u->n_obs, m = u->M;
-    if (E) HM_HIP(hipMemcpyAsync(u->E.p, E, nl * m * e, hipMemcpyHostToDevice, s));
+    if (E) { int rc = hm_h2d_large(u->ctx, u->E.p, E, nl * m * e); if (rc) return rc; }
     if (obs_ens) HM_HIP(hipMemcpyAsync(u->obs_ens.p, obs_ens, nl * no * e, hipMemcpyHostToDevice, s));
     if (obs) HM_HIP(hipMemcpyAsync(u->obs.p, obs, no * e, hipMemcpyHostToDevice, s));
     if (perturbs) HM_HIP(hipMemcpyAsync(u->perturbs.p, perturbs, nl * no * e, hipMemcpyHostToDevice, s));
@@ -1187,8 +1187,7 @@ extern "C" int hm_upd_get_output(hm_upd* u, void* E_out) {
     HM_REQUIRE(u && E_out, "hm_upd_get_output: NULL argument");
     HM_HIP(hipSetDevice(u->ctx->device));
     HM_HIP(hipStreamSynchronize(u->ctx->stream));
-    HM_HIP(hipMemcpy(E_out, u->E_out.p, (size_t)u->N_local * u->M * u->esz, hipMemcpyDeviceToHost));
-    return 0;
+    return hm_d2h_large(u->ctx, E_out, u->E_out.p, (size_t)u->N_local * u->M * u->esz);
 }
 
 extern "C" void* hm_upd_device_ptr(hm_upd* u, const char* name) {
