@@ -280,6 +280,7 @@ def main():
     ap.add_argument("--members", type=int, default=N_E, help="members per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-esmda", action="store_true", help="skip the 4-pass ES-MDA leg (config 3)")
+    ap.add_argument("--no-host-call", action="store_true", help="skip the PCIe-inclusive leg (the drop-in call with host arrays in and out)")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (N_e=4096 at 256x256 over the ranks)")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the two-stream leg (profiling runs: one kernel shape per name)")
     ap.add_argument("--config5", action="store_true", help="run the config-5 leg (N_e=1000 at 512x512, localised) also below 4 ranks")
@@ -370,6 +371,29 @@ def main():
                 hp.close()
         except Exception as e:
             two_streams = {"error": str(e)}
+
+    # The same workload through the drop-in call itself -- forward_model(perms) -> [wsats (N, 41, Nxy), prods] with host arrays in
+    # and the whole 5.4 GB saturation history out (HistoryMatch.py:383-387).  PCIe-inclusive; reported beside `value`, never as it.
+    host_call = None
+    if world == 1 and args.variant == 0 and args.members == N_E and not args.no_host_call:
+        try:
+            from historymatching_amd.forward import make_forward_model
+            fm = make_forward_model(model, DT, NTIME, return_history=True)
+            fm(perms)  # builds and keeps the device plan
+            best = 1e9
+            for _ in range(2):
+                t1 = time.perf_counter()
+                w_h, p_h = fm(perms)
+                best = min(best, time.perf_counter() - t1)
+            host_call = {"value": n_e * NTIME / best, "unit": "ensemble-steps/s", "wall_s": best, "device_s": model.last_stats["ms_total"] / 1e3,
+                         "bytes_in": int(perms.nbytes), "bytes_out": int(w_h.nbytes + p_h.nbytes),
+                         "producer_series_identical_to_device_resident_run": bool(np.array_equal(p_h, prods)),
+                         "how": "forward_model(perms) of the host mirror: host arrays in, saturation history of every member and step out "
+                                "(copied out time index by time index while the run goes on: hm_fwd_run_to_host)"}
+            fm.release()
+            del w_h, p_h, fm
+        except Exception as e:
+            host_call = {"error": str(e)}
 
     upd_sharded = c4 = None
     if world > 1 or comm.rccl is not None:  # every rank: the analysis step sharded over the ranks (outside the timed region of `value`)
@@ -468,7 +492,7 @@ def main():
                        "members_per_gpu": n_e, "grid": [NX, NY], "nTime": NTIME, "device": ctx.name(),
                        "kernel_variant": args.variant, "results_finite_and_status_ok": bool(ok),
                        "ranks": "one process per GPU, host channel for barriers/timing, RCCL from the library for the update's reductions (no PyTorch)"},
-            "roofline": roofline, "cpu_baseline": cpu, "two_streams": two_streams, "es_update": upd, "config4": c4, "config5": c5,
+            "roofline": roofline, "cpu_baseline": cpu, "two_streams": two_streams, "host_call": host_call, "es_update": upd, "config4": c4, "config5": c5,
             "device_ms": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
         }
         print(json.dumps(out))

@@ -211,5 +211,12 @@ def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True
         wsats, prods = forward_model(np.asarray(perm)[None, :], w0[None, :])
         return wsats[0], prods[0]
 
+    def release():
+        """Free the cached device plan (it is rebuilt by the next call)."""
+        if cache.get("plan") is not None:
+            cache["plan"].close()
+        cache["plan"], cache["sig"] = None, None
+
     forward_model.comp1 = comp1
+    forward_model.release = release
     return forward_model
