@@ -22,6 +22,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -395,16 +396,8 @@ def main():
         except Exception as e:
             host_call = {"error": str(e)}
 
-    upd_sharded = c4 = None
-    if world > 1 or comm.rccl is not None:  # every rank: the analysis step sharded over the ranks (outside the timed region of `value`)
-        upd_sharded = guarded(lambda: es_update_sharded_timing(local_rank, comm))
-    if not args.no_config4 and args.members == N_E:
-        c4 = guarded(lambda: config4_sharded(local_rank, comm))
-    c5 = None
-    if args.members == N_E and (args.config5 or (world >= 4 and not args.no_config4)):
-        c5 = guarded(lambda: config5_sharded(local_rank, comm))
-
-    if rank == 0:
+    def report(upd_sharded, c4, c5):
+        """Rank 0: the one JSON line, from the headline's statistics and whatever the later legs produced."""
         member_steps = n_e * NTIME * args.steps * world
         value = member_steps / elapsed
         # ---- roofline of the dominant kernel (HIP events recorded on the launch stream, inside the library)
@@ -495,7 +488,35 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "two_streams": two_streams, "host_call": host_call, "es_update": upd, "config4": c4, "config5": c5,
             "device_ms": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+
+    # The legs below run collectives between the ranks.  Should one of them hang, the headline -- measured and complete at this
+    # point -- is still reported: a watchdog prints the line without them and ends the process.
+    legs_done = threading.Event()
+    deadline = float(os.environ.get("HM_BENCH_LEG_DEADLINE", "600"))
+
+    def watchdog():
+        if legs_done.wait(deadline):
+            return
+        late = {"error": f"did not finish within {deadline:.0f} s (HM_BENCH_LEG_DEADLINE); the line was printed by the watchdog"}
+        if rank == 0:
+            report(late, late, late)
+        os._exit(0 if ok else 3)
+
+    if world > 1:
+        threading.Thread(target=watchdog, daemon=True).start()
+    upd_sharded = c4 = None
+    if world > 1 or comm.rccl is not None:  # every rank: the analysis step sharded over the ranks (outside the timed region of `value`)
+        upd_sharded = guarded(lambda: es_update_sharded_timing(local_rank, comm))
+    if not args.no_config4 and args.members == N_E:
+        c4 = guarded(lambda: config4_sharded(local_rank, comm))
+    c5 = None
+    if args.members == N_E and (args.config5 or (world >= 4 and not args.no_config4)):
+        c5 = guarded(lambda: config5_sharded(local_rank, comm))
+
+    legs_done.set()
+    if rank == 0:
+        report(upd_sharded, c4, c5)
     comm.barrier()
     comm.close()
     if not ok:
