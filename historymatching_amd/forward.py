@@ -211,6 +211,14 @@ def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True
         wsats, prods = forward_model(np.asarray(perm)[None, :], w0[None, :])
         return wsats[0], prods[0]
 
+    def comp1_batched(perms, wsat0=None):
+        """``utils.apply(comp1, perms[, wsat0s])`` in one device call: the list of per-member ``(wsats, prods)`` pairs the
+        notebook's ``forward_model`` transposes (HistoryMatch.py:383-387)."""
+        wsats, prods = forward_model(perms) if wsat0 is None else forward_model(perms, wsat0)
+        return list(zip(wsats, prods))
+
+    comp1.batched = comp1_batched
+
     def release():
         """Free the cached device plan (it is rebuilt by the next call)."""
         if cache.get("plan") is not None:

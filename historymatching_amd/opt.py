@@ -104,6 +104,16 @@ class NpvBatch:
 
     __del__ = close
 
+    def as_objective(self, make_params):
+        """A per-member objective ``obj(u)`` for ``utils.apply(obj, U)`` (Optimise.py:259, 441, 514, 655): ``make_params(u)`` gives
+        the member's model parameters (``dict(inj_xy=...)``, ``dict(inj_rates=...)`` ...).  ``apply`` finds the batched form on
+        it and values the whole ensemble of controls in one device run."""
+        def obj(u):
+            return float(self([make_params(u)])[0])
+
+        obj.batched = lambda U: list(self([make_params(u) for u in U]))
+        return obj
+
     def __call__(self, params_list, perms=None):
         m, nT = self.model, self.nTime
         N = len(params_list)
