@@ -8,6 +8,7 @@ call; multi-GPU runs shard contiguous member blocks over ranks (``historymatchin
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -103,13 +104,18 @@ class ForwardPlan:
         _lib.check(self.lib.hm_fwd_sync(self.h, C.byref(st)), "hm_fwd_sync")
         return st.asdict()
 
-    def run_to_host(self):
+    def run_to_host(self, out=None):
         """All steps, then ``(wsats, prods, status, stats)`` on the host; a large saturation history is copied out time index
-        by time index while the later steps run (hm_fwd_run_to_host)."""
+        by time index while the later steps run (hm_fwd_run_to_host).  ``out``: C-contiguous ``(wsats, prods, status)`` to fill
+        (slices of a larger ensemble's arrays along the member axis) instead of fresh arrays."""
         m = self.model
-        wsats = np.empty((self.N, self.nTime + 1, m.Nxy) if self.keep_history else (self.N, m.Nxy), dtype=self.ft)
-        prods = np.empty((self.N, self.nTime, m.nPrd), dtype=self.ft)
-        status = np.zeros(self.N, dtype=np.int32)
+        if out is None:
+            wsats = np.empty((self.N, self.nTime + 1, m.Nxy) if self.keep_history else (self.N, m.Nxy), dtype=self.ft)
+            prods = np.empty((self.N, self.nTime, m.nPrd), dtype=self.ft)
+            status = np.zeros(self.N, dtype=np.int32)
+        else:
+            wsats, prods, status = out
+            assert all(a.flags.c_contiguous and len(a) == self.N for a in out) and wsats.dtype == prods.dtype == self.ft
         st = _lib.hm_stats()
         _lib.check(self.lib.hm_fwd_run_to_host(self.h, _lib.ptr(wsats), _lib.ptr(prods), status.ctypes.data_as(C.POINTER(C.c_int)),
                                                C.byref(st)), "hm_fwd_run_to_host")
@@ -180,21 +186,62 @@ def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True
             raise ValueError(f"perms must have shape (N, {model.Nxy}), got {perms.shape}")
         if np.shape(wsat0s) != perms.shape:
             raise ValueError(f"wsat0s must have shape {perms.shape}, got {np.shape(wsat0s)}")
-        # The device plan (22 GB of buffers at N_e = 1000, 128 x 128) is kept between calls: creating and freeing it costs
-        # 0.25 s per call, a fifth of the run itself.  It is rebuilt when the ensemble size or the model's wells / rates /
+        # The device plans (22 GB of buffers at N_e = 1000, 128 x 128) are kept between calls: creating and freeing them costs
+        # 0.25 s per call, a fifth of the run itself.  They are rebuilt when the ensemble size or the model's wells / rates /
         # fluid / porosity change.
+        # A large ensemble on the 128 x 128 kernels runs as TWO member blocks on two streams, each driven by its own host
+        # thread: the pressure solve (matrix pipes, three SIMDs) of one block runs beside the saturation sweep (vector pipe) of
+        # the other and fills the partial last round of its launches -- 41.0 k against 39.3 k ensemble-steps/s at config 2
+        # (tests/tools/multi_stream_timing.py; three or more blocks are slower).  Members are independent: results are
+        # bit-identical to the one-block run.
+        N = len(perms)
+        blocks = 2 if (N >= 512 and model.Nx == 128 and model.Ny == 128) else 1
         inj_ind, inj, prd_ind, prd = model._wells(nTime)
-        sig = (len(perms), model.dtype, inj_ind.tobytes(), inj.tobytes(), prd_ind.tobytes(), prd.tobytes(), model.vw, model.vo, model.swc,
+        sig = (N, blocks, model.dtype, inj_ind.tobytes(), inj.tobytes(), prd_ind.tobytes(), prd.tobytes(), model.vw, model.vo, model.swc,
                model.sor, None if model.por is None else np.asarray(model.por, dtype=float).tobytes())
         if cache.get("sig") != sig:
-            if cache.get("plan") is not None:
-                cache["plan"].close()
-            cache["plan"], cache["sig"] = None, None
-            cache["plan"] = ForwardPlan(model, len(perms), dt, nTime, keep_history=return_history)
+            release()
+            bounds = np.linspace(0, N, blocks + 1).astype(int)
+            while len(cache.setdefault("ctxs", [])) < blocks - 1:  # the further blocks' own streams, kept for the closure's life
+                cache["ctxs"].append(_lib.Context(_lib.Context.get(model.device).device))
+            ctxs = [None] + cache["ctxs"][:blocks - 1]
+            cache["plans"] = [(ForwardPlan(model, hi - lo, dt, nTime, keep_history=return_history, ctx=c), lo, hi)
+                              for c, lo, hi in zip(ctxs, bounds[:-1], bounds[1:])]
             cache["sig"] = sig
-        plan = cache["plan"]
-        plan.set_inputs(perms, wsat0s, transformed=False)
-        wsats, prods, status, model.last_stats = plan.run_to_host()
+        ft = np.float64 if model.dtype == 64 else np.float32
+        wsats = np.empty((N, nTime + 1, model.Nxy) if return_history else (N, model.Nxy), dtype=ft)
+        prods = np.empty((N, nTime, model.nPrd), dtype=ft)
+        status = np.zeros(N, dtype=np.int32)
+        results = [None] * blocks
+
+        def run_block(b):
+            plan, lo, hi = cache["plans"][b]
+            try:
+                plan.set_inputs(perms[lo:hi], wsat0s[lo:hi], transformed=False)
+                results[b] = plan.run_to_host(out=(wsats[lo:hi], prods[lo:hi], status[lo:hi]))[3]
+            except BaseException as e:  # re-raised by the caller's thread
+                results[b] = e
+
+        workers = [threading.Thread(target=run_block, args=(b,)) for b in range(1, blocks)]
+        for t in workers:
+            t.start()
+        run_block(0)
+        for t in workers:
+            t.join()
+        for r in results:
+            if isinstance(r, BaseException):
+                raise r
+        # the blocks run side by side: device times are the longest block's, counts add up
+        st = dict(results[0])
+        for r in results[1:]:
+            for key, v in r.items():
+                if key.startswith("ms_"):
+                    st[key] = max(st[key], v)
+                elif key.startswith("mean_"):
+                    st[key] = (st[key] + v) / 2
+                elif isinstance(v, (int, float)):
+                    st[key] = st[key] + v
+        model.last_stats = st
         if status.any():
             bad = np.flatnonzero(status)
             raise _lib.HmError(f"forward model failed for members {bad[:8].tolist()} (status {status[bad[:8]].tolist()}): "
@@ -220,10 +267,10 @@ def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True
     comp1.batched = comp1_batched
 
     def release():
-        """Free the cached device plan (it is rebuilt by the next call)."""
-        if cache.get("plan") is not None:
-            cache["plan"].close()
-        cache["plan"], cache["sig"] = None, None
+        """Free the cached device plans (they are rebuilt by the next call)."""
+        for plan, _, _ in cache.get("plans", []):
+            plan.close()
+        cache["plans"], cache["sig"] = [], None
 
     forward_model.comp1 = comp1
     forward_model.release = release

@@ -298,6 +298,32 @@ def test_drop_in_call_streams_a_large_history_out_while_it_runs(n, N, nT):
         assert np.array_equal(w[:, 0], np.zeros_like(w0) if start is None else w0)
 
 
+def test_large_ensemble_runs_as_two_member_blocks_with_identical_results():
+    """forward_model on the 128 x 128 kernels splits an ensemble of 512 members or more into two blocks on two streams, one host
+    thread each (forward.make_forward_model); members are independent, so histories, producer series and member order equal the
+    one-block plan's bit for bit; the statistics cover both blocks."""
+    from historymatching_amd.forward import make_forward_model
+
+    n, N, nT = 128, 520, 3
+    _, gm = make_models(n, n)
+    x = perms(n, n, N, seed=29)
+    w0 = np.random.RandomState(7).uniform(0.0, 0.2, (N, n * n))
+    plan = _plan(gm, N, nTime=nT)
+    plan.set_inputs(x, w0, transformed=False)
+    plan.run()
+    st_ref = plan.sync()
+    w_ref, p_ref, status = plan.outputs()
+    plan.close()
+    assert not status.any()
+    fm = make_forward_model(gm, DT, nT)
+    for _ in range(2):  # the second call reuses both plans
+        w, p = fm(x, w0)
+        assert np.array_equal(w, w_ref) and np.array_equal(p, p_ref)
+    assert gm.last_stats["member_steps"] == st_ref["member_steps"] == N * nT
+    assert gm.last_stats["n_saturation_launches"] == 2 * nT and abs(gm.last_stats["mean_nts"] - st_ref["mean_nts"]) < 1.0
+    fm.release()
+
+
 def test_restart_from_member_states_and_order():
     """forward_model(perms, wsat0s): two zipped ensembles, member order preserved (HistoryMatch.py:1224-1227)."""
     from oracle.ressim import forward_model as oracle_forward
