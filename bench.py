@@ -390,7 +390,8 @@ def main():
                          "bytes_in": int(perms.nbytes), "bytes_out": int(w_h.nbytes + p_h.nbytes),
                          "producer_series_identical_to_device_resident_run": bool(np.array_equal(p_h, prods)),
                          "how": "forward_model(perms) of the host mirror: host arrays in, saturation history of every member and step out "
-                                "(copied out time index by time index while the run goes on: hm_fwd_run_to_host)"}
+                                "(copied out time index by time index while the run goes on: hm_fwd_run_to_host); as forward_model runs every ensemble of 512 members "
+                                "or more on these kernels: two member blocks on two streams, a host thread each"}
             fm.release()
             del w_h, p_h, fm
         except Exception as e:
