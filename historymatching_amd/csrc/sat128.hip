@@ -32,6 +32,8 @@
 // Neighbour flags in LDS instead of the two workgroup barriers per sub-step (a wave exchanges fw only with the bands above and
 // below its own) are bit-identical as well and slower: 14.3 ms, with or without s_sleep in the polls -- a wave at s_barrier takes
 // no issue slots from the wave it shares its SIMD with, a polling one does.
+// The 11 scratch instructions left in the sub-step loop (7 spilled doubles reloaded at the start of phase B) are not what bounds it
+// either: built with `-mllvm -amdgpu-use-amdgpu-trackers=1` the loop has 5 and the launch takes 14.05 ms instead of 13.92.
 //
 // Compiled with -ffp-contract=off (no FMA contraction: every product and sum is rounded separately, as NumPy does).
 #include "fracflow.h"
