@@ -649,6 +649,7 @@ extern "C" void hm_fwd_destroy(hm_fwd* f) {
                       &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells, &f->cg_r, &f->cg_p, &f->n_cg,
                       &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->tl_z1, &f->tl_dinv, &f->tl_parts, &f->team_mem, &f->Ky};
     for (DevBuf* b : bufs) hm_dev_free(*b);
+    hm_nd_free(f->nd);
     f->t_total.destroy(); f->t_press.destroy(); f->t_sat.destroy();
     delete f;
 }
@@ -829,7 +830,8 @@ static int launch_pressure(hm_fwd* f, int k) {
         }
         if (pv != 9 && f->cg_precond == 0 && pressure_two_level_applies(p)) done = launch_pressure_two_level(f, S, stride, k);
         else done = launch_pressure_pcg(f, S, stride, k);
-    } else if (pv != 1) done = launch_pressure_128s(f, S, stride, k);
+    } else if (pv == 12 && pressure_nd_applies(p)) done = launch_pressure_nd(f, S, stride, k);
+    else if (pv != 1) done = launch_pressure_128s(f, S, stride, k);
     if (done > 0) return done;
     if (done < 0) {
         int T = generic_threads(p.Ny);

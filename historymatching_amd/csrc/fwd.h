@@ -44,8 +44,12 @@ struct FwdParams {
     const double* pin;        // N: SPD pin per member (coarse level of the two-level preconditioner only)
 };
 
+struct hm_nd;  // nested-dissection pressure solve (press_nd.hip): tables + factor + arena, built on first use
+void hm_nd_free(hm_nd* n);
+
 struct hm_fwd {
     hm_ctx* ctx = nullptr;
+    hm_nd* nd = nullptr;
     FwdParams p{};
     int dtype = 64;
     int keep_history = 0;
@@ -85,6 +89,8 @@ static inline void* fwd_S_ptr(hm_fwd* f, int k, long long* stride) {
 // ---- kernels implemented in other translation units ------------------------------------------
 // 128x128 fp64 specialisations (press128s.hip / sat128.hip).  Return 0 if launched, -1 if not applicable.
 int launch_pressure_128s(hm_fwd* f, const void* S, long long S_stride, int k);  // MFMA panels, symmetric tile storage (default)
+bool pressure_nd_applies(const FwdParams& p);
+int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k);     // nested dissection, 128 x 128 (press_nd.hip)
 int launch_pressure_pcg(hm_fwd* f, const void* S, long long S_stride, int k);   // Jacobi-CG, any grid (press_pcg.hip)
 bool pressure_two_level_applies(const FwdParams& p);
 int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int k);  // two-level CG, Ny = 128 c

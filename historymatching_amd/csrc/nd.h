@@ -1,0 +1,43 @@
+// nd.h -- nested-dissection (multifrontal) pressure solve for the 128 x 128 grid: symbolic tables shared by the host
+// builder and the kernels of press_nd.hip.
+//
+// The elimination tree is the geometric dissection of the grid (SURVEY.md A.3's five-point system; tests/tools/nd_prototype.py):
+// a region is cut across its longer side by a one-cell separator until both sides are <= 4 cells.  For 128 x 128 the
+// tree is a complete binary tree: levels 0..9 are separators (128, 64, 64, 32, 32, 16, 16, 8, 8, 4 cells), level 10 the
+// 1024 leaves (3x3 .. 4x4 cells).  Front (level l, index i) has id 2^l - 1 + i; its children are (l+1, 2i) and (l+1, 2i+1).
+//
+// A front = s pivots (its separator / leaf cells) + b boundary cells (the part of the region's perimeter that is an
+// ancestor's separator) + ONE extra boundary row that carries the right-hand side.  In tiles of 16: st pivot tiles,
+// bt = ceil((b + 1) / 16) boundary tiles.  Front position p: [0, 16 st) pivots (padded with identity rows),
+// [16 st, 16 st + b) boundary cells, 16 st + b the right-hand-side row, then padding.
+#pragma once
+
+#define ND_FRONT_INTS 16
+// ints of one front record
+#define NDF_LEVEL 0
+#define NDF_S 1
+#define NDF_B 2
+#define NDF_ST 3
+#define NDF_BT 4
+#define NDF_C0 5       // child front ids (-1: leaf)
+#define NDF_C1 6
+#define NDF_CELLS 7    // offset of the front's 16 (st + bt) position -> cell entries in `cells` (-1 padding, -2 right-hand side)
+#define NDF_FACT 8     // offset (doubles) of the front's factor in a member's factor block
+#define NDF_UPD 9      // offset (doubles) of the front's update matrix in a member's arena (levels <= ND_ARENA_MAX_LEVEL), else -1
+#define NDF_KREG 10    // 4-row groups of the LAST pivot tile that hold real pivots (the other pivot tiles are full)
+#define NDF_BC0 11     // b of child 0 / child 1 (position of the child's right-hand-side row)
+#define NDF_BC1 12
+
+#define ND_LEVELS 11
+#define ND_ARENA_MAX_LEVEL 7   // updates of levels 0..7 live in the per-member arena (global memory); 8..10 in LDS slots
+#define ND_WAVE_TOP_LEVEL 5    // levels 10..5: one wave per front;  levels 4..0: one workgroup per front (per member)
+
+struct NdInfo {
+    int n_fronts;
+    int n_cells;              // entries of `cells` (and, twice, of `cpos`)
+    long long fact_doubles;   // per member
+    long long arena_doubles;  // per member
+    int lds_slot_doubles[3];  // update slot size of levels 8, 9, 10 (one slot per child parity)
+    int max_bt[ND_LEVELS];    // boundary tiles per level (for the kernels' static register arrays)
+    int max_st[ND_LEVELS];
+};

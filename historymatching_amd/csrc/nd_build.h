@@ -1,0 +1,160 @@
+// nd_build.h -- host-side symbolic phase of the nested-dissection pressure solve (grid only: shared by every member and
+// every time step).  Plain C++; used by press_nd.hip and, through hm_debug_nd_tables, by the CPU tests.
+#pragma once
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "nd.h"
+
+struct NdTablesHost {
+    NdInfo info{};
+    std::vector<int> fronts;   // n_fronts * ND_FRONT_INTS
+    std::vector<int> cells;    // position -> cell (-1 padding, -2 right-hand side)
+    std::vector<short> cpos;   // per front: [child 0: 16 T entries][child 1: 16 T entries] at 2 * cells_off:
+                               // position of the front position's cell in the child's boundary list (b_child = its
+                               // right-hand-side row), -1 if the child's update has no such row
+    std::string error;
+};
+
+namespace nd_detail {
+
+struct Region {
+    int x0, x1, y0, y1;
+    bool side[4];  // W, E, S, N border an ancestor's separator
+};
+
+inline void region_cells(std::vector<int>& out, int Ny, int x0, int x1, int y0, int y1) {
+    for (int x = x0; x < x1; ++x)
+        for (int y = y0; y < y1; ++y) out.push_back(x * Ny + y);
+}
+
+struct Builder {
+    int Nx, Ny, leaf;
+    std::vector<std::vector<int>> piv, bnd;  // per front id
+    std::vector<int> level, c0, c1;
+    bool complete = true;
+
+    void dissect(const Region& r, int lv, int idx) {
+        const int id = (1 << lv) - 1 + idx;
+        if ((int)piv.size() <= id) {
+            piv.resize(id + 1); bnd.resize(id + 1); level.resize(id + 1, -1); c0.resize(id + 1, -1); c1.resize(id + 1, -1);
+        }
+        level[id] = lv;
+        std::vector<int>& b = bnd[id];
+        if (r.side[0]) region_cells(b, Ny, r.x0 - 1, r.x0, r.y0, r.y1);
+        if (r.side[1]) region_cells(b, Ny, r.x1, r.x1 + 1, r.y0, r.y1);
+        if (r.side[2]) region_cells(b, Ny, r.x0, r.x1, r.y0 - 1, r.y0);
+        if (r.side[3]) region_cells(b, Ny, r.x0, r.x1, r.y1, r.y1 + 1);
+        const int w = r.x1 - r.x0, h = r.y1 - r.y0;
+        if (w <= leaf && h <= leaf) {
+            if (lv != ND_LEVELS - 1) complete = false;
+            region_cells(piv[id], Ny, r.x0, r.x1, r.y0, r.y1);
+            return;
+        }
+        if (lv >= ND_LEVELS - 1) { complete = false; return; }
+        Region a = r, c = r;
+        if (w >= h) {
+            const int xs = r.x0 + (w - 1) / 2;
+            region_cells(piv[id], Ny, xs, xs + 1, r.y0, r.y1);
+            a.x1 = xs; a.side[1] = true;
+            c.x0 = xs + 1; c.side[0] = true;
+            if (xs <= r.x0 || r.x1 <= xs + 1) { complete = false; return; }
+        } else {
+            const int ys = r.y0 + (h - 1) / 2;
+            region_cells(piv[id], Ny, r.x0, r.x1, ys, ys + 1);
+            a.y1 = ys; a.side[3] = true;
+            c.y0 = ys + 1; c.side[2] = true;
+            if (ys <= r.y0 || r.y1 <= ys + 1) { complete = false; return; }
+        }
+        c0[id] = (1 << (lv + 1)) - 1 + 2 * idx;
+        c1[id] = c0[id] + 1;
+        dissect(a, lv + 1, 2 * idx);
+        dissect(c, lv + 1, 2 * idx + 1);
+    }
+};
+
+}  // namespace nd_detail
+
+// Returns false (with t.error set) when the grid does not give the complete 11-level tree the kernels are written for.
+inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
+    using namespace nd_detail;
+    Builder B;
+    B.Nx = Nx; B.Ny = Ny; B.leaf = 4;
+    Region root{0, Nx, 0, Ny, {false, false, false, false}};
+    B.dissect(root, 0, 0);
+    const int nF = (1 << ND_LEVELS) - 1;
+    if (!B.complete || (int)B.piv.size() != nF) { t.error = "grid does not dissect into the complete 11-level tree"; return false; }
+    for (int f = 0; f < nF; ++f)
+        if (B.level[f] < 0) { t.error = "missing front"; return false; }
+    {  // every cell is a pivot exactly once
+        std::vector<int> seen((size_t)Nx * Ny, 0);
+        for (int f = 0; f < nF; ++f)
+            for (int c : B.piv[f]) seen[c]++;
+        for (int v : seen)
+            if (v != 1) { t.error = "a cell is not a pivot exactly once"; return false; }
+    }
+    NdInfo& I = t.info;
+    I = NdInfo{};
+    I.n_fronts = nF;
+    t.fronts.assign((size_t)nF * ND_FRONT_INTS, 0);
+    t.cells.clear();
+    long long fact = 0, arena = 0;
+    std::vector<int> where((size_t)Nx * Ny, -1);
+    for (int f = 0; f < nF; ++f) {
+        int* F = &t.fronts[(size_t)f * ND_FRONT_INTS];
+        const int lv = B.level[f], s = (int)B.piv[f].size(), b = (int)B.bnd[f].size();
+        const int st = (s + 15) / 16, bt = (b + 1 + 15) / 16, T = st + bt;
+        F[NDF_LEVEL] = lv; F[NDF_S] = s; F[NDF_B] = b; F[NDF_ST] = st; F[NDF_BT] = bt;
+        F[NDF_C0] = B.c0[f]; F[NDF_C1] = B.c1[f];
+        F[NDF_CELLS] = (int)t.cells.size();
+        const int last = s - 16 * (st - 1);
+        F[NDF_KREG] = (last + 3) / 4;
+        F[NDF_FACT] = (int)fact;
+        long long tiles_regs = 0;  // 64-double register rows
+        for (int p = 0; p < st; ++p) tiles_regs += (long long)(T - p - 1) * (p == st - 1 ? F[NDF_KREG] : 4);
+        fact += tiles_regs * 64;
+        if (lv <= ND_ARENA_MAX_LEVEL && lv > 0) {
+            F[NDF_UPD] = (int)arena;
+            long long n = (long long)(b + 1) * (b + 2) / 2;
+            arena += (n + 1) & ~1LL;
+        } else F[NDF_UPD] = -1;
+        if (lv >= 8) {
+            const int n = ((b + 1) * (b + 2) / 2 + 1) & ~1;
+            I.lds_slot_doubles[lv - 8] = std::max(I.lds_slot_doubles[lv - 8], n);
+        }
+        I.max_bt[lv] = std::max(I.max_bt[lv], bt);
+        I.max_st[lv] = std::max(I.max_st[lv], st);
+        t.cells.resize(t.cells.size() + (size_t)16 * T, -1);
+        int* C = &t.cells[F[NDF_CELLS]];
+        for (int i = 0; i < s; ++i) C[i] = B.piv[f][i];
+        for (int i = 0; i < b; ++i) C[16 * st + i] = B.bnd[f][i];
+        C[16 * st + b] = -2;
+    }
+    I.n_cells = (int)t.cells.size();
+    I.fact_doubles = fact;
+    I.arena_doubles = arena;
+    t.cpos.assign((size_t)2 * t.cells.size(), (short)-1);
+    for (int f = 0; f < nF; ++f) {
+        int* F = &t.fronts[(size_t)f * ND_FRONT_INTS];
+        const int T = F[NDF_ST] + F[NDF_BT];
+        const int* C = &t.cells[F[NDF_CELLS]];
+        F[NDF_BC0] = F[NDF_BC1] = 0;
+        for (int c = 0; c < 2; ++c) {
+            const int ch = c == 0 ? F[NDF_C0] : F[NDF_C1];
+            if (ch < 0) continue;
+            const std::vector<int>& cb = B.bnd[ch];
+            F[c == 0 ? NDF_BC0 : NDF_BC1] = (int)cb.size();
+            for (size_t i = 0; i < cb.size(); ++i) where[cb[i]] = (int)i;
+            short* P = &t.cpos[(size_t)2 * F[NDF_CELLS] + (size_t)c * 16 * T];
+            size_t found = 0;
+            for (int p = 0; p < 16 * T; ++p) {
+                if (C[p] >= 0 && where[C[p]] >= 0) { P[p] = (short)where[C[p]]; ++found; }
+                else if (C[p] == -2) P[p] = (short)cb.size();
+            }
+            for (size_t i = 0; i < cb.size(); ++i) where[cb[i]] = -1;
+            if (found != cb.size()) { t.error = "a child's boundary does not lie inside its parent's front"; return false; }
+        }
+    }
+    return true;
+}
