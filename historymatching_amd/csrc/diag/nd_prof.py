@@ -1,0 +1,36 @@
+"""Cycle stamps of the nested-dissection pressure kernels (block 0, wave 0).  Build first: diag/build_nd_prof.sh, then
+     HM_AMD_LIB=build_prof/libhm_ndprof.so python historymatching_amd/csrc/diag/nd_prof.py [N=1000]"""
+import ctypes as C
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[3] / "tests"))
+from helpers import make_models, perms  # noqa: E402
+from historymatching_amd import _lib  # noqa: E402
+from historymatching_amd.forward import ForwardPlan  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+_, gm = make_models(128, 128)
+plan = ForwardPlan(gm, N, 0.025, 4, keep_history=False, device=0)
+plan.set_variant(12, 0)
+plan.set_inputs(perms(128, 128, N, seed=1), None, transformed=False)
+for _ in range(4):
+    plan.pressure_only(0)
+st = plan.sync()
+print(f"pressure launch avg {st['ms_pressure'] / st['n_pressure_launches']:.2f} ms for {N} members")
+lib = _lib.load()
+buf = (C.c_longlong * 64)()
+lib.hm_debug_nd_prof.argtypes = [C.POINTER(C.c_longlong)]
+assert lib.hm_debug_nd_prof(buf) == 0
+top = ["between fronts", "tables -> LDS + barrier", "decode", "assemble V tiles", "assemble trailing tiles", "S1 sweep", "barrier 1", "S2 W = P V, publish",
+       "barrier 2", "S3 updates", "store update", "end barrier"]
+v = list(buf[:16])
+print(f"k_nd_top, block 0 wave 0: {sum(v)} cycles")
+for n, x in zip(top, v):
+    print(f"   {n:28s} {x:10d}  {100 * x / max(sum(v), 1):5.1f} %")
+sub = ["level 10 (8 leaves)", "level 9 (4 fronts)", "level 8 (2 fronts)", "level 7 (1 front)"]
+v = list(buf[16:32])
+print(f"k_nd_sub, block 0 wave 0: {sum(v)} cycles")
+for n, x in zip(sub, v):
+    print(f"   {n:28s} {x:10d}  {100 * x / max(sum(v), 1):5.1f} %")

@@ -27,9 +27,11 @@
 #define NDF_KREG 10    // 4-row groups of the LAST pivot tile that hold real pivots (the other pivot tiles are full)
 #define NDF_BC0 11     // b of child 0 / child 1 (position of the child's right-hand-side row)
 #define NDF_BC1 12
+#define NDF_PBOX 13    // bounding box of the front's pivot cells, x0 | y0 << 8 | x1 << 16 | y1 << 24 (x1, y1 exclusive)
+#define NDF_RBOX 14    // the front's whole region (pivots of the front and of all its descendants), same packing
 
 #define ND_LEVELS 11
-#define ND_ARENA_MAX_LEVEL 7   // updates of levels 0..7 live in the per-member arena (global memory); 8..10 in LDS slots
+#define ND_ARENA_MAX_LEVEL 8   // updates of levels 1..8 live in the per-member arena (global memory); 9, 10 in per-wave LDS slots
 #define ND_WAVE_TOP_LEVEL 5    // levels 10..5: one wave per front;  levels 4..0: one workgroup per front (per member)
 
 struct NdInfo {
@@ -37,7 +39,7 @@ struct NdInfo {
     int n_cells;              // entries of `cells` (and, twice, of `cpos`)
     long long fact_doubles;   // per member
     long long arena_doubles;  // per member
-    int lds_slot_doubles[3];  // update slot size of levels 8, 9, 10 (one slot per child parity)
+    int upd_doubles[ND_LEVELS];  // largest packed update matrix per level ((b + 1)(b + 2) / 2, rounded up to even)
     int max_bt[ND_LEVELS];    // boundary tiles per level (for the kernels' static register arrays)
     int max_st[ND_LEVELS];
 };

@@ -32,15 +32,16 @@ inline void region_cells(std::vector<int>& out, int Ny, int x0, int x1, int y0, 
 struct Builder {
     int Nx, Ny, leaf;
     std::vector<std::vector<int>> piv, bnd;  // per front id
-    std::vector<int> level, c0, c1;
+    std::vector<int> level, c0, c1, rbox;
     bool complete = true;
 
     void dissect(const Region& r, int lv, int idx) {
         const int id = (1 << lv) - 1 + idx;
         if ((int)piv.size() <= id) {
-            piv.resize(id + 1); bnd.resize(id + 1); level.resize(id + 1, -1); c0.resize(id + 1, -1); c1.resize(id + 1, -1);
+            piv.resize(id + 1); bnd.resize(id + 1); level.resize(id + 1, -1); c0.resize(id + 1, -1); c1.resize(id + 1, -1); rbox.resize(id + 1, 0);
         }
         level[id] = lv;
+        rbox[id] = r.x0 | (r.y0 << 8) | (r.x1 << 16) | (r.y1 << 24);
         std::vector<int>& b = bnd[id];
         if (r.side[0]) region_cells(b, Ny, r.x0 - 1, r.x0, r.y0, r.y1);
         if (r.side[1]) region_cells(b, Ny, r.x1, r.x1 + 1, r.y0, r.y1);
@@ -111,6 +112,12 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
         const int last = s - 16 * (st - 1);
         F[NDF_KREG] = (last + 3) / 4;
         F[NDF_FACT] = (int)fact;
+        {
+            int x0 = Nx, y0 = Ny, x1 = 0, y1 = 0;
+            for (int c : B.piv[f]) { x0 = std::min(x0, c / Ny); x1 = std::max(x1, c / Ny + 1); y0 = std::min(y0, c % Ny); y1 = std::max(y1, c % Ny + 1); }
+            F[NDF_PBOX] = x0 | (y0 << 8) | (x1 << 16) | (y1 << 24);
+            F[NDF_RBOX] = B.rbox[f];
+        }
         long long tiles_regs = 0;  // 64-double register rows
         for (int p = 0; p < st; ++p) tiles_regs += (long long)(T - p - 1) * (p == st - 1 ? F[NDF_KREG] : 4);
         fact += tiles_regs * 64;
@@ -119,10 +126,7 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
             long long n = (long long)(b + 1) * (b + 2) / 2;
             arena += (n + 1) & ~1LL;
         } else F[NDF_UPD] = -1;
-        if (lv >= 8) {
-            const int n = ((b + 1) * (b + 2) / 2 + 1) & ~1;
-            I.lds_slot_doubles[lv - 8] = std::max(I.lds_slot_doubles[lv - 8], n);
-        }
+        I.upd_doubles[lv] = std::max(I.upd_doubles[lv], ((b + 1) * (b + 2) / 2 + 1) & ~1);
         I.max_bt[lv] = std::max(I.max_bt[lv], bt);
         I.max_st[lv] = std::max(I.max_st[lv], st);
         t.cells.resize(t.cells.size() + (size_t)16 * T, -1);

@@ -26,6 +26,16 @@
 #include "nd_build.h"
 #include "sweep16.h"
 
+#ifdef HM_ND_PROF
+// cycle stamps: block 0, wave 0, lane 0.  [0..15] k_nd_top phases, [16..31] k_nd_sub (wave-front phases by level), [32..47] counts
+__device__ long long hm_nd_prof_buf[64];
+#define NPROF_DECL long long prof_t = clock64(), prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define NPROF(i) do { const long long now_ = clock64(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
+#else
+#define NPROF_DECL
+#define NPROF(i)
+#endif
+
 namespace {
 
 constexpr int NB = 128;
@@ -36,18 +46,15 @@ struct NdDev {
     const short* cpos;
     double* fact;
     double* arena;
-    double* dg;
+    double* cf;  // per member: [dg | -TX | -TY | q], CF_STRIDE doubles
     long long fact_stride, arena_stride;
-    int slot8, slot9, slot10;  // doubles per LDS update slot of levels 8, 9, 10
+    int slot9, slot10;      // doubles per LDS update slot of levels 9, 10 (k_nd_sub)
+    int child_doubles[3];   // largest child update of a level-7 / 6 / 5 front (k_nd_wave's LDS staging)
+    int top_child_doubles;  // largest child update of a level <= 4 front
 };
 
 struct NdGeo {
     int lane, lc, lq;
-};
-
-struct NdMem {  // one member's arrays
-    const double *dg, *TX, *TY, *q;
-    double *fact, *arena;
 };
 
 __device__ __forceinline__ int tri(int a, int b) {
@@ -55,25 +62,66 @@ __device__ __forceinline__ int tri(int a, int b) {
     return ((hi * (hi + 1)) >> 1) + lo;
 }
 
-// A[cm, ck] (five-point system; cell = ix * 128 + iy) or, for cm = -2, the right-hand side q[ck]; identity on padded pivots.
-__device__ __forceinline__ double nd_coef(const NdMem& mm, int cm, int ck, bool same_pos) {
-    double v = 0.0;
-    if (ck >= 0) {
-        if (cm >= 0) {
-            const int d = cm - ck;
-            const double* src = nullptr;
-            if (d == 0) src = mm.dg + ck;
-            else if (d == NB) src = mm.TX + ck + NB;
-            else if (d == -NB) src = mm.TX + ck;
-            else if (d == 1) src = mm.TY + ck + (ck >> 7) + 1;
-            else if (d == -1) src = mm.TY + ck + (ck >> 7);
-            if (src) {
-                v = *src;
-                if (d != 0) v = -v;
-            }
-        } else if (cm == -2) v = mm.q[ck];
-    } else if (same_pos) v = 1.0;
-    return v;
+// The member's coefficient block cf = [dg | -TX | -TY | q] (k_nd_assemble): A[cm, ck] of the five-point system (cell = ix * 128
+// + iy) is dg[ck], -TX[face between] or -TY[face between]; the right-hand-side row (cm = -2) reads q[ck].
+constexpr int CF_OX = NB * NB, CF_OY = CF_OX + (NB + 1) * NB, CF_OQ = CF_OY + NB * (NB + 1), CF_STRIDE = CF_OQ + NB * NB;
+
+__device__ __forceinline__ double nd_coef_global(const double* __restrict__ cf, int cm, int ck, bool same_pos) {
+    if (ck < 0) return same_pos ? 1.0 : 0.0;  // padded pivot: identity
+    if (cm == -2) return cf[CF_OQ + ck];
+    if (cm < 0) return 0.0;
+    const int d = cm - ck;
+    if (d == 0) return cf[ck];
+    if (d == NB) return cf[CF_OX + ck + NB];
+    if (d == -NB) return cf[CF_OX + ck];
+    if (d == 1) return cf[CF_OY + ck + (ck >> 7) + 1];
+    if (d == -1) return cf[CF_OY + ck + (ck >> 7)];
+    return 0.0;
+}
+
+// The same from an LDS copy of the coefficients around a box of cells [x0, x1) x [y0, y1): four planes (dg, -TX of the cell's
+// west face, -TY of its south face, q) over the box plus a ring of one cell, local index (ix - x0 + 1) * ld + (iy - y0 + 1),
+// ld = y1 - y0 + 2.  Every pivot of the fronts that use the copy lies inside the box.
+struct NdCfl {
+    const double* p;  // LDS
+    int plane, ld, x0, y0;
+};
+__device__ __forceinline__ void nd_stage_cf(const double* __restrict__ cf, double* cfl, int plane, int box, int lane, NdCfl& out) {
+    const int x0 = box & 255, y0 = (box >> 8) & 255, x1 = (box >> 16) & 255, y1 = (box >> 24) & 255;
+    const int ld = y1 - y0 + 2, n = (x1 - x0 + 2) * ld;
+    for (int i = lane; i < n; i += 64) {
+        const int lx = i / ld, ly = i - lx * ld;
+        const int ix = x0 - 1 + lx, iy = y0 - 1 + ly;
+        const bool xin = ix >= 0 && ix < NB, yin = iy >= 0 && iy < NB;
+        const int c = ix * NB + iy;
+        cfl[i] = (xin && yin) ? cf[c] : 0.0;
+        cfl[plane + i] = (yin && ix >= 0 && ix <= NB) ? cf[CF_OX + c] : 0.0;
+        cfl[2 * plane + i] = (xin && iy >= 0 && iy <= NB) ? cf[CF_OY + ix * (NB + 1) + iy] : 0.0;
+        cfl[3 * plane + i] = (xin && yin) ? cf[CF_OQ + c] : 0.0;
+    }
+    out.p = cfl; out.plane = plane; out.ld = ld; out.x0 = x0; out.y0 = y0;
+}
+// (index arithmetic only and the loaded value used unconditionally: with `if`s the lanes of a wave take up to six divergent paths,
+// each with its own LDS round trip; with a select around the load the compiler sinks the load into a branch and waits there)
+__device__ __forceinline__ double nd_coef_lds(const NdCfl& L, int cm, int ck, bool same_pos) {
+    const int li = ((ck >> 7) - L.x0 + 1) * L.ld + ((ck & 127) - L.y0 + 1);
+    const int d = cm - ck;
+    const bool cell = ck >= 0 && cm >= 0;
+    int off = -1;
+    off = (cell && d == 0) ? li : off;
+    off = (cell && d == NB) ? L.plane + li + L.ld : off;
+    off = (cell && d == -NB) ? L.plane + li : off;
+    off = (cell && d == 1) ? 2 * L.plane + li + 1 : off;
+    off = (cell && d == -1) ? 2 * L.plane + li : off;
+    off = (ck >= 0 && cm == -2) ? 3 * L.plane + li : off;
+    const double l = L.p[off >= 0 ? off : 0];
+    return l * (off >= 0 ? 1.0 : 0.0) + ((ck < 0 && same_pos) ? 1.0 : 0.0);
+}
+// children's updates in LDS (wave-level fronts): unconditional load, see above
+__device__ __forceinline__ double nd_gather(const double* ch, int a, int c) {
+    const bool ok = a >= 0 && c >= 0;
+    const double l = ch[ok ? tri(a, c) : 0];
+    return l * (ok ? 1.0 : 0.0);
 }
 
 template <typename GEO>
@@ -95,21 +143,32 @@ __device__ __forceinline__ void nd_wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// n doubles (n even, both 16-byte aligned) from global memory to LDS by one wave: every load is in flight before the first
+// LDS write waits for its data.
+__device__ __forceinline__ void nd_wave_copy(double* dst, const double* __restrict__ src, int n, int lane) {
+    const double2* s2 = reinterpret_cast<const double2*>(src);
+    double2* d2 = reinterpret_cast<double2*>(dst);
+    const int n2 = n >> 1;
+    int i = lane;
+    for (; i + 448 < n2; i += 512) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s2[i + 64 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d2[i + 64 * u] = v[u];
+    }
+    for (; i < n2; i += 64) d2[i] = s2[i];
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
-// One front with ONE pivot tile, processed by one wave in registers.  ch0 / ch1: the children's packed update matrices
-// (KIDS), out: this front's packed update matrix ((b + 1)(b + 2) / 2 doubles; nullptr for none).
+// One front with ONE pivot tile, processed by one wave in registers.  Everything it reads at random lies in LDS: the
+// position tables cl / cp0 / cp1, the coefficients (NdCfl), the children's packed update matrices ch0 / ch1 (KIDS).
+// out: this front's packed update matrix ((b + 1)(b + 2) / 2 doubles), LDS or global.  fa: the front's factor (global).
 // ------------------------------------------------------------------------------------------------------------------------
 template <int MAXBT, bool KIDS>
-__device__ __forceinline__ void nd_wave_front(const NdDev& nd, const NdMem& mm, int f, const double* ch0, const double* ch1,
-                                              double* out, const NdGeo& g, int& bad) {
-    const int* F = nd.fronts + f * ND_FRONT_INTS;
-    const int b = __builtin_amdgcn_readfirstlane(F[NDF_B]);
-    const int bt = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
-    const int co = __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
-    const int kreg = __builtin_amdgcn_readfirstlane(F[NDF_KREG]);
-    const int* cl = nd.cells + co;
-    const short* cp0 = nd.cpos + 2 * co;
-    const short* cp1 = cp0 + 16 * (1 + bt);
+__device__ __forceinline__ void nd_wave_front(int b, int bt, int kreg, const int* cl, const short* cp0, const short* cp1, const NdCfl& L,
+                                              const double* ch0, const double* ch1, double* out, double* __restrict__ fa, const NdGeo& g,
+                                              int& bad) {
     int ck[4], pk0[4], pk1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -119,30 +178,27 @@ __device__ __forceinline__ void nd_wave_front(const NdDev& nd, const NdMem& mm, 
     }
     // ---- the pivot panel, transposed: V[R][r] = F[front row 16 R + lc][pivot 4 r + lq]
     d4 V[MAXBT + 1];
+    int pm0[MAXBT + 1], pm1[MAXBT + 1];
 #pragma unroll
     for (int R = 0; R <= MAXBT; ++R) {
+        V[R] = d4{0.0, 0.0, 0.0, 0.0};
+        pm0[R] = pm1[R] = -1;
         if (R <= bt) {
             const int pm = 16 * R + g.lc;
             const int cm = cl[pm];
-            const int pm0 = KIDS ? cp0[pm] : -1, pm1 = KIDS ? cp1[pm] : -1;
+            if (KIDS) { pm0[R] = cp0[pm]; pm1[R] = cp1[pm]; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double v = nd_coef(mm, cm, ck[r], R == 0 && g.lc == 4 * r + g.lq);
-                if (KIDS) {
-                    if (pk0[r] >= 0 && pm0 >= 0) v += ch0[tri(pk0[r], pm0)];
-                    if (pk1[r] >= 0 && pm1 >= 0) v += ch1[tri(pk1[r], pm1)];
-                }
+                double v = nd_coef_lds(L, cm, ck[r], R == 0 && g.lc == 4 * r + g.lq);
+                if (KIDS) v += nd_gather(ch0, pk0[r], pm0[R]) + nd_gather(ch1, pk1[r], pm1[R]);
                 V[R][r] = v;
             }
-        } else {
-            V[R] = d4{0.0, 0.0, 0.0, 0.0};
         }
     }
     // ---- P = inverse of the pivot tile
     d4 P = V[0];
     sweep16_partial(P, g, bad, kreg);  // P = -inv
-    // ---- W_R^T = P V_R (stored negated: the products below subtract), factor rows to memory
-    double* fa = mm.fact + F[NDF_FACT];
+    // ---- W_R^T = P V_R (kept negated: the products below subtract), factor rows to memory
     d4 WTn[MAXBT];
 #pragma unroll
     for (int R = 1; R <= MAXBT; ++R) {
@@ -151,14 +207,12 @@ __device__ __forceinline__ void nd_wave_front(const NdDev& nd, const NdMem& mm, 
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
                 if (kk < kreg) w = __builtin_amdgcn_mfma_f64_16x16x4f64(P[kk], V[R][kk], w, 0, 0, 0);
-            // w = -W^T (P is the negated inverse)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (r < kreg) fa[((R - 1) * kreg + r) * 64 + g.lane] = -w[r];
         }
         WTn[R - 1] = w;
     }
-    if (!out) return;
     // ---- trailing tiles: update = children - W V^T, packed lower
 #pragma unroll
     for (int R = 1; R <= MAXBT; ++R) {
@@ -173,14 +227,8 @@ __device__ __forceinline__ void nd_wave_front(const NdDev& nd, const NdMem& mm, 
         for (int C = 1; C <= R; ++C) {
             d4 acc = {0.0, 0.0, 0.0, 0.0};
             if (KIDS) {
-                const int pc0 = cp0[16 * C + g.lc], pc1 = cp1[16 * C + g.lc];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double v = 0.0;
-                    if (pr0[r] >= 0 && pc0 >= 0) v += ch0[tri(pr0[r], pc0)];
-                    if (pr1[r] >= 0 && pc1 >= 0) v += ch1[tri(pr1[r], pc1)];
-                    acc[r] = v;
-                }
+                for (int r = 0; r < 4; ++r) acc[r] = nd_gather(ch0, pr0[r], pm0[C]) + nd_gather(ch1, pr1[r], pm1[C]);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -196,10 +244,10 @@ __device__ __forceinline__ void nd_wave_front(const NdDev& nd, const NdMem& mm, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// TX, TY and the matrix diagonal (one workgroup per member).
+// TX, TY (bit-exact: fwd_dev.h) and the coefficient block (one workgroup per member).
 // ------------------------------------------------------------------------------------------------------------------------
 template <typename TS>
-__global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, const TS* __restrict__ S_base, long long S_stride) {
+__global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, const TS* __restrict__ S_base, long long S_stride, int k) {
     const int m = blockIdx.x, tid = threadIdx.x;
     const int Nx = p.Nx, Nxy = p.Nxy;
     const TS* S = S_base + (long long)m * S_stride;
@@ -207,96 +255,157 @@ __global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, con
     const double* Kym = p.Ky ? p.Ky + (long long)m * Nxy : Km;
     double* TX = p.TX + (long long)m * (Nx + 1) * NB;
     double* TY = p.TY + (long long)m * Nx * (NB + 1);
-    double* dg = nd.dg + (long long)m * Nxy;
+    double* cf = nd.cf + (long long)m * CF_STRIDE;
+    const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
     assemble_transmissibilities<TS>(p, S, Km, Kym, p.P + (long long)m * Nxy, TX, TY, tid, 1024);
     for (int c = tid; c < Nxy; c += 1024) {
         const int ty = c + (c >> 7);
         double d = TY[ty] + TY[ty + 1] + TX[c] + TX[c + NB];
         if (c == 0) d += Km[0] + Kym[0];  // SPD pin: A[0,0] += Kx[0,0] + Ky[0,0]
-        dg[c] = d;
+        cf[c] = d;
+        cf[CF_OQ + c] = q[c];
+    }
+    for (int i = tid; i < (NB + 1) * NB; i += 1024) {
+        cf[CF_OX + i] = -TX[i];
+        cf[CF_OY + i] = -TY[i];
     }
 }
 
-__device__ __forceinline__ NdMem nd_member(const FwdParams& p, const NdDev& nd, int m, int k) {
-    NdMem mm;
-    mm.dg = nd.dg + (long long)m * p.Nxy;
-    mm.TX = p.TX + (long long)m * (p.Nx + 1) * NB;
-    mm.TY = p.TY + (long long)m * p.Nx * (NB + 1);
-    mm.q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * p.Nxy;
-    mm.fact = nd.fact + (long long)m * nd.fact_stride;
-    mm.arena = nd.arena + (long long)m * nd.arena_stride;
-    return mm;
-}
+// ------------------------------------------------------------------------------------------------------------------------
+// Levels 10..8: one wave per level-8 subtree (8 x 8 cells: 4 leaves, 2 level-9 fronts, the level-8 front), 4 waves per
+// workgroup, 64 workgroups per member.  Per wave in LDS: the subtree's position tables and coefficients (staged once, one
+// round trip to memory), two update slots each for levels 10 and 9.  The level-8 update goes to the arena.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int SUB_POS = 272;      // table positions of a level-8 subtree: 4 x 32 + 2 x 48 + 48
+constexpr int SUB_CF_PLANE = 100; // (8 + 2)^2
 
-// ------------------------------------------------------------------------------------------------------------------------
-// Levels 10..7: one wave per level-7 subtree, 4 waves per workgroup, 32 workgroups per member.
-// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nd_sub_lds_doubles(const NdDev& nd) { return 2 * (nd.slot9 + nd.slot10) + 4 * SUB_CF_PLANE + SUB_POS; }
+
 __global__ __launch_bounds__(256, 3) void k_nd_sub(FwdParams p, NdDev nd, int k) {
     extern __shared__ double nd_lds[];
-    const int m = blockIdx.x >> 5, g32 = blockIdx.x & 31;
+    const int m = blockIdx.x % p.N, blk = blockIdx.x / p.N;  // subtree-major: co-resident workgroups share table rows
     const int tid = threadIdx.x;
     NdGeo g;
     g.lane = tid & 63;
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const NdMem mm = nd_member(p, nd, m, k);
-    double* base = nd_lds + w * 2 * (nd.slot8 + nd.slot9 + nd.slot10);
-    double* s8 = base;
-    double* s9 = base + 2 * nd.slot8;
+    double* base = nd_lds + w * nd_sub_lds_doubles(nd);
+    double* s9 = base;
     double* s10 = s9 + 2 * nd.slot9;
+    double* cfl = s10 + 2 * nd.slot10;
+    int* cl_l = reinterpret_cast<int*>(cfl + 4 * SUB_CF_PLANE);
+    short* cp_l = reinterpret_cast<short*>(cl_l + SUB_POS);
+    const double* cf = nd.cf + (long long)m * CF_STRIDE;
+    double* fact = nd.fact + (long long)m * nd.fact_stride;
+    double* arena = nd.arena + (long long)m * nd.arena_stride;
+    const int i8 = 4 * blk + w;
+    const int f8 = 255 + i8, f9 = 511 + 2 * i8, f10 = 1023 + 4 * i8;
     int bad = 0;
-    const int i7 = 4 * g32 + w;
-    for (int a = 0; a < 2; ++a) {
-        const int i8 = 2 * i7 + a;
-        for (int bq = 0; bq < 2; ++bq) {
-            const int i9 = 2 * i8 + bq;
-            for (int cq = 0; cq < 2; ++cq) {
-                const int i10 = 2 * i9 + cq;
-                nd_wave_front<1, false>(nd, mm, 1023 + i10, nullptr, nullptr, s10 + cq * nd.slot10, g, bad);
-            }
-            nd_wave_fence();
-            nd_wave_front<2, true>(nd, mm, 511 + i9, s10, s10 + nd.slot10, s9 + bq * nd.slot9, g, bad);
-            nd_wave_fence();
-        }
-        nd_wave_front<2, true>(nd, mm, 255 + i8, s9, s9 + nd.slot9, s8 + a * nd.slot8, g, bad);
-        nd_wave_fence();
+    NPROF_DECL;
+    // ---- stage: tables of the 7 fronts (three contiguous chunks of the global tables), coefficients of the region
+    const int* F8 = nd.fronts + f8 * ND_FRONT_INTS;
+    const int co8 = F8[NDF_CELLS], co9 = nd.fronts[f9 * ND_FRONT_INTS + NDF_CELLS], co10 = nd.fronts[f10 * ND_FRONT_INTS + NDF_CELLS];
+    {
+        const int* F9b = nd.fronts + (f9 + 1) * ND_FRONT_INTS;
+        const int* F10d = nd.fronts + (f10 + 3) * ND_FRONT_INTS;
+        const int n10 = F10d[NDF_CELLS] + 16 * (F10d[NDF_ST] + F10d[NDF_BT]) - co10;
+        const int n9 = F9b[NDF_CELLS] + 16 * (F9b[NDF_ST] + F9b[NDF_BT]) - co9;
+        const int n8 = 16 * (F8[NDF_ST] + F8[NDF_BT]);
+        for (int i = g.lane; i < n10; i += 64) { cl_l[i] = nd.cells[co10 + i]; }
+        for (int i = g.lane; i < n9; i += 64) { cl_l[128 + i] = nd.cells[co9 + i]; }
+        for (int i = g.lane; i < n8; i += 64) { cl_l[224 + i] = nd.cells[co8 + i]; }
+        for (int i = g.lane; i < 2 * n10; i += 64) { cp_l[i] = nd.cpos[2 * co10 + i]; }
+        for (int i = g.lane; i < 2 * n9; i += 64) { cp_l[256 + i] = nd.cpos[2 * co9 + i]; }
+        for (int i = g.lane; i < 2 * n8; i += 64) { cp_l[448 + i] = nd.cpos[2 * co8 + i]; }
     }
-    const int f7 = 127 + i7;
-    nd_wave_front<3, true>(nd, mm, f7, s8, s8 + nd.slot8, mm.arena + nd.fronts[f7 * ND_FRONT_INTS + NDF_UPD], g, bad);
+    NdCfl L;
+    nd_stage_cf(cf, cfl, SUB_CF_PLANE, F8[NDF_RBOX], g.lane, L);
+    nd_wave_fence();
+    NPROF(0);
+    for (int bq = 0; bq < 2; ++bq) {
+        const int* F9 = nd.fronts + (f9 + bq) * ND_FRONT_INTS;
+        for (int cq = 0; cq < 2; ++cq) {
+            const int* F10 = nd.fronts + (f10 + 2 * bq + cq) * ND_FRONT_INTS;
+            const int o = F10[NDF_CELLS] - co10;
+            nd_wave_front<1, false>(F10[NDF_B], F10[NDF_BT], F10[NDF_KREG], cl_l + o, cp_l + 2 * o, cp_l + 2 * o, L, nullptr, nullptr,
+                                    s10 + cq * nd.slot10, fact + F10[NDF_FACT], g, bad);
+        }
+        nd_wave_fence();
+        NPROF(1);
+        const int o = F9[NDF_CELLS] - co9, T9 = 1 + F9[NDF_BT];
+        nd_wave_front<2, true>(F9[NDF_B], F9[NDF_BT], F9[NDF_KREG], cl_l + 128 + o, cp_l + 256 + 2 * o, cp_l + 256 + 2 * o + 16 * T9, L, s10,
+                               s10 + nd.slot10, s9 + bq * nd.slot9, fact + F9[NDF_FACT], g, bad);
+        nd_wave_fence();
+        NPROF(2);
+    }
+    nd_wave_front<2, true>(F8[NDF_B], F8[NDF_BT], F8[NDF_KREG], cl_l + 224, cp_l + 448, cp_l + 448 + 16 * (1 + F8[NDF_BT]), L, s9, s9 + nd.slot9,
+                           arena + F8[NDF_UPD], fact + F8[NDF_FACT], g, bad);
+    NPROF(3);
+#ifdef HM_ND_PROF
+    if (blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 16; ++i) hm_nd_prof_buf[16 + i] = prof_acc[i];
+#endif
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
-// Levels 6 and 5: one wave per front, children and update in the arena.
-template <int LEVEL, int MAXBT>
-__global__ __launch_bounds__(256) void k_nd_wave(FwdParams p, NdDev nd, int k) {
-    constexpr int NF = 1 << LEVEL, WPB = 4, BPM = NF / WPB;
-    const int m = blockIdx.x / BPM, blk = blockIdx.x % BPM;
+// ------------------------------------------------------------------------------------------------------------------------
+// Levels 7, 6, 5: one wave per front.  The two children's update matrices (arena), the front's tables and the coefficients
+// around its separator are staged into the wave's LDS first (bulk copies, one round trip); the update goes to the arena.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int WAVE_CF_PLANE = 56;  // (1 + 2) x (16 + 2), rounded up
+
+template <int LEVEL, int MAXBT, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int k) {
+    extern __shared__ double nd_lds[];
+    constexpr int NF = 1 << LEVEL, POS = 16 * (MAXBT + 1);
+    const int m = blockIdx.x % p.N, blk = blockIdx.x / p.N;
     const int tid = threadIdx.x;
     NdGeo g;
     g.lane = tid & 63;
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const NdMem mm = nd_member(p, nd, m, k);
+    const int chd = nd.child_doubles[7 - LEVEL];
+    double* base = nd_lds + w * (2 * chd + 4 * WAVE_CF_PLANE + POS);
+    double* c0l = base;
+    double* c1l = base + chd;
+    double* cfl = c1l + chd;
+    int* cl_l = reinterpret_cast<int*>(cfl + 4 * WAVE_CF_PLANE);
+    short* cp_l = reinterpret_cast<short*>(cl_l + POS);
+    const double* cf = nd.cf + (long long)m * CF_STRIDE;
+    double* fact = nd.fact + (long long)m * nd.fact_stride;
+    double* arena = nd.arena + (long long)m * nd.arena_stride;
     const int f = NF - 1 + blk * WPB + w;
     const int* F = nd.fronts + f * ND_FRONT_INTS;
-    const double* ch0 = mm.arena + nd.fronts[F[NDF_C0] * ND_FRONT_INTS + NDF_UPD];
-    const double* ch1 = mm.arena + nd.fronts[F[NDF_C1] * ND_FRONT_INTS + NDF_UPD];
+    const int bt = F[NDF_BT], co = F[NDF_CELLS];
+    const int* Fc0 = nd.fronts + F[NDF_C0] * ND_FRONT_INTS;
+    const int* Fc1 = nd.fronts + F[NDF_C1] * ND_FRONT_INTS;
+    const int n0 = (((Fc0[NDF_B] + 1) * (Fc0[NDF_B] + 2) >> 1) + 1) & ~1, n1 = (((Fc1[NDF_B] + 1) * (Fc1[NDF_B] + 2) >> 1) + 1) & ~1;
+    nd_wave_copy(c0l, arena + Fc0[NDF_UPD], n0, g.lane);
+    nd_wave_copy(c1l, arena + Fc1[NDF_UPD], n1, g.lane);
+    for (int i = g.lane; i < 16 * (1 + bt); i += 64) cl_l[i] = nd.cells[co + i];
+    for (int i = g.lane; i < 32 * (1 + bt); i += 64) cp_l[i] = nd.cpos[2 * co + i];
+    NdCfl L;
+    nd_stage_cf(cf, cfl, WAVE_CF_PLANE, F[NDF_PBOX], g.lane, L);
+    nd_wave_fence();
     int bad = 0;
-    nd_wave_front<MAXBT, true>(nd, mm, f, ch0, ch1, mm.arena + F[NDF_UPD], g, bad);
+    nd_wave_front<MAXBT, true>(F[NDF_B], bt, F[NDF_KREG], cl_l, cp_l, cp_l + 16 * (1 + bt), L, c0l, c1l, arena + F[NDF_UPD], fact + F[NDF_FACT], g,
+                               bad);
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Levels 4..0: one workgroup (8 waves) per member, front after front; the tiles of a front are dealt to the waves.
+// Levels 4..0: one workgroup (16 waves) per member, front after front; the tiles of a front are dealt to the waves.
 //   V tiles  (q, R), q < st, R >= q:   the transposed panel tile  F[rows of R][pivots of q]^T     (index = q-major)
 //   trailing (R, C), st <= C <= R < T: the update matrix, accumulated over the panels in registers
-// Per panel p:  S1 the owner of V(p, p) inverts it -> Pimg;  S2 the owners of V(p, R), R > p, form W_R^T = P V and publish
-// W_R^T and V_R as register images (lane-major, conflict-free 8-byte reads) and store the factor;  S3 every later tile is
-// updated with Y^T Z products of two published images.
+// Assembly: the children's update matrices are staged into LDS one after the other (bulk copy by the whole workgroup) and
+// gathered from there.  Per panel p:  the owner of V(p, p) inverts it -> Pimg (for p > 0 right after that tile's own update:
+// the sweep runs beside the other waves' updates);  the owners of V(p, R), R > p, form W_R^T = P V and publish W_R^T and V_R
+// as register images (lane-major, conflict-free 8-byte reads) and store the factor;  every later tile is updated with
+// Y^T Z products of two published images.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int TOP_NW = 8, TOP_NVS = 6, TOP_NTS = 7, TOP_MAXT = 13;
+constexpr int TOP_NW = 16, TOP_NVS = 3, TOP_NTS = 4, TOP_MAXT = 13;
 
 __device__ __forceinline__ d4 img_load(const double* img, int lane) {
     d4 v;
@@ -309,18 +418,26 @@ __device__ __forceinline__ void img_store(double* img, int lane, const d4& v) {
     for (int r = 0; r < 4; ++r) img[r * 64 + lane] = v[r];
 }
 
-__global__ __launch_bounds__(64 * TOP_NW, 2) void k_nd_top(FwdParams p, NdDev nd, int k) {
-    __shared__ double Pimg[256];
-    __shared__ double Wimg[TOP_MAXT][256];
-    __shared__ double Vimg[TOP_MAXT][256];
+__global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, int k) {
+    extern __shared__ double nd_lds[];
+    double* Pimg = nd_lds;                       // 256
+    double* Wimg = Pimg + 256;                   // TOP_MAXT x 256
+    double* Vimg = Wimg + TOP_MAXT * 256;        // TOP_MAXT x 256
+    int* cl_s = reinterpret_cast<int*>(Vimg + TOP_MAXT * 256);  // 16 TOP_MAXT ints
+    short* cp_s0 = reinterpret_cast<short*>(cl_s + 16 * TOP_MAXT);
+    short* cp_s1 = cp_s0 + 16 * TOP_MAXT;
+    double* chl = reinterpret_cast<double*>(cp_s1 + 16 * TOP_MAXT);  // one child's packed update
     const int m = blockIdx.x, tid = threadIdx.x;
     NdGeo g;
     g.lane = tid & 63;
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const NdMem mm = nd_member(p, nd, m, k);
+    const double* cf = nd.cf + (long long)m * CF_STRIDE;
+    double* fact = nd.fact + (long long)m * nd.fact_stride;
+    double* arena = nd.arena + (long long)m * nd.arena_stride;
     int bad = 0;
+    NPROF_DECL;
     for (int lv = 4; lv >= 0; --lv) {
         for (int fi = 0; fi < (1 << lv); ++fi) {
             const int f = (1 << lv) - 1 + fi;
@@ -331,15 +448,24 @@ __global__ __launch_bounds__(64 * TOP_NW, 2) void k_nd_top(FwdParams p, NdDev nd
             const int T = st + bt;
             const int co = __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
             const int kreg_last = __builtin_amdgcn_readfirstlane(F[NDF_KREG]);
-            const int* cl = nd.cells + co;
-            const short* cp0 = nd.cpos + 2 * co;
-            const short* cp1 = cp0 + 16 * T;
-            const double* ch0 = mm.arena + nd.fronts[F[NDF_C0] * ND_FRONT_INTS + NDF_UPD];
-            const double* ch1 = mm.arena + nd.fronts[F[NDF_C1] * ND_FRONT_INTS + NDF_UPD];
-            double* fa = mm.fact + F[NDF_FACT];
+            double* fa = fact + F[NDF_FACT];
             const int nV = st * T - ((st * (st - 1)) >> 1);
             const int nT = b > 0 ? ((bt * (bt + 1)) >> 1) : 0;
-            // ---- my tiles
+            NPROF(0);
+            // ---- the front's position tables and the first child's update to LDS
+            const int* Fc[2] = {nd.fronts + F[NDF_C0] * ND_FRONT_INTS, nd.fronts + F[NDF_C1] * ND_FRONT_INTS};
+            for (int i = tid; i < 16 * T; i += 64 * TOP_NW) {
+                cl_s[i] = nd.cells[co + i];
+                cp_s0[i] = nd.cpos[2 * co + i];
+                cp_s1[i] = nd.cpos[2 * co + 16 * T + i];
+            }
+            {
+                const int n2 = (((Fc[0][NDF_B] + 1) * (Fc[0][NDF_B] + 2) >> 1) + 1) >> 1;
+                const double2* s2 = reinterpret_cast<const double2*>(arena + Fc[0][NDF_UPD]);
+                double2* d2 = reinterpret_cast<double2*>(chl);
+                for (int i = tid; i < n2; i += 64 * TOP_NW) d2[i] = s2[i];
+            }
+            // ---- my tiles: decode (scalar)
             d4 vt[TOP_NVS], tr[TOP_NTS];
             int vq[TOP_NVS], vR[TOP_NVS], tR[TOP_NTS], tC[TOP_NTS];
 #pragma unroll
@@ -353,22 +479,6 @@ __global__ __launch_bounds__(64 * TOP_NW, 2) void k_nd_top(FwdParams p, NdDev nd
                     R = q + rem;
                 }
                 vq[s] = q; vR[s] = R;
-                vt[s] = d4{0.0, 0.0, 0.0, 0.0};
-                if (q >= 0) {
-                    const int pm = 16 * R + g.lc;
-                    const int cm = cl[pm];
-                    const int pm0 = cp0[pm], pm1 = cp1[pm];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int pk = 16 * q + 4 * r + g.lq;
-                        const int ck = cl[pk];
-                        double v = nd_coef(mm, cm, ck, pk == pm);
-                        const int a0 = cp0[pk], a1 = cp1[pk];
-                        if (a0 >= 0 && pm0 >= 0) v += ch0[tri(a0, pm0)];
-                        if (a1 >= 0 && pm1 >= 0) v += ch1[tri(a1, pm1)];
-                        vt[s][r] = v;
-                    }
-                }
             }
 #pragma unroll
             for (int s = 0; s < TOP_NTS; ++s) {
@@ -382,24 +492,63 @@ __global__ __launch_bounds__(64 * TOP_NW, 2) void k_nd_top(FwdParams p, NdDev nd
                     R += st; C += st;
                 }
                 tR[s] = R; tC[s] = C;
-                tr[s] = d4{0.0, 0.0, 0.0, 0.0};
-                if (R >= 0) {
-                    const int pc0 = cp0[16 * C + g.lc], pc1 = cp1[16 * C + g.lc];
+            }
+            __syncthreads();
+            NPROF(1);
+            // ---- coefficients + child 0
+#pragma unroll
+            for (int s = 0; s < TOP_NVS; ++s) {
+                vt[s] = d4{0.0, 0.0, 0.0, 0.0};
+                if (vq[s] >= 0) {
+                    const int pm = 16 * vR[s] + g.lc;
+                    const int cm = cl_s[pm], pm0 = cp_s0[pm];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int pr = 16 * R + 4 * r + g.lq;
-                        const int a0 = cp0[pr], a1 = cp1[pr];
-                        double v = 0.0;
-                        if (a0 >= 0 && pc0 >= 0) v += ch0[tri(a0, pc0)];
-                        if (a1 >= 0 && pc1 >= 0) v += ch1[tri(a1, pc1)];
-                        tr[s][r] = v;
+                        const int pk = 16 * vq[s] + 4 * r + g.lq;
+                        vt[s][r] = nd_coef_global(cf, cm, cl_s[pk], pk == pm) + nd_gather(chl, cp_s0[pk], pm0);
                     }
                 }
             }
-            // ---- panels
-            int fo = 0;  // factor offset of panel p, in 64-double register rows
-            for (int pp = 0; pp < st; ++pp) {
-                const int kreg = pp == st - 1 ? kreg_last : 4;
+#pragma unroll
+            for (int s = 0; s < TOP_NTS; ++s) {
+                tr[s] = d4{0.0, 0.0, 0.0, 0.0};
+                if (tR[s] >= 0) {
+                    const int pc0 = cp_s0[16 * tC[s] + g.lc];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tr[s][r] = nd_gather(chl, cp_s0[16 * tR[s] + 4 * r + g.lq], pc0);
+                }
+            }
+            NPROF(2);
+            __syncthreads();
+            {
+                const int n2 = (((Fc[1][NDF_B] + 1) * (Fc[1][NDF_B] + 2) >> 1) + 1) >> 1;
+                const double2* s2 = reinterpret_cast<const double2*>(arena + Fc[1][NDF_UPD]);
+                double2* d2 = reinterpret_cast<double2*>(chl);
+                for (int i = tid; i < n2; i += 64 * TOP_NW) d2[i] = s2[i];
+            }
+            __syncthreads();
+            NPROF(3);
+            // ---- child 1
+#pragma unroll
+            for (int s = 0; s < TOP_NVS; ++s) {
+                if (vq[s] >= 0) {
+                    const int pm1 = cp_s1[16 * vR[s] + g.lc];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vt[s][r] += nd_gather(chl, cp_s1[16 * vq[s] + 4 * r + g.lq], pm1);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < TOP_NTS; ++s) {
+                if (tR[s] >= 0) {
+                    const int pc1 = cp_s1[16 * tC[s] + g.lc];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tr[s][r] += nd_gather(chl, cp_s1[16 * tR[s] + 4 * r + g.lq], pc1);
+                }
+            }
+            NPROF(4);
+            // ---- panels.  The inverse of the NEXT pivot tile is formed by its owner right after that tile's own update (look-ahead):
+            // the in-wave sweep then runs beside the other waves' updates instead of in front of a barrier.
+            auto sweep_diag = [&](int pp, int kreg) {
                 const int ipp = pp * T - ((pp * (pp - 1)) >> 1);  // index of V(pp, pp)
                 if (w == ipp % TOP_NW) {
                     const int sl = ipp / TOP_NW;
@@ -412,7 +561,20 @@ __global__ __launch_bounds__(64 * TOP_NW, 2) void k_nd_top(FwdParams p, NdDev nd
                             for (int r = 0; r < 4; ++r) Pimg[r * 64 + g.lane] = t[r];  // -inv
                         }
                 }
-                __syncthreads();
+            };
+            auto update_v = [&](int s, int kreg) {  // V(q, R) -= V(pp, q)^T W(pp, R)^T
+                const d4 Y = img_load(Vimg + 256 * vq[s], g.lane), Z = img_load(Wimg + 256 * vR[s], g.lane);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    if (kk < kreg) vt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kk], Z[kk], vt[s], 0, 0, 0);
+            };
+            int fo = 0;  // factor offset of panel p, in 64-double register rows
+            sweep_diag(0, st == 1 ? kreg_last : 4);
+            NPROF(5);
+            for (int pp = 0; pp < st; ++pp) {
+                const int kreg = pp == st - 1 ? kreg_last : 4;
+                __syncthreads();  // P(pp) published; every read of the previous panel's images is done
+                NPROF(6);
                 {
                     const d4 Pn = img_load(Pimg, g.lane);
 #pragma unroll
@@ -423,39 +585,48 @@ __global__ __launch_bounds__(64 * TOP_NW, 2) void k_nd_top(FwdParams p, NdDev nd
 #pragma unroll
                             for (int kk = 0; kk < 4; ++kk)
                                 if (kk < kreg) wv = __builtin_amdgcn_mfma_f64_16x16x4f64(Pn[kk], vt[s][kk], wv, 0, 0, 0);
-                            img_store(Wimg[R], g.lane, wv);  // -W^T
-                            img_store(Vimg[R], g.lane, vt[s]);
+                            img_store(Wimg + 256 * R, g.lane, wv);  // -W^T
+                            img_store(Vimg + 256 * R, g.lane, vt[s]);
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 if (r < kreg) fa[(fo + (R - pp - 1) * kreg + r) * 64 + g.lane] = -wv[r];
                         }
                     }
                 }
-                __syncthreads();
+                NPROF(7);
+                __syncthreads();  // images of panel pp visible; P(pp) no longer read
+                NPROF(8);
+                if (pp + 1 < st) {
+                    const int inx = (pp + 1) * T - (((pp + 1) * pp) >> 1);
+                    if (w == inx % TOP_NW) {
+                        const int sl = inx / TOP_NW;
 #pragma unroll
-                for (int s = 0; s < TOP_NVS; ++s) {
-                    if (vq[s] > pp) {  // V(q, R) -= V(pp, q)^T W(pp, R)^T
-                        const d4 Y = img_load(Vimg[vq[s]], g.lane), Z = img_load(Wimg[vR[s]], g.lane);
+                        for (int s = 0; s < TOP_NVS; ++s)
+                            if (s == sl) update_v(s, kreg);
+                    }
+                    sweep_diag(pp + 1, pp + 1 == st - 1 ? kreg_last : 4);
+                    NPROF(12);
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-                            if (kk < kreg) vt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kk], Z[kk], vt[s], 0, 0, 0);
+                    for (int s = 0; s < TOP_NVS; ++s) {
+                        const int idx = s * TOP_NW + w;
+                        if (vq[s] > pp && idx != inx) update_v(s, kreg);
                     }
                 }
 #pragma unroll
                 for (int s = 0; s < TOP_NTS; ++s) {
                     if (tR[s] >= 0) {  // F22(R, C) -= W(pp, R) V(pp, C)^T
-                        const d4 Y = img_load(Wimg[tR[s]], g.lane), Z = img_load(Vimg[tC[s]], g.lane);
+                        const d4 Y = img_load(Wimg + 256 * tR[s], g.lane), Z = img_load(Vimg + 256 * tC[s], g.lane);
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk)
                             if (kk < kreg) tr[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kk], Z[kk], tr[s], 0, 0, 0);
                     }
                 }
                 fo += (T - pp - 1) * kreg;
-                // (the next panel's S1 writes Pimg only; its S2 rewrites the images behind the next barrier)
+                NPROF(9);
             }
             // ---- the update matrix to the arena
             if (nT > 0) {
-                double* out = mm.arena + F[NDF_UPD];
+                double* out = arena + F[NDF_UPD];
 #pragma unroll
                 for (int s = 0; s < TOP_NTS; ++s) {
                     if (tR[s] >= 0) {
@@ -468,9 +639,15 @@ __global__ __launch_bounds__(64 * TOP_NW, 2) void k_nd_top(FwdParams p, NdDev nd
                     }
                 }
             }
+            NPROF(10);
             __syncthreads();  // children before parents; the images are free again
+            NPROF(11);
         }
     }
+#ifdef HM_ND_PROF
+    if (blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 16; ++i) hm_nd_prof_buf[i] = prof_acc[i];
+#endif
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
@@ -478,9 +655,62 @@ __global__ __launch_bounds__(64 * TOP_NW, 2) void k_nd_top(FwdParams p, NdDev nd
 // Back substitution, root to leaves: per front and panel (last first)  x1 = -W^T [x of the rows below; -1 for the rhs row],
 // one wave per front, levels separated by workgroup barriers; pressures in P; then the face fluxes.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int SOL_NW = 16;
+constexpr int SOL_NW = 8;
 
-__global__ __launch_bounds__(64 * SOL_NW) void k_nd_solve(FwdParams p, NdDev nd, int k) {
+// Fronts with one pivot tile (levels >= 5), UNR of them per wave at a time: the cell indices of all of them, then the known
+// pressures and the factor tiles of all of them are requested before anything is used -- two round trips to memory per UNR
+// fronts (the back substitution does 16 multiply-adds per 8 bytes: it is a stream of the factor, bound by loads in flight).
+template <int UNR, int MAXBT>
+__device__ __forceinline__ void nd_solve_single(const NdDev& nd, const double* __restrict__ fact, double* P, int nf, int w, const NdGeo& g) {
+    for (int fi0 = w * UNR; fi0 < nf; fi0 += SOL_NW * UNR) {
+        int bt[UNR], kreg[UNR], cb[UNR][MAXBT], cpv[UNR][4];
+        const double* fa[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int fi = fi0 + u < nf ? fi0 + u : nf - 1;  // (a wave's surplus slots redo its last front: same values, harmless)
+            const int* F = nd.fronts + (nf - 1 + fi) * ND_FRONT_INTS;
+            bt[u] = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
+            kreg[u] = __builtin_amdgcn_readfirstlane(F[NDF_KREG]);
+            const int* cl = nd.cells + __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
+            fa[u] = fact + F[NDF_FACT];
+#pragma unroll
+            for (int R = 0; R < MAXBT; ++R) cb[u][R] = cl[16 * (1 + (R < bt[u] ? R : 0)) + g.lc];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cpv[u][r] = cl[4 * r + g.lq];
+        }
+        double xv[UNR][MAXBT], t[UNR][MAXBT][4];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int R = 0; R < MAXBT; ++R) {
+                const int c = cb[u][R];
+                const double l = P[c >= 0 ? c : 0];
+                xv[u][R] = R < bt[u] ? l * (c >= 0 ? 1.0 : 0.0) + (c == -2 ? -1.0 : 0.0) : 0.0;
+                const int Rc = R < bt[u] ? R : 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[u][R][r] = fa[u][(Rc * kreg[u] + (r < kreg[u] ? r : 0)) * 64 + g.lane];
+            }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int R = 0; R < MAXBT; ++R)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fma(t[u][R][r], xv[u][R], acc[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = acc[r];
+                v += __shfl_xor(v, 8);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 1);
+                if (g.lc == 0 && r < kreg[u] && cpv[u][r] >= 0) P[cpv[u][r]] = -v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * SOL_NW, 2) void k_nd_solve(FwdParams p, NdDev nd, int k) {
     __shared__ double xe_all[SOL_NW][16 * TOP_MAXT];
     const int m = blockIdx.x, tid = threadIdx.x;
     NdGeo g;
@@ -494,6 +724,15 @@ __global__ __launch_bounds__(64 * SOL_NW) void k_nd_solve(FwdParams p, NdDev nd,
     double* xe = xe_all[w];
     for (int lv = 0; lv < ND_LEVELS; ++lv) {
         const int nf = 1 << lv;
+        if (lv >= 5) {
+            if (lv == 5) nd_solve_single<1, 6>(nd, fact, P, nf, w, g);
+            else if (lv == 6) nd_solve_single<2, 4>(nd, fact, P, nf, w, g);
+            else if (lv == 7) nd_solve_single<2, 3>(nd, fact, P, nf, w, g);
+            else if (lv == 10) nd_solve_single<8, 1>(nd, fact, P, nf, w, g);
+            else nd_solve_single<4, 2>(nd, fact, P, nf, w, g);
+            __syncthreads();
+            continue;
+        }
         for (int fi = w; fi < nf; fi += SOL_NW) {
             const int f = nf - 1 + fi;
             const int* F = nd.fronts + f * ND_FRONT_INTS;
@@ -514,12 +753,25 @@ __global__ __launch_bounds__(64 * SOL_NW) void k_nd_solve(FwdParams p, NdDev nd,
             for (int pp = st - 1; pp >= 0; --pp) {
                 const int kreg = pp == st - 1 ? kreg_last : 4;
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                for (int R = pp + 1; R < T; ++R) {
-                    const double xv = xe[16 * R + g.lc];
-                    const double* tl = fa + (long long)(fo + (R - pp - 1) * kreg) * 64 + g.lane;
+                if (kreg == 4) {
+#pragma unroll 4
+                    for (int R = pp + 1; R < T; ++R) {
+                        const double xv = xe[16 * R + g.lc];
+                        const double* tl = fa + (long long)(fo + (R - pp - 1) * 4) * 64 + g.lane;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r < kreg) acc[r] = fma(tl[r * 64], xv, acc[r]);
+                        for (int r = 0; r < 4; ++r) acc[r] = fma(tl[r * 64], xv, acc[r]);
+                    }
+                } else {
+#pragma unroll 2
+                    for (int R = pp + 1; R < T; ++R) {
+                        const double xv = xe[16 * R + g.lc];
+                        const double* tl = fa + (long long)(fo + (R - pp - 1) * kreg) * 64 + g.lane;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            const double l = tl[(r < kreg ? r : 0) * 64];
+                            acc[r] = fma(l * (r < kreg ? 1.0 : 0.0), xv, acc[r]);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -594,7 +846,7 @@ static int nd_setup(hm_fwd* f) {
     const size_t N = p.N;
     if ((rc = hm_dev_alloc(n->fronts, t.fronts.size() * 4)) || (rc = hm_dev_alloc(n->cells, t.cells.size() * 4)) ||
         (rc = hm_dev_alloc(n->cpos, t.cpos.size() * 2)) || (rc = hm_dev_alloc(n->fact, N * t.info.fact_doubles * 8)) ||
-        (rc = hm_dev_alloc(n->arena, N * t.info.arena_doubles * 8)) || (rc = hm_dev_alloc(n->dg, N * p.Nxy * 8))) {
+        (rc = hm_dev_alloc(n->arena, N * t.info.arena_doubles * 8)) || (rc = hm_dev_alloc(n->dg, N * (size_t)CF_STRIDE * 8))) {
         hm_nd_free(n);
         return rc;
     }
@@ -607,12 +859,22 @@ static int nd_setup(hm_fwd* f) {
     d.cpos = (const short*)n->cpos.p;
     d.fact = (double*)n->fact.p;
     d.arena = (double*)n->arena.p;
-    d.dg = (double*)n->dg.p;
+    d.cf = (double*)n->dg.p;
     d.fact_stride = t.info.fact_doubles;
     d.arena_stride = t.info.arena_doubles;
-    d.slot8 = t.info.lds_slot_doubles[0];
-    d.slot9 = t.info.lds_slot_doubles[1];
-    d.slot10 = t.info.lds_slot_doubles[2];
+    d.slot9 = t.info.upd_doubles[9];
+    d.slot10 = t.info.upd_doubles[10];
+    d.child_doubles[0] = t.info.upd_doubles[8];
+    d.child_doubles[1] = t.info.upd_doubles[7];
+    d.child_doubles[2] = t.info.upd_doubles[6];
+    d.top_child_doubles = 0;
+    for (int lv = 1; lv <= 5; ++lv) d.top_child_doubles = std::max(d.top_child_doubles, t.info.upd_doubles[lv]);
+    // dynamic LDS beyond 64 KB must be requested per kernel
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<5, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<6, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<7, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_sub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     f->nd = n;
     return 0;
 }
@@ -627,17 +889,23 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
     }
     hipStream_t s = f->ctx->stream;
     const NdDev& nd = f->nd->dev;
-    if (f->dtype == 64) hipLaunchKernelGGL(k_nd_assemble<double>, dim3(p.N), dim3(1024), 0, s, p, nd, (const double*)S, S_stride);
-    else hipLaunchKernelGGL(k_nd_assemble<float>, dim3(p.N), dim3(1024), 0, s, p, nd, (const float*)S, S_stride);
-    const size_t lds = (size_t)4 * 2 * (nd.slot8 + nd.slot9 + nd.slot10) * 8;
-    hipLaunchKernelGGL(k_nd_sub, dim3(p.N * 32), dim3(256), lds, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<6, 4>), dim3(p.N * 16), dim3(256), 0, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<5, 6>), dim3(p.N * 8), dim3(256), 0, s, p, nd, k);
-    hipLaunchKernelGGL(k_nd_top, dim3(p.N), dim3(64 * TOP_NW), 0, s, p, nd, k);
+    if (f->dtype == 64) hipLaunchKernelGGL(k_nd_assemble<double>, dim3(p.N), dim3(1024), 0, s, p, nd, (const double*)S, S_stride, k);
+    else hipLaunchKernelGGL(k_nd_assemble<float>, dim3(p.N), dim3(1024), 0, s, p, nd, (const float*)S, S_stride, k);
+    const size_t lds_sub = (size_t)4 * (2 * (nd.slot9 + nd.slot10) + 4 * SUB_CF_PLANE + SUB_POS) * 8;
+    hipLaunchKernelGGL(k_nd_sub, dim3(p.N * 64), dim3(256), lds_sub, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * 32), dim3(256), (size_t)4 * (2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE + 64) * 8, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * 16), dim3(256), (size_t)4 * (2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE + 80) * 8, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * 16), dim3(128), (size_t)2 * (2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE + 112) * 8, s, p, nd, k);
+    const size_t lds_top = (size_t)(256 + 2 * TOP_MAXT * 256 + 16 * TOP_MAXT + nd.top_child_doubles + 2) * 8;
+    hipLaunchKernelGGL(k_nd_top, dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_solve, dim3(p.N), dim3(64 * SOL_NW), 0, s, p, nd, k);
     HM_HIP(hipGetLastError());
     return 0;
 }
+
+#ifdef HM_ND_PROF
+extern "C" int hm_debug_nd_prof(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hm_nd_prof_buf), sizeof(long long) * 64); }
+#endif
 
 extern "C" int hm_debug_nd_tables(int Nx, int Ny, long long* info, int* fronts, int* cells, short* cpos) {
     HM_REQUIRE(info, "hm_debug_nd_tables: NULL info");
@@ -650,7 +918,7 @@ extern "C" int hm_debug_nd_tables(int Nx, int Ny, long long* info, int* fronts, 
     info[1] = t.info.n_cells;
     info[2] = t.info.fact_doubles;
     info[3] = t.info.arena_doubles;
-    for (int i = 0; i < 3; ++i) info[4 + i] = t.info.lds_slot_doubles[i];
+    for (int i = 0; i < 3; ++i) info[4 + i] = t.info.upd_doubles[8 + i];
     for (int i = 0; i < ND_LEVELS; ++i) info[8 + i] = t.info.max_bt[i] * 16 + t.info.max_st[i];
     if (fronts) memcpy(fronts, t.fronts.data(), t.fronts.size() * sizeof(int));
     if (cells) memcpy(cells, t.cells.data(), t.cells.size() * sizeof(int));

@@ -1,0 +1,77 @@
+"""Symbolic phase of the nested-dissection pressure solve (press_nd.hip; hm_debug_nd_tables runs on the host): the tables the
+kernels read describe a valid multifrontal elimination of the 128 x 128 five-point system -- checked by carrying out that
+elimination in NumPy exactly as the tables prescribe (tests/nd_emulate.py) against scipy's sparse direct solve."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from tests import nd_emulate as E
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from historymatching_amd import _lib
+
+    return _lib.load()
+
+
+def test_tables_structure(lib):
+    tab = E.tables(lib, 128, 128)
+    f = tab["fronts"]
+    assert len(f) == 2047
+    for lv in range(11):
+        assert (f[:, E.F_LEVEL] == lv).sum() == 1 << lv
+    piv = []
+    for F in f:
+        T = F[E.F_ST] + F[E.F_BT]
+        cl = tab["cells"][F[E.F_CELLS]:F[E.F_CELLS] + 16 * T]
+        s, b, st = F[E.F_S], F[E.F_B], F[E.F_ST]
+        assert (cl[:s] >= 0).all() and (cl[s:16 * st] == -1).all()
+        assert (cl[16 * st:16 * st + b] >= 0).all() and cl[16 * st + b] == -2 and (cl[16 * st + b + 1:] == -1).all()
+        piv.append(cl[:s])
+        if F[E.F_LEVEL] >= 5:
+            assert st == 1, "levels 5..10 are single-pivot-tile fronts (one wave each)"
+    piv = np.concatenate(piv)
+    assert np.array_equal(np.sort(piv), np.arange(128 * 128)), "every cell is a pivot exactly once"
+    # sizes the kernels' static register arrays assume (press_nd.hip: nd_setup)
+    info = tab["info"]
+    bt = [info[8 + lv] // 16 for lv in range(11)]
+    assert bt[10] <= 1 and bt[9] <= 2 and bt[8] <= 2 and bt[7] <= 3 and bt[6] <= 4 and bt[5] <= 6
+
+
+def test_unsupported_grid_is_refused(lib):
+    import ctypes as C
+
+    info = (C.c_longlong * 24)()
+    assert lib.hm_debug_nd_tables(64, 64, info, None, None, None) != 0
+    assert b"tree" in lib.hm_last_error()
+
+
+def test_elimination_by_the_tables_solves_the_system(lib):
+    Nx = Ny = 128
+    tab = E.tables(lib, Nx, Ny)
+    rng = np.random.RandomState(1)
+    z = rng.randn(Nx, Ny)
+    for _ in range(6):
+        z = (z + np.roll(z, 1, 0) + np.roll(z, -1, 0) + np.roll(z, 1, 1) + np.roll(z, -1, 1)) / 5
+    K = 0.1 + np.exp(5 * z / z.std())
+    L = 1 / K
+    TX = np.zeros((Nx + 1, Ny))
+    TY = np.zeros((Nx, Ny + 1))
+    TX[1:-1] = 2 / (L[:-1] + L[1:])
+    TY[:, 1:-1] = 2 / (L[:, :-1] + L[:, 1:])
+    dg = TX[:-1] + TX[1:] + TY[:, :-1] + TY[:, 1:]
+    dg[0, 0] += 2 * K[0, 0]
+    idx = np.arange(Nx * Ny).reshape(Nx, Ny)
+    rows = [idx.ravel(), idx[1:].ravel(), idx[:-1].ravel(), idx[:, 1:].ravel(), idx[:, :-1].ravel()]
+    cols = [idx.ravel(), idx[:-1].ravel(), idx[1:].ravel(), idx[:, :-1].ravel(), idx[:, 1:].ravel()]
+    vals = [dg.ravel(), -TX[1:-1].ravel(), -TX[1:-1].ravel(), -TY[:, 1:-1].ravel(), -TY[:, 1:-1].ravel()]
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(Nx * Ny, Nx * Ny))
+    q = np.zeros(Nx * Ny)
+    q[(Nx // 2) * Ny + Ny // 2] = 1
+    q[0] = q[Ny - 1] = q[(Nx - 1) * Ny] = q[Nx * Ny - 1] = -0.25
+    x = E.solve(tab, dg.ravel(), TX.ravel(), TY.ravel(), q)
+    xr = spla.spsolve(A.tocsc(), q)
+    assert np.abs(A @ x - q).max() <= 4 * np.abs(A @ xr - q).max() + 1e-12
+    assert np.abs(x - xr).max() <= 1e-6 * np.abs(xr).max()
