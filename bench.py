@@ -273,6 +273,55 @@ def load_profile_json(name):
         return None, None
 
 
+def self_launch(n):
+    """Start `n` ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* / HM_AMD_RDZV* set), relay rank 0's stdout, return the
+    largest exit code.  The parent imports nothing that touches the GPU."""
+    import secrets
+    import socket
+    import subprocess
+    import tempfile
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    rdzv_dir = tempfile.mkdtemp(prefix="hm_amd_bench_")  # 0700, ours
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HM_AMD_RDZV=os.path.join(rdzv_dir, "rdzv"),
+               HM_AMD_RDZV_KEY=secrets.token_hex(16), HSA_ENABLE_IPC_MODE_LEGACY="0", HM_BENCH_SELF_LAUNCHED="1")
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].stdout.read().decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    try:
+        os.rmdir(rdzv_dir)
+    except OSError:
+        pass
+    if any(rcs):
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+    return max(abs(rc) for rc in rcs)
+
+
+def dry_run(args):
+    """The N-rank launch path without a device: rendezvous over the host channel, a barrier, a max-over-ranks time, one line."""
+    from historymatching_amd.dist import Comm
+
+    comm = Comm.from_env()
+    comm.barrier()
+    t0 = time.perf_counter()
+    ranks = comm.host.all_gather((comm.rank, comm.local_rank, os.getpid()))
+    comm.barrier()
+    elapsed = comm.all_reduce_max(time.perf_counter() - t0)
+    if comm.rank == 0:
+        print(json.dumps({"metric": "ensemble-steps/sec", "value": None, "unit": "ensemble-steps/s", "n_gpus": comm.world_size, "dry_run": True,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "barrier_s": elapsed,
+                          "ranks": {"world": comm.world_size, "seen": [list(r) for r in ranks], "self_launched": os.environ.get("HM_BENCH_SELF_LAUNCHED") == "1"}}), flush=True)
+    comm.close()
+    return 0 if comm.world_size == args.gpus else 4
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,7 +336,17 @@ def main():
     ap.add_argument("--config5", action="store_true", help="run the config-5 leg (N_e=1000 at 512x512, localised) also below 4 ranks")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0, help="0 = fastest kernels, 1 = generic kernels")
+    ap.add_argument("--dry-run", action="store_true", help="no device work: the ranks rendezvous, agree on a time and rank 0 prints a line (tests of the N-rank launch path)")
     args = ap.parse_args()
+
+    # `--gpus N` run plainly (no launcher set WORLD_SIZE): become the launcher.  N fresh child processes, one per GPU, BEFORE this
+    # process has made any GPU call (a process that has initialised the GPU must never be replaced or forked); the parent only
+    # waits and relays rank 0's line.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
+    if args.dry_run:
+        sys.exit(dry_run(args))
 
     from historymatching_amd import _lib
     from historymatching_amd.dist import Comm
@@ -298,12 +357,19 @@ def main():
     world, rank, local_rank = comm.world_size, comm.rank, comm.local_rank
     if os.environ.get("HM_BENCH_ALL_ON_DEVICE0") == "1":  # functional check of the N > 1 path on a one-GPU box: every rank on device 0
         local_rank = comm.local_rank = 0                   # (RCCL refuses that; the reductions then run over the host channel)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if args.gpus != world:  # the line's n_gpus must be what was asked for: a mismatch is an error, not a silent one-GPU benchmark
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line for a different rank count", file=sys.stderr)
+        comm.close()
+        sys.exit(4)
 
     ctx = _lib.Context.get(local_rank)
     if world > 1 or os.environ.get("HM_BENCH_FORCE_DIST") == "1":  # the env switch exercises the RCCL path with 1 rank
         comm.enable_rccl(ctx, force_single=True)
+    # what the ranks saw: device count and device of every rank, whether the library's RCCL communicator spans all of them
+    rank_info = comm.host.all_gather({"rank": rank, "local_rank": local_rank, "device": ctx.name(), "visible_devices": ctx.device_count(),
+                                      "rccl": comm.rccl is not None}) if world > 1 else \
+        [{"rank": 0, "local_rank": local_rank, "device": ctx.name(), "visible_devices": ctx.device_count(), "rccl": comm.rccl is not None}]
     model = build_model(64, device=local_rank)
     n_e = args.members
     perms = gaussian_fields_kron(NX, NY, 2, 1, n_e, r=0.8, seed=1 + rank)  # synthetic prior, SURVEY.md 8d
@@ -345,7 +411,7 @@ def main():
     two_streams = None
     if world == 1 and args.variant == 0 and not args.no_two_streams:
         try:
-            ctx2 = _lib.Context(local_rank)
+            ctx2 = _lib.Context.secondary(local_rank)
             halves = []
             for c, lo, hi in ((ctx, 0, n_e // 2), (ctx2, n_e // 2, n_e)):
                 hp = ForwardPlan(model, hi - lo, DT, NTIME, keep_history=True, ctx=c)
@@ -486,6 +552,8 @@ def main():
                        "members_per_gpu": n_e, "grid": [NX, NY], "nTime": NTIME, "device": ctx.name(),
                        "kernel_variant": args.variant, "results_finite_and_status_ok": bool(ok),
                        "ranks": "one process per GPU, host channel for barriers/timing, RCCL from the library for the update's reductions (no PyTorch)"},
+            "ranks": {"world": world, "rccl_communicator_ranks": (world if all(r["rccl"] for r in rank_info) else 0), "rccl_error": comm.rccl_error,
+                      "per_rank": rank_info, "self_launched": os.environ.get("HM_BENCH_SELF_LAUNCHED") == "1"},
             "roofline": roofline, "cpu_baseline": cpu, "two_streams": two_streams, "host_call": host_call, "es_update": upd, "config4": c4, "config5": c5,
             "device_ms": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
         }

@@ -44,6 +44,7 @@ _vp, _ip, _dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
 SIGNATURES = {
     "hm_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "hm_destroy": (None, [_vp]),
+    "hm_device_count": (C.c_int, []),
     "hm_last_error": (C.c_char_p, []),
     "hm_device_name": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "hm_abi_version": (C.c_int, []),
@@ -174,6 +175,33 @@ class Context:
         if device not in cls._cache:
             cls._cache[device] = cls(device)
         return cls._cache[device]
+
+    _secondary = {}
+
+    @classmethod
+    def secondary(cls, device=None, index=0):
+        """A further context (streams of its own) on `device`, one per (device, index) for the life of the process: the second
+        member block of a large forward run uses it, and every forward-model closure shares it instead of making its own."""
+        device = cls.get(device).device
+        if (device, index) not in cls._secondary:
+            cls._secondary[(device, index)] = cls(device)
+        return cls._secondary[(device, index)]
+
+    def device_count(self):
+        return int(self.lib.hm_device_count())
+
+    def close(self):
+        """Release the streams, events and pinned staging buffers of a context made with ``Context(device)`` (the per-device
+        contexts of ``Context.get`` live as long as the process)."""
+        if self.handle and Context._cache.get(self.device) is not self and self not in Context._secondary.values():
+            self.lib.hm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def name(self):
         buf = C.create_string_buffer(256)

@@ -34,6 +34,12 @@ extern "C" int hm_create(int device_id, hm_ctx** out) {
     return 0;
 }
 
+extern "C" int hm_device_count(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return -1;
+    return ndev;
+}
+
 extern "C" void hm_destroy(hm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);

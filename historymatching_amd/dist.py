@@ -37,6 +37,31 @@ def shard_bounds(N, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _remove_own_file(path):
+    """Unlink `path` if it exists; a file another user planted there (sticky /tmp) is reported, not tripped over."""
+    try:
+        os.unlink(path)
+    except FileNotFoundError:
+        pass
+    except PermissionError as e:
+        raise PermissionError(f"rendezvous path {path} exists and belongs to another user; set HM_AMD_RDZV to a private path") from e
+
+
+def default_rdzv_dir():
+    """A directory only this user can enter: $XDG_RUNTIME_DIR when it is one, else /tmp/hm_amd_<uid> created 0700 (and
+    checked: a directory someone else made under that name is refused)."""
+    xdg = os.environ.get("XDG_RUNTIME_DIR")
+    for d in ([xdg] if xdg else []) + [f"/tmp/hm_amd_{os.geteuid()}"]:
+        try:
+            os.makedirs(d, mode=0o700, exist_ok=True)
+            st = os.stat(d)
+            if st.st_uid == os.geteuid() and not (st.st_mode & 0o077):
+                return d
+        except OSError:
+            continue
+    raise PermissionError("no private directory for the rendezvous file: set HM_AMD_RDZV")
+
+
 class HostChannel:
     """Star of localhost connections (``multiprocessing.connection``: length-prefixed messages, HMAC handshake).
     Rank 0 listens on a port the OS picks and publishes ``port key`` in the rendezvous file; the others poll the file and
@@ -47,16 +72,17 @@ class HostChannel:
         self.peers = {}
         if self.world_size == 1:
             return
+        env_key = os.environ.get("HM_AMD_RDZV_KEY")  # a launcher that owns the environment passes the key there: the file then holds the port only
         if self.rank == 0:
-            key = secrets.token_bytes(16)
-            try:
-                os.unlink(rdzv_file)  # left behind by a run that crashed
-            except FileNotFoundError:
-                pass
+            key = bytes.fromhex(env_key) if env_key else secrets.token_bytes(16)
+            _remove_own_file(rdzv_file)  # left behind by a run that crashed
             listener = Listener(("127.0.0.1", 0), authkey=key)
             tmp = f"{rdzv_file}.{os.getpid()}"
-            with open(tmp, "w") as fh:
-                fh.write(f"{listener.address[1]} {key.hex()}\n")
+            # created exclusively and readable by the owner only: the key (when it is in the file) authenticates a channel that
+            # unpickles what it receives
+            fd = os.open(tmp, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600)
+            with os.fdopen(fd, "w") as fh:
+                fh.write(f"{listener.address[1]} {'-' if env_key else key.hex()}\n")
             os.replace(tmp, rdzv_file)
             try:
                 try:  # bound the wait for peers that never show up (private attribute of the stdlib Listener: best effort)
@@ -68,21 +94,21 @@ class HostChannel:
                     self.peers[int(conn.recv())] = conn
             finally:
                 listener.close()
-                try:
-                    os.unlink(rdzv_file)
-                except FileNotFoundError:
-                    pass
+                _remove_own_file(rdzv_file)
         else:
             t_end = time.time() + timeout
             while True:
                 try:
+                    st = os.stat(rdzv_file)
+                    if st.st_uid != os.geteuid() or (st.st_mode & 0o077):
+                        raise PermissionError(f"{rdzv_file} is not a private file of this user")
                     with open(rdzv_file) as fh:
                         port, key = fh.read().split()
-                    conn = Client(("127.0.0.1", int(port)), authkey=bytes.fromhex(key))
+                    conn = Client(("127.0.0.1", int(port)), authkey=bytes.fromhex(env_key if key == "-" else key))
                     break
-                except Exception:  # no file yet, a stale file (refused / wrong key): try again
+                except Exception as e:  # no file yet, a stale file (refused / wrong key), a file that is not ours: try again
                     if time.time() > t_end:
-                        raise TimeoutError(f"rank {self.rank}: no rendezvous through {rdzv_file} within {timeout} s")
+                        raise TimeoutError(f"rank {self.rank}: no rendezvous through {rdzv_file} within {timeout} s ({type(e).__name__}: {e})")
                     time.sleep(0.05)
             conn.send(self.rank)
             self.peers[0] = conn
@@ -131,12 +157,15 @@ class Comm:
     @classmethod
     def from_env(cls, timeout=120.0):
         """RANK / WORLD_SIZE / LOCAL_RANK as set by ``torch.distributed.run``, ``mpirun`` wrappers and the like.  The
-        rendezvous file is ``$HM_AMD_RDZV`` or a name in /tmp built from the launcher's pid and MASTER_PORT (both are
-        the same for all ranks of a job and differ between concurrent jobs)."""
+        rendezvous file is ``$HM_AMD_RDZV`` or a name built from the launcher's pid and MASTER_PORT (both are the same for all
+        ranks of a job and differ between concurrent jobs) inside a directory only this user can enter (``default_rdzv_dir``);
+        ``$HM_AMD_RDZV_KEY`` (hex), when the launcher sets it, keeps the channel's key out of the file."""
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", str(rank)))
-        rdzv = os.environ.get("HM_AMD_RDZV") or f"/tmp/hm_amd_rdzv_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
+        rdzv = os.environ.get("HM_AMD_RDZV")
+        if not rdzv and world > 1:
+            rdzv = os.path.join(default_rdzv_dir(), f"rdzv_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL's dmabuf IPC between the ranks' processes
         return cls(rank, world, rdzv, local_rank=local, timeout=timeout)
 
@@ -196,25 +225,34 @@ class Comm:
             return True
         if self.world_size == 1 and not force_single:
             return False
-        err, uid = None, None
+        # Phase 1, every rank: a device context, librccl opened and its symbols bound (hm_comm_unique_id does both; only
+        # rank 0's id is used).  The outcome is agreed on BEFORE anyone enters ncclCommInitRank: a rank that cannot take part
+        # (no device, no librccl, a bad LOCAL_RANK) would otherwise leave the healthy ranks blocked in it for ever.
+        err, uid, lib = None, None, None
         try:
             ctx = ctx or _lib.Context.get(self.local_rank)
             lib = ctx.lib
+            buf = C.create_string_buffer(128)
+            _lib.check(lib.hm_comm_unique_id(buf), "hm_comm_unique_id")
             if self.rank == 0:
-                buf = C.create_string_buffer(128)
-                _lib.check(lib.hm_comm_unique_id(buf), "hm_comm_unique_id")
                 uid = buf.raw
         except Exception as e:  # no GPU / no RCCL on this rank
             err = e
+        if self.world_size > 1:
+            pre = [m for m in self.host.all_gather(None if err is None else f"rank {self.rank}: {err}") if m]
+            if pre:
+                self.rccl_error = "; ".join(pre)
+                return False
+        elif err is not None:
+            self.rccl_error = str(err)
+            return False
+        # Phase 2: every rank is known to be able to call it
         uid = self.host.bcast(uid)
         h = C.c_void_p()
-        if err is None and uid is not None:
-            try:
-                _lib.check(lib.hm_comm_create(ctx.handle, self.rank, self.world_size, uid, C.byref(h)), "hm_comm_create")
-            except Exception as e:
-                err = e
-        elif err is None:
-            err = RuntimeError("rank 0 could not create an RCCL unique id")
+        try:
+            _lib.check(lib.hm_comm_create(ctx.handle, self.rank, self.world_size, uid, C.byref(h)), "hm_comm_create")
+        except Exception as e:
+            err = e
         msgs = self.host.all_gather(None if err is None else f"rank {self.rank}: {err}") if self.world_size > 1 else [None if err is None else str(err)]
         bad = [m for m in msgs if m]
         if bad:

@@ -202,9 +202,8 @@ def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True
         if cache.get("sig") != sig:
             release()
             bounds = np.linspace(0, N, blocks + 1).astype(int)
-            while len(cache.setdefault("ctxs", [])) < blocks - 1:  # the further blocks' own streams, kept for the closure's life
-                cache["ctxs"].append(_lib.Context(_lib.Context.get(model.device).device))
-            ctxs = [None] + cache["ctxs"][:blocks - 1]
+            # the further blocks' own streams: one secondary context per device and block index, shared process-wide
+            ctxs = [None] + [_lib.Context.secondary(model.device, i) for i in range(blocks - 1)]
             cache["plans"] = [(ForwardPlan(model, hi - lo, dt, nTime, keep_history=return_history, ctx=c), lo, hi)
                               for c, lo, hi in zip(ctxs, bounds[:-1], bounds[1:])]
             cache["sig"] = sig

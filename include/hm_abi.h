@@ -42,6 +42,10 @@ typedef struct hm_stats {
 /* ---- context ------------------------------------------------------------------------------ */
 int         hm_create(int device_id, hm_ctx** out);
 void        hm_destroy(hm_ctx* ctx);
+/* HIP devices visible to this process (-1: the runtime could not be asked).  A launcher's ranks report it so that the
+ * reader of a multi-GPU benchmark line can see every rank had the node's GPUs in view (notebooks/tools/utils.py:201-224 is the
+ * reference's process pool this library's ranks replace). */
+int   hm_device_count(void);
 const char* hm_last_error(void);
 int         hm_device_name(hm_ctx* ctx, char* buf, int buflen);   /* e.g. "gfx950:..."           */
 int         hm_abi_version(void);

@@ -230,3 +230,96 @@ def test_single_process_comm_is_identity():
     assert np.abs(out - es.ens_update0(E, obs_ens, obs, perturbs, decorr)).max() < 1e-11
     with pytest.raises(ValueError):
         forward_model_sharded(lambda a, b: [a, b], np.zeros((4, 2)), np.zeros((3, 2)), comm=comm)
+
+
+def _worker_rdzv_hardening(rank, world, rdzv, q):
+    """Rank 0 publishes; rank 1 inspects the file before connecting (mode, no key when the launcher passed it in the
+    environment).  Then the RCCL pre-phase: rank 0 pretends it could initialise (a fake context whose hm_comm_create would
+    block for ever), rank 1 cannot -- both must come back with the refusal, nobody enters the create call."""
+    import stat
+    import time as _t
+
+    from historymatching_amd import _lib
+
+    if rank == 1:
+        t_end = _t.time() + 60
+        while not os.path.exists(rdzv) and _t.time() < t_end:
+            _t.sleep(0.01)
+        st = os.stat(rdzv)
+        mode_ok = stat.S_IMODE(st.st_mode) == 0o600 and st.st_uid == os.geteuid()
+        key_in_file = open(rdzv).read().split()[1]
+    comm = Comm(rank, world, rdzv)
+    try:
+        if rank == 0:
+            class FakeLib:
+                def hm_comm_unique_id(self, buf):
+                    return 0
+
+                def hm_comm_create(self, *a):
+                    _t.sleep(3600)
+
+                def hm_last_error(self):
+                    return b""
+
+            class FakeCtx:
+                lib, handle, device = FakeLib(), None, 0
+
+            ok = comm.enable_rccl(ctx=FakeCtx())
+        else:
+            ok = comm.enable_rccl()
+        res = comm.host.gather((ok, comm.rccl_error, None if rank == 0 else (mode_ok, key_in_file)))
+        if rank == 0:
+            q.put(res)
+    finally:
+        comm.close()
+
+
+@pytest.mark.timeout(120)
+def test_rendezvous_file_is_private_and_rccl_refusal_is_agreed_before_init(monkeypatch):
+    monkeypatch.setenv("HM_AMD_RDZV_KEY", "00112233445566778899aabbccddeeff")
+    with tempfile.TemporaryDirectory() as d:
+        res = _run(_worker_rdzv_hardening, 2, os.path.join(d, "rdzv"))
+    (ok0, err0, _), (ok1, err1, (mode_ok, key_in_file)) = res
+    assert ok0 is False and ok1 is False and "rank 1" in err0 and err0 == err1
+    assert mode_ok and key_in_file == "-"
+
+
+def test_peer_refuses_a_rendezvous_file_that_is_not_private(tmp_path):
+    from historymatching_amd.dist import HostChannel
+
+    f = tmp_path / "rdzv"
+    f.write_text("1 00\n")
+    os.chmod(f, 0o644)
+    with pytest.raises(TimeoutError, match="not a private file"):
+        HostChannel(1, 2, str(f), timeout=0.3)
+
+
+def test_default_rendezvous_directory_is_private():
+    from historymatching_amd.dist import default_rdzv_dir
+
+    st = os.stat(default_rdzv_dir())
+    assert st.st_uid == os.geteuid() and not (st.st_mode & 0o077)
+
+
+@pytest.mark.timeout(120)
+def test_bench_gpus_2_launches_its_own_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2` run plainly, as the driver runs `--gpus 1`: the script becomes the launcher (two child
+    processes, before any GPU call), the ranks rendezvous, one JSON line with n_gpus = 2 comes out.  --dry-run: no device."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HM_AMD_RDZV", "HM_AMD_RDZV_KEY")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, env=env, timeout=100)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry_run"] and line["ranks"]["self_launched"]
+    assert sorted(s[0] for s in line["ranks"]["seen"]) == [0, 1] and len({s[2] for s in line["ranks"]["seen"]}) == 2
+    # a launcher that set a different WORLD_SIZE: no line for the wrong rank count
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), timeout=100)
+    assert r.returncode == 4
