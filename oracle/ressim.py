@@ -204,6 +204,8 @@ class ResSim:
         cfl = ((1 - sat) / 3) * pm
         Nts = int(np.ceil(T / cfl))
         dtx = (T / Nts) / pv
+        if getattr(self, "_trace", None) is not None:  # test diagnostics: the sub-step count per time step and its argument
+            self._trace.append((Nts, T / cfl))
         return Nts, dtx, fi
 
     def saturation_step_upwind(self, S, q, Vx, Vy, T):
@@ -227,10 +229,14 @@ class ResSim:
         wsats = np.zeros((nTime + 1, self.Nxy))
         wsats[0] = wsat0
         inj, prd = [], []
+        self._trace = []  # (Nts, dt / cfl) per time step: `nts_trace` after the run
         for k in range(nTime):
             wsats[k + 1], ri, rp = self.step(wsats[k], k, dt)
             inj.append(ri)
             prd.append(rp)
+        self.nts_trace = np.array([t[0] for t in self._trace], dtype=np.int64)
+        self.cfl_arg_trace = np.array([t[1] for t in self._trace])
+        self._trace = None
         self.actual_rates = dict(inj=np.array(inj).T.reshape(self.nInj, -1),
                                  prd=np.array(prd).T.reshape(self.nPrd, -1))
         return wsats

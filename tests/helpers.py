@@ -34,16 +34,29 @@ def oracle_sim_and_noise(om, x, dt, nTime, wsat0=None):
     import oracle.ressim as orc
     from scipy.sparse.linalg import spsolve
 
+    ref, noise, _ = oracle_sim_noise_and_nts(om, x, dt, nTime, wsat0)
+    return ref, noise
+
+
+def oracle_sim_noise_and_nts(om, x, dt, nTime, wsat0=None):
+    """`oracle_sim_and_noise` plus the oracle's per-step CFL sub-step counts (Nts = ceil(dt / cfl) is a
+    discontinuity; a whole-run comparison only means something where GPU and oracle took the same counts).  The counts of
+    the two orderings are asserted equal: a member on which the oracle disagrees with itself about Nts cannot be a parity case."""
+    import oracle.ressim as orc
+    from scipy.sparse.linalg import spsolve
+
     orc.set_perm(om, x)
     w0 = np.zeros(om.Nxy) if wsat0 is None else wsat0
     ref = om.sim(dt, nTime, w0)
+    nts = om.nts_trace.copy()
     orig = orc.spsolve
     orc.spsolve = lambda A, b: spsolve(A.tocsc(), b, permc_spec="NATURAL")
     try:
         ref2 = om.sim(dt, nTime, w0)
     finally:
         orc.spsolve = orig
-    return ref, float(np.abs(ref2 - ref).max())
+    assert np.array_equal(nts, om.nts_trace), "the oracle's two solver orderings disagree on the sub-step counts"
+    return ref, float(np.abs(ref2 - ref).max()), nts
 
 
 def _oracle_sim_task(args):

@@ -57,6 +57,82 @@ def test_config3_full_size_fp32_update_vs_oracle():
     assert np.abs(out64 - ref).max() < 1e-10
 
 
+def test_config3_one_full_size_es_mda_pass_vs_oracle():
+    """Config 3 at its own size, one assimilation pass of the device-resident driver: N = 1000 members at 128 x 128 through
+    `update.es_mda_device` (forward model in fp64 on the ensemble held by the update plan, producer series handed over on the
+    device, fp32 matrix-core analysis step) against oracle.es.ens_update0 applied to the same prior with the GPU's own
+    simulated observations and the same perturbations (HistoryMatch.py:578-586 with R12 -> sqrt(alpha) R12, alpha = n_iter = 1);
+    every element, bar 1e-4 of the largest increment."""
+    import scipy.linalg as sla
+
+    from historymatching_amd.forward import ForwardPlan
+    from historymatching_amd.update import es_mda_device
+    from oracle import es
+
+    n, N, nTime = 128, 1000, 40
+    _, gm = make_models(n, n)
+    prior = perms(n, n, N, seed=21).astype(np.float32).astype(np.float64)  # exactly representable in the fp32 plan
+    _, R12, decorr = es.obs_error_model(nTime, 4)
+    fwd = ForwardPlan(gm, N, DT, nTime, keep_history=False)
+    fwd.set_inputs(prior, transformed=False)
+    fwd.run()
+    fwd.sync()
+    _, prods, status = fwd.outputs(want_wsats=False)
+    fwd.close()
+    assert not status.any()
+    obs_ens = es.vect(prods, nTime)
+    obs = np.clip(obs_ens[0] + R12 @ np.random.RandomState(5).randn(4 * nTime), 0, 1)
+    post = es_mda_device(gm, prior, obs, R12, DT, nTime, n_iter=1, rng=np.random.RandomState(77), dtype=32)
+    perturbs = np.random.RandomState(77).randn(N, 4 * nTime) @ R12.T
+    ref = es.ens_update0(prior, obs_ens, obs, perturbs, sla.inv(R12.T))
+    inc = np.abs(ref - prior).max()
+    assert inc > 0.05
+    assert np.abs(post - ref).max() <= 1e-4 * inc
+
+
+def test_config4_analysis_shape_whole_and_row_sharded_vs_oracle():
+    """Config 4's analysis step at its own size: N = 4096 members, M = 256 * 256 state elements, n_obs = 160, fp32 plans, the
+    reference's correlated R -- once as one plan holding every member (what bench.py times under `es_update.by_shape`) and once
+    as the 8 row shards of 512 members the node's GPUs hold, run one after the other on this GPU through the three phases the
+    ranks run, their reduce buffers summed on the host where the ranks all-reduce.  Both against
+    oracle.es.ens_update0 on 2 048 random state columns (the update is column-separable in M: HistoryMatch.py:586 multiplies
+    X from the left only), all 4096 members, bar 1e-4 of the largest increment."""
+    from historymatching_amd.update import UpdatePlan
+    from oracle import es
+
+    N, M, G, n_obs = 4096, 256 * 256, 8, 160
+    E, obs_ens, obs, perturbs, decorr = _hm_inputs(N, M, n_obs, seed=44)
+    cols = np.sort(np.random.RandomState(6).choice(M, 2048, replace=False))
+    ref = es.ens_update0(np.ascontiguousarray(E[:, cols]), obs_ens, obs, perturbs, decorr)
+    inc = np.abs(ref - E[:, cols]).max()
+    assert inc > 0.05
+    plan = UpdatePlan(N, N, M, n_obs, dtype=32)
+    plan.set_inputs(E, obs_ens, obs, perturbs, decorr)
+    plan.run_local()
+    whole = plan.output()[:, cols]
+    plan.close()
+    assert np.abs(whole - ref).max() <= 1e-4 * inc
+    Nl = N // G
+    plans = []
+    for r in range(G):
+        sl = slice(r * Nl, (r + 1) * Nl)
+        p = UpdatePlan(N, Nl, M, n_obs, dtype=32)
+        p.set_inputs(E[sl], obs_ens[sl], obs, perturbs[sl], decorr)
+        plans.append(p)
+    for ph in range(3):
+        for p in plans:
+            p.phase(ph)
+        if ph < 2:
+            for which in UpdatePlan.REDUCE_AFTER_PHASE[ph]:
+                tot = sum(p.get_reduce(which).astype(np.float64) for p in plans)
+                for p in plans:
+                    p.set_reduce(which, tot)
+    out = np.concatenate([(p.sync(), p.output()[:, cols])[1] for p in plans])
+    for p in plans:
+        p.close()
+    assert np.abs(out - ref).max() <= 1e-4 * inc
+
+
 def test_config4_shard_whole_run_properties():
     """One rank's shard of config 4: 512 members at 256 x 256, all 40 steps, default kernels (two-level CG + tile teams: 8 rounds
     of 64 teams).  Mass-balance bracket, bounds, monotone producer series, and a sub-ensemble from different team rounds run

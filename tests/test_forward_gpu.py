@@ -704,22 +704,38 @@ def test_rectangular_grids_mixed_kernels(nx, ny):
 
 
 def test_whole_run_40_steps_at_config2_shape():
-    """BASELINE config 2 shape (128x128, nTime = 40, dt = 0.025, wells of HistoryMatch.py:177-190): one member of the
-    synthetic prior through the default kernels for the full run stays within the oracle's own solver noise at every
-    stored step, and the producer series equals the saturation history at the producer cells."""
+    """BASELINE config 2 shape (128x128, nTime = 40, dt = 0.025, wells of HistoryMatch.py:177-190): members of the synthetic
+    prior through the default kernels for the full run.  The per-step CFL sub-step counts of GPU and oracle are EQUAL (the
+    `ceil` of SURVEY.md A.4 never flips: its argument is 614.4, set by the injector cell), so the comparison is between two
+    direct solvers of the same systems and the bar is SURVEY.md 8d's 1e-8 -- for a member whose systems are well conditioned.
+    Member 2 of this prior is not: K spans 0.1 .. 1.2e6, cond_1(A) ~ 4e12, SuperLU's own two column orderings differ by
+    4e-6 in pressure and 1.5e-7 in flux after ONE solve (residuals 4e-9 and 1.6e-8) and by 1.1e-5 in saturation after 40
+    steps with identical sub-step counts (profiles/r03/long_parity.txt); no fp64 solver can be asked for more than that
+    spread there, so for such a member -- named here, not hidden in a wide bar -- the bar is 10 x the oracle's own spread."""
+    from tests.helpers import oracle_sim_noise_and_nts
+
     n, steps = 128, 40
     om, gm = make_models(n, n)
-    x = perms(n, n, 1, seed=1)
-    plan = _plan(gm, 1, nTime=steps)
+    x = perms(n, n, 3, seed=1)[[0, 2]]
+    plan = _plan(gm, 2, nTime=steps)
     plan.set_inputs(x, transformed=False)
     plan.run()
     st = plan.sync()
     w, p, status = plan.outputs()
+    nts = plan.get_field("nts")
     plan.close()
     assert not status.any() and st["mean_nts"] > 100
-    ref, noise = oracle_sim_and_noise(om, x[0], DT, steps)
-    assert np.abs(w[0] - ref).max() <= 10 * noise + 1e-9
-    assert np.array_equal(p[0], w[0][1:, om.xy2ind(*om.prd_xy.T)])
+    ill_conditioned = {1}  # row 1 = member 2 of the seed-1 prior
+    for m in range(2):
+        ref, noise, nts_o = oracle_sim_noise_and_nts(om, x[m], DT, steps)
+        assert np.array_equal(nts[m], nts_o), f"member {m}: sub-step counts differ at steps {np.flatnonzero(nts[m] != nts_o)}"
+        err = np.abs(w[m] - ref).max()
+        if m in ill_conditioned:
+            assert noise > 1e-7, "member 2 is the ill-conditioned case this test names; if it no longer is, tighten its bar"
+            assert err <= 10 * noise, (m, err, noise)
+        else:
+            assert noise < 1e-9 and err <= 1e-8, (m, err, noise)
+        assert np.array_equal(p[m], w[m][1:, om.xy2ind(*om.prd_xy.T)])
 
 
 def test_nested_dissection_pressure_whole_run():
