@@ -476,6 +476,11 @@ def main():
         dominant = "saturation" if stats["ms_saturation"] >= stats["ms_pressure"] else "pressure"
         isa, isa_src = load_profile_json("isa_counts.json")
         pmc, pmc_src = load_profile_json("pmc_hbm_traffic.json")
+        # the committed counts were taken from particular builds of sat128.o / press128s.o: if the objects this process runs
+        # differ, every figure derived from them is stale -- say so and report no fraction
+        sys.path.insert(0, str(ROOT / "profiles" / "tools"))
+        from obj_hash import object_hashes
+        built = object_hashes()
         # saturation sweep (k_sat128): member state register/LDS resident, bound by the CU's double-precision VALU.  Work per
         # launch = DP VALU instructions of the sub-step loop (counted from the built object: profiles/tools/isa_count.py) x
         # cells x sub-steps x members, in lane-instructions; the peak is one DP lane-instruction per lane-slot.
@@ -484,6 +489,9 @@ def main():
         # ratio is measured (SQ_INSTS_VALU over the same workload, profiles/rNN/fp64_roofline.json) -- `frac` uses EXECUTED work
         f64r, f64r_src = load_profile_json("fp64_roofline.json")
         executed_ratio = ((f64r or {}).get("kernels", {}).get("k_sat128", {}).get("executed_over_algorithmic", 1.0)) if args.variant == 0 else 1.0
+        recorded = {"isa_counts.json": (isa or {}).get("object_sha256"), "fp64_roofline.json": (f64r or {}).get("object_sha256")}
+        stale = [f"{src}: {obj}" for src, h in recorded.items() for obj in ("sat128.o", "press128s.o")
+                 if not h or h.get(obj) != built.get(obj)] if args.variant == 0 else []
         sat_lane_instr_algorithmic = dp_per_cell * nxy * nts * n_e
         sat_lane_instr = sat_lane_instr_algorithmic * executed_ratio
         # pressure (k_press128s): fp64 matrix cores; flops = rank-16 updates of the 36 stored tiles x 8 panels x Nx blocks
@@ -506,7 +514,14 @@ def main():
         prs_bytes = w * nxy * (4 + 2 * NY * 36 / 64) * n_e
         roofline = {
             "bound": bound, "kernel": {"saturation": "k_sat128", "pressure": "k_press128s"}[dominant] if args.variant == 0 else dominant,
-            "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+            "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None if stale else ach / FP64_PEAK_TFLOPS,
+            "stale_inputs": bool(stale), "stale_inputs_detail": stale or None,
+            "inputs_taken_from_objects": recorded, "objects_run": {k: built.get(k) for k in ("sat128.o", "press128s.o")},
+            "unit_note": "for bound fp64_valu `achieved` is an issue-slot rate: DP lane-instructions/s x 2 (every DP VALU instruction priced as one FMA "
+                         "slot, whether it is an FMA, an add, a compare or part of a division) against 2 x the lane-slot peak; the plain rate is "
+                         "in achieved_dp_lane_instr_per_s / peak_dp_lane_instr_per_s",
+            "achieved_dp_lane_instr_per_s": sat_lane_instr / (sat_ms * 1e-3) if dominant == "saturation" else None,
+            "peak_dp_lane_instr_per_s": DP_LANE_RATE,
             "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
             "hbm_frac_of_peak_from_measured_traffic": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "work_counted": what, "dp_valu_per_cell_substep": dp_per_cell, "isa_count_source": isa_src,
@@ -516,8 +531,12 @@ def main():
                                        "5.4 cycles, not 4 (v_rcp_f64: 16.4; an FMA with three distinct register operands: 6.9) -- "
                                        "historymatching_amd/csrc/diag/valu_rate.hip, profiles/README.md"},
             "avg_launch_ms": {"saturation": sat_ms, "pressure": prs_ms},
-            "per_kernel": {"saturation_fp64_valu_frac": 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                           "pressure_fp64_mfma_frac": prs_flops / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+            "per_kernel": {"saturation_fp64_valu_frac": None if stale else 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                           "pressure_fp64_mfma_frac": prs_flops / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                           # counter-based: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flop per launch (committed PMC pass) over THIS run's launch time
+                           "pressure_fp64_mfma_frac_from_counters": None if stale or not (f64r or {}).get("kernels", {}).get("k_press128s") else
+                           f64r["kernels"]["k_press128s"]["fp64_mfma_flops_per_launch"] * (n_e / f64r["kernels"]["k_press128s"]["members_per_launch"])
+                           / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
             "effective_bandwidth_diagnostic": {
                 "note": "SURVEY.md 8d 'effective GB/s' (algorithmic bytes / launch time); exceeds the HBM peak by construction for the register-resident sweep",
                 "saturation_GBps": sat_bytes / (sat_ms * 1e-3) / 1e9, "pressure_GBps": prs_bytes / (prs_ms * 1e-3) / 1e9,

@@ -52,6 +52,8 @@ struct hm_upd {
     int use_mfma = 1;  // fp32 only: 0 forces the generic VALU GEMMs (tests compare both)
     EvTimer t_upd;
     int ldl_gain = 1;               // hm_upd_run: gain from a block L D L^T factorisation instead of the explicit inverse
+    bool last_run_fused = false;    // the work queued since the last sync is one or more hm_upd_run of the fused path
+    int chain_fallbacks = 0;        // times hm_upd_sync redid a step through the two-kernel factorisation + gain (see there)
     int fused_front = 1;            // hm_upd_run: centring and Gram matrix (of shifted observations) in one launch
     int overlap = 0;                // hm_upd_run: 1 = small fp64 chain on a second stream beside the big contraction.  Measured, no gain:
                                     // the 16-wave inverse does not fit on a CU beside a contraction workgroup (it waits for one to finish);
@@ -908,6 +910,7 @@ extern "C" int hm_upd_run(hm_upd* u) {
                "with the reductions in between", u->N_local, u->N_total);
     HM_HIP(hipSetDevice(u->ctx->device));
     const bool fused = u->dtype == 32 && u->use_mfma && !u->localized && u->M % 4 == 0 && u->n_obs % 32 == 0 && u->n_obs <= 256;
+    u->last_run_fused = fused;
     if (!fused) {
         for (int ph = 0; ph < 3; ++ph) {
             int rc = u->dtype == 64 ? upd_phase<double>(u, ph) : upd_phase<float>(u, ph);
@@ -1063,6 +1066,15 @@ extern "C" int hm_upd_set_option(hm_upd* u, const char* name, int value) {
     if (std::string(name) == "ldl_gain") { u->ldl_gain = value; return 0; }
     if (std::string(name) == "overlap") { u->overlap = value; return 0; }  // hm_upd_run: second stream for the small chain
     if (std::string(name) == "kalman_form") { u->kalman_form = value; return 0; }
+#ifndef HM_AB_VARIANTS
+    // the superseded kernel forms behind these selectors are only compiled with -DHM_AB_VARIANTS (make EXTRA=-DHM_AB_VARIANTS)
+    for (const char* ab : {"gxt_depth", "gxt_halves"})
+        if (std::string(name) == ab) { hm_set_error("hm_upd_set_option: '%s' needs a library built with -DHM_AB_VARIANTS", name); return 2; }
+    if ((std::string(name) == "gxt_dma" && value >= 2) || (std::string(name) == "apply_variant" && value == 2)) {
+        hm_set_error("hm_upd_set_option: %s = %d needs a library built with -DHM_AB_VARIANTS", name, value);
+        return 2;
+    }
+#endif
     if (std::string(name) == "gxt_chunk") { mfma_set_gxt_chunk(value); return 0; }
     if (std::string(name) == "small_inverse") { spd_inverse_set_small(value); return 0; }  // 8-wave matrix-core inverse (co-resident form)
     if (std::string(name) == "gxt_dma") { mfma_set_gxt_dma(value); return 0; }  // 1: LDS-DMA staging (k_gxt_dma) | 0: register staging (k_gxt_lds)
@@ -1077,6 +1089,7 @@ extern "C" int hm_upd_set_option(hm_upd* u, const char* name, int value) {
 
 extern "C" int hm_upd_phase(hm_upd* u, int phase) {
     HM_REQUIRE(u, "hm_upd_phase: NULL plan");
+    u->last_run_fused = false;
     HM_HIP(hipSetDevice(u->ctx->device));
     return u->dtype == 64 ? upd_phase<double>(u, phase) : upd_phase<float>(u, phase);
 }
@@ -1174,6 +1187,19 @@ extern "C" int hm_upd_sync(hm_upd* u, hm_stats* st) {
     }
     u->t_upd.reset();
     u->t_comm.reset();
+    if ((flag & 2) && !(flag & 1) && u->last_run_fused && u->ldl_gain == 1) {
+        // The one-launch factorisation + gain (k_ldl_chain) lets the gain's workgroups wait for columns workgroup 0 publishes in the
+        // same launch.  That assumes workgroup 0 is resident while they wait -- true on an otherwise idle device, not guaranteed
+        // when another stream or process holds the CUs.  A stalled launch gives up (bounded spins) and raises flag 2: the step is
+        // redone here through the two-kernel form (k_ldl_factor, then k_ldl_gain: same factors, same tile products, bit-identical
+        // result), and the plan stays on that form.
+        HM_HIP(hipMemset(u->flags.p, 0, 16));
+        u->ldl_gain = 2;
+        u->chain_fallbacks++;
+        int rc = hm_upd_run(u);
+        if (rc) return rc;
+        return hm_upd_sync(u, st);
+    }
     if (flag) {
         HM_HIP(hipMemset(u->flags.p, 0, 16));
         if (flag & 2) hm_set_error("ensemble update: the gain's workgroups gave up waiting for the factorisation (kernel defect or a hung device)");

@@ -882,6 +882,7 @@ int mfma_gxt_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const f
                  float* Gx) {
     if (n_obs % 32 != 0 || n_obs > 256 || M % 4 != 0 || M < 4) return -1;
     const int nj = n_obs / 32;
+#ifdef HM_AB_VARIANTS  // superseded forms kept for A/B timing (make EXTRA=-DHM_AB_VARIANTS); the default build does not instantiate them
     if (g_gxt_dma == 2 && M % 64 == 0 && N >= 4 && nj <= 5 && (16 * n_obs) % 256 == 0) {
         dim3 grid(M / 64), block(256);
         const size_t chunks = (size_t)4 * 2 * 16 * (64 + n_obs) * 4, red = (size_t)3 * 2 * nj * 16 * 64 * 4;
@@ -909,15 +910,21 @@ int mfma_gxt_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const f
         HM_HIP(hipGetLastError());
         return 0;
     }
+#endif
     if (g_gxt_dma && M % 64 == 0 && N >= 4) {
         constexpr int KC = 64;
         dim3 grid(M / 64), block(512);
         const size_t lds = (size_t)2 * KC * (64 + n_obs) * 4;
         if (lds <= 160 * 1024) {
+#ifdef HM_AB_VARIANTS
 #define LD(NJ) case NJ: if (g_gxt_dma == 3) { HM_HIP(hipFuncSetAttribute((const void*)k_gxt_dma<NJ, KC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                         hipLaunchKernelGGL((k_gxt_dma<NJ, KC, 8>), grid, dim3(1024), lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); } else { \
                         HM_HIP(hipFuncSetAttribute((const void*)k_gxt_dma<NJ, KC, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                         hipLaunchKernelGGL((k_gxt_dma<NJ, KC, 4>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); } break
+#else
+#define LD(NJ) case NJ: HM_HIP(hipFuncSetAttribute((const void*)k_gxt_dma<NJ, KC, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                        hipLaunchKernelGGL((k_gxt_dma<NJ, KC, 4>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); break
+#endif
             switch (nj) { LD(1); LD(2); LD(3); LD(4); LD(5); default: goto no_dma; }
 #undef LD
             HM_HIP(hipGetLastError());
@@ -925,7 +932,12 @@ int mfma_gxt_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const f
         }
     }
 no_dma:
-    const int sh = g_gxt_sh, kc = sh == 1 ? 32 : g_gxt_kc, sw = 32 * sh;
+#ifdef HM_AB_VARIANTS
+    const int sh = g_gxt_sh;
+#else
+    const int sh = 2;
+#endif
+    const int kc = sh == 1 ? 32 : g_gxt_kc, sw = 32 * sh;
     dim3 grid((M + sw - 1) / sw), block(256 * sh);
     const size_t chunks = (size_t)2 * kc * (sw + n_obs) * 4, red = (size_t)2 * sh * nj * 16 * 64 * 4;
     const size_t lds = chunks > red ? chunks : red;
@@ -934,7 +946,11 @@ no_dma:
                            hipLaunchKernelGGL((k_gxt_lds<NJ, KC, SH>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)(g_gxt_debug ? -inv_n : inv_n), S, Gx); } while (0)
 #define L4(NJ, KC) do { HM_HIP(hipFuncSetAttribute((const void*)k_gxt_lds<NJ, KC, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                         hipLaunchKernelGGL((k_gxt_lds<NJ, KC, 2, 2>), grid, block, lds, s, N, M, n_obs, E, colsum, (float)inv_n, S, Gx); } while (0)
+#ifdef HM_AB_VARIANTS
 #define L(NJ) case NJ: if (sh == 1) L3(NJ, 32, 1); else if (g_gxt_depth == 2 && kc == 64) L4(NJ, 64); else if (kc == 64) L3(NJ, 64, 2); else L3(NJ, 32, 2); break
+#else
+#define L(NJ) case NJ: if (kc == 64) L3(NJ, 64, 2); else L3(NJ, 32, 2); break
+#endif
     switch (nj) { L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); default: return -1; }
 #undef L
 #undef L4
@@ -957,6 +973,7 @@ int mfma_apply_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const
         HM_HIP(hipGetLastError());
         return 0;
     }
+#ifdef HM_AB_VARIANTS
     if (g_apply_variant >= 2 && lds <= 78 * 1024 && M % 64 == 0 && N >= 32 && n_obs % 16 == 0) {  // two workgroups per CU
         HM_HIP(hipFuncSetAttribute((const void*)k_apply_lds2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         dim3 grid((M + 63) / 64, 2), block(256);
@@ -964,6 +981,7 @@ int mfma_apply_lds(hipStream_t s, int N, int M, int n_obs, const float* E, const
         HM_HIP(hipGetLastError());
         return 0;
     }
+#endif
     HM_HIP(hipFuncSetAttribute((const void*)k_apply_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((M + 63) / 64, (N + 127) / 128), block(256);
     hipLaunchKernelGGL(k_apply_lds, grid, block, lds, s, N, M, n_obs, E, At, Gx, Eout);

@@ -82,4 +82,10 @@ for name, cs in sorted(agg.items()):
         e["fp64_mfma_frac_of_peak"] = flops / (ns * 1e-9) / FP64_PEAK
         e["mfma_busy_frac_of_cu_busy"] = avg("SQ_VALU_MFMA_BUSY_CYCLES") / max(avg("SQ_BUSY_CU_CYCLES"), 1.0)
     out[name] = e
-print(json.dumps({"peaks": {"dp_lane_instr_per_s": DP_LANE_RATE, "fp64_tflops": FP64_PEAK / 1e12, "assumed_clock_GHz": 2.4}, "kernels": out}, indent=1))
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent))
+try:
+    from obj_hash import object_hashes
+    hashes = object_hashes()
+except Exception:
+    hashes = None
+print(json.dumps({"object_sha256": hashes, "peaks": {"dp_lane_instr_per_s": DP_LANE_RATE, "fp64_tflops": FP64_PEAK / 1e12, "assumed_clock_GHz": 2.4}, "kernels": out}, indent=1))
