@@ -29,14 +29,35 @@
 #define NDF_BC1 12
 #define NDF_PBOX 13    // bounding box of the front's pivot cells, x0 | y0 << 8 | x1 << 16 | y1 << 24 (x1, y1 exclusive)
 #define NDF_RBOX 14    // the front's whole region (pivots of the front and of all its descendants), same packing
+#define NDF_REC 15     // offset of the front's assembly recipes in `rec`, in blocks of 256 int16 (nd.h: recipes)
 
 #define ND_LEVELS 11
 #define ND_ARENA_MAX_LEVEL 8   // updates of levels 1..8 live in the per-member arena (global memory); 9, 10 in per-wave LDS slots
 #define ND_WAVE_TOP_LEVEL 5    // levels 10..5: one wave per front;  levels 4..0: one workgroup per front (per member)
 
+// Assembly RECIPES: what each lane of a wave reads, adds and writes when it assembles a front, precomputed per front (they depend on
+// the grid only), so that the kernels spend no instructions on index arithmetic.  One block = 256 int16 in the accumulator layout's
+// lane order: entry [lane][r], lane = lq * 16 + lc, r = 0..3  (a lane loads its four values of a block as one 8-byte word).
+// Tile entry (lane, r) of a PANEL tile R (transposed panel: pivot k = 4 r + lq, front row m = 16 R + lc) and of a TRAILING tile
+// (R, C) (front rows i = 16 R + 4 r + lq, j = 16 C + lc, both counted from the first boundary row).  Kinds:
+//   COEF  where A[cell m, cell k] (or q[cell k] on the right-hand-side row) lies: levels >= 5: offset into the wave's LDS copy of the
+//         coefficient planes (ND_CF_* below); levels <= 4: index into the member's coefficient block, as int32 over two blocks.
+//         -1: the entry is zero, -2: padded pivot (identity)
+//   G0,G1 offset of the entry in child 0 / child 1's packed lower-triangular update matrix, -1: none
+//   OUT   offset of the entry in this front's packed update matrix, -1: not stored (upper triangle, padding)
+// Block order per front:  leaves: COEF(R) for R = 0..bt, then OUT(R, C) for R = 1..bt, C = 1..R;
+//   levels 5..9: [COEF, G0, G1](R) for R = 0..bt, then [G0, G1, OUT](R, C);
+//   levels 0..4: [COEF lo/hi, G0, G1](V tile idx) for idx = 0..nV-1 (q-major), then [G0, G1, OUT](trailing idx) for idx = 0..nT-1.
+#define ND_CF_PLANE_SUB 100   // LDS coefficient planes of a level-8 subtree: (8 + 2)^2 cells, box = the level-8 front's region
+#define ND_CF_PLANE_WAVE 56   // of a level 5..7 front: (1 + 2) x (16 + 2) cells, box = the front's pivot line
+#define ND_CF_OX (128 * 128)                        // member coefficient block [dg | -TX | -TY | q]
+#define ND_CF_OY (ND_CF_OX + 129 * 128)
+#define ND_CF_OQ (ND_CF_OY + 128 * 129)
+
 struct NdInfo {
     int n_fronts;
     int n_cells;              // entries of `cells` (and, twice, of `cpos`)
+    int n_rec_blocks;         // blocks of 256 int16 in `rec`
     long long fact_doubles;   // per member
     long long arena_doubles;  // per member
     int upd_doubles[ND_LEVELS];  // largest packed update matrix per level ((b + 1)(b + 2) / 2, rounded up to even)

@@ -2,6 +2,7 @@
 // every time step).  Plain C++; used by press_nd.hip and, through hm_debug_nd_tables, by the CPU tests.
 #pragma once
 #include <algorithm>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -11,6 +12,7 @@ struct NdTablesHost {
     NdInfo info{};
     std::vector<int> fronts;   // n_fronts * ND_FRONT_INTS
     std::vector<int> cells;    // position -> cell (-1 padding, -2 right-hand side)
+    std::vector<short> rec;    // assembly recipes (nd.h), n_rec_blocks * 256
     std::vector<short> cpos;   // per front: [child 0: 16 T entries][child 1: 16 T entries] at 2 * cells_off:
                                // position of the front position's cell in the child's boundary list (b_child = its
                                // right-hand-side row), -1 if the child's update has no such row
@@ -160,5 +162,119 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
             if (found != cb.size()) { t.error = "a child's boundary does not lie inside its parent's front"; return false; }
         }
     }
+    // ---- assembly recipes (nd.h)
+    t.rec.clear();
+    auto tri = [](int a, int c) { const int hi = a > c ? a : c, lo = a > c ? c : a; return hi * (hi + 1) / 2 + lo; };
+    auto coef_global = [&](int cm, int ck, bool same_pos) -> int {  // index into [dg | -TX | -TY | q], -1 zero, -2 identity
+        if (ck < 0) return same_pos ? -2 : -1;
+        if (cm == -2) return ND_CF_OQ + ck;
+        if (cm < 0) return -1;
+        const int d = cm - ck;
+        if (d == 0) return ck;
+        if (d == Ny) return ND_CF_OX + ck + Ny;
+        if (d == -Ny) return ND_CF_OX + ck;
+        if (d == 1 && ck % Ny != Ny - 1) return ND_CF_OY + ck + ck / Ny + 1;
+        if (d == -1 && ck % Ny != 0) return ND_CF_OY + ck + ck / Ny;
+        return -1;
+    };
+    auto coef_local = [&](int cm, int ck, bool same_pos, int box, int plane) -> int {  // offset into the staged LDS planes
+        if (ck < 0) return same_pos ? -2 : -1;
+        const int x0 = box & 255, y0 = (box >> 8) & 255, y1 = (box >> 24) & 255, ld = y1 - y0 + 2;
+        const int li = (ck / Ny - x0 + 1) * ld + (ck % Ny - y0 + 1);
+        if (cm == -2) return 3 * plane + li;
+        if (cm < 0) return -1;
+        const int d = cm - ck;
+        if (d == 0) return li;
+        if (d == Ny) return plane + li + ld;
+        if (d == -Ny) return plane + li;
+        if (d == 1 && ck % Ny != Ny - 1) return 2 * plane + li + 1;
+        if (d == -1 && ck % Ny != 0) return 2 * plane + li;
+        return -1;
+    };
+    for (int f = 0; f < nF; ++f) {
+        int* F = &t.fronts[(size_t)f * ND_FRONT_INTS];
+        const int lv = F[NDF_LEVEL], b = F[NDF_B], st = F[NDF_ST], bt = F[NDF_BT], T = st + bt;
+        const int* C = &t.cells[F[NDF_CELLS]];
+        const short* P0 = &t.cpos[(size_t)2 * F[NDF_CELLS]];
+        const short* P1 = P0 + 16 * T;
+        const bool kids = F[NDF_C0] >= 0;
+        F[NDF_REC] = (int)(t.rec.size() / 256);
+        auto block = [&]() -> size_t { t.rec.resize(t.rec.size() + 256, (short)-1); return t.rec.size() - 256; };
+        auto gather_block = [&](const short* P, int rowpos0, int colpos0) {
+            // entry (lane, r): row position rowpos0 + 4 r + lq, column position colpos0 + lc  (positions in the front)
+            short* B = &t.rec[block()];
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int a = P[rowpos0 + 4 * r + (lane >> 4)], c = P[colpos0 + (lane & 15)];
+                    int v = (a >= 0 && c >= 0) ? tri(a, c) : -1;
+                    if (v > 32767) { t.error = "recipe offset exceeds int16"; v = -1; }
+                    B[lane * 4 + r] = (short)v;
+                }
+        };
+        auto out_block = [&](int R, int Cc) {  // R, Cc: boundary tile rows counted from 0
+            short* B = &t.rec[block()];
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * R + 4 * r + (lane >> 4), j = 16 * Cc + (lane & 15);
+                    const int v = (j <= i && i <= b) ? i * (i + 1) / 2 + j : -1;
+                    B[lane * 4 + r] = (short)v;
+                }
+        };
+        if (lv >= 5) {
+            int box = F[NDF_PBOX], plane = ND_CF_PLANE_WAVE;
+            if (lv >= 8) {
+                const int idx = f - ((1 << lv) - 1), f8 = 255 + (idx >> (lv - 8));
+                box = t.fronts[(size_t)f8 * ND_FRONT_INTS + NDF_RBOX];
+                plane = ND_CF_PLANE_SUB;
+            }
+            {   // the staged planes must hold the box plus its ring
+                const int x0 = box & 255, y0 = (box >> 8) & 255, x1 = (box >> 16) & 255, y1 = (box >> 24) & 255;
+                if ((x1 - x0 + 2) * (y1 - y0 + 2) > plane) { t.error = "coefficient box larger than its LDS plane"; return false; }
+            }
+            for (int R = 0; R <= bt; ++R) {
+                short* B = &t.rec[block()];
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 4 * r + (lane >> 4), m = 16 * R + (lane & 15);
+                        B[lane * 4 + r] = (short)coef_local(C[m], C[k], k == m, box, plane);
+                    }
+                if (kids) {
+                    gather_block(P0, 0, 16 * R);
+                    gather_block(P1, 0, 16 * R);
+                }
+            }
+            for (int R = 1; R <= bt; ++R)
+                for (int Cc = 1; Cc <= R; ++Cc) {
+                    if (kids) {
+                        gather_block(P0, 16 * R, 16 * Cc);
+                        gather_block(P1, 16 * R, 16 * Cc);
+                    }
+                    out_block(R - 1, Cc - 1);
+                }
+        } else {
+            for (int q = 0; q < st; ++q)
+                for (int R = q; R < T; ++R) {
+                    const size_t lo_at = block();
+                    block();
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 4; ++r) {
+                            const int k = 16 * q + 4 * r + (lane >> 4), m = 16 * R + (lane & 15);
+                            const int v = coef_global(C[m], C[k], k == m);
+                            memcpy(&t.rec[lo_at + 2 * (lane * 4 + r)], &v, 4);  // 256 int32 over the two blocks, entry [lane][r]
+                        }
+                    gather_block(P0, 16 * q, 16 * R);
+                    gather_block(P1, 16 * q, 16 * R);
+                }
+            if (b > 0)
+                for (int R = 0; R < bt; ++R)
+                    for (int Cc = 0; Cc <= R; ++Cc) {
+                        gather_block(P0, 16 * (st + R), 16 * (st + Cc));
+                        gather_block(P1, 16 * (st + R), 16 * (st + Cc));
+                        out_block(R, Cc);
+                    }
+        }
+    }
+    if (!t.error.empty()) return false;
+    I.n_rec_blocks = (int)(t.rec.size() / 256);
     return true;
 }

@@ -44,6 +44,7 @@ struct NdDev {
     const int* fronts;
     const int* cells;
     const short* cpos;
+    const short* rec;  // assembly recipes (nd.h), blocks of 256 int16
     double* fact;
     double* arena;
     double* cf;  // per member: [dg | -TX | -TY | q], CF_STRIDE doubles
@@ -161,40 +162,76 @@ __device__ __forceinline__ void nd_wave_copy(double* dst, const double* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// One front with ONE pivot tile, processed by one wave in registers.  Everything it reads at random lies in LDS: the
-// position tables cl / cp0 / cp1, the coefficients (NdCfl), the children's packed update matrices ch0 / ch1 (KIDS).
-// out: this front's packed update matrix ((b + 1)(b + 2) / 2 doubles), LDS or global.  fa: the front's factor (global).
+// One front with ONE pivot tile, processed by one wave in registers.  What each lane reads, adds and writes is spelled out in
+// the front's assembly RECIPES (nd.h: offsets precomputed on the host): no index arithmetic here.  cfl: the wave's LDS copy of
+// the coefficient planes; ch0 / ch1: the children's packed update matrices in LDS (KIDS); out: this front's packed update
+// matrix (LDS or global); fa: the front's factor (global).
 // ------------------------------------------------------------------------------------------------------------------------
+typedef short s4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ s4 rec_load(const short* __restrict__ rec, int blk, int lane) {
+    return *reinterpret_cast<const s4*>(rec + ((long long)blk * 64 + lane) * 4);
+}
+// value at a recipe offset, 0 for offset < 0.  The loaded value is USED unconditionally (multiplied by 1 or 0) on purpose: with a
+// select the compiler sinks the load into a branch and waits for it there -- one LDS round trip per entry.
+__device__ __forceinline__ double rec_val(const double* base, int off) {
+    const double l = base[off >= 0 ? off : 0];
+    return l * (off >= 0 ? 1.0 : 0.0);
+}
+
+// The panel's recipes, requested ahead of the front that uses them (a front's first instructions would otherwise wait a round trip
+// to L2 for them): while front i computes, front i + 1's are in flight.
 template <int MAXBT, bool KIDS>
-__device__ __forceinline__ void nd_wave_front(int b, int bt, int kreg, const int* cl, const short* cp0, const short* cp1, const NdCfl& L,
-                                              const double* ch0, const double* ch1, double* out, double* __restrict__ fa, const NdGeo& g,
-                                              int& bad) {
-    int ck[4], pk0[4], pk1[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        ck[r] = cl[4 * r + g.lq];
-        pk0[r] = KIDS ? cp0[4 * r + g.lq] : -1;
-        pk1[r] = KIDS ? cp1[4 * r + g.lq] : -1;
-    }
-    // ---- the pivot panel, transposed: V[R][r] = F[front row 16 R + lc][pivot 4 r + lq]
-    d4 V[MAXBT + 1];
-    int pm0[MAXBT + 1], pm1[MAXBT + 1];
+struct NdPanelRec {
+    s4 rc[MAXBT + 1], r0[MAXBT + 1], r1[MAXBT + 1];
+};
+template <int MAXBT, bool KIDS>
+__device__ __forceinline__ void nd_panel_rec_load(NdPanelRec<MAXBT, KIDS>& pr, const short* __restrict__ rec, int bt, int lane) {
+    constexpr int NK = KIDS ? 3 : 1;
 #pragma unroll
     for (int R = 0; R <= MAXBT; ++R) {
-        V[R] = d4{0.0, 0.0, 0.0, 0.0};
-        pm0[R] = pm1[R] = -1;
-        if (R <= bt) {
-            const int pm = 16 * R + g.lc;
-            const int cm = cl[pm];
-            if (KIDS) { pm0[R] = cp0[pm]; pm1[R] = cp1[pm]; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double v = nd_coef_lds(L, cm, ck[r], R == 0 && g.lc == 4 * r + g.lq);
-                if (KIDS) v += nd_gather(ch0, pk0[r], pm0[R]) + nd_gather(ch1, pk1[r], pm1[R]);
-                V[R][r] = v;
-            }
+        const int Rc = R <= bt ? R : bt;
+        pr.rc[R] = rec_load(rec, NK * Rc, lane);
+        if (KIDS) {
+            pr.r0[R] = rec_load(rec, NK * Rc + 1, lane);
+            pr.r1[R] = rec_load(rec, NK * Rc + 2, lane);
         }
     }
+}
+
+template <int MAXBT, bool KIDS>
+__device__ __forceinline__ void nd_wave_front(int bt, int kreg, const NdPanelRec<MAXBT, KIDS>& pr, const short* __restrict__ rec, const double* cfl,
+                                              const double* ch0, const double* ch1, double* out, double* __restrict__ fa, const NdGeo& g, int& bad) {
+    constexpr int NK = KIDS ? 3 : 1;
+    // ---- recipes of the trailing tiles, one tile row at a time: row 1 requested now (used after the sweep), row R + 1 while row R
+    // is computed (all rows at once would be 126 registers for a level-5 front)
+    const short* rect = rec + (long long)NK * (bt + 1) * 256;
+    s4 t0[2][MAXBT], t1[2][MAXBT], to[2][MAXBT];
+    auto load_row = [&](int R, int buf) {  // R static at every call site
+#pragma unroll
+        for (int C = 1; C <= MAXBT; ++C) {
+            if (C > R) break;
+            const int t = R * (R - 1) / 2 + C - 1;
+            const int tc = R <= bt ? t : 0;
+            if (KIDS) {
+                t0[buf][C - 1] = rec_load(rect, NK * tc, g.lane);
+                t1[buf][C - 1] = rec_load(rect, NK * tc + 1, g.lane);
+            }
+            to[buf][C - 1] = rec_load(rect, NK * tc + NK - 1, g.lane);
+        }
+    };
+    load_row(1, 1);
+    // ---- the pivot panel, transposed: V[R][r] = F[front row 16 R + lc][pivot 4 r + lq]
+    d4 V[MAXBT + 1];
+#pragma unroll
+    for (int R = 0; R <= MAXBT; ++R)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = rec_val(cfl, pr.rc[R][r]);
+            if (R == 0) v += pr.rc[0][r] == -2 ? 1.0 : 0.0;  // padded pivot: identity
+            if (KIDS) v += rec_val(ch0, pr.r0[R][r]) + rec_val(ch1, pr.r1[R][r]);
+            V[R][r] = R <= bt ? v : 0.0;
+        }
     // ---- P = inverse of the pivot tile
     d4 P = V[0];
     sweep16_partial(P, g, bad, kreg);  // P = -inv
@@ -217,27 +254,21 @@ __device__ __forceinline__ void nd_wave_front(int b, int bt, int kreg, const int
 #pragma unroll
     for (int R = 1; R <= MAXBT; ++R) {
         if (R > bt) break;
-        int pr0[4], pr1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pr0[r] = KIDS ? cp0[16 * R + 4 * r + g.lq] : -1;
-            pr1[r] = KIDS ? cp1[16 * R + 4 * r + g.lq] : -1;
-        }
+        if (R < MAXBT) load_row(R + 1, (R + 1) & 1);
 #pragma unroll
         for (int C = 1; C <= R; ++C) {
             d4 acc = {0.0, 0.0, 0.0, 0.0};
             if (KIDS) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = nd_gather(ch0, pr0[r], pm0[C]) + nd_gather(ch1, pr1[r], pm1[C]);
+                for (int r = 0; r < 4; ++r) acc[r] = rec_val(ch0, t0[R & 1][C - 1][r]) + rec_val(ch1, t1[R & 1][C - 1][r]);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
                 if (kk < kreg) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(WTn[R - 1][kk], V[C][kk], acc, 0, 0, 0);
-            const int j = 16 * (C - 1) + g.lc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = 16 * (R - 1) + 4 * r + g.lq;
-                if (j <= i && i <= b) out[((i * (i + 1)) >> 1) + j] = acc[r];
+                const int o = to[R & 1][C - 1][r];
+                if (o >= 0) out[o] = acc[r];
             }
         }
     }
@@ -276,14 +307,13 @@ __global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, con
 // workgroup, 64 workgroups per member.  Per wave in LDS: the subtree's position tables and coefficients (staged once, one
 // round trip to memory), two update slots each for levels 10 and 9.  The level-8 update goes to the arena.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int SUB_POS = 272;      // table positions of a level-8 subtree: 4 x 32 + 2 x 48 + 48
-constexpr int SUB_CF_PLANE = 100; // (8 + 2)^2
+constexpr int SUB_CF_PLANE = ND_CF_PLANE_SUB;
 
-__device__ __forceinline__ int nd_sub_lds_doubles(const NdDev& nd) { return 2 * (nd.slot9 + nd.slot10) + 4 * SUB_CF_PLANE + SUB_POS; }
+__device__ __forceinline__ int nd_sub_lds_doubles(const NdDev& nd) { return 2 * (nd.slot9 + nd.slot10) + 4 * SUB_CF_PLANE; }
 
 __global__ __launch_bounds__(256, 3) void k_nd_sub(FwdParams p, NdDev nd, int k) {
     extern __shared__ double nd_lds[];
-    const int m = blockIdx.x % p.N, blk = blockIdx.x / p.N;  // subtree-major: co-resident workgroups share table rows
+    const int m = blockIdx.x % p.N, blk = blockIdx.x / p.N;  // subtree-major: co-resident workgroups read the same recipes
     const int tid = threadIdx.x;
     NdGeo g;
     g.lane = tid & 63;
@@ -294,8 +324,6 @@ __global__ __launch_bounds__(256, 3) void k_nd_sub(FwdParams p, NdDev nd, int k)
     double* s9 = base;
     double* s10 = s9 + 2 * nd.slot9;
     double* cfl = s10 + 2 * nd.slot10;
-    int* cl_l = reinterpret_cast<int*>(cfl + 4 * SUB_CF_PLANE);
-    short* cp_l = reinterpret_cast<short*>(cl_l + SUB_POS);
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* arena = nd.arena + (long long)m * nd.arena_stride;
@@ -303,44 +331,41 @@ __global__ __launch_bounds__(256, 3) void k_nd_sub(FwdParams p, NdDev nd, int k)
     const int f8 = 255 + i8, f9 = 511 + 2 * i8, f10 = 1023 + 4 * i8;
     int bad = 0;
     NPROF_DECL;
-    // ---- stage: tables of the 7 fronts (three contiguous chunks of the global tables), coefficients of the region
     const int* F8 = nd.fronts + f8 * ND_FRONT_INTS;
-    const int co8 = F8[NDF_CELLS], co9 = nd.fronts[f9 * ND_FRONT_INTS + NDF_CELLS], co10 = nd.fronts[f10 * ND_FRONT_INTS + NDF_CELLS];
-    {
-        const int* F9b = nd.fronts + (f9 + 1) * ND_FRONT_INTS;
-        const int* F10d = nd.fronts + (f10 + 3) * ND_FRONT_INTS;
-        const int n10 = F10d[NDF_CELLS] + 16 * (F10d[NDF_ST] + F10d[NDF_BT]) - co10;
-        const int n9 = F9b[NDF_CELLS] + 16 * (F9b[NDF_ST] + F9b[NDF_BT]) - co9;
-        const int n8 = 16 * (F8[NDF_ST] + F8[NDF_BT]);
-        for (int i = g.lane; i < n10; i += 64) { cl_l[i] = nd.cells[co10 + i]; }
-        for (int i = g.lane; i < n9; i += 64) { cl_l[128 + i] = nd.cells[co9 + i]; }
-        for (int i = g.lane; i < n8; i += 64) { cl_l[224 + i] = nd.cells[co8 + i]; }
-        for (int i = g.lane; i < 2 * n10; i += 64) { cp_l[i] = nd.cpos[2 * co10 + i]; }
-        for (int i = g.lane; i < 2 * n9; i += 64) { cp_l[256 + i] = nd.cpos[2 * co9 + i]; }
-        for (int i = g.lane; i < 2 * n8; i += 64) { cp_l[448 + i] = nd.cpos[2 * co8 + i]; }
-    }
+    // per-front scalars of the 7 fronts (wave-uniform): boundary tiles, pivot register rows, recipe and factor offsets
+    auto recp = [&](const int* F) { return nd.rec + (long long)__builtin_amdgcn_readfirstlane(F[NDF_REC]) * 256; };
+    auto btof = [&](const int* F) { return __builtin_amdgcn_readfirstlane(F[NDF_BT]); };
+    auto krof = [&](const int* F) { return __builtin_amdgcn_readfirstlane(F[NDF_KREG]); };
+    const int* F10[4];
+    const int* F9[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) F10[i] = nd.fronts + (f10 + i) * ND_FRONT_INTS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) F9[i] = nd.fronts + (f9 + i) * ND_FRONT_INTS;
+    NdPanelRec<1, false> pl[2];
+    NdPanelRec<2, true> pp;
+    nd_panel_rec_load(pl[0], recp(F10[0]), btof(F10[0]), g.lane);
     NdCfl L;
     nd_stage_cf(cf, cfl, SUB_CF_PLANE, F8[NDF_RBOX], g.lane, L);
     nd_wave_fence();
     NPROF(0);
+#pragma unroll
     for (int bq = 0; bq < 2; ++bq) {
-        const int* F9 = nd.fronts + (f9 + bq) * ND_FRONT_INTS;
-        for (int cq = 0; cq < 2; ++cq) {
-            const int* F10 = nd.fronts + (f10 + 2 * bq + cq) * ND_FRONT_INTS;
-            const int o = F10[NDF_CELLS] - co10;
-            nd_wave_front<1, false>(F10[NDF_B], F10[NDF_BT], F10[NDF_KREG], cl_l + o, cp_l + 2 * o, cp_l + 2 * o, L, nullptr, nullptr,
-                                    s10 + cq * nd.slot10, fact + F10[NDF_FACT], g, bad);
-        }
+        // two leaves (the second one's recipes requested while the first computes), then their parent
+        nd_panel_rec_load(pl[1], recp(F10[2 * bq + 1]), btof(F10[2 * bq + 1]), g.lane);
+        nd_wave_front<1, false>(btof(F10[2 * bq]), krof(F10[2 * bq]), pl[0], recp(F10[2 * bq]), cfl, nullptr, nullptr, s10, fact + F10[2 * bq][NDF_FACT], g, bad);
+        nd_panel_rec_load(pp, recp(F9[bq]), btof(F9[bq]), g.lane);
+        nd_wave_front<1, false>(btof(F10[2 * bq + 1]), krof(F10[2 * bq + 1]), pl[1], recp(F10[2 * bq + 1]), cfl, nullptr, nullptr, s10 + nd.slot10,
+                                fact + F10[2 * bq + 1][NDF_FACT], g, bad);
         nd_wave_fence();
         NPROF(1);
-        const int o = F9[NDF_CELLS] - co9, T9 = 1 + F9[NDF_BT];
-        nd_wave_front<2, true>(F9[NDF_B], F9[NDF_BT], F9[NDF_KREG], cl_l + 128 + o, cp_l + 256 + 2 * o, cp_l + 256 + 2 * o + 16 * T9, L, s10,
-                               s10 + nd.slot10, s9 + bq * nd.slot9, fact + F9[NDF_FACT], g, bad);
+        if (bq == 0) nd_panel_rec_load(pl[0], recp(F10[2]), btof(F10[2]), g.lane);
+        nd_wave_front<2, true>(btof(F9[bq]), krof(F9[bq]), pp, recp(F9[bq]), cfl, s10, s10 + nd.slot10, s9 + bq * nd.slot9, fact + F9[bq][NDF_FACT], g, bad);
+        if (bq == 1) nd_panel_rec_load(pp, recp(F8), btof(F8), g.lane);
         nd_wave_fence();
         NPROF(2);
     }
-    nd_wave_front<2, true>(F8[NDF_B], F8[NDF_BT], F8[NDF_KREG], cl_l + 224, cp_l + 448, cp_l + 448 + 16 * (1 + F8[NDF_BT]), L, s9, s9 + nd.slot9,
-                           arena + F8[NDF_UPD], fact + F8[NDF_FACT], g, bad);
+    nd_wave_front<2, true>(btof(F8), krof(F8), pp, recp(F8), cfl, s9, s9 + nd.slot9, arena + F8[NDF_UPD], fact + F8[NDF_FACT], g, bad);
     NPROF(3);
 #ifdef HM_ND_PROF
     if (blockIdx.x == 0 && tid == 0)
@@ -350,15 +375,15 @@ __global__ __launch_bounds__(256, 3) void k_nd_sub(FwdParams p, NdDev nd, int k)
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Levels 7, 6, 5: one wave per front.  The two children's update matrices (arena), the front's tables and the coefficients
-// around its separator are staged into the wave's LDS first (bulk copies, one round trip); the update goes to the arena.
+// Levels 7, 6, 5: one wave per front.  The two children's update matrices (arena) and the coefficients around the front's
+// separator are staged into the wave's LDS first (bulk copies, one round trip); the update goes to the arena.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int WAVE_CF_PLANE = 56;  // (1 + 2) x (16 + 2), rounded up
+constexpr int WAVE_CF_PLANE = ND_CF_PLANE_WAVE;
 
 template <int LEVEL, int MAXBT, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int k) {
     extern __shared__ double nd_lds[];
-    constexpr int NF = 1 << LEVEL, POS = 16 * (MAXBT + 1);
+    constexpr int NF = 1 << LEVEL;
     const int m = blockIdx.x % p.N, blk = blockIdx.x / p.N;
     const int tid = threadIdx.x;
     NdGeo g;
@@ -367,31 +392,29 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chd = nd.child_doubles[7 - LEVEL];
-    double* base = nd_lds + w * (2 * chd + 4 * WAVE_CF_PLANE + POS);
+    double* base = nd_lds + w * (2 * chd + 4 * WAVE_CF_PLANE);
     double* c0l = base;
     double* c1l = base + chd;
     double* cfl = c1l + chd;
-    int* cl_l = reinterpret_cast<int*>(cfl + 4 * WAVE_CF_PLANE);
-    short* cp_l = reinterpret_cast<short*>(cl_l + POS);
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* arena = nd.arena + (long long)m * nd.arena_stride;
     const int f = NF - 1 + blk * WPB + w;
     const int* F = nd.fronts + f * ND_FRONT_INTS;
-    const int bt = F[NDF_BT], co = F[NDF_CELLS];
     const int* Fc0 = nd.fronts + F[NDF_C0] * ND_FRONT_INTS;
     const int* Fc1 = nd.fronts + F[NDF_C1] * ND_FRONT_INTS;
     const int n0 = (((Fc0[NDF_B] + 1) * (Fc0[NDF_B] + 2) >> 1) + 1) & ~1, n1 = (((Fc1[NDF_B] + 1) * (Fc1[NDF_B] + 2) >> 1) + 1) & ~1;
+    const int bt = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
+    const short* rec = nd.rec + (long long)__builtin_amdgcn_readfirstlane(F[NDF_REC]) * 256;
+    NdPanelRec<MAXBT, true> pr;
+    nd_panel_rec_load(pr, rec, bt, g.lane);  // in flight beside the bulk copies below
     nd_wave_copy(c0l, arena + Fc0[NDF_UPD], n0, g.lane);
     nd_wave_copy(c1l, arena + Fc1[NDF_UPD], n1, g.lane);
-    for (int i = g.lane; i < 16 * (1 + bt); i += 64) cl_l[i] = nd.cells[co + i];
-    for (int i = g.lane; i < 32 * (1 + bt); i += 64) cp_l[i] = nd.cpos[2 * co + i];
     NdCfl L;
     nd_stage_cf(cf, cfl, WAVE_CF_PLANE, F[NDF_PBOX], g.lane, L);
     nd_wave_fence();
     int bad = 0;
-    nd_wave_front<MAXBT, true>(F[NDF_B], bt, F[NDF_KREG], cl_l, cp_l, cp_l + 16 * (1 + bt), L, c0l, c1l, arena + F[NDF_UPD], fact + F[NDF_FACT], g,
-                               bad);
+    nd_wave_front<MAXBT, true>(bt, __builtin_amdgcn_readfirstlane(F[NDF_KREG]), pr, rec, cfl, c0l, c1l, arena + F[NDF_UPD], fact + F[NDF_FACT], g, bad);
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
@@ -655,7 +678,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
 // Back substitution, root to leaves: per front and panel (last first)  x1 = -W^T [x of the rows below; -1 for the rhs row],
 // one wave per front, levels separated by workgroup barriers; pressures in P; then the face fluxes.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int SOL_NW = 8;
+constexpr int SOL_NW = 4;
 
 // Fronts with one pivot tile (levels >= 5), UNR of them per wave at a time: the cell indices of all of them, then the known
 // pressures and the factor tiles of all of them are requested before anything is used -- two round trips to memory per UNR
@@ -710,7 +733,7 @@ __device__ __forceinline__ void nd_solve_single(const NdDev& nd, const double* _
     }
 }
 
-__global__ __launch_bounds__(64 * SOL_NW, 2) void k_nd_solve(FwdParams p, NdDev nd, int k) {
+__global__ __launch_bounds__(64 * SOL_NW, 3) void k_nd_solve(FwdParams p, NdDev nd, int k) {
     __shared__ double xe_all[SOL_NW][16 * TOP_MAXT];
     const int m = blockIdx.x, tid = threadIdx.x;
     NdGeo g;
@@ -809,7 +832,7 @@ __global__ __launch_bounds__(64 * SOL_NW, 2) void k_nd_solve(FwdParams p, NdDev 
 // ------------------------------------------------------------------------------------------------------------------------
 struct hm_nd {
     NdInfo info{};
-    DevBuf fronts, cells, cpos, fact, arena, dg;
+    DevBuf fronts, cells, cpos, rec, fact, arena, dg;
     NdDev dev{};
 };
 
@@ -817,7 +840,7 @@ bool pressure_nd_applies(const FwdParams& p) { return p.Nx == NB && p.Ny == NB; 
 
 void hm_nd_free(hm_nd* n) {
     if (!n) return;
-    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->fact, &n->arena, &n->dg};
+    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->rec, &n->fact, &n->arena, &n->dg};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     delete n;
 }
@@ -845,7 +868,7 @@ static int nd_setup(hm_fwd* f) {
     int rc = 0;
     const size_t N = p.N;
     if ((rc = hm_dev_alloc(n->fronts, t.fronts.size() * 4)) || (rc = hm_dev_alloc(n->cells, t.cells.size() * 4)) ||
-        (rc = hm_dev_alloc(n->cpos, t.cpos.size() * 2)) || (rc = hm_dev_alloc(n->fact, N * t.info.fact_doubles * 8)) ||
+        (rc = hm_dev_alloc(n->cpos, t.cpos.size() * 2)) || (rc = hm_dev_alloc(n->rec, t.rec.size() * 2)) || (rc = hm_dev_alloc(n->fact, N * t.info.fact_doubles * 8)) ||
         (rc = hm_dev_alloc(n->arena, N * t.info.arena_doubles * 8)) || (rc = hm_dev_alloc(n->dg, N * (size_t)CF_STRIDE * 8))) {
         hm_nd_free(n);
         return rc;
@@ -853,10 +876,12 @@ static int nd_setup(hm_fwd* f) {
     HM_HIP(hipMemcpy(n->fronts.p, t.fronts.data(), t.fronts.size() * 4, hipMemcpyHostToDevice));
     HM_HIP(hipMemcpy(n->cells.p, t.cells.data(), t.cells.size() * 4, hipMemcpyHostToDevice));
     HM_HIP(hipMemcpy(n->cpos.p, t.cpos.data(), t.cpos.size() * 2, hipMemcpyHostToDevice));
+    HM_HIP(hipMemcpy(n->rec.p, t.rec.data(), t.rec.size() * 2, hipMemcpyHostToDevice));
     NdDev& d = n->dev;
     d.fronts = (const int*)n->fronts.p;
     d.cells = (const int*)n->cells.p;
     d.cpos = (const short*)n->cpos.p;
+    d.rec = (const short*)n->rec.p;
     d.fact = (double*)n->fact.p;
     d.arena = (double*)n->arena.p;
     d.cf = (double*)n->dg.p;
@@ -891,11 +916,11 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
     const NdDev& nd = f->nd->dev;
     if (f->dtype == 64) hipLaunchKernelGGL(k_nd_assemble<double>, dim3(p.N), dim3(1024), 0, s, p, nd, (const double*)S, S_stride, k);
     else hipLaunchKernelGGL(k_nd_assemble<float>, dim3(p.N), dim3(1024), 0, s, p, nd, (const float*)S, S_stride, k);
-    const size_t lds_sub = (size_t)4 * (2 * (nd.slot9 + nd.slot10) + 4 * SUB_CF_PLANE + SUB_POS) * 8;
+    const size_t lds_sub = (size_t)4 * (2 * (nd.slot9 + nd.slot10) + 4 * SUB_CF_PLANE) * 8;
     hipLaunchKernelGGL(k_nd_sub, dim3(p.N * 64), dim3(256), lds_sub, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * 32), dim3(256), (size_t)4 * (2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE + 64) * 8, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * 16), dim3(256), (size_t)4 * (2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE + 80) * 8, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * 16), dim3(128), (size_t)2 * (2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE + 112) * 8, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * 32), dim3(256), (size_t)4 * (2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * 16), dim3(256), (size_t)4 * (2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * 16), dim3(128), (size_t)2 * (2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     const size_t lds_top = (size_t)(256 + 2 * TOP_MAXT * 256 + 16 * TOP_MAXT + nd.top_child_doubles + 2) * 8;
     hipLaunchKernelGGL(k_nd_top, dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_solve, dim3(p.N), dim3(64 * SOL_NW), 0, s, p, nd, k);
@@ -907,7 +932,7 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
 extern "C" int hm_debug_nd_prof(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hm_nd_prof_buf), sizeof(long long) * 64); }
 #endif
 
-extern "C" int hm_debug_nd_tables(int Nx, int Ny, long long* info, int* fronts, int* cells, short* cpos) {
+extern "C" int hm_debug_nd_tables(int Nx, int Ny, long long* info, int* fronts, int* cells, short* cpos, short* rec) {
     HM_REQUIRE(info, "hm_debug_nd_tables: NULL info");
     NdTablesHost t;
     if (!nd_build_tables(Nx, Ny, t)) {
@@ -922,6 +947,8 @@ extern "C" int hm_debug_nd_tables(int Nx, int Ny, long long* info, int* fronts, 
     for (int i = 0; i < ND_LEVELS; ++i) info[8 + i] = t.info.max_bt[i] * 16 + t.info.max_st[i];
     if (fronts) memcpy(fronts, t.fronts.data(), t.fronts.size() * sizeof(int));
     if (cells) memcpy(cells, t.cells.data(), t.cells.size() * sizeof(int));
+    info[7] = t.info.n_rec_blocks;
     if (cpos) memcpy(cpos, t.cpos.data(), t.cpos.size() * sizeof(short));
+    if (rec) memcpy(rec, t.rec.data(), t.rec.size() * sizeof(short));
     return 0;
 }

@@ -6,22 +6,23 @@ import ctypes as C
 
 import numpy as np
 
-F_LEVEL, F_S, F_B, F_ST, F_BT, F_C0, F_C1, F_CELLS, F_FACT, F_UPD, F_KREG, F_BC0, F_BC1 = range(13)
+F_LEVEL, F_S, F_B, F_ST, F_BT, F_C0, F_C1, F_CELLS, F_FACT, F_UPD, F_KREG, F_BC0, F_BC1, F_PBOX, F_RBOX, F_REC = range(16)
 
 
 def tables(lib, Nx, Ny):
     info = (C.c_longlong * 24)()
-    rc = lib.hm_debug_nd_tables(Nx, Ny, info, None, None, None)
+    rc = lib.hm_debug_nd_tables(Nx, Ny, info, None, None, None, None)
     if rc:
         raise RuntimeError(lib.hm_last_error().decode())
     nF, nC = int(info[0]), int(info[1])
     fronts = np.zeros((nF, 16), dtype=np.int32)
     cells = np.zeros(nC, dtype=np.int32)
     cpos = np.zeros(2 * nC, dtype=np.int16)
+    rec = np.zeros(256 * int(info[7]), dtype=np.int16)
     rc = lib.hm_debug_nd_tables(Nx, Ny, info, fronts.ctypes.data_as(C.POINTER(C.c_int)), cells.ctypes.data_as(C.POINTER(C.c_int)),
-                                cpos.ctypes.data_as(C.POINTER(C.c_short)))
+                                cpos.ctypes.data_as(C.POINTER(C.c_short)), rec.ctypes.data_as(C.POINTER(C.c_short)))
     assert rc == 0
-    return dict(info=[int(v) for v in info], fronts=fronts, cells=cells, cpos=cpos, Nx=Nx, Ny=Ny)
+    return dict(info=[int(v) for v in info], fronts=fronts, cells=cells, cpos=cpos, rec=rec.reshape(-1, 64, 4), Nx=Nx, Ny=Ny)
 
 
 def coefficient(tab, dg, TX, TY, cm, ck):

@@ -44,7 +44,7 @@ def test_unsupported_grid_is_refused(lib):
     import ctypes as C
 
     info = (C.c_longlong * 24)()
-    assert lib.hm_debug_nd_tables(64, 64, info, None, None, None) != 0
+    assert lib.hm_debug_nd_tables(64, 64, info, None, None, None, None) != 0
     assert b"tree" in lib.hm_last_error()
 
 
