@@ -39,6 +39,7 @@ DT = 0.025
 HBM_PEAK_GBS = 8000.0
 CLOCK_HZ = 2.4e9
 N_CU = 256
+ND_FACTOR_DOUBLES, ND_ARENA_DOUBLES = 629312, 612620  # per member: hm_debug_nd_tables info[2], info[3] at 128 x 128
 DP_LANE_RATE = N_CU * 4 * 16 * CLOCK_HZ          # double-precision lane-instructions / s (39.3e12)
 FP64_PEAK_TFLOPS = 2 * DP_LANE_RATE / 1e12        # 78.6: one FMA per lane-slot
 FP32_MATRIX_PEAK_TFLOPS = 157.3
@@ -71,6 +72,31 @@ def cpu_baseline(members, steps, nproc):
         forward_model(om, x, None, DT, steps, pool=pool)
         wall = time.perf_counter() - t0
     return members * steps / wall, wall
+
+
+def nd_mfma_count():
+    """v_mfma_f64_16x16x4 instructions per member and time step of the nested-dissection factorisation (press_nd.hip), from the
+    symbolic tables: a front with st pivot tiles and bt boundary tiles runs, per pivot tile p with kreg 4-row groups, kreg matrix
+    instructions for every tile it forms or updates: W^T tiles (T - p - 1), later panel tiles, and the bt (bt + 1) / 2 trailing tiles."""
+    import ctypes as C
+
+    from historymatching_amd import _lib
+
+    lib = _lib.load()
+    info = (C.c_longlong * 24)()
+    _lib.check(lib.hm_debug_nd_tables(NX, NY, info, None, None, None, None), "hm_debug_nd_tables")
+    fronts = np.zeros((int(info[0]), 16), dtype=np.int32)
+    _lib.check(lib.hm_debug_nd_tables(NX, NY, info, fronts.ctypes.data_as(C.POINTER(C.c_int)), None, None, None), "hm_debug_nd_tables")
+    total = 0
+    for F in fronts:
+        b, st, bt, kreg_last = int(F[2]), int(F[3]), int(F[4]), int(F[10])
+        T = st + bt
+        ntrail = bt * (bt + 1) // 2 if b > 0 else 0
+        for p in range(st):
+            kreg = kreg_last if p == st - 1 else 4
+            later_panel = sum(T - q for q in range(p + 1, st))
+            total += kreg * ((T - p - 1) + later_panel + ntrail)
+    return total
 
 
 def reference_obs_error(n_obs):
@@ -490,33 +516,35 @@ def main():
         f64r, f64r_src = load_profile_json("fp64_roofline.json")
         executed_ratio = ((f64r or {}).get("kernels", {}).get("k_sat128", {}).get("executed_over_algorithmic", 1.0)) if args.variant == 0 else 1.0
         recorded = {"isa_counts.json": (isa or {}).get("object_sha256"), "fp64_roofline.json": (f64r or {}).get("object_sha256")}
-        stale = [f"{src}: {obj}" for src, h in recorded.items() for obj in ("sat128.o", "press128s.o")
+        stale = [f"{src}: {obj}" for src, h in recorded.items() for obj in ("sat128.o", "press_nd.o")
                  if not h or h.get(obj) != built.get(obj)] if args.variant == 0 else []
         sat_lane_instr_algorithmic = dp_per_cell * nxy * nts * n_e
         sat_lane_instr = sat_lane_instr_algorithmic * executed_ratio
-        # pressure (k_press128s): fp64 matrix cores; flops = rank-16 updates of the 36 stored tiles x 8 panels x Nx blocks
-        prs_flops = 2.0 * 36 * 16 * 16 * 16 * 8 * NX * n_e
+        # pressure (press_nd.hip, nested dissection): fp64 matrix cores; flops = the v_mfma_f64_16x16x4 instructions the factorisation
+        # issues per member (counted from the symbolic tables the kernels read, hm_debug_nd_tables) x 2 x 16 x 16 x 4
+        prs_mfma_per_member = nd_mfma_count() if args.variant == 0 else 36 * 4 * 8 * NX
+        prs_flops = 2048.0 * prs_mfma_per_member * n_e
         if dominant == "saturation":
             ach = 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12
             bound, what = "fp64_valu", ("double-precision VALU issue slots actually executed: every DP VALU instruction of the sub-step loop counted as "
                                         "one FMA slot (2 flop) per lane, dry bands' skipped instructions not counted; peak = 256 CUs x 4 SIMDs x 16 DP lanes x 2.4 GHz x 2")
         else:
             ach = prs_flops / (prs_ms * 1e-3) / 1e12
-            bound, what = "fp64_mfma", "v_mfma_f64_16x16x4 flops of the block elimination's rank-16 panel updates"
+            bound, what = "fp64_mfma", "v_mfma_f64_16x16x4 flops of the nested-dissection factorisation (tile products of the fronts)"
         traffic = None
-        key = {"saturation": "sat128", "pressure": "press128s"}[dominant]
+        key = {"saturation": "sat128", "pressure": "press_nd"}[dominant]
         if pmc and args.variant == 0 and key in pmc.get("kernels", {}):
             traffic = pmc["kernels"][key]["hbm_bytes_per_member_corrected"] * n_e
         dom_ms = sat_ms if dominant == "saturation" else prs_ms
         # SURVEY.md 8d accounting kept as a separately named diagnostic: "effective" bytes (read S,Vx,Vy + write S per explicit
         # sub-step; compulsory + factor write + factor read for the pressure solver) -- NOT a roofline for a register-resident sweep
         sat_bytes = w * nxy * 4 * nts * n_e
-        prs_bytes = w * nxy * (4 + 2 * NY * 36 / 64) * n_e
+        prs_bytes = w * (4 * nxy + 2 * ND_FACTOR_DOUBLES + 2 * ND_ARENA_DOUBLES) * n_e  # compulsory + factor write/read + update matrices write/read
         roofline = {
-            "bound": bound, "kernel": {"saturation": "k_sat128", "pressure": "k_press128s"}[dominant] if args.variant == 0 else dominant,
+            "bound": bound, "kernel": {"saturation": "k_sat128", "pressure": "k_nd_* (press_nd.hip: assemble, sub, wave x3, top, solve)"}[dominant] if args.variant == 0 else dominant,
             "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None if stale else ach / FP64_PEAK_TFLOPS,
             "stale_inputs": bool(stale), "stale_inputs_detail": stale or None,
-            "inputs_taken_from_objects": recorded, "objects_run": {k: built.get(k) for k in ("sat128.o", "press128s.o")},
+            "inputs_taken_from_objects": recorded, "objects_run": {k: built.get(k) for k in ("sat128.o", "press_nd.o")},
             "unit_note": "for bound fp64_valu `achieved` is an issue-slot rate: DP lane-instructions/s x 2 (every DP VALU instruction priced as one FMA "
                          "slot, whether it is an FMA, an add, a compare or part of a division) against 2 x the lane-slot peak; the plain rate is "
                          "in achieved_dp_lane_instr_per_s / peak_dp_lane_instr_per_s",
@@ -534,9 +562,8 @@ def main():
             "per_kernel": {"saturation_fp64_valu_frac": None if stale else 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                            "pressure_fp64_mfma_frac": prs_flops / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                            # counter-based: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flop per launch (committed PMC pass) over THIS run's launch time
-                           "pressure_fp64_mfma_frac_from_counters": None if stale or not (f64r or {}).get("kernels", {}).get("k_press128s") else
-                           f64r["kernels"]["k_press128s"]["fp64_mfma_flops_per_launch"] * (n_e / f64r["kernels"]["k_press128s"]["members_per_launch"])
-                           / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                           "pressure_fp64_mfma_frac_from_counters": None if stale or not (f64r or {}).get("pressure_nd") else
+                           f64r["pressure_nd"]["fp64_mfma_flops_per_member_step"] * n_e / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
             "effective_bandwidth_diagnostic": {
                 "note": "SURVEY.md 8d 'effective GB/s' (algorithmic bytes / launch time); exceeds the HBM peak by construction for the register-resident sweep",
                 "saturation_GBps": sat_bytes / (sat_ms * 1e-3) / 1e9, "pressure_GBps": prs_bytes / (prs_ms * 1e-3) / 1e9,

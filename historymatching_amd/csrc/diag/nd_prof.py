@@ -34,3 +34,5 @@ v = list(buf[16:32])
 print(f"k_nd_sub, block 0 wave 0: {sum(v)} cycles")
 for n, x in zip(sub, v):
     print(f"   {n:28s} {x:10d}  {100 * x / max(sum(v), 1):5.1f} %")
+v = list(buf[32:48])
+print(f"k_nd_solve, block 0 wave 0: {sum(v)} cycles; slots (level 5..10 compute at 5..10, barrier waits at 0..5, levels 0-4 at 12): {v}")

@@ -601,7 +601,8 @@ extern "C" int hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, doub
     ALLOC(TX, n * (Nx + 1) * Ny * 8);
     ALLOC(TY, n * Nx * (Ny + 1) * 8);
     const bool direct = Ny <= 128;  // block elimination with explicit inverse Schur complements; else CG
-    if (direct) ALLOC(G, n * Nxy * Ny * 8);
+    // (the inverse Schur complements of the block elimination -- n * Nxy * Ny * 8 bytes, 16.8 GB at N_e = 1000, 128 x 128 -- are
+    // allocated on the first launch of a kernel that needs them: launch_pressure)
     ALLOC(cg_r, direct ? 8 : n * Nxy * 8);
     ALLOC(cg_p, direct ? 8 : n * Nxy * 8);
     ALLOC(n_cg, n * nTime * 4);
@@ -815,8 +816,9 @@ static int launch_pressure(hm_fwd* f, int k) {
     int rc = f->t_press.begin(s);
     if (rc) return rc;
     int done = -1;
-    // press_variant: 1 generic (the in-library cross-check), 9 Jacobi-CG, 7 the 16-wave form of press128s, every other value
-    // press128s (symmetric tiles, 8 waves).  (The first three generations of the 128-wide solver -- rank-1 VALU sweeps, full-tile
+    // press_variant: 0 the default (128 x 128: nested dissection, press_nd.hip; other grids with Ny = 128: press128s), 1 generic (the
+    // in-library cross-check), 9 Jacobi-CG, 7 the 16-wave form of press128s, 12 nested dissection, 13 press128s (block elimination,
+    // symmetric tiles, 8 waves) also at 128 x 128.  (The first three generations of the 128-wide solver -- rank-1 VALU sweeps, full-tile
     // rank-4 and rank-16 matrix-core panels -- were removed in round 2; their timings are in profiles/README.md.)
     const int pv = f->press_variant;
     if (pv == 9 || p.Ny > 128) {
@@ -830,8 +832,15 @@ static int launch_pressure(hm_fwd* f, int k) {
         }
         if (pv != 9 && f->cg_precond == 0 && pressure_two_level_applies(p)) done = launch_pressure_two_level(f, S, stride, k);
         else done = launch_pressure_pcg(f, S, stride, k);
-    } else if (pv == 12 && pressure_nd_applies(p)) done = launch_pressure_nd(f, S, stride, k);
-    else if (pv != 1) done = launch_pressure_128s(f, S, stride, k);
+    } else if ((pv == 0 || pv == 12) && pressure_nd_applies(p)) done = launch_pressure_nd(f, S, stride, k);  // 128 x 128: nested dissection
+    if (done < 0 && p.Ny <= 128 && pv != 9) {
+        if (!f->G.p) {  // every other direct solver keeps its inverse Schur complements
+            int rc2 = hm_dev_alloc(f->G, (size_t)p.N * p.Nxy * p.Ny * 8);
+            if (rc2) return rc2;
+            f->p.G = (double*)f->G.p;
+        }
+        if (pv != 1) done = launch_pressure_128s(f, S, stride, k);  // 13: the block elimination also where nested dissection applies
+    }
     if (done > 0) return done;
     if (done < 0) {
         int T = generic_threads(p.Ny);

@@ -684,35 +684,51 @@ constexpr int SOL_NW = 4;
 // pressures and the factor tiles of all of them are requested before anything is used -- two round trips to memory per UNR
 // fronts (the back substitution does 16 multiply-adds per 8 bytes: it is a stream of the factor, bound by loads in flight).
 template <int UNR, int MAXBT>
+struct NdSolveIdx {
+    int bt[UNR], kreg[UNR], cb[UNR][MAXBT], cpv[UNR][4];
+    const double* fa[UNR];
+};
+template <int UNR, int MAXBT>
+__device__ __forceinline__ void nd_solve_idx(NdSolveIdx<UNR, MAXBT>& I, const NdDev& nd, const double* __restrict__ fact, int nf, int fi0, const NdGeo& g) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int fi = fi0 + u < nf ? fi0 + u : nf - 1;  // (a wave's surplus slots redo its last front: same values, harmless)
+        const int* F = nd.fronts + (nf - 1 + fi) * ND_FRONT_INTS;
+        I.bt[u] = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
+        I.kreg[u] = __builtin_amdgcn_readfirstlane(F[NDF_KREG]);
+        const int* cl = nd.cells + __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
+        I.fa[u] = fact + F[NDF_FACT];
+#pragma unroll
+        for (int R = 0; R < MAXBT; ++R) I.cb[u][R] = cl[16 * (1 + (R < I.bt[u] ? R : 0)) + g.lc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) I.cpv[u][r] = cl[4 * r + g.lq];
+    }
+}
+template <int UNR, int MAXBT>
 __device__ __forceinline__ void nd_solve_single(const NdDev& nd, const double* __restrict__ fact, double* P, int nf, int w, const NdGeo& g) {
+    // software pipeline: the cell indices of batch i + 1 are requested before batch i's values are waited for, so a batch costs one
+    // round trip to memory, not two
+    NdSolveIdx<UNR, MAXBT> I, In;
+    nd_solve_idx(I, nd, fact, nf, w * UNR < nf ? w * UNR : 0, g);
     for (int fi0 = w * UNR; fi0 < nf; fi0 += SOL_NW * UNR) {
-        int bt[UNR], kreg[UNR], cb[UNR][MAXBT], cpv[UNR][4];
-        const double* fa[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int fi = fi0 + u < nf ? fi0 + u : nf - 1;  // (a wave's surplus slots redo its last front: same values, harmless)
-            const int* F = nd.fronts + (nf - 1 + fi) * ND_FRONT_INTS;
-            bt[u] = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
-            kreg[u] = __builtin_amdgcn_readfirstlane(F[NDF_KREG]);
-            const int* cl = nd.cells + __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
-            fa[u] = fact + F[NDF_FACT];
-#pragma unroll
-            for (int R = 0; R < MAXBT; ++R) cb[u][R] = cl[16 * (1 + (R < bt[u] ? R : 0)) + g.lc];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cpv[u][r] = cl[4 * r + g.lq];
-        }
         double xv[UNR][MAXBT], t[UNR][MAXBT][4];
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
             for (int R = 0; R < MAXBT; ++R) {
-                const int c = cb[u][R];
+                const int c = I.cb[u][R];
                 const double l = P[c >= 0 ? c : 0];
-                xv[u][R] = R < bt[u] ? l * (c >= 0 ? 1.0 : 0.0) + (c == -2 ? -1.0 : 0.0) : 0.0;
-                const int Rc = R < bt[u] ? R : 0;
+                xv[u][R] = R < I.bt[u] ? l * (c >= 0 ? 1.0 : 0.0) + (c == -2 ? -1.0 : 0.0) : 0.0;
+                const int Rc = R < I.bt[u] ? R : 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t[u][R][r] = fa[u][(Rc * kreg[u] + (r < kreg[u] ? r : 0)) * 64 + g.lane];
+#ifdef HM_ND_SOLVE_NOLOAD
+                for (int r = 0; r < 4; ++r) t[u][R][r] = 1e-3 * (Rc + r);
+#else
+                for (int r = 0; r < 4; ++r) t[u][R][r] = I.fa[u][(Rc * I.kreg[u] + (r < I.kreg[u] ? r : 0)) * 64 + g.lane];
+#endif
             }
+        const int fin = fi0 + SOL_NW * UNR;
+        nd_solve_idx(In, nd, fact, nf, fin < nf ? fin : fi0, g);
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -723,13 +739,16 @@ __device__ __forceinline__ void nd_solve_single(const NdDev& nd, const double* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double v = acc[r];
+#ifndef HM_ND_SOLVE_NOSHFL
                 v += __shfl_xor(v, 8);
                 v += __shfl_xor(v, 4);
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 1);
-                if (g.lc == 0 && r < kreg[u] && cpv[u][r] >= 0) P[cpv[u][r]] = -v;
+#endif
+                if (g.lc == 0 && r < I.kreg[u] && I.cpv[u][r] >= 0) P[I.cpv[u][r]] = -v;
             }
         }
+        I = In;
     }
 }
 
@@ -745,14 +764,17 @@ __global__ __launch_bounds__(64 * SOL_NW, 3) void k_nd_solve(FwdParams p, NdDev 
     double* P = p.P + (long long)m * Nxy;
     const double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* xe = xe_all[w];
+    NPROF_DECL;
     for (int lv = 0; lv < ND_LEVELS; ++lv) {
         const int nf = 1 << lv;
+        NPROF(lv < 5 ? 12 : lv - 5);
         if (lv >= 5) {
             if (lv == 5) nd_solve_single<1, 6>(nd, fact, P, nf, w, g);
             else if (lv == 6) nd_solve_single<2, 4>(nd, fact, P, nf, w, g);
             else if (lv == 7) nd_solve_single<2, 3>(nd, fact, P, nf, w, g);
-            else if (lv == 10) nd_solve_single<8, 1>(nd, fact, P, nf, w, g);
+            else if (lv == 10) nd_solve_single<4, 1>(nd, fact, P, nf, w, g);
             else nd_solve_single<4, 2>(nd, fact, P, nf, w, g);
+            NPROF(lv - 5 + 6 > 11 ? 11 : lv);
             __syncthreads();
             continue;
         }
@@ -821,6 +843,11 @@ __global__ __launch_bounds__(64 * SOL_NW, 3) void k_nd_solve(FwdParams p, NdDev 
         }
         __syncthreads();
     }
+    NPROF(13);
+#ifdef HM_ND_PROF
+    if (blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 16; ++i) hm_nd_prof_buf[32 + i] = prof_acc[i];
+#endif
     face_fluxes(p, P, p.TX + (long long)m * (Nx + 1) * NB, p.TY + (long long)m * Nx * (NB + 1), p.Vx + (long long)m * (Nx + 1) * NB,
                 p.Vy + (long long)m * Nx * (NB + 1), tid, 64 * SOL_NW);
 }

@@ -70,7 +70,7 @@ def test_perm_transform_on_device():
     assert np.max(np.abs(K - ref) / ref) < 4e-16
 
 
-@pytest.mark.parametrize("n,variant", [(20, 1), (20, 0), (20, 9), (128, 1), (128, 7), (128, 9), (128, 0), (128, 12),
+@pytest.mark.parametrize("n,variant", [(20, 1), (20, 0), (20, 9), (128, 1), (128, 7), (128, 9), (128, 0), (128, 12), (128, 13),
                                        (160, 0), (256, 0)])
 def test_assembly_bitexact_and_pressure_within_solver_noise(n, variant):
     from oracle.ressim import perm_transf
@@ -739,14 +739,14 @@ def test_whole_run_40_steps_at_config2_shape():
 
 
 def test_nested_dissection_pressure_whole_run():
-    """press_variant 12 (press_nd.hip: nested-dissection factorisation of the same TPFA system) through a
-    20-step run at 128 x 128: within the oracle's own solver noise at every stored step, same sub-step counts as the block
-    elimination, and a second ensemble on the same plan reproduces the first bit for bit (no state leaks between runs)."""
+    """press_variant 12 (press_nd.hip: nested-dissection factorisation of the same TPFA system; the default at
+    128 x 128) through a 20-step run: within the oracle's own solver noise at every stored step, same sub-step counts as the block
+    elimination (variant 13), and a second ensemble on the same plan reproduces the first bit for bit (no state leaks between runs)."""
     n, steps, N = 128, 20, 3
     om, gm = make_models(n, n)
     x = perms(n, n, N, seed=5)
     res = {}
-    for v in (0, 12):
+    for v in (13, 12):
         plan = _plan(gm, N, nTime=steps)
         plan.set_variant(v, 0)
         plan.set_inputs(x, transformed=False)
@@ -762,7 +762,7 @@ def test_nested_dissection_pressure_whole_run():
             w2, _, _ = plan.outputs()
             assert np.array_equal(w, w2)
         plan.close()
-    assert res[0][1] == res[12][1], "the two direct solvers must give the same CFL sub-step counts"
+    assert res[13][1] == res[12][1], "the two direct solvers must give the same CFL sub-step counts"
     for m in range(N):
         ref, noise = oracle_sim_and_noise(om, x[m], DT, steps)
         assert np.abs(res[12][0][m] - ref).max() <= 10 * noise + 1e-9, (m, np.abs(res[12][0][m] - ref).max(), noise)
