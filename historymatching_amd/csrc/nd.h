@@ -40,14 +40,22 @@
 // lane order: entry [lane][r], lane = lq * 16 + lc, r = 0..3  (a lane loads its four values of a block as one 8-byte word).
 // Tile entry (lane, r) of a PANEL tile R (transposed panel: pivot k = 4 r + lq, front row m = 16 R + lc) and of a TRAILING tile
 // (R, C) (front rows i = 16 R + 4 r + lq, j = 16 C + lc, both counted from the first boundary row).  Kinds:
-//   COEF  where A[cell m, cell k] (or q[cell k] on the right-hand-side row) lies: levels >= 5: offset into the wave's LDS copy of the
-//         coefficient planes (ND_CF_* below); levels <= 4: index into the member's coefficient block, as int32 over two blocks.
-//         -1: the entry is zero, -2: padded pivot (identity)
-//   G0,G1 offset of the entry in child 0 / child 1's packed lower-triangular update matrix, -1: none
+//   COEF  where A[cell m, cell k] (or q[cell k] on the right-hand-side row) lies: levels >= 5: byte offset into the wave's LDS block
+//         (below); levels <= 4: index into the member's coefficient block, as int32 over two blocks, -1: zero, -2: padded pivot (identity)
+//   G0,G1 where the entry lies in child 0 / child 1's packed lower-triangular update matrix: levels >= 5: byte offset into the wave's LDS
+//         block; levels <= 4: offset in the child's packed array, -1: none
 //   OUT   offset of the entry in this front's packed update matrix, -1: not stored (upper triangle, padding)
 // Block order per front:  leaves: COEF(R) for R = 0..bt, then OUT(R, C) for R = 1..bt, C = 1..R;
 //   levels 5..9: [COEF, G0, G1](R) for R = 0..bt, then [G0, G1, OUT](R, C);
 //   levels 0..4: [COEF lo/hi, G0, G1](V tile idx) for idx = 0..nV-1 (q-major), then [G0, G1, OUT](trailing idx) for idx = 0..nT-1.
+// Levels >= 5 (one wave per front): COEF, G0 and G1 are BYTE offsets into the wave's LDS block, so that an entry is one ds_read
+// and one add -- "none" points at a cell that holds 0.0, "identity" at one that holds 1.0:
+//   block (doubles): [0] = 0.0, [1] = 1.0, data from ND_LDS_DATA on:
+//     levels 8..10 (k_nd_sub): level-9 slots A, B | level-10 slots A, B | 4 coefficient planes of ND_CF_PLANE_SUB
+//     levels 5..7 (k_nd_wave): child 0's update | child 1's update (upd_doubles[level + 1] each) | 4 planes of ND_CF_PLANE_WAVE
+#define ND_LDS_ZERO 0
+#define ND_LDS_ONE 1
+#define ND_LDS_DATA 2
 #define ND_CF_PLANE_SUB 100   // LDS coefficient planes of a level-8 subtree: (8 + 2)^2 cells, box = the level-8 front's region
 #define ND_CF_PLANE_WAVE 56   // of a level 5..7 front: (1 + 2) x (16 + 2) cells, box = the front's pivot line
 #define ND_CF_OX (128 * 128)                        // member coefficient block [dg | -TX | -TY | q]

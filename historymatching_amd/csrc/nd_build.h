@@ -200,13 +200,15 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
         const bool kids = F[NDF_C0] >= 0;
         F[NDF_REC] = (int)(t.rec.size() / 256);
         auto block = [&]() -> size_t { t.rec.resize(t.rec.size() + 256, (short)-1); return t.rec.size() - 256; };
-        auto gather_block = [&](const short* P, int rowpos0, int colpos0) {
+        // (levels >= 5: `base` >= 0 makes the entry a BYTE offset into the wave's LDS block, nd.h, with "none" -> the zero cell)
+        auto gather_block = [&](const short* P, int rowpos0, int colpos0, int base = -1) {
             // entry (lane, r): row position rowpos0 + 4 r + lq, column position colpos0 + lc  (positions in the front)
             short* B = &t.rec[block()];
             for (int lane = 0; lane < 64; ++lane)
                 for (int r = 0; r < 4; ++r) {
                     const int a = P[rowpos0 + 4 * r + (lane >> 4)], c = P[colpos0 + (lane & 15)];
                     int v = (a >= 0 && c >= 0) ? tri(a, c) : -1;
+                    if (base >= 0) v = 8 * (v >= 0 ? base + v : ND_LDS_ZERO);
                     if (v > 32767) { t.error = "recipe offset exceeds int16"; v = -1; }
                     B[lane * 4 + r] = (short)v;
                 }
@@ -222,10 +224,21 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
         };
         if (lv >= 5) {
             int box = F[NDF_PBOX], plane = ND_CF_PLANE_WAVE;
+            // the wave's LDS block (nd.h): where the children's updates and the coefficient planes lie
+            int c0base, c1base, cfbase;
             if (lv >= 8) {
                 const int idx = f - ((1 << lv) - 1), f8 = 255 + (idx >> (lv - 8));
                 box = t.fronts[(size_t)f8 * ND_FRONT_INTS + NDF_RBOX];
                 plane = ND_CF_PLANE_SUB;
+                const int s9 = I.upd_doubles[9], s10 = I.upd_doubles[10];
+                c0base = lv == 8 ? ND_LDS_DATA : ND_LDS_DATA + 2 * s9;            // level 8 reads the level-9 slots, level 9 the level-10 slots
+                c1base = c0base + (lv == 8 ? s9 : s10);
+                cfbase = ND_LDS_DATA + 2 * (s9 + s10);
+            } else {
+                const int chd = I.upd_doubles[lv + 1];
+                c0base = ND_LDS_DATA;
+                c1base = ND_LDS_DATA + chd;
+                cfbase = ND_LDS_DATA + 2 * chd;
             }
             {   // the staged planes must hold the box plus its ring
                 const int x0 = box & 255, y0 = (box >> 8) & 255, x1 = (box >> 16) & 255, y1 = (box >> 24) & 255;
@@ -236,18 +249,21 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
                 for (int lane = 0; lane < 64; ++lane)
                     for (int r = 0; r < 4; ++r) {
                         const int k = 4 * r + (lane >> 4), m = 16 * R + (lane & 15);
-                        B[lane * 4 + r] = (short)coef_local(C[m], C[k], k == m, box, plane);
+                        const int v = coef_local(C[m], C[k], k == m, box, plane);
+                        const int off = 8 * (v >= 0 ? cfbase + v : (v == -2 ? ND_LDS_ONE : ND_LDS_ZERO));
+                        if (off > 32767) { t.error = "recipe offset exceeds int16"; return false; }
+                        B[lane * 4 + r] = (short)off;
                     }
                 if (kids) {
-                    gather_block(P0, 0, 16 * R);
-                    gather_block(P1, 0, 16 * R);
+                    gather_block(P0, 0, 16 * R, c0base);
+                    gather_block(P1, 0, 16 * R, c1base);
                 }
             }
             for (int R = 1; R <= bt; ++R)
                 for (int Cc = 1; Cc <= R; ++Cc) {
                     if (kids) {
-                        gather_block(P0, 16 * R, 16 * Cc);
-                        gather_block(P1, 16 * R, 16 * Cc);
+                        gather_block(P0, 16 * R, 16 * Cc, c0base);
+                        gather_block(P1, 16 * R, 16 * Cc, c1base);
                     }
                     out_block(R - 1, Cc - 1);
                 }

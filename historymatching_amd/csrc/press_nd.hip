@@ -172,11 +172,10 @@ typedef short s4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ s4 rec_load(const short* __restrict__ rec, int blk, int lane) {
     return *reinterpret_cast<const s4*>(rec + ((long long)blk * 64 + lane) * 4);
 }
-// value at a recipe offset, 0 for offset < 0.  The loaded value is USED unconditionally (multiplied by 1 or 0) on purpose: with a
-// select the compiler sinks the load into a branch and waits for it there -- one LDS round trip per entry.
-__device__ __forceinline__ double rec_val(const double* base, int off) {
-    const double l = base[off >= 0 ? off : 0];
-    return l * (off >= 0 ? 1.0 : 0.0);
+// value at a recipe's byte offset into the wave's LDS block ("none" points at a cell holding 0.0, "identity" at one holding 1.0:
+// no clamp, no mask, no select -- one ds_read per entry)
+__device__ __forceinline__ double rec_val(const double* blk, int byte_off) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(blk) + byte_off);
 }
 
 // The panel's recipes, requested ahead of the front that uses them (a front's first instructions would otherwise wait a round trip
@@ -200,8 +199,8 @@ __device__ __forceinline__ void nd_panel_rec_load(NdPanelRec<MAXBT, KIDS>& pr, c
 }
 
 template <int MAXBT, bool KIDS>
-__device__ __forceinline__ void nd_wave_front(int bt, int kreg, const NdPanelRec<MAXBT, KIDS>& pr, const short* __restrict__ rec, const double* cfl,
-                                              const double* ch0, const double* ch1, double* out, double* __restrict__ fa, const NdGeo& g, int& bad) {
+__device__ __forceinline__ void nd_wave_front(int bt, int kreg, const NdPanelRec<MAXBT, KIDS>& pr, const short* __restrict__ rec, const double* blk,
+                                              double* out, double* __restrict__ fa, const NdGeo& g, int& bad) {
     constexpr int NK = KIDS ? 3 : 1;
     // ---- recipes of the trailing tiles, one tile row at a time: row 1 requested now (used after the sweep), row R + 1 while row R
     // is computed (all rows at once would be 126 registers for a level-5 front)
@@ -224,14 +223,15 @@ __device__ __forceinline__ void nd_wave_front(int bt, int kreg, const NdPanelRec
     // ---- the pivot panel, transposed: V[R][r] = F[front row 16 R + lc][pivot 4 r + lq]
     d4 V[MAXBT + 1];
 #pragma unroll
-    for (int R = 0; R <= MAXBT; ++R)
+    for (int R = 0; R <= MAXBT; ++R) {
+        if (R > bt) break;  // (tile rows beyond bt are never used below)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double v = rec_val(cfl, pr.rc[R][r]);
-            if (R == 0) v += pr.rc[0][r] == -2 ? 1.0 : 0.0;  // padded pivot: identity
-            if (KIDS) v += rec_val(ch0, pr.r0[R][r]) + rec_val(ch1, pr.r1[R][r]);
-            V[R][r] = R <= bt ? v : 0.0;
+            double v = rec_val(blk, pr.rc[R][r]);
+            if (KIDS) v += rec_val(blk, pr.r0[R][r]) + rec_val(blk, pr.r1[R][r]);
+            V[R][r] = v;
         }
+    }
     // ---- P = inverse of the pivot tile
     d4 P = V[0];
     sweep16_partial(P, g, bad, kreg);  // P = -inv
@@ -260,7 +260,7 @@ __device__ __forceinline__ void nd_wave_front(int bt, int kreg, const NdPanelRec
             d4 acc = {0.0, 0.0, 0.0, 0.0};
             if (KIDS) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = rec_val(ch0, t0[R & 1][C - 1][r]) + rec_val(ch1, t1[R & 1][C - 1][r]);
+                for (int r = 0; r < 4; ++r) acc[r] = rec_val(blk, t0[R & 1][C - 1][r]) + rec_val(blk, t1[R & 1][C - 1][r]);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -309,25 +309,26 @@ __global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, con
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int SUB_CF_PLANE = ND_CF_PLANE_SUB;
 
-__device__ __forceinline__ int nd_sub_lds_doubles(const NdDev& nd) { return 2 * (nd.slot9 + nd.slot10) + 4 * SUB_CF_PLANE; }
+__device__ __host__ __forceinline__ int nd_sub_lds_doubles(const NdDev& nd) { return ND_LDS_DATA + 2 * (nd.slot9 + nd.slot10) + 4 * SUB_CF_PLANE; }
 
-__global__ __launch_bounds__(256, 3) void k_nd_sub(FwdParams p, NdDev nd, int k) {
+__global__ __launch_bounds__(256, 4) void k_nd_sub(FwdParams p, NdDev nd, int k) {
     extern __shared__ double nd_lds[];
-    const int m = blockIdx.x % p.N, blk = blockIdx.x / p.N;  // subtree-major: co-resident workgroups read the same recipes
+    const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;  // subtree-major: co-resident workgroups read the same recipes
     const int tid = threadIdx.x;
     NdGeo g;
     g.lane = tid & 63;
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double* base = nd_lds + w * nd_sub_lds_doubles(nd);
-    double* s9 = base;
+    double* blk = nd_lds + w * nd_sub_lds_doubles(nd);  // the wave's LDS block (nd.h): the recipes' offsets refer to it
+    double* s9 = blk + ND_LDS_DATA;
     double* s10 = s9 + 2 * nd.slot9;
     double* cfl = s10 + 2 * nd.slot10;
+    if (g.lane == 0) { blk[ND_LDS_ZERO] = 0.0; blk[ND_LDS_ONE] = 1.0; }
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* arena = nd.arena + (long long)m * nd.arena_stride;
-    const int i8 = 4 * blk + w;
+    const int i8 = 4 * bidx + w;
     const int f8 = 255 + i8, f9 = 511 + 2 * i8, f10 = 1023 + 4 * i8;
     int bad = 0;
     NPROF_DECL;
@@ -353,19 +354,19 @@ __global__ __launch_bounds__(256, 3) void k_nd_sub(FwdParams p, NdDev nd, int k)
     for (int bq = 0; bq < 2; ++bq) {
         // two leaves (the second one's recipes requested while the first computes), then their parent
         nd_panel_rec_load(pl[1], recp(F10[2 * bq + 1]), btof(F10[2 * bq + 1]), g.lane);
-        nd_wave_front<1, false>(btof(F10[2 * bq]), krof(F10[2 * bq]), pl[0], recp(F10[2 * bq]), cfl, nullptr, nullptr, s10, fact + F10[2 * bq][NDF_FACT], g, bad);
+        nd_wave_front<1, false>(btof(F10[2 * bq]), krof(F10[2 * bq]), pl[0], recp(F10[2 * bq]), blk, s10, fact + F10[2 * bq][NDF_FACT], g, bad);
         nd_panel_rec_load(pp, recp(F9[bq]), btof(F9[bq]), g.lane);
-        nd_wave_front<1, false>(btof(F10[2 * bq + 1]), krof(F10[2 * bq + 1]), pl[1], recp(F10[2 * bq + 1]), cfl, nullptr, nullptr, s10 + nd.slot10,
+        nd_wave_front<1, false>(btof(F10[2 * bq + 1]), krof(F10[2 * bq + 1]), pl[1], recp(F10[2 * bq + 1]), blk, s10 + nd.slot10,
                                 fact + F10[2 * bq + 1][NDF_FACT], g, bad);
         nd_wave_fence();
         NPROF(1);
         if (bq == 0) nd_panel_rec_load(pl[0], recp(F10[2]), btof(F10[2]), g.lane);
-        nd_wave_front<2, true>(btof(F9[bq]), krof(F9[bq]), pp, recp(F9[bq]), cfl, s10, s10 + nd.slot10, s9 + bq * nd.slot9, fact + F9[bq][NDF_FACT], g, bad);
+        nd_wave_front<2, true>(btof(F9[bq]), krof(F9[bq]), pp, recp(F9[bq]), blk, s9 + bq * nd.slot9, fact + F9[bq][NDF_FACT], g, bad);
         if (bq == 1) nd_panel_rec_load(pp, recp(F8), btof(F8), g.lane);
         nd_wave_fence();
         NPROF(2);
     }
-    nd_wave_front<2, true>(btof(F8), krof(F8), pp, recp(F8), cfl, s9, s9 + nd.slot9, arena + F8[NDF_UPD], fact + F8[NDF_FACT], g, bad);
+    nd_wave_front<2, true>(btof(F8), krof(F8), pp, recp(F8), blk, arena + F8[NDF_UPD], fact + F8[NDF_FACT], g, bad);
     NPROF(3);
 #ifdef HM_ND_PROF
     if (blockIdx.x == 0 && tid == 0)
@@ -384,7 +385,7 @@ template <int LEVEL, int MAXBT, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int k) {
     extern __shared__ double nd_lds[];
     constexpr int NF = 1 << LEVEL;
-    const int m = blockIdx.x % p.N, blk = blockIdx.x / p.N;
+    const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;
     const int tid = threadIdx.x;
     NdGeo g;
     g.lane = tid & 63;
@@ -392,14 +393,15 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chd = nd.child_doubles[7 - LEVEL];
-    double* base = nd_lds + w * (2 * chd + 4 * WAVE_CF_PLANE);
-    double* c0l = base;
-    double* c1l = base + chd;
+    double* blk = nd_lds + w * (ND_LDS_DATA + 2 * chd + 4 * WAVE_CF_PLANE);  // the wave's LDS block (nd.h)
+    double* c0l = blk + ND_LDS_DATA;
+    double* c1l = c0l + chd;
     double* cfl = c1l + chd;
+    if (g.lane == 0) { blk[ND_LDS_ZERO] = 0.0; blk[ND_LDS_ONE] = 1.0; }
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* arena = nd.arena + (long long)m * nd.arena_stride;
-    const int f = NF - 1 + blk * WPB + w;
+    const int f = NF - 1 + bidx * WPB + w;
     const int* F = nd.fronts + f * ND_FRONT_INTS;
     const int* Fc0 = nd.fronts + F[NDF_C0] * ND_FRONT_INTS;
     const int* Fc1 = nd.fronts + F[NDF_C1] * ND_FRONT_INTS;
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     nd_stage_cf(cf, cfl, WAVE_CF_PLANE, F[NDF_PBOX], g.lane, L);
     nd_wave_fence();
     int bad = 0;
-    nd_wave_front<MAXBT, true>(bt, __builtin_amdgcn_readfirstlane(F[NDF_KREG]), pr, rec, cfl, c0l, c1l, arena + F[NDF_UPD], fact + F[NDF_FACT], g, bad);
+    nd_wave_front<MAXBT, true>(bt, __builtin_amdgcn_readfirstlane(F[NDF_KREG]), pr, rec, blk, arena + F[NDF_UPD], fact + F[NDF_FACT], g, bad);
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
@@ -943,11 +945,11 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
     const NdDev& nd = f->nd->dev;
     if (f->dtype == 64) hipLaunchKernelGGL(k_nd_assemble<double>, dim3(p.N), dim3(1024), 0, s, p, nd, (const double*)S, S_stride, k);
     else hipLaunchKernelGGL(k_nd_assemble<float>, dim3(p.N), dim3(1024), 0, s, p, nd, (const float*)S, S_stride, k);
-    const size_t lds_sub = (size_t)4 * (2 * (nd.slot9 + nd.slot10) + 4 * SUB_CF_PLANE) * 8;
+    const size_t lds_sub = (size_t)4 * nd_sub_lds_doubles(nd) * 8;
     hipLaunchKernelGGL(k_nd_sub, dim3(p.N * 64), dim3(256), lds_sub, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * 32), dim3(256), (size_t)4 * (2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * 16), dim3(256), (size_t)4 * (2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * 16), dim3(128), (size_t)2 * (2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * 32), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * 16), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * 16), dim3(128), (size_t)2 * (ND_LDS_DATA + 2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     const size_t lds_top = (size_t)(256 + 2 * TOP_MAXT * 256 + 16 * TOP_MAXT + nd.top_child_doubles + 2) * 8;
     hipLaunchKernelGGL(k_nd_top, dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_solve, dim3(p.N), dim3(64 * SOL_NW), 0, s, p, nd, k);
