@@ -767,7 +767,7 @@ __global__ __launch_bounds__(64 * SOL_NW, 3) void k_nd_solve(FwdParams p, NdDev 
     const double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* xe = xe_all[w];
     NPROF_DECL;
-    for (int lv = 0; lv < ND_LEVELS; ++lv) {
+    for (int lv = 0; lv < 8; ++lv) {  // levels 8..10: k_nd_solve_sub
         const int nf = 1 << lv;
         NPROF(lv < 5 ? 12 : lv - 5);
         if (lv >= 5) {
@@ -850,8 +850,93 @@ __global__ __launch_bounds__(64 * SOL_NW, 3) void k_nd_solve(FwdParams p, NdDev 
     if (blockIdx.x == 0 && tid == 0)
         for (int i = 0; i < 16; ++i) hm_nd_prof_buf[32 + i] = prof_acc[i];
 #endif
-    face_fluxes(p, P, p.TX + (long long)m * (Nx + 1) * NB, p.TY + (long long)m * Nx * (NB + 1), p.Vx + (long long)m * (Nx + 1) * NB,
-                p.Vy + (long long)m * Nx * (NB + 1), tid, 64 * SOL_NW);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Back substitution of levels 8..10: one wave per level-8 subtree (the workgroups of k_nd_sub), top-down.  Every factor row of the
+// subtree's 7 fronts and every cell index is requested up front (one round trip to memory), the pressures live in an LDS plane
+// over the subtree's region and its ring of separator cells (known from the levels above: one gather), and the region's 8 x 8
+// pressures go to memory at the end.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void k_nd_solve_sub(FwdParams p, NdDev nd, int k) {
+    __shared__ double xl_all[4][ND_CF_PLANE_SUB];
+    const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;
+    const int tid = threadIdx.x;
+    NdGeo g;
+    g.lane = tid & 63;
+    g.lc = g.lane & 15;
+    g.lq = g.lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* xl = xl_all[w];
+    double* P = p.P + (long long)m * p.Nxy;
+    const double* fact = nd.fact + (long long)m * nd.fact_stride;
+    const int i8 = 4 * bidx + w;
+    const int fid[7] = {255 + i8, 511 + 2 * i8, 512 + 2 * i8, 1023 + 4 * i8, 1024 + 4 * i8, 1025 + 4 * i8, 1026 + 4 * i8};
+    constexpr int MB[7] = {2, 2, 2, 1, 1, 1, 1}, MK[7] = {2, 1, 1, 4, 4, 4, 4};  // most boundary tiles / pivot register rows per front
+    int bt[7], kreg[7], cb[7][2], cpv[7][4];
+    double t[7][2][4];
+    const int box = nd.fronts[fid[0] * ND_FRONT_INTS + NDF_RBOX];
+    const int x0 = box & 255, y0 = (box >> 8) & 255, x1 = (box >> 16) & 255, y1 = (box >> 24) & 255, ld = y1 - y0 + 2;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int* F = nd.fronts + fid[i] * ND_FRONT_INTS;
+        bt[i] = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
+        kreg[i] = __builtin_amdgcn_readfirstlane(F[NDF_KREG]);
+        const int* cl = nd.cells + __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
+        const double* fa = fact + F[NDF_FACT];
+#pragma unroll
+        for (int R = 0; R < MB[i]; ++R) {
+            cb[i][R] = cl[16 * (1 + (R < bt[i] ? R : 0)) + g.lc];
+#pragma unroll
+            for (int r = 0; r < MK[i]; ++r) t[i][R][r] = fa[((R < bt[i] ? R : 0) * kreg[i] + (r < kreg[i] ? r : 0)) * 64 + g.lane];
+        }
+#pragma unroll
+        for (int r = 0; r < MK[i]; ++r) cpv[i][r] = cl[4 * r + g.lq];
+    }
+    auto li = [&](int c) { return ((c >> 7) - x0 + 1) * ld + ((c & 127) - y0 + 1); };
+    // the ring: the level-8 front's boundary cells, solved by the levels above
+#pragma unroll
+    for (int R = 0; R < 2; ++R) {
+        const int c = cb[0][R];
+        if (R < bt[0] && c >= 0) xl[li(c)] = P[c];
+    }
+    nd_wave_fence();
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int R = 0; R < MB[i]; ++R) {
+            const int c = cb[i][R];
+            const double xv = (R < bt[i]) ? (c >= 0 ? xl[li(c >= 0 ? c : 0)] : (c == -2 ? -1.0 : 0.0)) : 0.0;
+#pragma unroll
+            for (int r = 0; r < MK[i]; ++r) acc[r] = fma(t[i][R][r], xv, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < MK[i]; ++r) {
+            double v = acc[r];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            if (g.lc == 0 && r < kreg[i] && cpv[i][r] >= 0) xl[li(cpv[i][r])] = -v;
+        }
+        if (i == 0 || i == 2) nd_wave_fence();  // level boundaries: 8 | 9, 9 | 10
+    }
+    nd_wave_fence();
+    {   // the region's cells to memory
+        const int h = y1 - y0, n = (x1 - x0) * h;
+        if (g.lane < n) {
+            const int ix = x0 + g.lane / h, iy = y0 + g.lane % h;
+            P[ix * NB + iy] = xl[(ix - x0 + 1) * ld + (iy - y0 + 1)];
+        }
+    }
+}
+
+// Face fluxes from the pressures (fwd_dev.h), one workgroup per member.
+__global__ __launch_bounds__(1024) void k_nd_flux(FwdParams p) {
+    const int m = blockIdx.x, Nx = p.Nx;
+    face_fluxes(p, p.P + (long long)m * p.Nxy, p.TX + (long long)m * (Nx + 1) * NB, p.TY + (long long)m * Nx * (NB + 1),
+                p.Vx + (long long)m * (Nx + 1) * NB, p.Vy + (long long)m * Nx * (NB + 1), threadIdx.x, 1024);
 }
 
 }  // namespace
@@ -953,6 +1038,8 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
     const size_t lds_top = (size_t)(256 + 2 * TOP_MAXT * 256 + 16 * TOP_MAXT + nd.top_child_doubles + 2) * 8;
     hipLaunchKernelGGL(k_nd_top, dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_solve, dim3(p.N), dim3(64 * SOL_NW), 0, s, p, nd, k);
+    hipLaunchKernelGGL(k_nd_solve_sub, dim3(p.N * 64), dim3(256), 0, s, p, nd, k);
+    hipLaunchKernelGGL(k_nd_flux, dim3(p.N), dim3(1024), 0, s, p);
     HM_HIP(hipGetLastError());
     return 0;
 }
