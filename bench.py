@@ -85,7 +85,7 @@ def nd_mfma_count():
     lib = _lib.load()
     info = (C.c_longlong * 24)()
     _lib.check(lib.hm_debug_nd_tables(NX, NY, info, None, None, None, None), "hm_debug_nd_tables")
-    fronts = np.zeros((int(info[0]), 16), dtype=np.int32)
+    fronts = np.zeros((int(info[0]), int(info[19])), dtype=np.int32)
     _lib.check(lib.hm_debug_nd_tables(NX, NY, info, fronts.ctypes.data_as(C.POINTER(C.c_int)), None, None, None), "hm_debug_nd_tables")
     total = 0
     for F in fronts:

@@ -12,7 +12,7 @@
 // [16 st, 16 st + b) boundary cells, 16 st + b the right-hand-side row, then padding.
 #pragma once
 
-#define ND_FRONT_INTS 16
+#define ND_FRONT_INTS 20
 // ints of one front record
 #define NDF_LEVEL 0
 #define NDF_S 1
@@ -30,6 +30,8 @@
 #define NDF_PBOX 13    // bounding box of the front's pivot cells, x0 | y0 << 8 | x1 << 16 | y1 << 24 (x1, y1 exclusive)
 #define NDF_RBOX 14    // the front's whole region (pivots of the front and of all its descendants), same packing
 #define NDF_REC 15     // offset of the front's assembly recipes in `rec`, in blocks of 256 int16 (nd.h: recipes)
+#define NDF_UC0 16     // NDF_UPD of child 0 / child 1 (a parent finds its children's updates without reading their records)
+#define NDF_UC1 17
 
 #define ND_LEVELS 11
 #define ND_ARENA_MAX_LEVEL 8   // updates of levels 1..8 live in the per-member arena (global memory); 9, 10 in per-wave LDS slots

@@ -151,6 +151,7 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
             if (ch < 0) continue;
             const std::vector<int>& cb = B.bnd[ch];
             F[c == 0 ? NDF_BC0 : NDF_BC1] = (int)cb.size();
+            F[c == 0 ? NDF_UC0 : NDF_UC1] = t.fronts[(size_t)ch * ND_FRONT_INTS + NDF_UPD];
             for (size_t i = 0; i < cb.size(); ++i) where[cb[i]] = (int)i;
             short* P = &t.cpos[(size_t)2 * F[NDF_CELLS] + (size_t)c * 16 * T];
             size_t found = 0;

@@ -94,11 +94,16 @@ __device__ __forceinline__ void nd_stage_cf(const double* __restrict__ cf, doubl
         const int lx = i / ld, ly = i - lx * ld;
         const int ix = x0 - 1 + lx, iy = y0 - 1 + ly;
         const bool xin = ix >= 0 && ix < NB, yin = iy >= 0 && iy < NB;
+        const bool vx = yin && ix >= 0 && ix <= NB, vy = xin && iy >= 0 && iy <= NB;
         const int c = ix * NB + iy;
-        cfl[i] = (xin && yin) ? cf[c] : 0.0;
-        cfl[plane + i] = (yin && ix >= 0 && ix <= NB) ? cf[CF_OX + c] : 0.0;
-        cfl[2 * plane + i] = (xin && iy >= 0 && iy <= NB) ? cf[CF_OY + ix * (NB + 1) + iy] : 0.0;
-        cfl[3 * plane + i] = (xin && yin) ? cf[CF_OQ + c] : 0.0;
+        // four unconditional loads (a harmless address where the cell lies outside the grid), then the masks: under selects the
+        // compiler branches around each load and waits for it there, four round trips to memory instead of one
+        const double l0 = cf[(xin && yin) ? c : 0], l1 = cf[CF_OX + (vx ? c : 0)], l2 = cf[CF_OY + (vy ? ix * (NB + 1) + iy : 0)],
+                     l3 = cf[CF_OQ + ((xin && yin) ? c : 0)];
+        cfl[i] = l0 * ((xin && yin) ? 1.0 : 0.0);
+        cfl[plane + i] = l1 * (vx ? 1.0 : 0.0);
+        cfl[2 * plane + i] = l2 * (vy ? 1.0 : 0.0);
+        cfl[3 * plane + i] = l3 * ((xin && yin) ? 1.0 : 0.0);
     }
     out.p = cfl; out.plane = plane; out.ld = ld; out.x0 = x0; out.y0 = y0;
 }
@@ -403,15 +408,14 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     double* arena = nd.arena + (long long)m * nd.arena_stride;
     const int f = NF - 1 + bidx * WPB + w;
     const int* F = nd.fronts + f * ND_FRONT_INTS;
-    const int* Fc0 = nd.fronts + F[NDF_C0] * ND_FRONT_INTS;
-    const int* Fc1 = nd.fronts + F[NDF_C1] * ND_FRONT_INTS;
-    const int n0 = (((Fc0[NDF_B] + 1) * (Fc0[NDF_B] + 2) >> 1) + 1) & ~1, n1 = (((Fc1[NDF_B] + 1) * (Fc1[NDF_B] + 2) >> 1) + 1) & ~1;
+    const int bc0 = F[NDF_BC0], bc1 = F[NDF_BC1];
+    const int n0 = (((bc0 + 1) * (bc0 + 2) >> 1) + 1) & ~1, n1 = (((bc1 + 1) * (bc1 + 2) >> 1) + 1) & ~1;
     const int bt = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
     const short* rec = nd.rec + (long long)__builtin_amdgcn_readfirstlane(F[NDF_REC]) * 256;
     NdPanelRec<MAXBT, true> pr;
     nd_panel_rec_load(pr, rec, bt, g.lane);  // in flight beside the bulk copies below
-    nd_wave_copy(c0l, arena + Fc0[NDF_UPD], n0, g.lane);
-    nd_wave_copy(c1l, arena + Fc1[NDF_UPD], n1, g.lane);
+    nd_wave_copy(c0l, arena + F[NDF_UC0], n0, g.lane);
+    nd_wave_copy(c1l, arena + F[NDF_UC1], n1, g.lane);
     NdCfl L;
     nd_stage_cf(cf, cfl, WAVE_CF_PLANE, F[NDF_PBOX], g.lane, L);
     nd_wave_fence();
@@ -463,30 +467,36 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
     double* arena = nd.arena + (long long)m * nd.arena_stride;
     int bad = 0;
     NPROF_DECL;
+    // the records of fronts 0..30 in LDS, read once (they carry their children's sizes and offsets): per front they would otherwise
+    // cost two dependent round trips to memory (the front's record, then its children's) before anything else can start
+    int* frec = reinterpret_cast<int*>(chl + ((nd.top_child_doubles + 1) & ~1));  // 31 records behind the child buffer
+    for (int i = tid; i < 31 * ND_FRONT_INTS; i += 64 * TOP_NW) frec[i] = nd.fronts[i];
+    __syncthreads();
     for (int lv = 4; lv >= 0; --lv) {
         for (int fi = 0; fi < (1 << lv); ++fi) {
             const int f = (1 << lv) - 1 + fi;
-            const int* F = nd.fronts + f * ND_FRONT_INTS;
+            const int* F = frec + f * ND_FRONT_INTS;
             const int b = __builtin_amdgcn_readfirstlane(F[NDF_B]);
             const int st = __builtin_amdgcn_readfirstlane(F[NDF_ST]);
             const int bt = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
             const int T = st + bt;
             const int co = __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
             const int kreg_last = __builtin_amdgcn_readfirstlane(F[NDF_KREG]);
-            double* fa = fact + F[NDF_FACT];
+            double* fa = fact + __builtin_amdgcn_readfirstlane(F[NDF_FACT]);
             const int nV = st * T - ((st * (st - 1)) >> 1);
             const int nT = b > 0 ? ((bt * (bt + 1)) >> 1) : 0;
             NPROF(0);
             // ---- the front's position tables and the first child's update to LDS
-            const int* Fc[2] = {nd.fronts + F[NDF_C0] * ND_FRONT_INTS, nd.fronts + F[NDF_C1] * ND_FRONT_INTS};
+            const int bch[2] = {__builtin_amdgcn_readfirstlane(F[NDF_BC0]), __builtin_amdgcn_readfirstlane(F[NDF_BC1])};
+            const int uch[2] = {__builtin_amdgcn_readfirstlane(F[NDF_UC0]), __builtin_amdgcn_readfirstlane(F[NDF_UC1])};
             for (int i = tid; i < 16 * T; i += 64 * TOP_NW) {
                 cl_s[i] = nd.cells[co + i];
                 cp_s0[i] = nd.cpos[2 * co + i];
                 cp_s1[i] = nd.cpos[2 * co + 16 * T + i];
             }
             {
-                const int n2 = (((Fc[0][NDF_B] + 1) * (Fc[0][NDF_B] + 2) >> 1) + 1) >> 1;
-                const double2* s2 = reinterpret_cast<const double2*>(arena + Fc[0][NDF_UPD]);
+                const int n2 = (((bch[0] + 1) * (bch[0] + 2) >> 1) + 1) >> 1;
+                const double2* s2 = reinterpret_cast<const double2*>(arena + uch[0]);
                 double2* d2 = reinterpret_cast<double2*>(chl);
                 for (int i = tid; i < n2; i += 64 * TOP_NW) d2[i] = s2[i];
             }
@@ -546,8 +556,8 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             NPROF(2);
             __syncthreads();
             {
-                const int n2 = (((Fc[1][NDF_B] + 1) * (Fc[1][NDF_B] + 2) >> 1) + 1) >> 1;
-                const double2* s2 = reinterpret_cast<const double2*>(arena + Fc[1][NDF_UPD]);
+                const int n2 = (((bch[1] + 1) * (bch[1] + 2) >> 1) + 1) >> 1;
+                const double2* s2 = reinterpret_cast<const double2*>(arena + uch[1]);
                 double2* d2 = reinterpret_cast<double2*>(chl);
                 for (int i = tid; i < n2; i += 64 * TOP_NW) d2[i] = s2[i];
             }
@@ -1035,8 +1045,9 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
     hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * 32), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * 16), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * 16), dim3(128), (size_t)2 * (ND_LDS_DATA + 2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
-    const size_t lds_top = (size_t)(256 + 2 * TOP_MAXT * 256 + 16 * TOP_MAXT + nd.top_child_doubles + 2) * 8;
+    const size_t lds_top = (size_t)(256 + 2 * TOP_MAXT * 256 + 16 * TOP_MAXT + ((nd.top_child_doubles + 1) & ~1)) * 8 + 31 * ND_FRONT_INTS * 4;
     hipLaunchKernelGGL(k_nd_top, dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k);
+    if (hipError_t e_ = hipGetLastError()) { hm_set_error("k_nd_top launch with %zu bytes of LDS: %s", lds_top, hipGetErrorString(e_)); return 1; }
     hipLaunchKernelGGL(k_nd_solve, dim3(p.N), dim3(64 * SOL_NW), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_solve_sub, dim3(p.N * 64), dim3(256), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_flux, dim3(p.N), dim3(1024), 0, s, p);
@@ -1064,6 +1075,7 @@ extern "C" int hm_debug_nd_tables(int Nx, int Ny, long long* info, int* fronts, 
     if (fronts) memcpy(fronts, t.fronts.data(), t.fronts.size() * sizeof(int));
     if (cells) memcpy(cells, t.cells.data(), t.cells.size() * sizeof(int));
     info[7] = t.info.n_rec_blocks;
+    info[19] = ND_FRONT_INTS;
     if (cpos) memcpy(cpos, t.cpos.data(), t.cpos.size() * sizeof(short));
     if (rec) memcpy(rec, t.rec.data(), t.rec.size() * sizeof(short));
     return 0;

@@ -15,7 +15,7 @@ def tables(lib, Nx, Ny):
     if rc:
         raise RuntimeError(lib.hm_last_error().decode())
     nF, nC = int(info[0]), int(info[1])
-    fronts = np.zeros((nF, 16), dtype=np.int32)
+    fronts = np.zeros((nF, int(info[19])), dtype=np.int32)
     cells = np.zeros(nC, dtype=np.int32)
     cpos = np.zeros(2 * nC, dtype=np.int16)
     rec = np.zeros(256 * int(info[7]), dtype=np.int16)
