@@ -20,6 +20,15 @@ import re
 import sys
 from collections import defaultdict
 
+def short(name):
+    """k_sat128, k_nd_sub, k_nd_wave<7, 3, 4> ...: the kernel's name with its template arguments where several instantiations run."""
+    m = re.search(r"(k_nd_wave<[^>]*>)", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"(k_\w+)", name)
+    return m.group(1) if m else name[:40]
+
+
 DP_LANE_RATE = 256 * 4 * 16 * 2.4e9
 FP64_PEAK = 2 * DP_LANE_RATE
 
@@ -27,9 +36,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 stats = {}
 if len(sys.argv) > 2:
     for r in csv.DictReader(open(sys.argv[2])):
-        m = re.search(r"(k_\w+)", r["Name"])
-        if m:
-            stats.setdefault(m.group(1), float(r["AverageNs"]))
+        stats.setdefault(short(r["Name"]), float(r["AverageNs"]))
 isa = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else {}
 bench_line = {}
 if len(sys.argv) > 4:  # the JSON line bench.py printed under the kernel trace: measured mean sub-steps per member-step
@@ -46,8 +53,7 @@ for r in rows:
     disp[key]["_wg"] = float(r["Workgroup_Size"])
 agg = defaultdict(list)
 for (_, name), c in disp.items():
-    m = re.search(r"(k_\w+)", name)
-    agg[m.group(1) if m else name[:40]].append(c)
+    agg[short(name)].append(c)
 out = {}
 for name, cs in sorted(agg.items()):
     n = len(cs)
@@ -82,10 +88,21 @@ for name, cs in sorted(agg.items()):
         e["fp64_mfma_frac_of_peak"] = flops / (ns * 1e-9) / FP64_PEAK
         e["mfma_busy_frac_of_cu_busy"] = avg("SQ_VALU_MFMA_BUSY_CYCLES") / max(avg("SQ_BUSY_CU_CYCLES"), 1.0)
     out[name] = e
+# the nested-dissection pressure solve is several launches per time step: their matrix-core work and time together
+nd = {k: v for k, v in out.items() if k.startswith("k_nd_")}
+pressure_nd = None
+if nd:
+    members = max(v["members_per_launch"] for k, v in nd.items() if k in ("k_nd_top", "k_nd_assemble", "k_nd_flux")) if any(k in nd for k in ("k_nd_top",)) else None
+    flops = sum(v.get("fp64_mfma_flops_per_launch", 0.0) for v in nd.values())
+    us = sum(v["avg_us"] for v in nd.values())
+    if members:
+        pressure_nd = {"kernels": sorted(nd), "sum_avg_us": us, "members_per_step": members, "fp64_mfma_flops_per_member_step": flops / members,
+                       "fp64_mfma_frac_of_peak": flops / (us * 1e-6) / FP64_PEAK,
+                       "valu_wave_instr_per_member_step": sum(v["SQ_INSTS_VALU"] for v in nd.values()) / members}
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent))
 try:
     from obj_hash import object_hashes
     hashes = object_hashes()
 except Exception:
     hashes = None
-print(json.dumps({"object_sha256": hashes, "peaks": {"dp_lane_instr_per_s": DP_LANE_RATE, "fp64_tflops": FP64_PEAK / 1e12, "assumed_clock_GHz": 2.4}, "kernels": out}, indent=1))
+print(json.dumps({"object_sha256": hashes, "pressure_nd": pressure_nd, "peaks": {"dp_lane_instr_per_s": DP_LANE_RATE, "fp64_tflops": FP64_PEAK / 1e12, "assumed_clock_GHz": 2.4}, "kernels": out}, indent=1))

@@ -12,7 +12,9 @@ from pathlib import Path
 
 out_dir, members = Path(sys.argv[1]), int(sys.argv[2])
 KEYS = {"k_perm_transform": "perm_transform", "k_press128m": "press128m", "k_press128s": "press128s", "k_pressure_pcg": "pressure_pcg", "k_press128<": "press128", "k_sat128": "sat128",
-        "k_pressure_generic": "pressure_generic", "k_saturation_generic": "saturation_generic"}
+        "k_pressure_generic": "pressure_generic", "k_saturation_generic": "saturation_generic",
+        "k_nd_assemble": "nd_assemble", "k_nd_sub(": "nd_sub", "k_nd_wave<7": "nd_wave7", "k_nd_wave<6": "nd_wave6", "k_nd_wave<5": "nd_wave5",
+        "k_nd_top": "nd_top", "k_nd_solve(": "nd_solve", "k_nd_solve_sub": "nd_solve_sub", "k_nd_flux": "nd_flux"}
 
 
 def per_launch(counter):
@@ -38,6 +40,11 @@ for k in sorted(set(fetch) | set(write)):
         "hbm_bytes_per_member_uncorrected": (f + w) / members,
         "hbm_bytes_per_member_fetch_x2": (2.0 * f + w) / members,
     }
+nd_keys = [k for k in kernels if k.startswith("nd_")]
+if nd_keys:  # the nested-dissection pressure solve as a whole (its launches of one time step together)
+    kernels["press_nd"] = {kk: sum(kernels[k][kk] for k in nd_keys) for kk in kernels[nd_keys[0]]}
+    kernels["press_nd"]["hbm_bytes_per_member_corrected"] = kernels["press_nd"]["hbm_bytes_per_member_uncorrected"]
+    kernels["press_nd"]["launches"] = nd_keys
 print(json.dumps({
     "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --members %d --steps 1; gfx950 "
             "correction: FETCH_SIZE counts 1/2 of the bytes of wide coalesced reads (x2 applied to press128s/press128m and "
