@@ -89,6 +89,8 @@ def nd_mfma_count():
     _lib.check(lib.hm_debug_nd_tables(NX, NY, info, fronts.ctypes.data_as(C.POINTER(C.c_int)), None, None, None), "hm_debug_nd_tables")
     total = 0
     for F in fronts:
+        if int(F[0]) == 10:  # the leaves are eliminated one per lane by a banded L D L^T on the vector pipe (k_nd_leaf)
+            continue
         b, st, bt, kreg_last = int(F[2]), int(F[3]), int(F[4]), int(F[10])
         T = st + bt
         ntrail = bt * (bt + 1) // 2 if b > 0 else 0

@@ -34,7 +34,8 @@
 #define NDF_UC1 17
 
 #define ND_LEVELS 11
-#define ND_ARENA_MAX_LEVEL 8   // updates of levels 1..8 live in the per-member arena (global memory); 9, 10 in per-wave LDS slots
+#define ND_ARENA_MAX_LEVEL 8   // updates of levels 1..8 and of the leaves (level 10: written by k_nd_leaf) live in the per-member arena
+                               // (global memory); level 9's in per-wave LDS slots
 #define ND_WAVE_TOP_LEVEL 5    // levels 10..5: one wave per front;  levels 4..0: one workgroup per front (per member)
 
 // Assembly RECIPES: what each lane of a wave reads, adds and writes when it assembles a front, precomputed per front (they depend on

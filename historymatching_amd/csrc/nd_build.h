@@ -122,8 +122,8 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
         }
         long long tiles_regs = 0;  // 64-double register rows
         for (int p = 0; p < st; ++p) tiles_regs += (long long)(T - p - 1) * (p == st - 1 ? F[NDF_KREG] : 4);
-        fact += tiles_regs * 64;
-        if (lv <= ND_ARENA_MAX_LEVEL && lv > 0) {
+        if (lv < ND_LEVELS - 1) fact += tiles_regs * 64;  // (the leaves keep no factor: k_nd_leaf_solve eliminates them again)
+        if ((lv <= ND_ARENA_MAX_LEVEL && lv > 0) || lv == ND_LEVELS - 1) {  // leaves: their updates go from k_nd_leaf to k_nd_sub through the arena
             F[NDF_UPD] = (int)arena;
             long long n = (long long)(b + 1) * (b + 2) / 2;
             arena += (n + 1) & ~1LL;

@@ -308,6 +308,173 @@ __global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, con
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The leaves (level 10: 3 x 3 .. 4 x 4 cells, at most 12 boundary cells), ONE LANE PER LEAF.  A leaf's pivot block is the five-point
+// matrix of a tiny grid -- banded, bandwidth 4 in the padded 4 x 4 ordering i = 4 lx + ly -- and every boundary cell touches exactly one
+// of its cells.  As a front on the matrix cores a leaf costs a whole wave ~900 instructions (a 16-pivot in-wave sweep, two padded
+// tiles); as a banded L D L^T in one lane's registers the 64 leaves of a wave cost ~3 k instructions together.  Per lane:
+//   band of A_II from the coefficient block, L D L^T (16 x 4 band), z = A_II^-1 q_I and the columns g = A_II^-1 e_i of the cells next
+//   to the boundary; update matrix U[j][l] = -t_j t_l G[i_l][i_j], right-hand-side row U[rhs][l] = -t_l z[i_l]   (t = A[boundary, cell])
+// written packed to the arena (k_nd_sub stages them for the level-9 fronts).  No factor is stored: k_nd_leaf_solve, the last step of the
+// back substitution, repeats the band factorisation and solves A_II x_I = q_I - A_Ib x_b with the boundary pressures known.
+// ------------------------------------------------------------------------------------------------------------------------
+struct NdLeaf {
+    double l[16][4];   // L[i][i-1-k], k = 0..3
+    double invd[16];
+    int cell[16];      // global cell of local cell i = 4 lx + ly, -1: padding
+};
+
+// band + factorisation of leaf front `f` (per lane); returns false for a non-positive pivot
+__device__ __forceinline__ bool nd_leaf_factor(NdLeaf& Lf, const NdDev& nd, const double* __restrict__ cf, int f) {
+    const int box = nd.fronts[f * ND_FRONT_INTS + NDF_RBOX];
+    const int x0 = box & 255, y0 = (box >> 8) & 255, w = ((box >> 16) & 255) - x0, h = ((box >> 24) & 255) - y0;
+    double d[16], e1[16], e4[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int lx = i >> 2, ly = i & 3;
+        const bool alive = lx < w && ly < h;
+        const int c = alive ? (x0 + lx) * NB + y0 + ly : 0;
+        Lf.cell[i] = alive ? c : -1;
+        const double dg = cf[c], tn = cf[CF_OY + c + (c >> 7) + 1], te = cf[CF_OX + c + NB];
+        d[i] = alive ? dg : 1.0;
+        e1[i] = (alive && ly + 1 < h) ? tn : 0.0;   // A[i+1][i]: the north face (cf holds -TY)
+        e4[i] = (alive && lx + 1 < w) ? te : 0.0;   // A[i+4][i]: the east face (cf holds -TX)
+    }
+    bool ok = true;
+    double ld[16][4];  // L[i][j] D[j]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {  // j = i - 1 - k ascending
+            const int j = i - 1 - k;
+            if (j < 0) { Lf.l[i][k] = 0.0; ld[i][k] = 0.0; continue; }
+            double sacc = k == 0 ? e1[j] : (k == 3 ? e4[j] : 0.0);
+            if (k == 0 && (i & 3) == 0) sacc = 0.0;  // i and i - 1 lie in different columns of the 4 x 4 layout
+#pragma unroll
+            for (int mm = i - 4; mm < j; ++mm) {
+                if (mm < 0) continue;
+                sacc -= ld[i][i - 1 - mm] * Lf.l[j][j - 1 - mm];
+            }
+            ld[i][k] = sacc;
+            Lf.l[i][k] = sacc * Lf.invd[j];
+        }
+        double dd = d[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i - 1 - k >= 0) dd -= Lf.l[i][k] * ld[i][k];
+        ok = ok && dd > 0.0;
+        Lf.invd[i] = 1.0 / dd;
+    }
+    return ok;
+}
+// x = A_II^-1 v in place
+__device__ __forceinline__ void nd_leaf_solve(const NdLeaf& Lf, double (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i - 1 - k >= 0) v[i] -= Lf.l[i][k] * v[i - 1 - k];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] *= Lf.invd[i];
+#pragma unroll
+    for (int i = 15; i >= 0; --i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + 1 + k < 16) v[i] -= Lf.l[i + 1 + k][k] * v[i + 1 + k];
+}
+// boundary entry j of the leaf: the local cell it touches and the coefficient A[boundary cell, that cell] (0: no such entry)
+__device__ __forceinline__ void nd_leaf_boundary(const NdDev& nd, const double* __restrict__ cf, int f, int j, int& il, double& t, int& bcell) {
+    const int* F = nd.fronts + f * ND_FRONT_INTS;
+    const int box = F[NDF_RBOX], b = F[NDF_B];
+    const int x0 = box & 255, y0 = (box >> 8) & 255, x1 = (box >> 16) & 255, y1 = (box >> 24) & 255;
+    const bool on = j < b;
+    const int c = on ? nd.cells[F[NDF_CELLS] + 16 + j] : 0;
+    const int bx = c >> 7, by = c & 127;
+    // the one region cell next to it, and the face between them
+    int ix = bx, iy = by, fidx;
+    if (bx < x0) { ix = x0; fidx = CF_OX + ix * NB + iy; }                 // west side: the cell's west face
+    else if (bx >= x1) { ix = x1 - 1; fidx = CF_OX + bx * NB + by; }      // east side: the boundary cell's west face
+    else if (by < y0) { iy = y0; fidx = CF_OY + ix * (NB + 1) + iy; }      // south side: the cell's south face
+    else { iy = y1 - 1; fidx = CF_OY + bx * (NB + 1) + by; }              // north side: the boundary cell's south face
+    const double tv = cf[on ? fidx : 0];
+    il = on ? (ix - x0) * 4 + (iy - y0) : 0;
+    t = on ? tv : 0.0;
+    bcell = on ? c : -1;
+}
+
+__global__ __launch_bounds__(256) void k_nd_leaf(FwdParams p, NdDev nd, int k) {
+    __shared__ double gsh[4][16][64];  // per wave: one solution vector per lane, [cell][lane]
+    const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int f = 1023 + bidx * 256 + tid;  // 4 blocks of 256 leaves per member
+    const double* cf = nd.cf + (long long)m * CF_STRIDE;
+    double* out = nd.arena + (long long)m * nd.arena_stride + nd.fronts[f * ND_FRONT_INTS + NDF_UPD];
+    const int b = nd.fronts[f * ND_FRONT_INTS + NDF_B];
+    NdLeaf Lf;
+    const bool ok = nd_leaf_factor(Lf, nd, cf, f);
+    int il[12];
+    double t[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        int bc;
+        nd_leaf_boundary(nd, cf, f, j, il[j], t[j], bc);
+    }
+    double (*gl)[64] = gsh[w];
+    // right-hand-side row: z = A_II^-1 q_I
+    {
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = Lf.cell[i] >= 0 ? cf[CF_OQ + Lf.cell[i]] : 0.0;
+        nd_leaf_solve(Lf, v);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gl[i][lane] = v[i];
+#pragma unroll
+        for (int l = 0; l < 12; ++l)
+            if (l < b) out[((b * (b + 1)) >> 1) + l] = -t[l] * gl[il[l]][lane];
+        out[((b * (b + 1)) >> 1) + b] = 0.0;
+    }
+    // boundary rows: g = A_II^-1 e_{il[j]}
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (i == il[j]) ? 1.0 : 0.0;
+        nd_leaf_solve(Lf, v);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gl[i][lane] = v[i];
+#pragma unroll
+        for (int l = 0; l <= j; ++l)
+            if (j < b) out[((j * (j + 1)) >> 1) + l] = -(t[j] * t[l]) * gl[il[l]][lane];
+    }
+    if (!ok) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
+}
+
+// The last step of the back substitution: the leaves' own cells, with every separator pressure known.
+__global__ __launch_bounds__(256) void k_nd_leaf_solve(FwdParams p, NdDev nd, int k) {
+    const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;
+    const int f = 1023 + bidx * 256 + threadIdx.x;
+    const double* cf = nd.cf + (long long)m * CF_STRIDE;
+    double* P = p.P + (long long)m * p.Nxy;
+    NdLeaf Lf;
+    nd_leaf_factor(Lf, nd, cf, f);
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = Lf.cell[i] >= 0 ? cf[CF_OQ + Lf.cell[i]] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        int il, bc;
+        double t;
+        nd_leaf_boundary(nd, cf, f, j, il, t, bc);
+        const double s = t * P[bc >= 0 ? bc : 0];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] -= (i == il) ? s : 0.0;
+    }
+    nd_leaf_solve(Lf, v);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (Lf.cell[i] >= 0) P[Lf.cell[i]] = v[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Levels 10..8: one wave per level-8 subtree (8 x 8 cells: 4 leaves, 2 level-9 fronts, the level-8 front), 4 waves per
 // workgroup, 64 workgroups per member.  Per wave in LDS: the subtree's position tables and coefficients (staged once, one
 // round trip to memory), two update slots each for levels 10 and 9.  The level-8 update goes to the arena.
@@ -348,29 +515,41 @@ __global__ __launch_bounds__(256, 4) void k_nd_sub(FwdParams p, NdDev nd, int k)
     for (int i = 0; i < 4; ++i) F10[i] = nd.fronts + (f10 + i) * ND_FRONT_INTS;
 #pragma unroll
     for (int i = 0; i < 2; ++i) F9[i] = nd.fronts + (f9 + i) * ND_FRONT_INTS;
-    NdPanelRec<1, false> pl[2];
     NdPanelRec<2, true> pp;
-    nd_panel_rec_load(pl[0], recp(F10[0]), btof(F10[0]), g.lane);
+    // the four leaves' update matrices (k_nd_leaf wrote them to the arena; <= 92 doubles each: one double2 per lane): the first pair
+    // straight into the level-10 slots, the second pair into registers until the first level-9 front has read the slots
+    auto leaf_d2 = [&](int i) {
+        const int bl = __builtin_amdgcn_readfirstlane(F10[i][NDF_B]);
+        const int n2 = ((((bl + 1) * (bl + 2)) >> 1) + 1) >> 1;
+        const double2* src = reinterpret_cast<const double2*>(arena + __builtin_amdgcn_readfirstlane(F10[i][NDF_UPD]));
+        return src[g.lane < n2 ? g.lane : n2 - 1];
+    };
+    static_assert(true, "slot10 <= 128 doubles is checked on the host (nd_setup)");
+    double2 lf0 = leaf_d2(0), lf1 = leaf_d2(1), lf2 = leaf_d2(2), lf3 = leaf_d2(3);
+    nd_panel_rec_load(pp, recp(F9[0]), btof(F9[0]), g.lane);
     NdCfl L;
     nd_stage_cf(cf, cfl, SUB_CF_PLANE, F8[NDF_RBOX], g.lane, L);
+    {
+        double2* a2 = reinterpret_cast<double2*>(s10);
+        double2* b2 = reinterpret_cast<double2*>(s10 + nd.slot10);
+        if (2 * g.lane < nd.slot10) { a2[g.lane] = lf0; b2[g.lane] = lf1; }
+    }
     nd_wave_fence();
     NPROF(0);
-#pragma unroll
-    for (int bq = 0; bq < 2; ++bq) {
-        // two leaves (the second one's recipes requested while the first computes), then their parent
-        nd_panel_rec_load(pl[1], recp(F10[2 * bq + 1]), btof(F10[2 * bq + 1]), g.lane);
-        nd_wave_front<1, false>(btof(F10[2 * bq]), krof(F10[2 * bq]), pl[0], recp(F10[2 * bq]), blk, s10, fact + F10[2 * bq][NDF_FACT], g, bad);
-        nd_panel_rec_load(pp, recp(F9[bq]), btof(F9[bq]), g.lane);
-        nd_wave_front<1, false>(btof(F10[2 * bq + 1]), krof(F10[2 * bq + 1]), pl[1], recp(F10[2 * bq + 1]), blk, s10 + nd.slot10,
-                                fact + F10[2 * bq + 1][NDF_FACT], g, bad);
-        nd_wave_fence();
-        NPROF(1);
-        if (bq == 0) nd_panel_rec_load(pl[0], recp(F10[2]), btof(F10[2]), g.lane);
-        nd_wave_front<2, true>(btof(F9[bq]), krof(F9[bq]), pp, recp(F9[bq]), blk, s9 + bq * nd.slot9, fact + F9[bq][NDF_FACT], g, bad);
-        if (bq == 1) nd_panel_rec_load(pp, recp(F8), btof(F8), g.lane);
-        nd_wave_fence();
-        NPROF(2);
+    nd_wave_front<2, true>(btof(F9[0]), krof(F9[0]), pp, recp(F9[0]), blk, s9, fact + F9[0][NDF_FACT], g, bad);
+    nd_panel_rec_load(pp, recp(F9[1]), btof(F9[1]), g.lane);
+    nd_wave_fence();
+    {
+        double2* a2 = reinterpret_cast<double2*>(s10);
+        double2* b2 = reinterpret_cast<double2*>(s10 + nd.slot10);
+        if (2 * g.lane < nd.slot10) { a2[g.lane] = lf2; b2[g.lane] = lf3; }
     }
+    nd_wave_fence();
+    NPROF(1);
+    nd_wave_front<2, true>(btof(F9[1]), krof(F9[1]), pp, recp(F9[1]), blk, s9 + nd.slot9, fact + F9[1][NDF_FACT], g, bad);
+    nd_panel_rec_load(pp, recp(F8), btof(F8), g.lane);
+    nd_wave_fence();
+    NPROF(2);
     nd_wave_front<2, true>(btof(F8), krof(F8), pp, recp(F8), blk, arena + F8[NDF_UPD], fact + F8[NDF_FACT], g, bad);
     NPROF(3);
 #ifdef HM_ND_PROF
@@ -881,14 +1060,15 @@ __global__ __launch_bounds__(256, 4) void k_nd_solve_sub(FwdParams p, NdDev nd, 
     double* P = p.P + (long long)m * p.Nxy;
     const double* fact = nd.fact + (long long)m * nd.fact_stride;
     const int i8 = 4 * bidx + w;
-    const int fid[7] = {255 + i8, 511 + 2 * i8, 512 + 2 * i8, 1023 + 4 * i8, 1024 + 4 * i8, 1025 + 4 * i8, 1026 + 4 * i8};
-    constexpr int MB[7] = {2, 2, 2, 1, 1, 1, 1}, MK[7] = {2, 1, 1, 4, 4, 4, 4};  // most boundary tiles / pivot register rows per front
-    int bt[7], kreg[7], cb[7][2], cpv[7][4];
-    double t[7][2][4];
+    constexpr int NFR = 3;  // the level-8 front and its two level-9 children (the leaves: k_nd_leaf_solve)
+    const int fid[NFR] = {255 + i8, 511 + 2 * i8, 512 + 2 * i8};
+    constexpr int MB[NFR] = {2, 2, 2}, MK[NFR] = {2, 1, 1};  // most boundary tiles / pivot register rows per front
+    int bt[NFR], kreg[NFR], cb[NFR][2], cpv[NFR][4];
+    double t[NFR][2][4];
     const int box = nd.fronts[fid[0] * ND_FRONT_INTS + NDF_RBOX];
     const int x0 = box & 255, y0 = (box >> 8) & 255, x1 = (box >> 16) & 255, y1 = (box >> 24) & 255, ld = y1 - y0 + 2;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < NFR; ++i) {
         const int* F = nd.fronts + fid[i] * ND_FRONT_INTS;
         bt[i] = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
         kreg[i] = __builtin_amdgcn_readfirstlane(F[NDF_KREG]);
@@ -912,7 +1092,7 @@ __global__ __launch_bounds__(256, 4) void k_nd_solve_sub(FwdParams p, NdDev nd, 
     }
     nd_wave_fence();
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < NFR; ++i) {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int R = 0; R < MB[i]; ++R) {
@@ -928,18 +1108,14 @@ __global__ __launch_bounds__(256, 4) void k_nd_solve_sub(FwdParams p, NdDev nd, 
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 1);
-            if (g.lc == 0 && r < kreg[i] && cpv[i][r] >= 0) xl[li(cpv[i][r])] = -v;
+            if (g.lc == 0 && r < kreg[i] && cpv[i][r] >= 0) {
+                xl[li(cpv[i][r])] = -v;
+                P[cpv[i][r]] = -v;
+            }
         }
-        if (i == 0 || i == 2) nd_wave_fence();  // level boundaries: 8 | 9, 9 | 10
+        if (i == 0) nd_wave_fence();  // level boundary 8 | 9
     }
-    nd_wave_fence();
-    {   // the region's cells to memory
-        const int h = y1 - y0, n = (x1 - x0) * h;
-        if (g.lane < n) {
-            const int ix = x0 + g.lane / h, iy = y0 + g.lane % h;
-            P[ix * NB + iy] = xl[(ix - x0 + 1) * ld + (iy - y0 + 1)];
-        }
-    }
+    (void)x1;
 }
 
 // Face fluxes from the pressures (fwd_dev.h), one workgroup per member.
@@ -979,6 +1155,7 @@ static int nd_setup(hm_fwd* f) {
         const int T = t.info.max_st[lv] + t.info.max_bt[lv];
         HM_REQUIRE(T <= TOP_MAXT, "nested-dissection tables: a top-level front has %d tile rows (max %d)", T, TOP_MAXT);
     }
+    HM_REQUIRE(t.info.upd_doubles[10] <= 128 && t.info.max_bt[10] == 1, "nested-dissection tables: a leaf has more than 12 boundary cells");
     for (int lv = 5; lv < ND_LEVELS; ++lv) HM_REQUIRE(t.info.max_st[lv] == 1, "nested-dissection tables: level %d has several pivot tiles", lv);
     for (int fI = 0; fI < t.info.n_fronts; ++fI) {
         const int* F = &t.fronts[(size_t)fI * ND_FRONT_INTS];
@@ -1041,6 +1218,7 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
     if (f->dtype == 64) hipLaunchKernelGGL(k_nd_assemble<double>, dim3(p.N), dim3(1024), 0, s, p, nd, (const double*)S, S_stride, k);
     else hipLaunchKernelGGL(k_nd_assemble<float>, dim3(p.N), dim3(1024), 0, s, p, nd, (const float*)S, S_stride, k);
     const size_t lds_sub = (size_t)4 * nd_sub_lds_doubles(nd) * 8;
+    hipLaunchKernelGGL(k_nd_leaf, dim3(p.N * 4), dim3(256), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_sub, dim3(p.N * 64), dim3(256), lds_sub, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * 32), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * 16), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
@@ -1050,6 +1228,7 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
     if (hipError_t e_ = hipGetLastError()) { hm_set_error("k_nd_top launch with %zu bytes of LDS: %s", lds_top, hipGetErrorString(e_)); return 1; }
     hipLaunchKernelGGL(k_nd_solve, dim3(p.N), dim3(64 * SOL_NW), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_solve_sub, dim3(p.N * 64), dim3(256), 0, s, p, nd, k);
+    hipLaunchKernelGGL(k_nd_leaf_solve, dim3(p.N * 4), dim3(256), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_flux, dim3(p.N), dim3(1024), 0, s, p);
     HM_HIP(hipGetLastError());
     return 0;
