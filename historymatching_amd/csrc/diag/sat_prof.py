@@ -1,0 +1,37 @@
+"""Cycle stamps of the register-resident saturation sweep (k_sat128r, workgroup 0, every wave), one launch per time step of a forward run.
+Build first: diag/build_sat_prof.sh, then
+     HM_AMD_LIB=build_prof/libhm_satprof.so python historymatching_amd/csrc/diag/sat_prof.py [sat_variant=7] [steps=0,5,20,39] [N=256]"""
+import ctypes as C
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[3] / "tests"))
+from helpers import make_models, perms  # noqa: E402
+from historymatching_amd import _lib  # noqa: E402
+from historymatching_amd.forward import ForwardPlan  # noqa: E402
+
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+steps = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0,5,20,39").split(",")]
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+_, gm = make_models(128, 128)
+plan = ForwardPlan(gm, N, 0.025, 40, keep_history=False, device=0)
+plan.set_variant(0, variant)
+plan.set_inputs(perms(128, 128, N, seed=1), None, transformed=False)
+lib = _lib.load()
+lib.hm_debug_sat_prof.argtypes = [C.POINTER(C.c_longlong)]
+buf = (C.c_longlong * 64)()
+names = ["publish", "barrier 1", "sweep", "barrier 2"]
+for k in range(40):
+    plan.run(k, 1)
+    if k not in steps:
+        continue
+    st = plan.sync()
+    assert lib.hm_debug_sat_prof(buf) == 0
+    v = [list(buf[8 * w:8 * w + 8]) for w in range(8)]
+    nts = v[0][7]
+    print(f"time step {k}: Nts {nts}, loop {v[0][4] / nts:.0f} cycles per sub-step, {v[0][5] * 10 / nts:.0f} ns per sub-step "
+          f"({v[0][4] / (v[0][5] * 10e-9) / 1e9:.2f} GHz)")
+    for w in range(8):
+        print(f"   wave {w}: dry {v[w][6]:4d} of {nts}   " + "   ".join(f"{n} {v[w][i] / nts:7.0f}" for i, n in enumerate(names)))
+plan.close()

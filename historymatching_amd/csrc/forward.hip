@@ -869,7 +869,9 @@ static int launch_saturation(hm_fwd* f, int k) {
     if (rc) return rc;
     int done = -1;
     if (f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
-        done = launch_saturation_128(f, Sin, Sout, stride, k);                  // fp64, register/LDS resident
+        // fp64, register/LDS resident: fw in registers, scaled fluxes (sat128r.hip); sat_variant 5: fw image in LDS (sat128.hip)
+        if (f->sat_variant != 5) done = launch_saturation_128r(f, Sin, Sout, stride, k);
+        if (done < 0) done = launch_saturation_128(f, Sin, Sout, stride, k);
         if (done < 0) done = launch_saturation_128f(f, Sin, Sout, stride, k);  // fp32 twin
         if (done < 0) done = launch_saturation_128t(f, Sin, Sout, stride, k);  // fp64, grids of 128 x 128 tiles (workgroup teams)
         if (done < 0) done = launch_saturation_128ft(f, Sin, Sout, stride, k); // fp32 twin

@@ -95,6 +95,7 @@ int launch_pressure_pcg(hm_fwd* f, const void* S, long long S_stride, int k);   
 bool pressure_two_level_applies(const FwdParams& p);
 int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int k);  // two-level CG, Ny = 128 c
 int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);
+int launch_saturation_128r(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // fw in registers, scaled fluxes (sat128r.hip)
 int launch_saturation_128f(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // dtype = 32 plans
 int launch_saturation_128t(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // grids of 128 x 128 tiles, fp64
 int launch_saturation_128ft(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // the same, dtype = 32 plans

@@ -401,7 +401,7 @@ __device__ __forceinline__ void nd_leaf_boundary(const NdDev& nd, const double* 
     bcell = on ? c : -1;
 }
 
-__global__ __launch_bounds__(256) void k_nd_leaf(FwdParams p, NdDev nd, int k) {
+__global__ __launch_bounds__(256, 2) void k_nd_leaf(FwdParams p, NdDev nd, int k) {
     __shared__ double gsh[4][16][64];  // per wave: one solution vector per lane, [cell][lane]
     const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
