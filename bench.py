@@ -504,21 +504,21 @@ def main():
         dominant = "saturation" if stats["ms_saturation"] >= stats["ms_pressure"] else "pressure"
         isa, isa_src = load_profile_json("isa_counts.json")
         pmc, pmc_src = load_profile_json("pmc_hbm_traffic.json")
-        # the committed counts were taken from particular builds of sat128.o / press128s.o: if the objects this process runs
+        # the committed counts were taken from particular builds of sat128r.o / press_nd.o: if the objects this process runs
         # differ, every figure derived from them is stale -- say so and report no fraction
         sys.path.insert(0, str(ROOT / "profiles" / "tools"))
         from obj_hash import object_hashes
         built = object_hashes()
-        # saturation sweep (k_sat128): member state register/LDS resident, bound by the CU's double-precision VALU.  Work per
+        # saturation sweep (k_sat128r): member state register/LDS resident, bound by the CU's double-precision VALU.  Work per
         # launch = DP VALU instructions of the sub-step loop (counted from the built object: profiles/tools/isa_count.py) x
         # cells x sub-steps x members, in lane-instructions; the peak is one DP lane-instruction per lane-slot.
-        dp_per_cell = (isa or {}).get("k_sat128", {}).get("dp_valu_per_cell_substep", 39.25)
-        # dry bands are skipped (sat128.hip): the instructions actually executed are fewer than cells x sub-steps x count; the
+        dp_per_cell = (isa or {}).get("k_sat128r", {}).get("dp_valu_per_cell_substep", 26.0)
+        # dry bands are skipped (sat128r.hip): the instructions actually executed are fewer than cells x sub-steps x count; the
         # ratio is measured (SQ_INSTS_VALU over the same workload, profiles/rNN/fp64_roofline.json) -- `frac` uses EXECUTED work
         f64r, f64r_src = load_profile_json("fp64_roofline.json")
-        executed_ratio = ((f64r or {}).get("kernels", {}).get("k_sat128", {}).get("executed_over_algorithmic", 1.0)) if args.variant == 0 else 1.0
+        executed_ratio = ((f64r or {}).get("kernels", {}).get("k_sat128r", {}).get("executed_over_algorithmic", 1.0)) if args.variant == 0 else 1.0
         recorded = {"isa_counts.json": (isa or {}).get("object_sha256"), "fp64_roofline.json": (f64r or {}).get("object_sha256")}
-        stale = [f"{src}: {obj}" for src, h in recorded.items() for obj in ("sat128.o", "press_nd.o")
+        stale = [f"{src}: {obj}" for src, h in recorded.items() for obj in ("sat128r.o", "press_nd.o")
                  if not h or h.get(obj) != built.get(obj)] if args.variant == 0 else []
         sat_lane_instr_algorithmic = dp_per_cell * nxy * nts * n_e
         sat_lane_instr = sat_lane_instr_algorithmic * executed_ratio
@@ -543,10 +543,10 @@ def main():
         sat_bytes = w * nxy * 4 * nts * n_e
         prs_bytes = w * (4 * nxy + 2 * ND_FACTOR_DOUBLES + 2 * ND_ARENA_DOUBLES) * n_e  # compulsory + factor write/read + update matrices write/read
         roofline = {
-            "bound": bound, "kernel": {"saturation": "k_sat128", "pressure": "k_nd_* (press_nd.hip: assemble, sub, wave x3, top, solve)"}[dominant] if args.variant == 0 else dominant,
+            "bound": bound, "kernel": {"saturation": "k_sat128r", "pressure": "k_nd_* (press_nd.hip: assemble, sub, wave x3, top, solve)"}[dominant] if args.variant == 0 else dominant,
             "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None if stale else ach / FP64_PEAK_TFLOPS,
             "stale_inputs": bool(stale), "stale_inputs_detail": stale or None,
-            "inputs_taken_from_objects": recorded, "objects_run": {k: built.get(k) for k in ("sat128.o", "press_nd.o")},
+            "inputs_taken_from_objects": recorded, "objects_run": {k: built.get(k) for k in ("sat128r.o", "press_nd.o")},
             "unit_note": "for bound fp64_valu `achieved` is an issue-slot rate: DP lane-instructions/s x 2 (every DP VALU instruction priced as one FMA "
                          "slot, whether it is an FMA, an add, a compare or part of a division) against 2 x the lane-slot peak; the plain rate is "
                          "in achieved_dp_lane_instr_per_s / peak_dp_lane_instr_per_s",

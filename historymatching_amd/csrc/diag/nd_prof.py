@@ -23,12 +23,14 @@ lib = _lib.load()
 buf = (C.c_longlong * 64)()
 lib.hm_debug_nd_prof.argtypes = [C.POINTER(C.c_longlong)]
 assert lib.hm_debug_nd_prof(buf) == 0
-top = ["between fronts", "tables -> LDS + barrier", "decode", "assemble V tiles", "assemble trailing tiles", "S1 sweep", "barrier 1", "S2 W = P V, publish",
+top = ["between fronts", "tables + child 0 -> LDS, tile decode, barrier", "coefficients + child 0 gather", "child 1 -> LDS (2 barriers)", "child 1 gather", "S1 sweep", "barrier 1", "S2 W = P V, publish",
        "barrier 2", "S3 updates", "store update", "end barrier"]
 v = list(buf[:16])
 print(f"k_nd_top, block 0 wave 0: {sum(v)} cycles")
 for n, x in zip(top, v):
     print(f"   {n:28s} {x:10d}  {100 * x / max(sum(v), 1):5.1f} %")
+lv = list(buf[48:54])
+print("   by level (4, 3, 2, 1, 0): " + ", ".join(f"{lv[i - 1] - lv[i]}" for i in (4, 3, 2, 1)) + f", {lv[5] - lv[0]} cycles")
 sub = ["level 10 (8 leaves)", "level 9 (4 fronts)", "level 8 (2 fronts)", "level 7 (1 front)"]
 v = list(buf[16:32])
 print(f"k_nd_sub, block 0 wave 0: {sum(v)} cycles")

@@ -67,17 +67,38 @@ __device__ __forceinline__ int tri(int a, int b) {
 // + iy) is dg[ck], -TX[face between] or -TY[face between]; the right-hand-side row (cm = -2) reads q[ck].
 constexpr int CF_OX = NB * NB, CF_OY = CF_OX + (NB + 1) * NB, CF_OQ = CF_OY + NB * (NB + 1), CF_STRIDE = CF_OQ + NB * NB;
 
+// (index arithmetic only and ONE load used unconditionally: behind `if`s the compiler sinks each load into its branch and waits for
+// it there -- a round trip to memory per entry instead of one for all the entries a lane assembles)
+#ifndef HM_TOP_COEF
+#define HM_TOP_COEF 1
+#endif
+#ifndef HM_TOP_COPY
+#define HM_TOP_COPY 0
+#endif
 __device__ __forceinline__ double nd_coef_global(const double* __restrict__ cf, int cm, int ck, bool same_pos) {
+#if HM_TOP_COEF == 0
     if (ck < 0) return same_pos ? 1.0 : 0.0;  // padded pivot: identity
     if (cm == -2) return cf[CF_OQ + ck];
     if (cm < 0) return 0.0;
-    const int d = cm - ck;
-    if (d == 0) return cf[ck];
-    if (d == NB) return cf[CF_OX + ck + NB];
-    if (d == -NB) return cf[CF_OX + ck];
-    if (d == 1) return cf[CF_OY + ck + (ck >> 7) + 1];
-    if (d == -1) return cf[CF_OY + ck + (ck >> 7)];
+    const int d0 = cm - ck;
+    if (d0 == 0) return cf[ck];
+    if (d0 == NB) return cf[CF_OX + ck + NB];
+    if (d0 == -NB) return cf[CF_OX + ck];
+    if (d0 == 1) return cf[CF_OY + ck + (ck >> 7) + 1];
+    if (d0 == -1) return cf[CF_OY + ck + (ck >> 7)];
     return 0.0;
+#endif
+    const int d = cm - ck;
+    const bool cell = ck >= 0 && cm >= 0;
+    int off = -1;
+    off = (cell && d == 0) ? ck : off;
+    off = (cell && d == NB) ? CF_OX + ck + NB : off;
+    off = (cell && d == -NB) ? CF_OX + ck : off;
+    off = (cell && d == 1) ? CF_OY + ck + (ck >> 7) + 1 : off;
+    off = (cell && d == -1) ? CF_OY + ck + (ck >> 7) : off;
+    off = (ck >= 0 && cm == -2) ? CF_OQ + ck : off;
+    const double l = cf[off >= 0 ? off : 0];
+    return l * (off >= 0 ? 1.0 : 0.0) + ((ck < 0 && same_pos) ? 1.0 : 0.0);  // padded pivot: identity
 }
 
 // The same from an LDS copy of the coefficients around a box of cells [x0, x1) x [y0, y1): four planes (dg, -TX of the cell's
@@ -615,6 +636,25 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int TOP_NW = 16, TOP_NVS = 3, TOP_NTS = 4, TOP_MAXT = 13;
 
+// A child's packed update matrix, arena -> LDS, by the whole workgroup: every load of a thread is issued before its first store
+// (one round trip to memory; a load-store loop makes one per trip).  TOP_CH chunks of 1024 double2 cover the largest child.
+constexpr int TOP_CH = 7;
+struct TopChild {  // (named members: as an array it is kept in scratch)
+    double2 c0, c1, c2, c3, c4, c5, c6;
+};
+__device__ __forceinline__ void top_child_load(TopChild& c, const double* __restrict__ src, int n2, int tid) {
+    const double2* s2 = reinterpret_cast<const double2*>(src);
+#define TOP_LD(K) c.c##K = s2[tid + K * 1024 < n2 ? tid + K * 1024 : n2 - 1]
+    TOP_LD(0); TOP_LD(1); TOP_LD(2); TOP_LD(3); TOP_LD(4); TOP_LD(5); TOP_LD(6);
+#undef TOP_LD
+}
+__device__ __forceinline__ void top_child_store(const TopChild& c, double* dst, int n2, int tid) {
+    double2* d2 = reinterpret_cast<double2*>(dst);
+#define TOP_ST(K) if (tid + K * 1024 < n2) d2[tid + K * 1024] = c.c##K
+    TOP_ST(0); TOP_ST(1); TOP_ST(2); TOP_ST(3); TOP_ST(4); TOP_ST(5); TOP_ST(6);
+#undef TOP_ST
+}
+
 __device__ __forceinline__ d4 img_load(const double* img, int lane) {
     d4 v;
 #pragma unroll
@@ -652,6 +692,9 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
     for (int i = tid; i < 31 * ND_FRONT_INTS; i += 64 * TOP_NW) frec[i] = nd.fronts[i];
     __syncthreads();
     for (int lv = 4; lv >= 0; --lv) {
+#ifdef HM_ND_PROF
+        if (blockIdx.x == 0 && tid == 0) hm_nd_prof_buf[48 + lv] = clock64();
+#endif
         for (int fi = 0; fi < (1 << lv); ++fi) {
             const int f = (1 << lv) - 1 + fi;
             const int* F = frec + f * ND_FRONT_INTS;
@@ -673,12 +716,18 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
                 cp_s0[i] = nd.cpos[2 * co + i];
                 cp_s1[i] = nd.cpos[2 * co + 16 * T + i];
             }
+            const int n2c[2] = {(((bch[0] + 1) * (bch[0] + 2) >> 1) + 1) >> 1, (((bch[1] + 1) * (bch[1] + 2) >> 1) + 1) >> 1};
+#if HM_TOP_COPY == 1
+            TopChild chr;
+            top_child_load(chr, arena + uch[0], n2c[0], tid);
+            top_child_store(chr, chl, n2c[0], tid);
+#else
             {
-                const int n2 = (((bch[0] + 1) * (bch[0] + 2) >> 1) + 1) >> 1;
                 const double2* s2 = reinterpret_cast<const double2*>(arena + uch[0]);
                 double2* d2 = reinterpret_cast<double2*>(chl);
-                for (int i = tid; i < n2; i += 64 * TOP_NW) d2[i] = s2[i];
+                for (int i = tid; i < n2c[0]; i += 64 * TOP_NW) d2[i] = s2[i];
             }
+#endif
             // ---- my tiles: decode (scalar)
             d4 vt[TOP_NVS], tr[TOP_NTS];
             int vq[TOP_NVS], vR[TOP_NVS], tR[TOP_NTS], tC[TOP_NTS];
@@ -709,7 +758,10 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             }
             __syncthreads();
             NPROF(1);
-            // ---- coefficients + child 0
+            // ---- coefficients + child 0 (the second child's loads are in flight meanwhile)
+#if HM_TOP_COPY == 1
+            top_child_load(chr, arena + uch[1], n2c[1], tid);
+#endif
 #pragma unroll
             for (int s = 0; s < TOP_NVS; ++s) {
                 vt[s] = d4{0.0, 0.0, 0.0, 0.0};
@@ -734,12 +786,15 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             }
             NPROF(2);
             __syncthreads();
+#if HM_TOP_COPY == 1
+            top_child_store(chr, chl, n2c[1], tid);
+#else
             {
-                const int n2 = (((bch[1] + 1) * (bch[1] + 2) >> 1) + 1) >> 1;
                 const double2* s2 = reinterpret_cast<const double2*>(arena + uch[1]);
                 double2* d2 = reinterpret_cast<double2*>(chl);
-                for (int i = tid; i < n2; i += 64 * TOP_NW) d2[i] = s2[i];
+                for (int i = tid; i < n2c[1]; i += 64 * TOP_NW) d2[i] = s2[i];
             }
+#endif
             __syncthreads();
             NPROF(3);
             // ---- child 1
@@ -859,8 +914,10 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
         }
     }
 #ifdef HM_ND_PROF
-    if (blockIdx.x == 0 && tid == 0)
+    if (blockIdx.x == 0 && tid == 0) {
         for (int i = 0; i < 16; ++i) hm_nd_prof_buf[i] = prof_acc[i];
+        hm_nd_prof_buf[53] = clock64();
+    }
 #endif
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
@@ -1195,6 +1252,7 @@ static int nd_setup(hm_fwd* f) {
     d.child_doubles[2] = t.info.upd_doubles[6];
     d.top_child_doubles = 0;
     for (int lv = 1; lv <= 5; ++lv) d.top_child_doubles = std::max(d.top_child_doubles, t.info.upd_doubles[lv]);
+    HM_REQUIRE(d.top_child_doubles <= TOP_CH * 64 * TOP_NW * 2, "nested dissection: a child update of %d doubles does not fit the top kernel's %d copy chunks", d.top_child_doubles, TOP_CH);
     // dynamic LDS beyond 64 KB must be requested per kernel
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_top, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<5, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -58,6 +58,21 @@ __device__ __forceinline__ double prev_lane(double v) {  // value of lane - 1
     return __hiloint2double(hi, lo);
 }
 
+// max(a, z) / min(a, z) as the one instruction they are.  fmax() / fmin() compile to the same instruction behind a canonicalising
+// v_max_f64 x, x of every operand the compiler cannot prove free of signalling NaNs -- here every flux, because they live in
+// registers across the sub-step loop's back edge: 78 extra instructions per thread and sub-step.  Same result for every operand that
+// is not a signalling NaN.  z is the loop's opaque zero (an SGPR pair).
+__device__ __forceinline__ double vmax(double a, double z) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(z));
+    return r;
+}
+__device__ __forceinline__ double vmin(double a, double z) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(z));
+    return r;
+}
+
 template <bool FD>
 __global__ __launch_bounds__(NT) void k_sat128r(FwdParams p, const double* __restrict__ Sin_base, double* __restrict__ Sout_base,
                                                 long long S_stride, double* __restrict__ prods, int k) {
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(NT) void k_sat128r(FwdParams p, const double* __res
                 for (int j = 0; j < PY; ++j) fc[j] = f7[j] = 0.0;
             }
 #pragma unroll
-            for (int j = 0; j < PY; ++j) te[j] = (-fmin(Vx[0][j], z)) * fc[j];  // c_E f_E of the cell above, (ix0 - 1, iy0 + j)
+            for (int j = 0; j < PY; ++j) te[j] = (-vmin(Vx[0][j], z)) * fc[j];  // c_E f_E of the cell above, (ix0 - 1, iy0 + j)
             if (px > 0) st4(pubE, te);
             st4(pubW, f7);
         }
@@ -268,10 +283,10 @@ __global__ __launch_bounds__(NT) void k_sat128r(FwdParams p, const double* __res
 #pragma unroll
                 for (int j = 0; j < PY; ++j) {
                     const double vyn = j + 1 < PY ? Vy[i][j + 1 < PY ? j + 1 : 0] : vyn3;
-                    const double cW = fmax(Vx[i][j], z), cS = fmax(Vy[i][j], z), cN = -fmin(vyn, z);
+                    const double cW = vmax(Vx[i][j], z), cS = vmax(Vy[i][j], z), cN = -vmin(vyn, z);
                     const double fs = j > 0 ? fc[j > 0 ? j - 1 : 0] : fS;
                     const double fnn = j + 1 < PY ? fc[j + 1 < PY ? j + 1 : 0] : fN;
-                    double a = i + 1 < PX ? (-fmin(Vx[i + 1 < PX ? i + 1 : 0][j], z)) * fn[j] : fn[j];
+                    double a = i + 1 < PX ? (-vmin(Vx[i + 1 < PX ? i + 1 : 0][j], z)) * fn[j] : fn[j];
                     a = a + cN * fnn;
                     a = a + ar[j] * fc[j];
                     a = a + cS * fs;

@@ -6,6 +6,7 @@
 #  4. the update at config 3's shape: kernel trace                                          -> kernel_stats_update.csv
 #  5. isa_counts.json + fp64_roofline.json, both carrying the sha256 of the objects they were taken from
 #  6. the pressure variants side by side (nested dissection vs block elimination)            -> pressure_variants.txt
+#     the saturation sweeps side by side (fw image in LDS vs fw in registers)               -> saturation_variants.txt
 set -u
 R=${1:-r03}
 OUT=gpurun_out/profiles/$R
@@ -34,11 +35,15 @@ python3 - <<PY > $OUT/isa_counts.json
 import json, subprocess, sys
 sys.path.insert(0, "profiles/tools")
 from obj_hash import object_hashes
-d = json.loads(subprocess.run(["python3", "profiles/tools/isa_count.py", "historymatching_amd/csrc/sat128.o", "k_sat128ILb1", "32", "2"], capture_output=True, text=True, check=True).stdout)
-print(json.dumps({"object_sha256": object_hashes(), "k_sat128": d, "how": "profiles/tools/isa_count.py historymatching_amd/csrc/sat128.o k_sat128ILb1 32 2"}, indent=1))
+def census(obj, sub):
+    return json.loads(subprocess.run(["python3", "profiles/tools/isa_count.py", obj, sub, "32", "2"], capture_output=True, text=True, check=True).stdout)
+print(json.dumps({"object_sha256": object_hashes(), "k_sat128r": census("historymatching_amd/csrc/sat128r.o", "k_sat128rILb1"),
+                  "k_sat128": census("historymatching_amd/csrc/sat128.o", "k_sat128ILb1"),
+                  "how": "profiles/tools/isa_count.py historymatching_amd/csrc/sat128r.o k_sat128rILb1 32 2 (and sat128.o k_sat128ILb1: sat_variant 5)"}, indent=1))
 PY
 python3 profiles/tools/fp64_roofline.py $OUT/pmc_fp64_forward_counter_collection.csv $OUT/kernel_stats_bench.csv $OUT/isa_counts.json $OUT/bench_under_rocprof.json > $OUT/fp64_roofline.json
 python3 tests/tools/nd_check.py 1000 20 > $OUT/pressure_variants.txt 2>&1
+python3 tests/tools/sat_check.py 1000 5,0 > $OUT/saturation_variants.txt 2>&1
 python3 tests/tools/long_parity.py 4 > $OUT/long_parity.txt 2>&1
 python3 tests/tools/ies_iterate_timing.py > $OUT/ies_iterate.txt 2>&1
 ls -la $OUT

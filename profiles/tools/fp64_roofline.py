@@ -8,7 +8,7 @@
 Counters (own pass, counters only): SQ_INSTS_VALU, SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES,
 GRBM_GUI_ACTIVE.  Per kernel, averaged over its dispatches:
   * effective clock  = GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration (MI355X_MICROARCH.md, DVFS give-back)
-  * k_sat128   : DP lane-instructions = SQ_INSTS_VALU (wave-instructions) x 64 lanes x the double-precision share of the VALU
+  * k_sat128r (k_sat128): DP lane-instructions = SQ_INSTS_VALU (wave-instructions) x 64 lanes x the double-precision share of the VALU
                  instructions in the sub-step loop (static census of the built object, isa_counts.json);
                  frac = DP lane-instructions / duration / (256 CUs x 4 SIMDs x 16 DP lanes x 2.4 GHz)
   * k_press128s: fp64 matrix flops = SQ_INSTS_VALU_MFMA_MOPS_F64 x 512; frac = flops / duration / 78.6 TF
@@ -67,8 +67,8 @@ for name, cs in sorted(agg.items()):
          "GRBM_GUI_ACTIVE": avg("GRBM_GUI_ACTIVE"), "effective_clock_GHz_under_pmc": avg("GRBM_GUI_ACTIVE") / 8 / ns_pmc}
     lane_instr = avg("SQ_INSTS_VALU") * 64
     e["valu_lane_instr_per_launch"] = lane_instr
-    if name == "k_sat128" and "k_sat128" in isa:
-        c = isa["k_sat128"]["counts"]
+    if name in ("k_sat128", "k_sat128r") and name in isa:
+        c = isa[name]["counts"]
         share = c["dp_valu"] / (c["dp_valu"] + c["other_valu"])
         e["dp_share_of_valu_from_isa_census"] = share
         e["dp_lane_instr_per_launch"] = lane_instr * share

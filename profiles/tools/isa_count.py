@@ -97,14 +97,53 @@ def main():
     name = next(n for n in fns if sub in n)
     body = fns[name]
     lo, hi = hot_loop(body, barriers)
+    # blocks the compiler laid out behind the loop's back edge that are entered from the loop and jump back into it (k_sat128r: the
+    # fractional flow of the two published rows, the not-dry side of a wave-uniform branch) belong to the trip
+    def target_of(a, args):
+        m16 = re.match(r"(\d+)", args.strip())
+        if not m16:
+            return None
+        off = int(m16.group(1))
+        return a + 4 + 4 * (off - 0x10000 if off >= 0x8000 else off)
+    a_lo, a_hi = body[lo][0], body[hi][0]
+    tail = []
+    e = hi + 1
+    while e < len(body):
+        a, op, args = body[e]
+        if op == "s_branch":
+            t = target_of(a, args)
+            if t is not None and a_lo <= t <= a_hi:
+                entered = any(o.startswith(("s_cbranch", "s_branch")) and (target_of(x, g) or 0) > a_hi and (target_of(x, g) or 0) <= a
+                              for x, o, g in body[lo:hi + 1])
+                if entered:
+                    tail = list(range(hi + 1, e + 1))
+            break
+        if op in ("s_endpgm",):
+            break
+        e += 1
     counts = {}
+    rare = {}
     divisions = 0
-    for _, op, _ in body[lo:hi + 1]:
+    # short blocks skipped by a forward scalar branch (k_sat128r: the injector's addend, taken on one patch row of one wave) are
+    # counted apart: a trip that does not take them executes none of their instructions
+    skip_until = -1
+    addr = [a for a, _, _ in body]
+    for idx in list(range(lo, hi + 1)) + tail:
+        a, op, args = body[idx]
+        if idx <= skip_until:
+            rare[classify(op)] = rare.get(classify(op), 0) + 1
+            continue
         c = classify(op)
         counts[c] = counts.get(c, 0) + 1
         if op.startswith("v_rcp_f64"):  # one reciprocal per division (compiler's IEEE sequence or fracflow.h's unscaled form)
             divisions += 1
-    out = {"object": obj, "kernel": name, "loop_instructions": hi - lo + 1, "loop_start": hex(body[lo][0]), "loop_end": hex(body[hi][0]), "counts": counts, "fp64_divisions": divisions,
+        if op in ("s_cbranch_scc0", "s_cbranch_scc1"):
+            m16 = re.match(r"(\d+)", args.strip())
+            off = int(m16.group(1)) if m16 else 0
+            if 0 < off <= 24:
+                target = a + 4 + 4 * off
+                skip_until = max(i for i in range(idx, hi + 1) if addr[i] < target)
+    out = {"object": obj, "kernel": name, "loop_instructions": hi - lo + 1 + len(tail), "out_of_line_instructions": len(tail), "loop_start": hex(body[lo][0]), "loop_end": hex(body[hi][0]), "counts": counts, "rarely_taken_blocks": rare, "fp64_divisions": divisions,
            "cells_per_thread_per_trip": per, "dp_valu_per_cell_substep": counts.get("dp_valu", 0) / per,
            "valu_per_cell_substep": (counts.get("dp_valu", 0) + counts.get("other_valu", 0)) / per}
     print(json.dumps(out, indent=1))

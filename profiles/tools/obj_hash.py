@@ -9,7 +9,7 @@ import sys
 from pathlib import Path
 
 CSRC = Path(__file__).resolve().parents[2] / "historymatching_amd" / "csrc"
-OBJECTS = ("sat128.o", "press128s.o", "press_nd.o")
+OBJECTS = ("sat128r.o", "sat128.o", "press128s.o", "press_nd.o")
 
 
 def object_hashes(names=OBJECTS):

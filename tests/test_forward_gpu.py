@@ -517,6 +517,56 @@ def test_fp32_saturation_mode_tolerance():
     assert np.abs(w - wr).max() < 1e-3 and np.abs(p - pr).max() < 1e-3
 
 
+def _cell_xy(model, ix, iy):
+    """Coordinates of the centre of cell (ix, iy)."""
+    return [(ix + 0.5) * model.Lx / model.Nx, (iy + 0.5) * model.Ly / model.Ny]
+
+
+@pytest.mark.parametrize("layout", ["default", "odd", "two_injectors", "injectors_share_a_band", "time_varying"])
+def test_saturation_128_register_sweep_bitexact_vs_generic_and_image_sweeps(layout):
+    """The three fp64 sweeps at 128 x 128 -- generic (sat_variant 1), fw image in LDS (sat128.hip, 5), fw in registers with scaled
+    fluxes (sat128r.hip, the default) -- give identical saturations, producer series and sub-step counts over whole runs, for wells
+    anywhere in a thread's 8 x 4 patch: injector and producers on patch corners, edges and interiors, on the first and last patch
+    row (whose east / west terms cross the LDS halo), next to each other, two injectors in different bands; two injectors in
+    one band of 16 rows, which the register sweep declines (the host falls back to the image sweep); rates that change per step."""
+    n, N, steps = 128, 3, 5
+    om, gm = make_models(n, n)
+    if layout == "odd":  # injector in a patch interior (row 5, column 2), producers on patch row 7 / row 0 / a corner / beside the injector's patch
+        cells = dict(inj=[(45, 70)], prd=[(7, 3), (120, 127), (15, 124), (47, 75)])
+    elif layout == "two_injectors":
+        cells = dict(inj=[(40, 17), (88, 100)], prd=[(3, 120), (125, 6), (64, 64)])
+    elif layout == "injectors_share_a_band":
+        cells = dict(inj=[(65, 20), (78, 100)], prd=[(3, 120), (125, 6)])
+    else:
+        cells = None
+    if cells:
+        gm.inj_xy = [_cell_xy(gm, *c) for c in cells["inj"]]
+        gm.prd_xy = [_cell_xy(gm, *c) for c in cells["prd"]]
+        gm.inj_rates = np.ones((len(cells["inj"]), 1)) / len(cells["inj"])
+        gm.prd_rates = np.ones((len(cells["prd"]), 1)) / len(cells["prd"])
+    if layout == "time_varying":
+        r = 0.4 + np.arange(steps) / steps
+        gm.inj_rates = r[None, :]
+        gm.prd_rates = np.tile(r / 4, (4, 1))
+    x = perms(n, n, N, seed=61)
+    out = {}
+    for sat_variant in (1, 5, 0):
+        plan = _plan(gm, N, nTime=steps)
+        plan.set_variant(13, sat_variant)  # the same pressure kernel for all three
+        plan.set_inputs(x, transformed=False)
+        plan.run()
+        plan.sync()
+        w, p, status = plan.outputs()
+        assert not status.any()
+        out[sat_variant] = (w, p, plan.get_field("nts"))
+        plan.close()
+    assert out[1][0][:, -1].max() > 0.5  # water did go in
+    for v in (5, 0):
+        for a, b in zip(out[1], out[v]):
+            assert np.array_equal(a, b), (layout, v, np.abs(a - b).max())
+        assert np.array_equal(np.signbit(out[1][0]), np.signbit(out[v][0]))
+
+
 @pytest.mark.parametrize("general_fluid", [False, True])
 def test_fp32_saturation_128_register_kernel_bitexact_vs_generic(general_fluid):
     """dtype=32 at 128x128: the register/LDS-resident fp32 sweep (sat128f.hip, coefficients formed once in fp64 and
