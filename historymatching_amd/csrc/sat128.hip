@@ -72,6 +72,20 @@ __device__ __forceinline__ double from_prev_lane(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// max(a, z) / min(a, z) as the one instruction they are: fmax() / fmin() put a canonicalising v_max_f64 x, x in front of every operand
+// the compiler cannot prove free of signalling NaNs (the fluxes: they live in registers across the sub-step loop).  Same result for
+// every operand that is not a signalling NaN.
+__device__ __forceinline__ double vmax(double a, double z) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(z));
+    return r;
+}
+__device__ __forceinline__ double vmin(double a, double z) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(z));
+    return r;
+}
+
 template <bool FD>
 __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __restrict__ Sin_base,
                                                double* __restrict__ Sout_base, long long S_stride,
@@ -306,12 +320,12 @@ __global__ __launch_bounds__(NT) void k_sat128(FwdParams p, const double* __rest
                     const double vxw = Vx[i][j], vxe = (i == PX - 1) ? VX8(j) : Vx[i + 1 < PX ? i + 1 : 0][j];
                     const double vys = (i == PX - 1 && j < 2) ? VY7(j) : Vy[i][j];
                     const double vyn = j + 1 < PY ? ((i == PX - 1 && j + 1 < 2) ? VY7(j + 1 < 2 ? j + 1 : 0) : Vy[i][j + 1 < PY ? j + 1 : 0]) : vyn3;
-                    const double x1 = fmin(vxw, z), x2 = fmax(vxe, z), y1 = fmin(vys, z), y2 = fmax(vyn, z);
+                    const double x1 = vmin(vxw, z), x2 = vmax(vxe, z), y1 = vmin(vys, z), y2 = vmax(vyn, z);
                     const double cC = dd * (x1 - x2 + y1 - y2);
-                    const double cW = dd * fmax(vxw, z);
-                    const double cE = dd * (-fmin(vxe, z));
-                    const double cS = dd * fmax(vys, z);
-                    const double cN = dd * (-fmin(vyn, z));
+                    const double cW = dd * vmax(vxw, z);
+                    const double cE = dd * (-vmin(vxe, z));
+                    const double cS = dd * vmax(vys, z);
+                    const double cN = dd * (-vmin(vyn, z));
                     const double fs = j > 0 ? fc[j > 0 ? j - 1 : 0] : fS;
                     const double fn = j + 1 < PY ? fc[j + 1 < PY ? j + 1 : 0] : fN;
                     double acc = cE * (jj ? fep.y : fep.x);
