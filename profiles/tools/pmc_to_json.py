@@ -14,7 +14,7 @@ out_dir, members = Path(sys.argv[1]), int(sys.argv[2])
 KEYS = {"k_perm_transform": "perm_transform", "k_press128m": "press128m", "k_press128s": "press128s", "k_pressure_pcg": "pressure_pcg", "k_press128<": "press128", "k_sat128": "sat128",
         "k_pressure_generic": "pressure_generic", "k_saturation_generic": "saturation_generic",
         "k_nd_assemble": "nd_assemble", "k_nd_sub(": "nd_sub", "k_nd_wave<7": "nd_wave7", "k_nd_wave<6": "nd_wave6", "k_nd_wave<5": "nd_wave5",
-        "k_nd_top": "nd_top", "k_nd_solve(": "nd_solve", "k_nd_solve_sub": "nd_solve_sub", "k_nd_flux": "nd_flux"}
+        "k_nd_top": "nd_top", "k_nd_solve(": "nd_solve", "k_nd_solve_sub": "nd_solve_sub", "k_nd_flux": "nd_flux", "k_nd_leaf(": "nd_leaf", "k_nd_leaf_solve": "nd_leaf_solve"}
 
 
 def per_launch(counter):
