@@ -69,25 +69,7 @@ constexpr int CF_OX = NB * NB, CF_OY = CF_OX + (NB + 1) * NB, CF_OQ = CF_OY + NB
 
 // (index arithmetic only and ONE load used unconditionally: behind `if`s the compiler sinks each load into its branch and waits for
 // it there -- a round trip to memory per entry instead of one for all the entries a lane assembles)
-#ifndef HM_TOP_COEF
-#define HM_TOP_COEF 1
-#endif
-#ifndef HM_TOP_COPY
-#define HM_TOP_COPY 0
-#endif
 __device__ __forceinline__ double nd_coef_global(const double* __restrict__ cf, int cm, int ck, bool same_pos) {
-#if HM_TOP_COEF == 0
-    if (ck < 0) return same_pos ? 1.0 : 0.0;  // padded pivot: identity
-    if (cm == -2) return cf[CF_OQ + ck];
-    if (cm < 0) return 0.0;
-    const int d0 = cm - ck;
-    if (d0 == 0) return cf[ck];
-    if (d0 == NB) return cf[CF_OX + ck + NB];
-    if (d0 == -NB) return cf[CF_OX + ck];
-    if (d0 == 1) return cf[CF_OY + ck + (ck >> 7) + 1];
-    if (d0 == -1) return cf[CF_OY + ck + (ck >> 7)];
-    return 0.0;
-#endif
     const int d = cm - ck;
     const bool cell = ck >= 0 && cm >= 0;
     int off = -1;
@@ -636,24 +618,24 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int TOP_NW = 16, TOP_NVS = 3, TOP_NTS = 4, TOP_MAXT = 13;
 
-// A child's packed update matrix, arena -> LDS, by the whole workgroup: every load of a thread is issued before its first store
-// (one round trip to memory; a load-store loop makes one per trip).  TOP_CH chunks of 1024 double2 cover the largest child.
-constexpr int TOP_CH = 7;
-struct TopChild {  // (named members: as an array it is kept in scratch)
-    double2 c0, c1, c2, c3, c4, c5, c6;
-};
-__device__ __forceinline__ void top_child_load(TopChild& c, const double* __restrict__ src, int n2, int tid) {
+// A child's packed update matrix (n2 double2), arena -> LDS, by the whole workgroup through LDS-DMA (global_load_lds_dwordx4: no
+// registers, every piece in flight at once, retired by the issuing wave's vmcnt): pieces of 64 double2 = 1 KB, wave w takes pieces
+// w, w + 16, ...; the lanes of the last piece past n2 re-read the last element (the destination is padded to whole pieces).
+typedef __attribute__((address_space(3))) void* nd_lds_ptr;
+typedef const __attribute__((address_space(1))) void* nd_glb_ptr;
+__device__ __host__ __forceinline__ int top_pad(int doubles) { return (doubles + 127) & ~127; }
+__device__ __forceinline__ void top_dma(double* dst, const double* __restrict__ src, int n2, int w, int lane) {
     const double2* s2 = reinterpret_cast<const double2*>(src);
-#define TOP_LD(K) c.c##K = s2[tid + K * 1024 < n2 ? tid + K * 1024 : n2 - 1]
-    TOP_LD(0); TOP_LD(1); TOP_LD(2); TOP_LD(3); TOP_LD(4); TOP_LD(5); TOP_LD(6);
-#undef TOP_LD
-}
-__device__ __forceinline__ void top_child_store(const TopChild& c, double* dst, int n2, int tid) {
     double2* d2 = reinterpret_cast<double2*>(dst);
-#define TOP_ST(K) if (tid + K * 1024 < n2) d2[tid + K * 1024] = c.c##K
-    TOP_ST(0); TOP_ST(1); TOP_ST(2); TOP_ST(3); TOP_ST(4); TOP_ST(5); TOP_ST(6);
-#undef TOP_ST
+    for (int pc = w; pc * 64 < n2; pc += 16) {
+        const int i = pc * 64 + lane;
+        __builtin_amdgcn_global_load_lds((nd_glb_ptr)(s2 + (i < n2 ? i : n2 - 1)), (nd_lds_ptr)(d2 + pc * 64), 16, 0, 0);
+    }
 }
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding vector-memory operation of the wave,
+// which would end the flight of the next front's DMA pieces at the first barrier behind their issue.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ d4 img_load(const double* img, int lane) {
     d4 v;
@@ -671,10 +653,9 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
     double* Pimg = nd_lds;                       // 256
     double* Wimg = Pimg + 256;                   // TOP_MAXT x 256
     double* Vimg = Wimg + TOP_MAXT * 256;        // TOP_MAXT x 256
-    int* cl_s = reinterpret_cast<int*>(Vimg + TOP_MAXT * 256);  // 16 TOP_MAXT ints
-    short* cp_s0 = reinterpret_cast<short*>(cl_s + 16 * TOP_MAXT);
-    short* cp_s1 = cp_s0 + 16 * TOP_MAXT;
-    double* chl = reinterpret_cast<double*>(cp_s1 + 16 * TOP_MAXT);  // one child's packed update
+    int* cl_s = reinterpret_cast<int*>(Vimg + TOP_MAXT * 256);  // 16 T ints (<= 832 B) in one DMA piece of 1 KB
+    short* cp_s0 = reinterpret_cast<short*>(cl_s + 256);        // 16 T shorts for child 0, then 16 T for child 1, as in memory: one piece
+    double* chl = reinterpret_cast<double*>(cp_s0 + 512);       // the children's packed updates
     const int m = blockIdx.x, tid = threadIdx.x;
     NdGeo g;
     g.lane = tid & 63;
@@ -688,7 +669,8 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
     NPROF_DECL;
     // the records of fronts 0..30 in LDS, read once (they carry their children's sizes and offsets): per front they would otherwise
     // cost two dependent round trips to memory (the front's record, then its children's) before anything else can start
-    int* frec = reinterpret_cast<int*>(chl + ((nd.top_child_doubles + 1) & ~1));  // 31 records behind the child buffer
+    const int chl_cap = top_pad(nd.top_child_doubles);  // doubles: whole DMA pieces
+    int* frec = reinterpret_cast<int*>(chl + chl_cap);  // 31 records behind the child buffer
     for (int i = tid; i < 31 * ND_FRONT_INTS; i += 64 * TOP_NW) frec[i] = nd.fronts[i];
     __syncthreads();
     for (int lv = 4; lv >= 0; --lv) {
@@ -702,32 +684,29 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             const int st = __builtin_amdgcn_readfirstlane(F[NDF_ST]);
             const int bt = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
             const int T = st + bt;
-            const int co = __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
             const int kreg_last = __builtin_amdgcn_readfirstlane(F[NDF_KREG]);
             double* fa = fact + __builtin_amdgcn_readfirstlane(F[NDF_FACT]);
             const int nV = st * T - ((st * (st - 1)) >> 1);
             const int nT = b > 0 ? ((bt * (bt + 1)) >> 1) : 0;
             NPROF(0);
-            // ---- the front's position tables and the first child's update to LDS
+            // ---- the front's position tables and its children's updates to LDS: issued during the PREVIOUS front's panels (below) except for
+            // the first front; both children at once where they fit the buffer together (level 4), else one after the other
             const int bch[2] = {__builtin_amdgcn_readfirstlane(F[NDF_BC0]), __builtin_amdgcn_readfirstlane(F[NDF_BC1])};
-            const int uch[2] = {__builtin_amdgcn_readfirstlane(F[NDF_UC0]), __builtin_amdgcn_readfirstlane(F[NDF_UC1])};
-            for (int i = tid; i < 16 * T; i += 64 * TOP_NW) {
-                cl_s[i] = nd.cells[co + i];
-                cp_s0[i] = nd.cpos[2 * co + i];
-                cp_s1[i] = nd.cpos[2 * co + 16 * T + i];
-            }
             const int n2c[2] = {(((bch[0] + 1) * (bch[0] + 2) >> 1) + 1) >> 1, (((bch[1] + 1) * (bch[1] + 2) >> 1) + 1) >> 1};
-#if HM_TOP_COPY == 1
-            TopChild chr;
-            top_child_load(chr, arena + uch[0], n2c[0], tid);
-            top_child_store(chr, chl, n2c[0], tid);
-#else
-            {
-                const double2* s2 = reinterpret_cast<const double2*>(arena + uch[0]);
-                double2* d2 = reinterpret_cast<double2*>(chl);
-                for (int i = tid; i < n2c[0]; i += 64 * TOP_NW) d2[i] = s2[i];
-            }
-#endif
+            const int c1off = top_pad(2 * n2c[0]);                       // where the second child goes when both are staged at once
+            const bool both = c1off + top_pad(2 * n2c[1]) <= chl_cap;
+            auto stage_front = [&](const int* Fn) {  // tables + child 0 (+ child 1) of front record Fn; wave-uniform arguments
+                const int con = __builtin_amdgcn_readfirstlane(Fn[NDF_CELLS]);
+                const int b0 = __builtin_amdgcn_readfirstlane(Fn[NDF_BC0]), b1 = __builtin_amdgcn_readfirstlane(Fn[NDF_BC1]);
+                const int m0 = (((b0 + 1) * (b0 + 2) >> 1) + 1) >> 1, m1 = (((b1 + 1) * (b1 + 2) >> 1) + 1) >> 1;
+                if (w == 0) __builtin_amdgcn_global_load_lds((nd_glb_ptr)(nd.cells + con + 4 * g.lane), (nd_lds_ptr)cl_s, 16, 0, 0);
+                if (w == 1) __builtin_amdgcn_global_load_lds((nd_glb_ptr)(nd.cpos + 2 * con + 8 * g.lane), (nd_lds_ptr)cp_s0, 16, 0, 0);
+                top_dma(chl, arena + __builtin_amdgcn_readfirstlane(Fn[NDF_UC0]), m0, w, g.lane);
+                const int o1 = top_pad(2 * m0);
+                if (o1 + top_pad(2 * m1) <= chl_cap) top_dma(chl + o1, arena + __builtin_amdgcn_readfirstlane(Fn[NDF_UC1]), m1, w, g.lane);
+            };
+            if (f == 15) stage_front(F);
+            const short* cp_s1 = cp_s0 + 16 * T;
             // ---- my tiles: decode (scalar)
             d4 vt[TOP_NVS], tr[TOP_NTS];
             int vq[TOP_NVS], vR[TOP_NVS], tR[TOP_NTS], tC[TOP_NTS];
@@ -756,12 +735,10 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
                 }
                 tR[s] = R; tC[s] = C;
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
             __syncthreads();
             NPROF(1);
-            // ---- coefficients + child 0 (the second child's loads are in flight meanwhile)
-#if HM_TOP_COPY == 1
-            top_child_load(chr, arena + uch[1], n2c[1], tid);
-#endif
+            // ---- coefficients + child 0
 #pragma unroll
             for (int s = 0; s < TOP_NVS; ++s) {
                 vt[s] = d4{0.0, 0.0, 0.0, 0.0};
@@ -785,17 +762,13 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
                 }
             }
             NPROF(2);
-            __syncthreads();
-#if HM_TOP_COPY == 1
-            top_child_store(chr, chl, n2c[1], tid);
-#else
-            {
-                const double2* s2 = reinterpret_cast<const double2*>(arena + uch[1]);
-                double2* d2 = reinterpret_cast<double2*>(chl);
-                for (int i = tid; i < n2c[1]; i += 64 * TOP_NW) d2[i] = s2[i];
+            if (!both) {
+                __syncthreads();
+                top_dma(chl, arena + __builtin_amdgcn_readfirstlane(F[NDF_UC1]), n2c[1], w, g.lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
             }
-#endif
-            __syncthreads();
+            const double* ch1 = both ? chl + c1off : chl;
             NPROF(3);
             // ---- child 1
 #pragma unroll
@@ -803,7 +776,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
                 if (vq[s] >= 0) {
                     const int pm1 = cp_s1[16 * vR[s] + g.lc];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vt[s][r] += nd_gather(chl, cp_s1[16 * vq[s] + 4 * r + g.lq], pm1);
+                    for (int r = 0; r < 4; ++r) vt[s][r] += nd_gather(ch1, cp_s1[16 * vq[s] + 4 * r + g.lq], pm1);
                 }
             }
 #pragma unroll
@@ -811,7 +784,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
                 if (tR[s] >= 0) {
                     const int pc1 = cp_s1[16 * tC[s] + g.lc];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tr[s][r] += nd_gather(chl, cp_s1[16 * tR[s] + 4 * r + g.lq], pc1);
+                    for (int r = 0; r < 4; ++r) tr[s][r] += nd_gather(ch1, cp_s1[16 * tR[s] + 4 * r + g.lq], pc1);
                 }
             }
             NPROF(4);
@@ -842,7 +815,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             NPROF(5);
             for (int pp = 0; pp < st; ++pp) {
                 const int kreg = pp == st - 1 ? kreg_last : 4;
-                __syncthreads();  // P(pp) published; every read of the previous panel's images is done
+                lds_barrier();  // P(pp) published; every read of the previous panel's images is done
                 NPROF(6);
                 {
                     const d4 Pn = img_load(Pimg, g.lane);
@@ -863,8 +836,14 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
                     }
                 }
                 NPROF(7);
-                __syncthreads();  // images of panel pp visible; P(pp) no longer read
+                lds_barrier();  // images of panel pp visible; P(pp) no longer read
                 NPROF(8);
+                if (pp == 0 && f != 0) {
+                    // every wave is past its gathers: the tables and the child buffer are free -- the NEXT front's go in now, beside the
+                    // panels (its children are fronts of the level below this one's or of this level's predecessor: complete long ago)
+                    const int fnext = fi + 1 < (1 << lv) ? f + 1 : (1 << (lv - 1)) - 1;
+                    stage_front(frec + fnext * ND_FRONT_INTS);
+                }
                 if (pp + 1 < st) {
                     const int inx = (pp + 1) * T - (((pp + 1) * pp) >> 1);
                     if (w == inx % TOP_NW) {
@@ -1250,9 +1229,10 @@ static int nd_setup(hm_fwd* f) {
     d.child_doubles[0] = t.info.upd_doubles[8];
     d.child_doubles[1] = t.info.upd_doubles[7];
     d.child_doubles[2] = t.info.upd_doubles[6];
+    for (int f = 0; f < 31; ++f)
+        HM_REQUIRE(t.fronts[f * ND_FRONT_INTS + NDF_CELLS] + 256 <= (int)t.cells.size(), "nested dissection: the table piece of front %d runs past the tables", f);
     d.top_child_doubles = 0;
     for (int lv = 1; lv <= 5; ++lv) d.top_child_doubles = std::max(d.top_child_doubles, t.info.upd_doubles[lv]);
-    HM_REQUIRE(d.top_child_doubles <= TOP_CH * 64 * TOP_NW * 2, "nested dissection: a child update of %d doubles does not fit the top kernel's %d copy chunks", d.top_child_doubles, TOP_CH);
     // dynamic LDS beyond 64 KB must be requested per kernel
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_top, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<5, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1281,7 +1261,7 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
     hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * 32), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * 16), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * 16), dim3(128), (size_t)2 * (ND_LDS_DATA + 2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
-    const size_t lds_top = (size_t)(256 + 2 * TOP_MAXT * 256 + 16 * TOP_MAXT + ((nd.top_child_doubles + 1) & ~1)) * 8 + 31 * ND_FRONT_INTS * 4;
+    const size_t lds_top = (size_t)(256 + 2 * TOP_MAXT * 256 + 256 + top_pad(nd.top_child_doubles)) * 8 + 31 * ND_FRONT_INTS * 4;  // images, 2 KB of tables, children, records
     hipLaunchKernelGGL(k_nd_top, dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k);
     if (hipError_t e_ = hipGetLastError()) { hm_set_error("k_nd_top launch with %zu bytes of LDS: %s", lds_top, hipGetErrorString(e_)); return 1; }
     hipLaunchKernelGGL(k_nd_solve, dim3(p.N), dim3(64 * SOL_NW), 0, s, p, nd, k);
