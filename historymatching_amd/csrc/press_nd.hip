@@ -486,7 +486,10 @@ constexpr int SUB_CF_PLANE = ND_CF_PLANE_SUB;
 
 __device__ __host__ __forceinline__ int nd_sub_lds_doubles(const NdDev& nd) { return ND_LDS_DATA + 2 * (nd.slot9 + nd.slot10) + 4 * SUB_CF_PLANE; }
 
-__global__ __launch_bounds__(256, 4) void k_nd_sub(FwdParams p, NdDev nd, int k) {
+#ifndef SUB_OCC
+#define SUB_OCC 4
+#endif
+__global__ __launch_bounds__(256, SUB_OCC) void k_nd_sub(FwdParams p, NdDev nd, int k) {
     extern __shared__ double nd_lds[];
     const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;  // subtree-major: co-resident workgroups read the same recipes
     const int tid = threadIdx.x;
@@ -906,6 +909,9 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
 // one wave per front, levels separated by workgroup barriers; pressures in P; then the face fluxes.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int SOL_NW = 4;
+#ifndef SOL_OCC
+#define SOL_OCC 4
+#endif
 
 // Fronts with one pivot tile (levels >= 5), UNR of them per wave at a time: the cell indices of all of them, then the known
 // pressures and the factor tiles of all of them are requested before anything is used -- two round trips to memory per UNR
@@ -979,7 +985,7 @@ __device__ __forceinline__ void nd_solve_single(const NdDev& nd, const double* _
     }
 }
 
-__global__ __launch_bounds__(64 * SOL_NW, 3) void k_nd_solve(FwdParams p, NdDev nd, int k) {
+__global__ __launch_bounds__(64 * SOL_NW, SOL_OCC) void k_nd_solve(FwdParams p, NdDev nd, int k) {
     __shared__ double xe_all[SOL_NW][16 * TOP_MAXT];
     const int m = blockIdx.x, tid = threadIdx.x;
     NdGeo g;
