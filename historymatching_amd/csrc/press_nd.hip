@@ -152,21 +152,19 @@ __device__ __forceinline__ void nd_wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// n doubles (n even, both 16-byte aligned) from global memory to LDS by one wave: every load is in flight before the first
-// LDS write waits for its data.
+// n doubles (n even, both 16-byte aligned) from global memory to LDS by one wave through LDS-DMA (global_load_lds_dwordx4: no registers,
+// every piece of 64 double2 in flight at once, retired by the wave's vmcnt -- the caller waits for vmcnt(0) before it reads); the last
+// n2 % 64 double2 by one ordinary load and store (a clamped last piece would write past the destination).
+typedef __attribute__((address_space(3))) void* nd_lds_ptr;
+typedef const __attribute__((address_space(1))) void* nd_glb_ptr;
 __device__ __forceinline__ void nd_wave_copy(double* dst, const double* __restrict__ src, int n, int lane) {
     const double2* s2 = reinterpret_cast<const double2*>(src);
     double2* d2 = reinterpret_cast<double2*>(dst);
-    const int n2 = n >> 1;
-    int i = lane;
-    for (; i + 448 < n2; i += 512) {
-        double2 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = s2[i + 64 * u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) d2[i + 64 * u] = v[u];
-    }
-    for (; i < n2; i += 64) d2[i] = s2[i];
+    const int n2 = n >> 1, full = n2 >> 6;
+    for (int pc = 0; pc < full; ++pc)
+        __builtin_amdgcn_global_load_lds((nd_glb_ptr)(s2 + pc * 64 + lane), (nd_lds_ptr)(d2 + pc * 64), 16, 0, 0);
+    const int i = full * 64 + lane;
+    if (i < n2) d2[i] = s2[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -603,6 +601,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     nd_wave_copy(c1l, arena + F[NDF_UC1], n1, g.lane);
     NdCfl L;
     nd_stage_cf(cf, cfl, WAVE_CF_PLANE, F[NDF_PBOX], g.lane, L);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA pieces have landed
     nd_wave_fence();
     int bad = 0;
     nd_wave_front<MAXBT, true>(bt, __builtin_amdgcn_readfirstlane(F[NDF_KREG]), pr, rec, blk, arena + F[NDF_UPD], fact + F[NDF_FACT], g, bad);
@@ -624,8 +623,6 @@ constexpr int TOP_NW = 16, TOP_NVS = 3, TOP_NTS = 4, TOP_MAXT = 13;
 // A child's packed update matrix (n2 double2), arena -> LDS, by the whole workgroup through LDS-DMA (global_load_lds_dwordx4: no
 // registers, every piece in flight at once, retired by the issuing wave's vmcnt): pieces of 64 double2 = 1 KB, wave w takes pieces
 // w, w + 16, ...; the lanes of the last piece past n2 re-read the last element (the destination is padded to whole pieces).
-typedef __attribute__((address_space(3))) void* nd_lds_ptr;
-typedef const __attribute__((address_space(1))) void* nd_glb_ptr;
 __device__ __host__ __forceinline__ int top_pad(int doubles) { return (doubles + 127) & ~127; }
 __device__ __forceinline__ void top_dma(double* dst, const double* __restrict__ src, int n2, int w, int lane) {
     const double2* s2 = reinterpret_cast<const double2*>(src);
