@@ -31,9 +31,9 @@ for n, x in zip(top, v):
     print(f"   {n:28s} {x:10d}  {100 * x / max(sum(v), 1):5.1f} %")
 lv = list(buf[48:54])
 print("   by level (4, 3, 2, 1, 0): " + ", ".join(f"{lv[i - 1] - lv[i]}" for i in (4, 3, 2, 1)) + f", {lv[5] - lv[0]} cycles")
-sub = ["level 10 (8 leaves)", "level 9 (4 fronts)", "level 8 (2 fronts)", "level 7 (1 front)"]
+sub = ["staging (leaf updates, recipes, coefficients)", "level 9, first front", "level 9, second front", "level 8 front"]
 v = list(buf[16:32])
-print(f"k_nd_sub, block 0 wave 0: {sum(v)} cycles")
+print(f"k_nd_sub, one workgroup (block 0, or -DHM_ND_PROF_SUB_BLOCK=n: one that starts on a busy GPU), wave 0: {sum(v)} cycles")
 for n, x in zip(sub, v):
     print(f"   {n:28s} {x:10d}  {100 * x / max(sum(v), 1):5.1f} %")
 v = list(buf[32:48])

@@ -29,6 +29,9 @@
 #ifdef HM_ND_PROF
 // cycle stamps: block 0, wave 0, lane 0.  [0..15] k_nd_top phases, [16..31] k_nd_sub (wave-front phases by level), [32..47] counts
 __device__ long long hm_nd_prof_buf[64];
+#ifndef HM_ND_PROF_SUB_BLOCK
+#define HM_ND_PROF_SUB_BLOCK 0
+#endif
 #define NPROF_DECL long long prof_t = clock64(), prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define NPROF(i) do { const long long now_ = clock64(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
 #else
@@ -484,18 +487,22 @@ constexpr int SUB_CF_PLANE = ND_CF_PLANE_SUB;
 
 __device__ __host__ __forceinline__ int nd_sub_lds_doubles(const NdDev& nd) { return ND_LDS_DATA + 2 * (nd.slot9 + nd.slot10) + 4 * SUB_CF_PLANE; }
 
-#ifndef SUB_OCC
-#define SUB_OCC 4
+#ifndef SUB_WPB
+#define SUB_WPB 4  // waves (level-8 subtrees) per workgroup
 #endif
-__global__ __launch_bounds__(256, SUB_OCC) void k_nd_sub(FwdParams p, NdDev nd, int k) {
+__global__ __launch_bounds__(64 * SUB_WPB) void k_nd_sub(FwdParams p, NdDev nd, int k) {
     extern __shared__ double nd_lds[];
-    const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;  // subtree-major: co-resident workgroups read the same recipes
+    // the waves of a workgroup work on the SAME level-8 subtree of SUB_WPB consecutive members: they read the same recipes, front
+    // records and position tables at the same time (one trip to L2 for the workgroup instead of one per wave); subtree-major grid
     const int tid = threadIdx.x;
     NdGeo g;
     g.lane = tid & 63;
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mgroups = (p.N + SUB_WPB - 1) / SUB_WPB;
+    const int m = SUB_WPB * (blockIdx.x % mgroups) + w, i8 = blockIdx.x / mgroups;
+    if (m >= p.N) return;  // (no workgroup barrier below)
     double* blk = nd_lds + w * nd_sub_lds_doubles(nd);  // the wave's LDS block (nd.h): the recipes' offsets refer to it
     double* s9 = blk + ND_LDS_DATA;
     double* s10 = s9 + 2 * nd.slot9;
@@ -504,7 +511,6 @@ __global__ __launch_bounds__(256, SUB_OCC) void k_nd_sub(FwdParams p, NdDev nd, 
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* arena = nd.arena + (long long)m * nd.arena_stride;
-    const int i8 = 4 * bidx + w;
     const int f8 = 255 + i8, f9 = 511 + 2 * i8, f10 = 1023 + 4 * i8;
     int bad = 0;
     NPROF_DECL;
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(256, SUB_OCC) void k_nd_sub(FwdParams p, NdDev nd, 
     nd_wave_front<2, true>(btof(F8), krof(F8), pp, recp(F8), blk, arena + F8[NDF_UPD], fact + F8[NDF_FACT], g, bad);
     NPROF(3);
 #ifdef HM_ND_PROF
-    if (blockIdx.x == 0 && tid == 0)
+    if (blockIdx.x == HM_ND_PROF_SUB_BLOCK && tid == 0)
         for (int i = 0; i < 16; ++i) hm_nd_prof_buf[16 + i] = prof_acc[i];
 #endif
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
@@ -1258,9 +1264,9 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
     const NdDev& nd = f->nd->dev;
     if (f->dtype == 64) hipLaunchKernelGGL(k_nd_assemble<double>, dim3(p.N), dim3(1024), 0, s, p, nd, (const double*)S, S_stride, k);
     else hipLaunchKernelGGL(k_nd_assemble<float>, dim3(p.N), dim3(1024), 0, s, p, nd, (const float*)S, S_stride, k);
-    const size_t lds_sub = (size_t)4 * nd_sub_lds_doubles(nd) * 8;
+    const size_t lds_sub = (size_t)SUB_WPB * nd_sub_lds_doubles(nd) * 8;
     hipLaunchKernelGGL(k_nd_leaf, dim3(p.N * 4), dim3(256), 0, s, p, nd, k);
-    hipLaunchKernelGGL(k_nd_sub, dim3(p.N * 64), dim3(256), lds_sub, s, p, nd, k);
+    hipLaunchKernelGGL(k_nd_sub, dim3(((p.N + SUB_WPB - 1) / SUB_WPB) * 256), dim3(64 * SUB_WPB), lds_sub, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * 32), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * 16), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * 16), dim3(128), (size_t)2 * (ND_LDS_DATA + 2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
