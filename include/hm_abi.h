@@ -134,11 +134,14 @@ int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status
  * `wsats_out` on a copy stream while step k runs, so the PCIe transfer of the history hides under the run. */
 int  hm_fwd_run_to_host(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member, hm_stats* stats);
 /* Kernel selection (tests and diagnostics; 0/0 = the fastest applicable kernels).
- *   pressure  : 1 generic block elimination in LDS (any Ny <= 128) | at Ny = 128: 0 symmetric-tile MFMA solver (press128s),
+ *   pressure  : 1 generic block elimination in LDS (any Ny <= 128) | 0: at 128 x 128 nested dissection (press_nd; 12 names it),
+ *               at other grids with Ny = 128 the symmetric-tile MFMA block elimination (press128s; 13 names it at 128 x 128),
  *               7 its 16-wave form | 9 Jacobi-CG (any grid; beyond 128 the default is two-level CG where
  *               Ny = 128 c, Nx = c Nx_c, else Jacobi-CG)
  *   saturation: 1 generic (coefficient + fw images) | 2 streaming | 3 LDS-tiled | 0: at 128 x 128 the register/LDS-resident
- *               sweep (sat128 fp64 / sat128f fp32; needs uniform porosity and at most one well per 8 x 4 cell patch), else the
+ *               sweep (fp64: sat128r, fractional flow in registers and scaled fluxes -- 5 names its predecessor sat128 with the
+ *               fw image in LDS, which is also what runs when two injectors share a band of 16 rows; fp32: sat128f; all need
+ *               uniform porosity and at most one well per 8 x 4 cell patch), else the
  *               tiled sweep from 64 x 64 cells up, the generic one below; grids of 128 x 128 tiles (256^2, 512^2 ...): teams of
  *               workgroups, one per tile (sat128t / sat128ft; a team that gives up waiting for a neighbour -- CUs held by
  *               someone else -- has its time step redone by the tiled sweep; 4 = take that retry path every step, a test
