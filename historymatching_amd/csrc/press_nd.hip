@@ -1209,6 +1209,12 @@ static int nd_setup(hm_fwd* f) {
         const int nV = st * T - st * (st - 1) / 2, nT = F[NDF_B] > 0 ? bt * (bt + 1) / 2 : 0;
         HM_REQUIRE(nV <= TOP_NVS * TOP_NW && nT <= TOP_NTS * TOP_NW, "nested-dissection tables: front %d has %d + %d tiles", fI, nV, nT);
     }
+    // the LDS-DMA copies move 16-byte pieces: every update matrix starts on an even double of an even-strided, 16-byte aligned arena
+    HM_REQUIRE(t.info.arena_doubles % 2 == 0, "nested dissection: odd arena stride %lld", (long long)t.info.arena_doubles);
+    for (int f = 1; f < (int)(t.fronts.size() / ND_FRONT_INTS); ++f)
+        HM_REQUIRE(t.fronts[f * ND_FRONT_INTS + NDF_LEVEL] > ND_ARENA_MAX_LEVEL && t.fronts[f * ND_FRONT_INTS + NDF_LEVEL] != ND_LEVELS - 1
+                       ? true : t.fronts[f * ND_FRONT_INTS + NDF_UPD] % 2 == 0,
+                   "nested dissection: the update matrix of front %d starts on an odd double", f);
     hm_nd* n = new hm_nd();
     n->info = t.info;
     int rc = 0;
