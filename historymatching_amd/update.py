@@ -258,7 +258,8 @@ def ies(prior_ens, obs_ens, obs, perturbs, decorr, xStep=1.0, iMax=4, dtype=64, 
 
     Gauss-Newton on the weights ``W`` of ``E = x0 + W X0``: with ``Y0 = center(W^+) Eo decorr`` the ensemble sensitivity,
     the step is ``[(y - D - Eo decorr) Y0^T + (N-1)(I - W)] (Y0 Y0^T + (N-1) I)^-1`` (`ies_step`: one LU solve and an n_obs x n_obs
-    Cholesky factorisation per iterate on the host, fp64; ``subspace="svd"`` = the reference's pseudo-inverse + SVD).  The two
+    Cholesky factorisation per iterate on the host, fp64; ``subspace="svd"`` = the reference's pseudo-inverse + SVD;
+    ``subspace="device"`` = the same step on the GPU through `IlesPlan` with one domain, weights resident between iterates).  The two
     O(N^2 M) pieces -- centring the prior and re-composing the ensemble -- and the forward model behind ``obs_ens`` run on the GPU."""
 
     prior_ens = np.asarray(prior_ens, dtype=float)
@@ -268,6 +269,25 @@ def ies(prior_ens, obs_ens, obs, perturbs, decorr, xStep=1.0, iMax=4, dtype=64, 
     Dp = np.asarray(perturbs, float) @ decorr
     W = np.eye(N)
     stats = {"E": [], "Eo": []}
+    if subspace == "device":
+        # The same Gauss-Newton step on the GPU: the localised smoother's device step (hm_iles_step: LU solve with W, n_obs x n_obs
+        # Cholesky, the push-through form) with ONE local domain that holds every state element and a taper of ones is this step
+        # (HistoryMatch.py:1031-1056 with c = 1 reduces to :927-942; its centred observations differ from the uncentred ones by a
+        # constant row, which center(W^-1 .) removes because W keeps constant vectors).  The weights stay on the device between
+        # iterates; only the N x N matrix comes back for the re-composition.
+        plan = IlesPlan(prior_ens, [np.arange(prior_ens.shape[1])], np.ones((1, y.shape[-1])), cutoff=0.5, device=device)
+        try:
+            for _ in range(int(iMax)):
+                E = recompose(plan.weights(0), X0, x0, dtype=dtype, device=device).astype(float)
+                Eo = np.asarray(obs_ens(E), dtype=float)
+                stats["E"].append(E)
+                stats["Eo"].append(Eo)
+                Eo = Eo @ decorr
+                plan.step(Eo - Eo.mean(0), y - Dp - Eo, xStep)
+            W = plan.weights(0)
+        finally:
+            plan.close()
+        return recompose(W, X0, x0, dtype=dtype, device=device).astype(float), stats
     for _ in range(int(iMax)):
         E = recompose(W, X0, x0, dtype=dtype, device=device).astype(float)
         Eo = np.asarray(obs_ens(E), dtype=float)

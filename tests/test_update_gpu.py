@@ -477,6 +477,36 @@ def test_ies_matches_reference_fixtures(golden):
     assert np.abs(recompose(W, X0, x0, dtype=32) - (x0 + W @ X0)).max() < 1e-3
 
 
+def test_ies_device_subspace_step_matches_host_and_fixtures(golden):
+    """`ies(subspace="device")`: the Gauss-Newton step of the weights on the GPU (the localised smoother's device step with one
+    domain and a taper of ones) against the REAL reference's outputs (F6) and against the host form on a nonlinear operator with
+    partial steps."""
+    from historymatching_amd.update import ies
+    from oracle import es
+
+    f1, f3, _, kw = _hm(golden)
+    f6 = np.load(golden / "f6_iterative.npz")
+    post, stats = ies(f1["gg_E"], lambda x: x, 4 * np.ones(3), f1["gg_perturbs"], 0.5 * np.eye(3), subspace="device")
+    assert len(stats["E"]) == 4
+    assert np.abs(post - f6["ies_gg"]).max() < 1e-9
+    H = f3["H"]
+    post, _ = ies(f1["perm_prior"], lambda x: x @ H, kw["obs"], kw["perturbs"], kw["decorr"], xStep=0.4, iMax=3, subspace="device")
+    assert np.abs(post - f6["ies_lin"]).max() < 1e-8
+    rng = np.random.RandomState(23)
+    N, M, n_obs = 60, 90, 12
+    E = rng.randn(N, M)
+    Hn = rng.randn(M, n_obs) / 8
+    fwd = lambda x: np.tanh(x @ Hn) + 0.1 * (x @ Hn) ** 2  # noqa: E731
+    _, R12, decorr = es.obs_error_model(3, 4)
+    obs = fwd(E[:1])[0] + R12 @ rng.randn(n_obs)
+    perturbs = rng.randn(N, n_obs) @ R12.T
+    dev, sd = ies(E, fwd, obs, perturbs, decorr, xStep=0.6, iMax=3, subspace="device")
+    host, sh = ies(E, fwd, obs, perturbs, decorr, xStep=0.6, iMax=3, subspace="gram")
+    assert np.abs(dev - host).max() < 1e-9 and np.abs(dev - E).max() > 1e-2
+    for a, b in zip(sd["Eo"], sh["Eo"]):
+        assert np.abs(a - b).max() < 1e-9
+
+
 @pytest.mark.parametrize("nx,ny,N", [(20, 20, 7), (128, 128, 5), (96, 160, 3)])
 def test_device_kronecker_prior_sampler_matches_host(nx, ny, N):
     """hm_sample_kron: the separable prior sampler with its two contractions on the fp64 matrix cores

@@ -14,7 +14,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 from helpers import make_models, perms  # noqa: E402
 from historymatching_amd.forward import ForwardPlan  # noqa: E402
-from historymatching_amd.update import center, ies_step, recompose  # noqa: E402
+from historymatching_amd.update import IlesPlan, center, ies_step, recompose  # noqa: E402
 
 N, n, nTime = 1000, 128, 40
 _, gm = make_models(n, n)
@@ -45,5 +45,17 @@ for form in ("gram", "svd"):
     out[form] = ies_step(W, Eo, innov, form)
     print(f"host subspace algebra, {form:4s}: {time.perf_counter() - t0:.3f} s", flush=True)
 print(f"max |gram - svd| = {np.abs(out['gram'] - out['svd']).max():.2e} (scale {np.abs(out['svd']).max():.2e})")
+# the same step on the device (update.ies(subspace="device")): hm_iles_step with one domain and a taper of ones, from the identity weights
+dplan = IlesPlan(prior, [np.arange(prior.shape[1])], np.ones((1, Eo.shape[1])), cutoff=0.5)
+Sd = Eo - Eo.mean(0)
+dplan.step(Sd, innov, 0.0)  # (a step of length 0: warm-up, the weights stay the identity)
+t0 = time.perf_counter()
+dplan.step(Sd, innov, 1.0)
+Wd = dplan.weights(0)
+t_dev = time.perf_counter() - t0
+ref = np.eye(N) + ies_step(np.eye(N), Eo, innov, "gram")
+print(f"device subspace algebra (hm_iles_step, one domain, incl. the copy of the {N} x {N} weights back): {t_dev:.3f} s; "
+      f"max |device - host gram| = {np.abs(Wd - ref).max():.2e}")
+dplan.close()
 print(f"forward pass (host call, upload + 40 steps + producer series back): {t_fwd:.3f} s, device {st['ms_total'] / 1e3:.3f} s; "
       f"re-composition x0 + W X0 (host call): {t_rec:.3f} s; status ok: {not status.any()}")
