@@ -188,6 +188,57 @@ __device__ __forceinline__ d4 invG(d4 t, int lane, int lc, int lq) {
     for (int r = 0; r < 4; ++r) t[r] *= mypinv;
     return t;
 }
+// H: as F with the NEXT pivot formed ahead of the tile update.  The pivot of step K + 1 is the diagonal entry (K+1, K+1) after step K,
+// a[K+1][K+1] - a[K+1][K] (a[K][K+1] pinv_K): its three inputs are read from the tile BEFORE step K's update (v_readlane), so the chain
+// pinv_K -> next pivot -> pinv_{K+1} no longer waits for the tile (and its row broadcast); bit-identical to F.  PERM: the pivot row to the
+// four lane-rows by v_permlane16_swap + v_permlane32_swap instead of ds_bpermute.
+__device__ __forceinline__ double rl64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+template <int S>
+__device__ __forceinline__ unsigned row_bcast32(unsigned v) {
+    const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    const unsigned x = (S & 1) ? p[1] : p[0];
+    const auto q = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (S & 2) ? q[1] : q[0];
+}
+template <int S>
+__device__ __forceinline__ double row_bcast64(double v) {
+    return __hiloint2double((int)row_bcast32<S>((unsigned)__double2hiint(v)), (int)row_bcast32<S>((unsigned)__double2loint(v)));
+}
+template <int K, bool PERM>
+__device__ __forceinline__ void stepH(d4& t, double& mypinv, double& dcur, int lane, int lc, int lq) {
+    double a_r = 0.0, a_c = 0.0, d_n = 1.0;
+    if (K < 15) {
+        a_r = rl64(t[(K + 1) >> 2], (((K + 1) & 3) << 4) | K);
+        a_c = rl64(t[K >> 2], ((K & 3) << 4) | ((K + 1) & 15));
+        d_n = rl64(t[(K + 1) >> 2], (((K + 1) & 3) << 4) | ((K + 1) & 15));
+    }
+    const double cc = PERM ? row_bcast64<(K & 3)>(t[K >> 2]) : __shfl(t[K >> 2], ((K & 3) << 4) | lc);
+    double cr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cr[r] = dpp64b<0x150 + K>(t[r]);
+    const double pinv = rcp_newton3(dcur);
+    const double tc = cc * pinv;
+    const bool pc = lc == K;
+    const double tce = pc ? 0.0 : tc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = fma(-cr[r], tce, t[r]);
+    if (lq == (K & 3)) t[K >> 2] = pc ? -1.0 : tc;
+    mypinv = pc ? pinv : mypinv;
+    dcur = fma(-a_r, a_c * pinv, d_n);
+}
+template <bool PERM>
+__device__ __forceinline__ d4 invH(d4 t, int lane, int lc, int lq) {
+    double mypinv = 0.0, dcur = rl64(t[0], 0);
+#define S(K) stepH<K, PERM>(t, mypinv, dcur, lane, lc, lq);
+    S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
+#undef S
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] *= mypinv;
+    return t;
+}
+
 template <int V>
 __global__ void k(const double* A, double* out, long long* cyc) {
     __shared__ double cb[16];
@@ -204,6 +255,8 @@ __global__ void k(const double* A, double* out, long long* cyc) {
         if (V == 4) t = invE(t, lane, lc, lq);
         if (V == 5) t = invF(t, lane, lc, lq);
         if (V == 6) t = invG(t, lane, lc, lq);
+        if (V == 7) t = invH<false>(t, lane, lc, lq);
+        if (V == 8) t = invH<true>(t, lane, lc, lq);
     }
     __syncthreads();
     long long t1 = clock64();
@@ -258,6 +311,8 @@ int main() {
     run<4>("dpp64", A, dA, o, dc);
     run<5>("dpp64, deferred col scale", A, dA, o, dc);
     run<6>("same + MFMA row broadcast", A, dA, o, dc);
+    run<7>("F + pivot look-ahead", A, dA, o, dc);
+    run<8>("F + look-ahead + permlane", A, dA, o, dc);
     for (int cfg = 0; cfg < 6; ++cfg) {
         const int lw[6] = {99, 4, 4, 1, 1, 4}, pr[6] = {0, 0, 1, 0, 1, 1};
         const int nthreads = cfg == 5 ? 64 * 13 : 64 * 5;
