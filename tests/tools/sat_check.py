@@ -1,8 +1,8 @@
-"""Saturation sweeps of the 128 x 128 fp64 path against each other: sat_variant 5 (fw image in LDS), 7 (fw in registers, raw fluxes),
-0 (fw in registers, scaled fluxes).  A whole forward run per variant with the same pressure kernel: S histories, producer series and
+"""Saturation sweeps of the 128 x 128 fp64 path against each other: sat_variant 5 (fw image in LDS, sat128.hip), 1 (generic),
+0 (fw in registers, scaled fluxes: sat128r.hip).  A whole forward run per variant with the same pressure kernel: S histories, producer series and
 sub-step counts must be array_equal; then the launch average of each at N members.
 
-    python tests/tools/sat_check.py [N=1000] [variants=5,7,0]"""
+    python tests/tools/sat_check.py [N=1000] [variants=5,0] [members=6] [steps=6]"""
 import sys
 from pathlib import Path
 
@@ -15,10 +15,11 @@ from helpers import make_models, perms  # noqa: E402
 from historymatching_amd.forward import ForwardPlan  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-variants = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "5,7,0").split(",")]
+variants = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "5,0").split(",")]
 n = 128
 _, gm = make_models(n, n)
-M, nT = 6, 6
+M = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+nT = int(sys.argv[4]) if len(sys.argv) > 4 else 6
 x = perms(n, n, M, seed=3)
 res = {}
 for v in variants:
