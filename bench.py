@@ -391,6 +391,13 @@ def main():
         comm.close()
         sys.exit(4)
 
+    # every rank needs a device of its own: each rank sees the same device count and takes the same decision, before any collective
+    n_dev = int(_lib.load().hm_device_count())
+    if world > n_dev and os.environ.get("HM_BENCH_ALL_ON_DEVICE0") != "1":
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} asks for {world} ranks with a GPU each but this node shows {n_dev} device(s): no line printed", file=sys.stderr)
+        comm.close()
+        sys.exit(4)
     ctx = _lib.Context.get(local_rank)
     if world > 1 or os.environ.get("HM_BENCH_FORCE_DIST") == "1":  # the env switch exercises the RCCL path with 1 rank
         comm.enable_rccl(ctx, force_single=True)
