@@ -570,6 +570,9 @@ def main():
             "avg_launch_ms": {"saturation": sat_ms, "pressure": prs_ms},
             "per_kernel": {"saturation_fp64_valu_frac": None if stale else 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                            "pressure_fp64_mfma_frac": prs_flops / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                           # the same solve by round 2's block elimination takes 36 x 4 x 8 x Nx matrix instructions per member (302 Mflop
+                           # against the nested dissection's 55): this launch time priced at THAT flop count, for comparison across rounds only
+                           "pressure_frac_at_block_elimination_flop_count": 2048.0 * 36 * 4 * 8 * NX * n_e / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                            # counter-based: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flop per launch (committed PMC pass) over THIS run's launch time
                            "pressure_fp64_mfma_frac_from_counters": None if stale or not (f64r or {}).get("pressure_nd") else
                            f64r["pressure_nd"]["fp64_mfma_flops_per_member_step"] * n_e / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
