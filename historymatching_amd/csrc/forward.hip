@@ -665,6 +665,7 @@ extern "C" int hm_fwd_set_solver(hm_fwd* f, double rtol, int max_iter) {
 
 extern "C" int hm_fwd_set_member_wells(hm_fwd* f, const double* q_all, int q_cols, const int* prd_ind_all) {
     HM_REQUIRE(f && q_all && prd_ind_all, "hm_fwd_set_member_wells: NULL argument");
+    ++f->inputs_gen;
     FwdParams& p = f->p;
     HM_REQUIRE(q_cols == 1 || q_cols == p.nTime, "hm_fwd_set_member_wells: q_cols must be 1 or nTime (%d), got %d", p.nTime, q_cols);
     for (long long i = 0; i < (long long)p.N * p.nPrd; ++i)
@@ -688,6 +689,7 @@ extern "C" int hm_fwd_set_member_wells(hm_fwd* f, const double* q_all, int q_col
 
 extern "C" int hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant) {
     HM_REQUIRE(f, "hm_fwd_set_variant: NULL plan");
+    ++f->inputs_gen;
     f->press_variant = pressure_variant;
     f->sat_variant = saturation_variant;
     return 0;
@@ -695,6 +697,7 @@ extern "C" int hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturatio
 
 extern "C" int hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transformed, const void* wsat0) {
     HM_REQUIRE(f && perm, "hm_fwd_set_inputs: NULL argument");
+    ++f->inputs_gen;
     HM_HIP(hipSetDevice(f->ctx->device));
     hipStream_t s = f->ctx->stream;
     const FwdParams& p = f->p;
@@ -734,6 +737,7 @@ extern "C" int hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transf
 // (TX from K[0], TY from K[1], the SPD pin K[0,0,0] + K[1,0,0]).  NULL returns the plan to Kx = Ky.
 extern "C" int hm_fwd_set_perm_y(hm_fwd* f, const void* perm_y, int perm_is_transformed) {
     HM_REQUIRE(f, "hm_fwd_set_perm_y: NULL plan");
+    ++f->inputs_gen;
     HM_HIP(hipSetDevice(f->ctx->device));
     hipStream_t s = f->ctx->stream;
     if (!perm_y) {
@@ -769,6 +773,7 @@ __global__ void k_convert(const TI* __restrict__ in, TO* __restrict__ out, long 
 // Same stream as the producer when both plans share the context: no synchronisation, no PCIe.
 extern "C" int hm_fwd_set_inputs_device(hm_fwd* f, const void* perm_dev, int perm_dtype, int perm_is_transformed) {
     HM_REQUIRE(f && perm_dev, "hm_fwd_set_inputs_device: NULL argument");
+    ++f->inputs_gen;
     HM_REQUIRE(perm_dtype == 64 || perm_dtype == 32, "hm_fwd_set_inputs_device: perm_dtype must be 64 or 32");
     HM_HIP(hipSetDevice(f->ctx->device));
     hipStream_t s = f->ctx->stream;
@@ -817,7 +822,7 @@ static int launch_pressure(hm_fwd* f, int k) {
     if (rc) return rc;
     int done = -1;
     // press_variant: 0 the default (128 x 128: nested dissection, press_nd.hip; other grids with Ny = 128: press128s), 1 generic (the
-    // in-library cross-check), 9 Jacobi-CG, 7 the 16-wave form of press128s, 12 nested dissection, 13 press128s (block elimination,
+    // in-library cross-check), 9 Jacobi-CG, 7 the 16-wave form of press128s, 12 nested dissection (14: every front eliminated every step), 13 press128s (block elimination,
     // symmetric tiles, 8 waves) also at 128 x 128.  (The first three generations of the 128-wide solver -- rank-1 VALU sweeps, full-tile
     // rank-4 and rank-16 matrix-core panels -- were removed in round 2; their timings are in profiles/README.md.)
     const int pv = f->press_variant;
@@ -832,7 +837,7 @@ static int launch_pressure(hm_fwd* f, int k) {
         }
         if (pv != 9 && f->cg_precond == 0 && pressure_two_level_applies(p)) done = launch_pressure_two_level(f, S, stride, k);
         else done = launch_pressure_pcg(f, S, stride, k);
-    } else if ((pv == 0 || pv == 12) && pressure_nd_applies(p)) done = launch_pressure_nd(f, S, stride, k);  // 128 x 128: nested dissection
+    } else if ((pv == 0 || pv == 12 || pv == 14) && pressure_nd_applies(p)) done = launch_pressure_nd(f, S, stride, k);  // 128 x 128: nested dissection (14: without reuse across time steps)
     if (done < 0 && p.Ny <= 128 && pv != 9) {
         if (!f->G.p) {  // every other direct solver keeps its inverse Schur complements
             int rc2 = hm_dev_alloc(f->G, (size_t)p.N * p.Nxy * p.Ny * 8);
@@ -1047,6 +1052,7 @@ extern "C" int hm_fwd_get_field(hm_fwd* f, const char* name, void* out) {
 
 extern "C" int hm_fwd_set_field(hm_fwd* f, const char* name, const void* in) {
     HM_REQUIRE(f && name && in, "hm_fwd_set_field: NULL argument");
+    ++f->inputs_gen;
     HM_HIP(hipSetDevice(f->ctx->device));
     HM_HIP(hipStreamSynchronize(f->ctx->stream));
     FieldRef r;
@@ -1065,6 +1071,7 @@ extern "C" int hm_fwd_set_field(hm_fwd* f, const char* name, const void* in) {
 
 extern "C" void* hm_fwd_device_ptr(hm_fwd* f, const char* name) {
     if (!f || !name) return nullptr;
+    ++f->inputs_gen;  // the caller may write through the pointer (device-to-device chaining of K)
     std::string s(name);
     if (s == "S") { long long st; return fwd_S_ptr(f, f->cur, &st); }
     if (s == "prods") return f->prods.p;

@@ -54,6 +54,7 @@ struct hm_fwd {
     int dtype = 64;
     int keep_history = 0;
     int press_variant = 0, sat_variant = 0;
+    long long inputs_gen = 0;  // bumped by every call that can change K, wells, rates or kernel selection: results cached across time steps (press_nd.hip) die with it
     bool cg_lazy = true;  // CG work vectors not allocated yet
     size_t esz = 8;  // bytes per saturation element
     DevBuf Ky;     // y-permeability of an anisotropic run (hm_fwd_set_perm_y), else unallocated

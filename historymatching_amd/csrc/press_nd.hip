@@ -55,7 +55,13 @@ struct NdDev {
     int slot9, slot10;      // doubles per LDS update slot of levels 9, 10 (k_nd_sub)
     int child_doubles[3];   // largest child update of a level-7 / 6 / 5 front (k_nd_wave's LDS staging)
     int top_child_doubles;  // largest child update of a level <= 4 front
+    // Reuse across time steps (k_nd_plan): per member the fronts of levels 8..5 that have to be eliminated this step, compacted
+    int* work;                   // N x ND_WORK_INTS: [n8, n7, n6, n5 | list8[256] | list7[128] | list6[64] | list5[32]]
+    unsigned char* cached;       // N x 512: front f (levels 5..8: f = 31..510) holds the results of its all-dry state
+    const unsigned char* wells;  // 512: a well inside the box the front's dryness is judged on
+    int reuse;                   // 0: every front is eliminated every step
 };
+constexpr int ND_WORK_INTS = 512, ND_W8 = 4, ND_W7 = ND_W8 + 256, ND_W6 = ND_W7 + 128, ND_W5 = ND_W6 + 64;
 
 struct NdGeo {
     int lane, lc, lq;
@@ -312,6 +318,65 @@ __global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, con
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// What has to be eliminated this time step.  Ahead of the water front the saturation is exactly zero, the mobilities and with them the
+// coefficients of every cell there are what they were the step before, and a front whose whole subtree lies there would reproduce its
+// factor rows and its update matrix bit for bit -- both are still in memory (the arena keeps one slot per front of levels 1..8 and per
+// leaf; level 9 lives in LDS inside k_nd_sub, whose level-8 subtree is skipped or redone as a whole).  A front of levels 8..5 is SKIPPED
+// when (a) every cell of the box its coefficients come from (its subtree's region for level 8, its separator for 7..5, plus a ring of
+// one cell) is dry now, (b) its children are skipped, (c) no well sits in that box (rates may change with time; a well cell is never
+// dry for long anyway) and (d) its stored results were computed from such an all-dry state since the plan's inputs last changed
+// (`cached`, cleared whenever K, wells or kernel selection change: hm_fwd::inputs_gen).  Levels 4..0 and the back substitution always run.
+// One workgroup of 256 threads per member; the surviving fronts are written as compacted lists that the elimination kernels index.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ __launch_bounds__(256) void k_nd_plan(FwdParams p, NdDev nd, const TS* __restrict__ S_base, long long S_stride) {
+    __shared__ unsigned char dry[512];  // by front id (31..510)
+    const int m = blockIdx.x, t = threadIdx.x;
+    const TS* S = S_base + (long long)m * S_stride;
+    int* work = nd.work + (long long)m * ND_WORK_INTS;
+    unsigned char* cached = nd.cached + (long long)m * 512;
+    auto box_dry = [&](int box) {
+        const int x0 = max((box & 255) - 1, 0), y0 = max(((box >> 8) & 255) - 1, 0), x1 = min(((box >> 16) & 255) + 1, NB), y1 = min(((box >> 24) & 255) + 1, NB);
+        bool any = false;
+        for (int ix = x0; ix < x1; ++ix)
+            for (int iy = y0; iy < y1; ++iy) any |= S[ix * NB + iy] != (TS)0;  // (-0.0 == 0: dry)
+        return !any;
+    };
+    // level 8: the subtree's region; levels 7..5: the separator, and both children
+    {
+        const int f = 255 + t;
+        dry[f] = nd.reuse && !nd.wells[f] && box_dry(nd.fronts[f * ND_FRONT_INTS + NDF_RBOX]);
+    }
+    __syncthreads();
+    for (int lv = 7; lv >= 5; --lv) {
+        const int nf = 1 << lv, f = nf - 1 + t;
+        if (t < nf) dry[f] = dry[2 * f + 1] && dry[2 * f + 2] && !nd.wells[f] && box_dry(nd.fronts[f * ND_FRONT_INTS + NDF_PBOX]);
+        __syncthreads();
+    }
+    // skip = dry and cached; what is computed now is the state of the cache afterwards
+    for (int lv = 8; lv >= 5; --lv) {
+        const int nf = 1 << lv, f = nf - 1 + t;
+        const int base = lv == 8 ? ND_W8 : lv == 7 ? ND_W7 : lv == 6 ? ND_W6 : ND_W5;
+        bool todo = false;
+        if (t < nf) {
+            todo = !(dry[f] && cached[f]);
+            cached[f] = dry[f];
+        }
+        // order-preserving compaction over the (at most four) waves
+        const unsigned long long mask = __ballot(todo);
+        const int w = t >> 6, lane = t & 63;
+        __shared__ int wcount[4];
+        if (lane == 0) wcount[w] = __popcll(mask);
+        __syncthreads();
+        int off = 0;
+        for (int q = 0; q < w; ++q) off += wcount[q];
+        if (todo) work[base + off + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+        if (t == 0) work[8 - lv] = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // The leaves (level 10: 3 x 3 .. 4 x 4 cells, at most 12 boundary cells), ONE LANE PER LEAF.  A leaf's pivot block is the five-point
 // matrix of a tiny grid -- banded, bandwidth 4 in the padded 4 x 4 ordering i = 4 lx + ly -- and every boundary cell touches exactly one
 // of its cells.  As a front on the matrix cores a leaf costs a whole wave ~900 instructions (a 16-pivot in-wave sweep, two padded
@@ -409,7 +474,11 @@ __global__ __launch_bounds__(256, 2) void k_nd_leaf(FwdParams p, NdDev nd, int k
     __shared__ double gsh[4][16][64];  // per wave: one solution vector per lane, [cell][lane]
     const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int f = 1023 + bidx * 256 + tid;  // 4 blocks of 256 leaves per member
+    // the leaves of the level-8 subtrees that are eliminated this step (k_nd_plan's list), four lanes per subtree
+    const int* work = nd.work + (long long)m * ND_WORK_INTS;
+    const int e = (bidx * 256 + tid) >> 2;
+    if (e >= work[0]) return;  // (no workgroup barrier below)
+    const int f = 1023 + 4 * work[ND_W8 + e] + (tid & 3);
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* out = nd.arena + (long long)m * nd.arena_stride + nd.fronts[f * ND_FRONT_INTS + NDF_UPD];
     const int b = nd.fronts[f * ND_FRONT_INTS + NDF_B];
@@ -501,8 +570,11 @@ __global__ __launch_bounds__(64 * SUB_WPB) void k_nd_sub(FwdParams p, NdDev nd, 
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mgroups = (p.N + SUB_WPB - 1) / SUB_WPB;
-    const int m = SUB_WPB * (blockIdx.x % mgroups) + w, i8 = blockIdx.x / mgroups;
+    const int m = SUB_WPB * (blockIdx.x % mgroups) + w, e8 = blockIdx.x / mgroups;
     if (m >= p.N) return;  // (no workgroup barrier below)
+    const int* work = nd.work + (long long)m * ND_WORK_INTS;
+    if (e8 >= __builtin_amdgcn_readfirstlane(work[0])) return;  // the member's subtrees that are eliminated this step: k_nd_plan's list
+    const int i8 = __builtin_amdgcn_readfirstlane(work[ND_W8 + e8]);
     double* blk = nd_lds + w * nd_sub_lds_doubles(nd);  // the wave's LDS block (nd.h): the recipes' offsets refer to it
     double* s9 = blk + ND_LDS_DATA;
     double* s10 = s9 + 2 * nd.slot9;
@@ -595,7 +667,10 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* arena = nd.arena + (long long)m * nd.arena_stride;
-    const int f = NF - 1 + bidx * WPB + w;
+    const int* work = nd.work + (long long)m * ND_WORK_INTS;
+    const int e = bidx * WPB + w;
+    if (e >= __builtin_amdgcn_readfirstlane(work[8 - LEVEL])) return;  // the level's fronts that are eliminated this step (k_nd_plan); no workgroup barrier below
+    const int f = NF - 1 + __builtin_amdgcn_readfirstlane(work[(LEVEL == 7 ? ND_W7 : LEVEL == 6 ? ND_W6 : ND_W5) + e]);
     const int* F = nd.fronts + f * ND_FRONT_INTS;
     const int bc0 = F[NDF_BC0], bc1 = F[NDF_BC1];
     const int n0 = (((bc0 + 1) * (bc0 + 2) >> 1) + 1) & ~1, n1 = (((bc1 + 1) * (bc1 + 2) >> 1) + 1) & ~1;
@@ -1177,15 +1252,16 @@ __global__ __launch_bounds__(1024) void k_nd_flux(FwdParams p) {
 // ------------------------------------------------------------------------------------------------------------------------
 struct hm_nd {
     NdInfo info{};
-    DevBuf fronts, cells, cpos, rec, fact, arena, dg;
+    DevBuf fronts, cells, cpos, rec, fact, arena, dg, work, cached, wells;
     NdDev dev{};
+    long long cached_gen = -1;  // hm_fwd::inputs_gen the cached results belong to
 };
 
 bool pressure_nd_applies(const FwdParams& p) { return p.Nx == NB && p.Ny == NB; }
 
 void hm_nd_free(hm_nd* n) {
     if (!n) return;
-    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->rec, &n->fact, &n->arena, &n->dg};
+    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->rec, &n->fact, &n->arena, &n->dg, &n->work, &n->cached, &n->wells};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     delete n;
 }
@@ -1221,7 +1297,8 @@ static int nd_setup(hm_fwd* f) {
     const size_t N = p.N;
     if ((rc = hm_dev_alloc(n->fronts, t.fronts.size() * 4)) || (rc = hm_dev_alloc(n->cells, t.cells.size() * 4)) ||
         (rc = hm_dev_alloc(n->cpos, t.cpos.size() * 2)) || (rc = hm_dev_alloc(n->rec, t.rec.size() * 2)) || (rc = hm_dev_alloc(n->fact, N * t.info.fact_doubles * 8)) ||
-        (rc = hm_dev_alloc(n->arena, N * t.info.arena_doubles * 8)) || (rc = hm_dev_alloc(n->dg, N * (size_t)CF_STRIDE * 8))) {
+        (rc = hm_dev_alloc(n->arena, N * t.info.arena_doubles * 8)) || (rc = hm_dev_alloc(n->dg, N * (size_t)CF_STRIDE * 8)) ||
+        (rc = hm_dev_alloc(n->work, N * (size_t)ND_WORK_INTS * 4)) || (rc = hm_dev_alloc(n->cached, N * (size_t)512)) || (rc = hm_dev_alloc(n->wells, 512))) {
         hm_nd_free(n);
         return rc;
     }
@@ -1237,6 +1314,22 @@ static int nd_setup(hm_fwd* f) {
     d.fact = (double*)n->fact.p;
     d.arena = (double*)n->arena.p;
     d.cf = (double*)n->dg.p;
+    d.work = (int*)n->work.p;
+    d.cached = (unsigned char*)n->cached.p;
+    d.wells = (const unsigned char*)n->wells.p;
+    d.reuse = 1;
+    {   // fronts of levels 5..8 with a well inside the box their dryness is judged on (region of a level-8 subtree, separator of 7..5; + 1 ring)
+        std::vector<unsigned char> wf(512, 0);
+        for (int fr = 31; fr < 511; ++fr) {
+            const int box = t.fronts[fr * ND_FRONT_INTS + (fr >= 255 ? NDF_RBOX : NDF_PBOX)];
+            const int x0 = (box & 255) - 1, y0 = ((box >> 8) & 255) - 1, x1 = ((box >> 16) & 255) + 1, y1 = ((box >> 24) & 255) + 1;
+            for (int cell : f->well_cells_host) {
+                const int ix = cell / NB, iy = cell % NB;
+                if (ix >= x0 && ix < x1 && iy >= y0 && iy < y1) wf[fr] = 1;
+            }
+        }
+        HM_HIP(hipMemcpy(n->wells.p, wf.data(), 512, hipMemcpyHostToDevice));
+    }
     d.fact_stride = t.info.fact_doubles;
     d.arena_stride = t.info.arena_doubles;
     d.slot9 = t.info.upd_doubles[9];
@@ -1267,9 +1360,21 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
         if (rc) return rc;
     }
     hipStream_t s = f->ctx->stream;
-    const NdDev& nd = f->nd->dev;
-    if (f->dtype == 64) hipLaunchKernelGGL(k_nd_assemble<double>, dim3(p.N), dim3(1024), 0, s, p, nd, (const double*)S, S_stride, k);
-    else hipLaunchKernelGGL(k_nd_assemble<float>, dim3(p.N), dim3(1024), 0, s, p, nd, (const float*)S, S_stride, k);
+    NdDev& nd = f->nd->dev;
+    // results kept from earlier time steps are only good for the inputs they were computed from; press_variant 14: no reuse at all; per-member
+    // wells: none either (the well flags are per plan)
+    nd.reuse = f->press_variant != 14 && p.q_mstride == 0;
+    if (f->nd->cached_gen != f->inputs_gen) {
+        HM_HIP(hipMemsetAsync(f->nd->cached.p, 0, (size_t)p.N * 512, s));
+        f->nd->cached_gen = f->inputs_gen;
+    }
+    if (f->dtype == 64) {
+        hipLaunchKernelGGL(k_nd_assemble<double>, dim3(p.N), dim3(1024), 0, s, p, nd, (const double*)S, S_stride, k);
+        hipLaunchKernelGGL(k_nd_plan<double>, dim3(p.N), dim3(256), 0, s, p, nd, (const double*)S, S_stride);
+    } else {
+        hipLaunchKernelGGL(k_nd_assemble<float>, dim3(p.N), dim3(1024), 0, s, p, nd, (const float*)S, S_stride, k);
+        hipLaunchKernelGGL(k_nd_plan<float>, dim3(p.N), dim3(256), 0, s, p, nd, (const float*)S, S_stride);
+    }
     const size_t lds_sub = (size_t)SUB_WPB * nd_sub_lds_doubles(nd) * 8;
     hipLaunchKernelGGL(k_nd_leaf, dim3(p.N * 4), dim3(256), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_sub, dim3(((p.N + SUB_WPB - 1) / SUB_WPB) * 256), dim3(64 * SUB_WPB), lds_sub, s, p, nd, k);
