@@ -569,7 +569,9 @@ def main():
                                        "historymatching_amd/csrc/diag/valu_rate.hip, profiles/README.md"},
             "avg_launch_ms": {"saturation": sat_ms, "pressure": prs_ms},
             "per_kernel": {"saturation_fp64_valu_frac": None if stale else 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                           "pressure_fp64_mfma_frac": prs_flops / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                           # the factorisation's matrix instructions counted from the symbolic tables, every front eliminated: since fronts
+                           # whose subtree is still dry are skipped (k_nd_plan) the EXECUTED work is lower -- the counter-based figure below
+                           "pressure_fp64_mfma_frac_skip_free_count": prs_flops / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                            # the same solve by round 2's block elimination takes 36 x 4 x 8 x Nx matrix instructions per member (302 Mflop
                            # against the nested dissection's 55): this launch time priced at THAT flop count, for comparison across rounds only
                            "pressure_frac_at_block_elimination_flop_count": 2048.0 * 36 * 4 * 8 * NX * n_e / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,

@@ -56,12 +56,12 @@ struct NdDev {
     int child_doubles[3];   // largest child update of a level-7 / 6 / 5 front (k_nd_wave's LDS staging)
     int top_child_doubles;  // largest child update of a level <= 4 front
     // Reuse across time steps (k_nd_plan): per member the fronts of levels 8..5 that have to be eliminated this step, compacted
-    int* work;                   // N x ND_WORK_INTS: [n8, n7, n6, n5 | list8[256] | list7[128] | list6[64] | list5[32]]
-    unsigned char* cached;       // N x 512: front f (levels 5..8: f = 31..510) holds the results of its all-dry state
+    int* work;                   // N x ND_WORK_INTS: [n8, n7, n6, n5 | list8[256] | list7[128] | list6[64] | list5[32] | nt, fronts of levels 4..0]
+    unsigned char* cached;       // N x 512: front f (levels 0..8: f = 0..510) holds the results of its all-dry state
     const unsigned char* wells;  // 512: a well inside the box the front's dryness is judged on
     int reuse;                   // 0: every front is eliminated every step
 };
-constexpr int ND_WORK_INTS = 512, ND_W8 = 4, ND_W7 = ND_W8 + 256, ND_W6 = ND_W7 + 128, ND_W5 = ND_W6 + 64;
+constexpr int ND_WORK_INTS = 576, ND_W8 = 4, ND_W7 = ND_W8 + 256, ND_W6 = ND_W7 + 128, ND_W5 = ND_W6 + 64, ND_WT = ND_W5 + 32;  // ND_WT: n, then the fronts of levels 4..0 in order
 
 struct NdGeo {
     int lane, lc, lq;
@@ -321,11 +321,11 @@ __global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, con
 // What has to be eliminated this time step.  Ahead of the water front the saturation is exactly zero, the mobilities and with them the
 // coefficients of every cell there are what they were the step before, and a front whose whole subtree lies there would reproduce its
 // factor rows and its update matrix bit for bit -- both are still in memory (the arena keeps one slot per front of levels 1..8 and per
-// leaf; level 9 lives in LDS inside k_nd_sub, whose level-8 subtree is skipped or redone as a whole).  A front of levels 8..5 is SKIPPED
-// when (a) every cell of the box its coefficients come from (its subtree's region for level 8, its separator for 7..5, plus a ring of
+// leaf; level 9 lives in LDS inside k_nd_sub, whose level-8 subtree is skipped or redone as a whole).  A front of levels 8..0 is SKIPPED
+// when (a) every cell of the box its coefficients come from (its subtree's region for level 8, its separator above that, plus a ring of
 // one cell) is dry now, (b) its children are skipped, (c) no well sits in that box (rates may change with time; a well cell is never
 // dry for long anyway) and (d) its stored results were computed from such an all-dry state since the plan's inputs last changed
-// (`cached`, cleared whenever K, wells or kernel selection change: hm_fwd::inputs_gen).  Levels 4..0 and the back substitution always run.
+// (`cached`, cleared whenever K, wells or kernel selection change: hm_fwd::inputs_gen).  The back substitution always runs in full.
 // One workgroup of 256 threads per member; the surviving fronts are written as compacted lists that the elimination kernels index.
 // ------------------------------------------------------------------------------------------------------------------------
 template <typename TS>
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_nd_plan(FwdParams p, NdDev nd, const TS
         dry[f] = nd.reuse && !nd.wells[f] && box_dry(nd.fronts[f * ND_FRONT_INTS + NDF_RBOX]);
     }
     __syncthreads();
-    for (int lv = 7; lv >= 5; --lv) {
+    for (int lv = 7; lv >= 0; --lv) {
         const int nf = 1 << lv, f = nf - 1 + t;
         if (t < nf) dry[f] = dry[2 * f + 1] && dry[2 * f + 2] && !nd.wells[f] && box_dry(nd.fronts[f * ND_FRONT_INTS + NDF_PBOX]);
         __syncthreads();
@@ -373,6 +373,16 @@ __global__ __launch_bounds__(256) void k_nd_plan(FwdParams p, NdDev nd, const TS
         if (todo) work[base + off + __popcll(mask & ((1ull << lane) - 1ull))] = t;
         if (t == 0) work[8 - lv] = wcount[0] + wcount[1] + wcount[2] + wcount[3];
         __syncthreads();
+    }
+    // levels 4..0 (k_nd_top): the fronts to eliminate, in that kernel's order
+    if (t == 0) {
+        int nt = 0;
+        for (int lv = 4; lv >= 0; --lv)
+            for (int f = (1 << lv) - 1; f < (2 << lv) - 1; ++f) {
+                if (!(dry[f] && cached[f])) work[ND_WT + 1 + nt++] = f;
+                cached[f] = dry[f];
+            }
+        work[ND_WT] = nt;
     }
 }
 
@@ -754,12 +764,18 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
     int* frec = reinterpret_cast<int*>(chl + chl_cap);  // 31 records behind the child buffer
     for (int i = tid; i < 31 * ND_FRONT_INTS; i += 64 * TOP_NW) frec[i] = nd.fronts[i];
     __syncthreads();
-    for (int lv = 4; lv >= 0; --lv) {
+    // the fronts of levels 4..0 that are eliminated this step, in order (k_nd_plan: those whose subtree is still dry keep the results they have)
+    const int* tlist = nd.work + (long long)m * ND_WORK_INTS + ND_WT;
+    const int nt = __builtin_amdgcn_readfirstlane(tlist[0]);
+    bool prefetched = false;  // (wave-uniform) this front's tables and children were issued during the previous front's panels
+    {
+        for (int idx = 0; idx < nt; ++idx) {
+            const int f = __builtin_amdgcn_readfirstlane(tlist[1 + idx]);
 #ifdef HM_ND_PROF
-        if (blockIdx.x == 0 && tid == 0) hm_nd_prof_buf[48 + lv] = clock64();
+            if (blockIdx.x == 0 && tid == 0)
+                for (int lv = 4; lv >= 0; --lv)
+                    if (f == (1 << lv) - 1 || (idx == 0 && f >= (1 << lv) - 1 && f < (2 << lv) - 1)) hm_nd_prof_buf[48 + lv] = clock64();
 #endif
-        for (int fi = 0; fi < (1 << lv); ++fi) {
-            const int f = (1 << lv) - 1 + fi;
             const int* F = frec + f * ND_FRONT_INTS;
             const int b = __builtin_amdgcn_readfirstlane(F[NDF_B]);
             const int st = __builtin_amdgcn_readfirstlane(F[NDF_ST]);
@@ -786,7 +802,8 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
                 const int o1 = top_pad(2 * m0);
                 if (o1 + top_pad(2 * m1) <= chl_cap) top_dma(chl + o1, arena + __builtin_amdgcn_readfirstlane(Fn[NDF_UC1]), m1, w, g.lane);
             };
-            if (f == 15) stage_front(F);
+            if (!prefetched) stage_front(F);
+            prefetched = false;
             const short* cp_s1 = cp_s0 + 16 * T;
             // ---- my tiles: decode (scalar)
             d4 vt[TOP_NVS], tr[TOP_NTS];
@@ -919,11 +936,14 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
                 NPROF(7);
                 lds_barrier();  // images of panel pp visible; P(pp) no longer read
                 NPROF(8);
-                if (pp == 0 && f != 0) {
+                if (pp == 0 && idx + 1 < nt) {
                     // every wave is past its gathers: the tables and the child buffer are free -- the NEXT front's go in now, beside the
-                    // panels (its children are fronts of the level below this one's or of this level's predecessor: complete long ago)
-                    const int fnext = fi + 1 < (1 << lv) ? f + 1 : (1 << (lv - 1)) - 1;
-                    stage_front(frec + fnext * ND_FRONT_INTS);
+                    // panels, unless this front is one of its children (possible since fronts are skipped: its update is not written yet)
+                    const int fnext = __builtin_amdgcn_readfirstlane(tlist[2 + idx]);
+                    if (f != 2 * fnext + 1 && f != 2 * fnext + 2) {
+                        stage_front(frec + fnext * ND_FRONT_INTS);
+                        prefetched = true;
+                    }
                 }
                 if (pp + 1 < st) {
                     const int inx = (pp + 1) * T - (((pp + 1) * pp) >> 1);
@@ -1320,7 +1340,7 @@ static int nd_setup(hm_fwd* f) {
     d.reuse = 1;
     {   // fronts of levels 5..8 with a well inside the box their dryness is judged on (region of a level-8 subtree, separator of 7..5; + 1 ring)
         std::vector<unsigned char> wf(512, 0);
-        for (int fr = 31; fr < 511; ++fr) {
+        for (int fr = 0; fr < 511; ++fr) {
             const int box = t.fronts[fr * ND_FRONT_INTS + (fr >= 255 ? NDF_RBOX : NDF_PBOX)];
             const int x0 = (box & 255) - 1, y0 = ((box >> 8) & 255) - 1, x1 = ((box >> 16) & 255) + 1, y1 = ((box >> 24) & 255) + 1;
             for (int cell : f->well_cells_host) {
