@@ -330,17 +330,29 @@ __global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, con
 // ------------------------------------------------------------------------------------------------------------------------
 template <typename TS>
 __global__ __launch_bounds__(256) void k_nd_plan(FwdParams p, NdDev nd, const TS* __restrict__ S_base, long long S_stride) {
-    __shared__ unsigned char dry[512];  // by front id (31..510)
+    __shared__ unsigned char dry[512];  // by front id (0..510)
+    __shared__ unsigned long long wet[NB][2];  // one bit per cell: S != 0 (-0.0 == 0: dry), 128 bits per grid row
     const int m = blockIdx.x, t = threadIdx.x;
     const TS* S = S_base + (long long)m * S_stride;
     int* work = nd.work + (long long)m * ND_WORK_INTS;
     unsigned char* cached = nd.cached + (long long)m * 512;
+    {   // the saturation field once, coalesced: thread t takes the half rows t and t + 256 (64 cells each)
+        for (int h = t; h < 2 * NB; h += 256) {
+            const TS* row = S + (h >> 1) * NB + (h & 1) * 64;
+            unsigned long long bits = 0ull;
+            for (int c = 0; c < 64; ++c) bits |= (unsigned long long)(row[c] != (TS)0) << c;
+            wet[h >> 1][h & 1] = bits;
+        }
+    }
+    __syncthreads();
     auto box_dry = [&](int box) {
         const int x0 = max((box & 255) - 1, 0), y0 = max(((box >> 8) & 255) - 1, 0), x1 = min(((box >> 16) & 255) + 1, NB), y1 = min(((box >> 24) & 255) + 1, NB);
-        bool any = false;
-        for (int ix = x0; ix < x1; ++ix)
-            for (int iy = y0; iy < y1; ++iy) any |= S[ix * NB + iy] != (TS)0;  // (-0.0 == 0: dry)
-        return !any;
+        // bits [y0, y1) of a 128-bit row
+        const unsigned long long lo = y0 < 64 ? (~0ull << y0) & (y1 >= 64 ? ~0ull : ~(~0ull << y1)) : 0ull;
+        const unsigned long long hi = y1 > 64 ? (y0 > 64 ? ~0ull << (y0 - 64) : ~0ull) & (y1 == 128 ? ~0ull : ~(~0ull << (y1 - 64))) : 0ull;
+        unsigned long long any = 0ull;
+        for (int ix = x0; ix < x1; ++ix) any |= (wet[ix][0] & lo) | (wet[ix][1] & hi);
+        return any == 0ull;
     };
     // level 8: the subtree's region; levels 7..5: the separator, and both children
     {
