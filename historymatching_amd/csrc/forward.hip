@@ -14,6 +14,7 @@
 // NumPy does; FMAs appear only where written explicitly (inside the pressure solve, which is not a
 // bit-exact path).
 #include "fwd_dev.h"
+#include <algorithm>
 #include <chrono>
 
 // ------------------------------------------------------------------------------------------------
@@ -558,6 +559,12 @@ static int build_q(hm_fwd* f, int nInj, const int* inj_ind, const double* inj_ra
                    "sum of injection rates (%g) must equal sum of production rates (%g) at step %d", si, sp, k);
     }
     f->p.q_cols = cols;
+    // runs of equal consecutive columns of the schedule: q_epoch[k] = first step of the run step k belongs to
+    f->q_epoch.assign(cols, 0);
+    for (int k = 1; k < cols; ++k) {
+        const double *a = f->q_host.data() + (size_t)(k - 1) * p.Nxy, *b = a + p.Nxy;
+        f->q_epoch[k] = std::equal(a, a + p.Nxy, b) ? f->q_epoch[k - 1] : k;
+    }
     f->well_cells_host.assign(inj_ind, inj_ind + nInj);
     f->well_cells_host.insert(f->well_cells_host.end(), prd_ind, prd_ind + nPrd);
     return 0;
@@ -1071,13 +1078,16 @@ extern "C" int hm_fwd_set_field(hm_fwd* f, const char* name, const void* in) {
 
 extern "C" void* hm_fwd_device_ptr(hm_fwd* f, const char* name) {
     if (!f || !name) return nullptr;
-    ++f->inputs_gen;  // the caller may write through the pointer (device-to-device chaining of K)
     std::string s(name);
     if (s == "S") { long long st; return fwd_S_ptr(f, f->cur, &st); }
     if (s == "prods") return f->prods.p;
     if (s == "S_all") return f->S.p;
     FieldRef r;
     if (field_ref(f, name, r)) return nullptr;
+    // the caller may write K, fluxes ... through this pointer at any later time without the library seeing it: results cached across
+    // time steps (press_nd.hip) are not kept for this plan any more
+    ++f->inputs_gen;
+    f->raw_field_exposed = true;
     return r.p;
 }
 

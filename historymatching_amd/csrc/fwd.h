@@ -54,6 +54,7 @@ struct hm_fwd {
     int dtype = 64;
     int keep_history = 0;
     int press_variant = 0, sat_variant = 0;
+    bool raw_field_exposed = false;  // a device pointer to K / TX / ... was handed out (hm_fwd_device_ptr): no caching across time steps
     long long inputs_gen = 0;  // bumped by every call that can change K, wells, rates or kernel selection: results cached across time steps (press_nd.hip) die with it
     bool cg_lazy = true;  // CG work vectors not allocated yet
     size_t esz = 8;  // bytes per saturation element
@@ -70,6 +71,7 @@ struct hm_fwd {
     long long n_press = 0, n_sat = 0;
     std::vector<double> q_host;
     std::vector<int> well_cells_host;
+    std::vector<int> q_epoch;  // per column of q_host: first time step of the run of equal columns it belongs to (build_q)
     DevBuf well_cells;
     DevBuf team_mem;  // synchronisation blocks of the multi-tile saturation sweep (sat128t.hip), allocated on first use
     long long team_retries = 0, team_retries_seen = 0;  // time steps redone by the tiled sweep after a team gave up waiting

@@ -58,7 +58,8 @@ struct NdDev {
     // Reuse across time steps (k_nd_plan): per member the fronts of levels 8..5 that have to be eliminated this step, compacted
     int* work;                   // N x ND_WORK_INTS: [n8, n7, n6, n5 | list8[256] | list7[128] | list6[64] | list5[32] | nt, fronts of levels 4..0]
     unsigned char* cached;       // N x 512: front f (levels 0..8: f = 0..510) holds the results of its all-dry state
-    const unsigned char* wells;  // 512: a well inside the box the front's dryness is judged on
+    const unsigned char* wells;  // 512: a well somewhere in the front's subtree (its right-hand side rows carry the rates)
+    int wells_ok;                // the rates of this time step are those the cached results of such fronts were computed with
     int reuse;                   // 0: every front is eliminated every step
 };
 constexpr int ND_WORK_INTS = 576, ND_W8 = 4, ND_W7 = ND_W8 + 256, ND_W6 = ND_W7 + 128, ND_W5 = ND_W6 + 64, ND_WT = ND_W5 + 32;  // ND_WT: n, then the fronts of levels 4..0 in order
@@ -323,9 +324,11 @@ __global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, con
 // factor rows and its update matrix bit for bit -- both are still in memory (the arena keeps one slot per front of levels 1..8 and per
 // leaf; level 9 lives in LDS inside k_nd_sub, whose level-8 subtree is skipped or redone as a whole).  A front of levels 8..0 is SKIPPED
 // when (a) every cell of the box its coefficients come from (its subtree's region for level 8, its separator above that, plus a ring of
-// one cell) is dry now, (b) its children are skipped, (c) no well sits in that box (rates may change with time; a well cell is never
-// dry for long anyway) and (d) its stored results were computed from such an all-dry state since the plan's inputs last changed
-// (`cached`, cleared whenever K, wells or kernel selection change: hm_fwd::inputs_gen).  The back substitution always runs in full.
+// one cell) is dry now, (b) its children are skipped, (c) the rates of the wells in its subtree -- they are its right-hand side -- are
+// those of the time step its results were stored at (`wells_ok`: constant rates, or the same run of equal columns of a rate schedule;
+// the producers' corners are the regions that stay dry longest) and (d) its stored results were computed from such an all-dry state
+// since the plan's inputs last changed (`cached`, cleared whenever K, wells or kernel selection change: hm_fwd::inputs_gen).  The
+// back substitution always runs in full.
 // One workgroup of 256 threads per member; the surviving fronts are written as compacted lists that the elimination kernels index.
 // ------------------------------------------------------------------------------------------------------------------------
 template <typename TS>
@@ -357,12 +360,12 @@ __global__ __launch_bounds__(256) void k_nd_plan(FwdParams p, NdDev nd, const TS
     // level 8: the subtree's region; levels 7..5: the separator, and both children
     {
         const int f = 255 + t;
-        dry[f] = nd.reuse && !nd.wells[f] && box_dry(nd.fronts[f * ND_FRONT_INTS + NDF_RBOX]);
+        dry[f] = nd.reuse && box_dry(nd.fronts[f * ND_FRONT_INTS + NDF_RBOX]);
     }
     __syncthreads();
     for (int lv = 7; lv >= 0; --lv) {
         const int nf = 1 << lv, f = nf - 1 + t;
-        if (t < nf) dry[f] = dry[2 * f + 1] && dry[2 * f + 2] && !nd.wells[f] && box_dry(nd.fronts[f * ND_FRONT_INTS + NDF_PBOX]);
+        if (t < nf) dry[f] = dry[2 * f + 1] && dry[2 * f + 2] && box_dry(nd.fronts[f * ND_FRONT_INTS + NDF_PBOX]);
         __syncthreads();
     }
     // skip = dry and cached; what is computed now is the state of the cache afterwards
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256) void k_nd_plan(FwdParams p, NdDev nd, const TS
         const int base = lv == 8 ? ND_W8 : lv == 7 ? ND_W7 : lv == 6 ? ND_W6 : ND_W5;
         bool todo = false;
         if (t < nf) {
-            todo = !(dry[f] && cached[f]);
+            todo = !(dry[f] && cached[f] && (nd.wells_ok || !nd.wells[f]));
             cached[f] = dry[f];
         }
         // order-preserving compaction over the (at most four) waves
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256) void k_nd_plan(FwdParams p, NdDev nd, const TS
         int nt = 0;
         for (int lv = 4; lv >= 0; --lv)
             for (int f = (1 << lv) - 1; f < (2 << lv) - 1; ++f) {
-                if (!(dry[f] && cached[f])) work[ND_WT + 1 + nt++] = f;
+                if (!(dry[f] && cached[f] && (nd.wells_ok || !nd.wells[f]))) work[ND_WT + 1 + nt++] = f;
                 cached[f] = dry[f];
             }
         work[ND_WT] = nt;
@@ -1287,6 +1290,7 @@ struct hm_nd {
     DevBuf fronts, cells, cpos, rec, fact, arena, dg, work, cached, wells;
     NdDev dev{};
     long long cached_gen = -1;  // hm_fwd::inputs_gen the cached results belong to
+    int cached_q_epoch = -1;    // hm_fwd::q_epoch of the time step the cached results of fronts with wells belong to
 };
 
 bool pressure_nd_applies(const FwdParams& p) { return p.Nx == NB && p.Ny == NB; }
@@ -1350,9 +1354,10 @@ static int nd_setup(hm_fwd* f) {
     d.cached = (unsigned char*)n->cached.p;
     d.wells = (const unsigned char*)n->wells.p;
     d.reuse = 1;
-    {   // fronts of levels 5..8 with a well inside the box their dryness is judged on (region of a level-8 subtree, separator of 7..5; + 1 ring)
+    {   // fronts with a well in their subtree: the region of a level-8 subtree, above that the separator and both children (+ 1 ring)
         std::vector<unsigned char> wf(512, 0);
-        for (int fr = 0; fr < 511; ++fr) {
+        for (int fr = 510; fr >= 0; --fr) {
+            if (fr < 255) wf[fr] = wf[2 * fr + 1] | wf[2 * fr + 2];
             const int box = t.fronts[fr * ND_FRONT_INTS + (fr >= 255 ? NDF_RBOX : NDF_PBOX)];
             const int x0 = (box & 255) - 1, y0 = ((box >> 8) & 255) - 1, x1 = ((box >> 16) & 255) + 1, y1 = ((box >> 24) & 255) + 1;
             for (int cell : f->well_cells_host) {
@@ -1395,10 +1400,15 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
     NdDev& nd = f->nd->dev;
     // results kept from earlier time steps are only good for the inputs they were computed from; press_variant 14: no reuse at all; per-member
     // wells: none either (the well flags are per plan)
-    nd.reuse = f->press_variant != 14 && p.q_mstride == 0;
+    nd.reuse = f->press_variant != 14 && p.q_mstride == 0 && !f->raw_field_exposed;
     if (f->nd->cached_gen != f->inputs_gen) {
         HM_HIP(hipMemsetAsync(f->nd->cached.p, 0, (size_t)p.N * 512, s));
         f->nd->cached_gen = f->inputs_gen;
+    }
+    {   // the right-hand side rows of fronts with wells in their subtree: kept while the rates stay what they were
+        const int ep = p.q_cols > 1 ? f->q_epoch[k] : 0;
+        nd.wells_ok = ep == f->nd->cached_q_epoch;
+        f->nd->cached_q_epoch = ep;
     }
     if (f->dtype == 64) {
         hipLaunchKernelGGL(k_nd_assemble<double>, dim3(p.N), dim3(1024), 0, s, p, nd, (const double*)S, S_stride, k);

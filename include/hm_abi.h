@@ -167,7 +167,10 @@ int  hm_fwd_pressure_only(hm_fwd* f, int k);
 int  hm_fwd_saturation_only(hm_fwd* f, int k);
 int  hm_fwd_get_field(hm_fwd* f, const char* name /* "S","P","Vx","Vy","TX","TY","K","nts" */, void* out);
 int  hm_fwd_set_field(hm_fwd* f, const char* name /* "S","Vx","Vy" */, const void* in);
-void* hm_fwd_device_ptr(hm_fwd* f, const char* name);   /* raw device pointer of a named buffer */
+/* Raw device pointer of a named buffer ("S", "S_all", "prods": outputs; any name of hm_fwd_get_field).  Asking for an INPUT field
+ * ("K", "TX", ...) tells the plan that it may be written behind its back from now on: the pressure step then keeps no results
+ * across time steps any more (press_nd.hip, reuse of dry fronts) -- prefer hm_fwd_set_inputs_device for device-to-device chaining. */
+void* hm_fwd_device_ptr(hm_fwd* f, const char* name);
 
 /* Hardware self-test: D(16x16) = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 with the lane maps the
  * pressure kernel assumes (host buffers, row-major). */

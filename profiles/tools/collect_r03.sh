@@ -7,6 +7,7 @@
 #  5. isa_counts.json + fp64_roofline.json, both carrying the sha256 of the objects they were taken from
 #  6. the pressure variants side by side (nested dissection vs block elimination)            -> pressure_variants.txt
 #     the saturation sweeps side by side (fw image in LDS vs fw in registers)               -> saturation_variants.txt
+#  7. pressure step alone: kernel_stats_nd_only.txt, occupancy_nd.txt, nd_reuse.txt;  8. python3 bench.py -> bench_default.json
 set -u
 R=${1:-r03}
 OUT=gpurun_out/profiles/$R
@@ -46,4 +47,12 @@ python3 tests/tools/nd_check.py 1000 20 > $OUT/pressure_variants.txt 2>&1
 python3 tests/tools/sat_check.py 1000 5,0 > $OUT/saturation_variants.txt 2>&1
 python3 tests/tools/long_parity.py 4 > $OUT/long_parity.txt 2>&1
 python3 tests/tools/ies_iterate_timing.py > $OUT/ies_iterate.txt 2>&1
+# 7. the pressure step alone: kernel trace of whole runs, occupancy counters (every front eliminated), the reuse of dry fronts
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/nd -o nd -- python3 tests/tools/nd_time.py 12 1000 1 > $W/nd.out 2> $W/nd.err
+python3 profiles/tools/print_stats.py $W/nd > $OUT/kernel_stats_nd_only.txt
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $W/occ -o occ -- python3 tests/tools/nd_time.py 14 1000 1 > /dev/null 2> $W/occ.err
+python3 profiles/tools/occupancy.py "$(find $W/occ -name '*counter_collection.csv' | head -1)" k_nd_ > $OUT/occupancy_nd.txt
+(python3 tests/tools/nd_reuse_check.py 1000 8 40; python3 tests/tools/dry_fraction.py 8) > $OUT/nd_reuse.txt 2>&1
+# 8. the default bench line of this build
+python3 bench.py > $OUT/bench_default.json 2> $W/bench.err
 ls -la $OUT

@@ -818,17 +818,18 @@ def test_nested_dissection_pressure_whole_run():
         assert np.abs(res[12][0][m] - ref).max() <= 10 * noise + 1e-9, (m, np.abs(res[12][0][m] - ref).max(), noise)
 
 
-@pytest.mark.parametrize("rates", ["constant", "time_varying"])
+@pytest.mark.parametrize("rates", ["constant", "time_varying", "piecewise_constant"])
 def test_nested_dissection_reuse_of_dry_fronts_is_bit_identical(rates):
-    """press_nd.hip does not eliminate a front again while its whole subtree is still dry (k_nd_plan): the stored factor rows and
-    update matrix are what it would recompute.  Whole runs with the reuse (press_variant 12, the default) and without (14) give
+    """press_nd.hip does not eliminate a front again while its whole subtree is still dry and the rates of the wells in it are unchanged
+    (k_nd_plan): the stored factor rows and update matrix are what it would recompute.  Whole runs with the reuse (press_variant 12, the default) and without (14) give
     array_equal saturations, producer series, sub-step counts and final pressures; so does a second run on the SAME plan from other
     permeabilities (the cache dies with the inputs it was computed from) and a pressure solve after a saturation field was written
     into the plan by hand."""
     n, N, steps = 128, 4, 14
     _, gm = make_models(n, n)
-    if rates == "time_varying":
-        r = 0.5 + np.arange(steps) / steps
+    if rates != "constant":
+        # the right-hand side rows of a front with a well in its subtree are kept only over runs of time steps with equal rates
+        r = 0.5 + np.arange(steps) / steps if rates == "time_varying" else np.where(np.arange(steps) < 5, 0.7, np.where(np.arange(steps) < 9, 1.3, 0.9))
         gm.inj_rates = r[None, :]
         gm.prd_rates = np.tile(r / 4, (4, 1))
     x = perms(n, n, 2 * N, seed=71)
@@ -859,6 +860,42 @@ def test_nested_dissection_reuse_of_dry_fronts_is_bit_identical(rates):
         for a, b in zip(a_run, b_run):
             assert np.array_equal(a, b), np.abs(a - b).max()
     assert np.array_equal(out[12][2][0], out[12][2][1])  # the solve from the cache equals the one that filled it
+
+
+def test_nested_dissection_reuse_ends_when_a_raw_field_pointer_is_handed_out():
+    """A device pointer to K taken with hm_fwd_device_ptr can be written at any later time without the library seeing it
+    (device-to-device chaining): from that call on the plan keeps no factor rows across solves (fwd.h raw_field_exposed), so a solve
+    after such a write equals the same solve on a fresh plan."""
+    import ctypes as C
+
+    from historymatching_amd import _lib
+
+    n, N = 128, 3
+    _, gm = make_models(n, n)
+    x = perms(n, n, 2 * N, seed=73)
+    S = np.zeros((N, n, n))
+    S[:, :20, :30] = 0.4
+    ref = _plan(gm, N, nTime=2)
+    ref.set_inputs(x[N:], transformed=False)
+    ref.set_field("S", S.reshape(N, -1))
+    ref.pressure_only(0)
+    P_ref = ref.get_field("P").copy()
+    K2 = np.ascontiguousarray(ref.get_field("K"))
+    ref.close()
+
+    plan = _plan(gm, N, nTime=2)
+    plan.set_inputs(x[:N], transformed=False)
+    plan.set_field("S", S.reshape(N, -1))
+    plan.pressure_only(0)
+    ptr = plan.device_ptr("K")
+    plan.pressure_only(0)  # would refill the cache under the generation the call above started
+    P1 = plan.get_field("P").copy()
+    _lib.check(plan.lib.hm_copy_to_device(plan.ctx.handle, C.c_void_p(ptr), K2.ctypes.data_as(C.c_void_p), K2.nbytes), "copy K")
+    plan.pressure_only(0)
+    P2 = plan.get_field("P").copy()
+    plan.close()
+    assert not np.array_equal(P1, P2)
+    assert np.array_equal(P2, P_ref), np.abs(P2 - P_ref).max()
 
 
 def test_comp1_single_member_composite():
