@@ -111,6 +111,7 @@ SIGNATURES = {
     "hm_iles_destroy": (None, [_vp]),
     "hm_iles_compose": (C.c_int, [_vp, _vp]),
     "hm_iles_step": (C.c_int, [_vp, _dp, _dp, C.c_double]),
+    "hm_iles_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "hm_iles_get_weights": (C.c_int, [_vp, C.c_int, _dp]),
     "hm_iles_device_ptr": (_vp, [_vp, C.c_char_p]),
     "hm_upd_sync": (C.c_int, [_vp, C.POINTER(hm_stats)]),

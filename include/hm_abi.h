@@ -274,6 +274,9 @@ int   hm_iles_create(hm_ctx* ctx, int N, int M, int n_obs, int B, const int* bat
 void  hm_iles_destroy(hm_iles* p);
 int   hm_iles_compose(hm_iles* p, double* E_out /* N*M or NULL */);
 int   hm_iles_step(hm_iles* p, const double* S, const double* D, double xstep);
+/* "blocked" = 1: the step as a blocked elimination over many workgroups per batch (the default from N = 256 members on; needs
+ * N <= 1024), 0: one workgroup per batch (the default below that). */
+int   hm_iles_set_option(hm_iles* p, const char* name, int value);
 int   hm_iles_get_weights(hm_iles* p, int batch, double* W_out /* N*N */);
 void* hm_iles_device_ptr(hm_iles* p, const char* name /* "E","W","X0" */);
 

@@ -463,7 +463,7 @@ def test_ies_matches_reference_fixtures(golden):
 
     f1, f3, _, kw = _hm(golden)
     f6 = np.load(golden / "f6_iterative.npz")
-    post, stats = ies(f1["gg_E"], lambda x: x, 4 * np.ones(3), f1["gg_perturbs"], 0.5 * np.eye(3))
+    post, stats = ies(f1["gg_E"], lambda x: x, 4 * np.ones(3), f1["gg_perturbs"], 0.5 * np.eye(3), subspace="gram")
     assert len(stats["E"]) == 4 and stats["Eo"][0].shape == (400, 3)
     assert np.abs(post - f6["ies_gg"]).max() < 1e-9
     assert np.allclose(post, f3["gg_postr"])
@@ -551,6 +551,56 @@ def test_device_iles_matches_reference_fixture_and_host_twin(golden):
     for a, b in zip(sd["Eo"], sh["Eo"]):
         assert np.abs(a - b).max() < 1e-9
     assert np.abs(dev - E).max() > 1e-2
+    # the blocked form of the step (the default from N = 256 on: the fixture run above took it) on the small case: same elimination
+    blk, _ = iles(E, fwd, obs, perturbs, decorr, taper, xStep=0.6, iMax=3, blocked=True)
+    assert np.abs(blk - dev).max() < 1e-12
+    one, _ = iles(f1["gg_E"], lambda x: x, 4 * np.ones(3), f1["gg_perturbs"], 0.5 * np.eye(3), taper=np.eye(3), blocked=False)
+    assert np.abs(one - post).max() < 1e-12
+
+
+def test_device_iles_blocked_form_equals_one_workgroup_form():
+    """iles.hip has two forms of the Gauss-Newton step: one workgroup per domain (small ensembles) and, from N = 256 members on, a
+    blocked elimination with partial pivoting over many workgroups per domain (panels of 16 columns, the products on the fp64
+    matrix cores).  Same pivots, same sequence of multiply-adds per element in the elimination: the two agree to rounding of the
+    products -- on an ensemble size that is not a multiple of the panel width, domains with different numbers of observations in
+    range (one with none), partial steps, three iterates; and the re-composition on the matrix cores (domains of >= 16 elements)
+    equals the scalar one."""
+    from historymatching_amd.update import IlesPlan, ies, iles
+    from oracle import es
+
+    rng = np.random.RandomState(23)
+    N, M, n_obs = 301, 90, 21
+    E = rng.randn(N, M)
+    H = rng.randn(M, n_obs) / 9
+    fwd = lambda x: np.tanh(x @ H) + 0.1 * (x @ H) ** 2  # noqa: E731
+    decorr = np.diag(1.0 + rng.rand(n_obs))
+    obs = fwd(E[:1])[0] + 0.3 * rng.randn(n_obs)
+    perturbs = 0.3 * rng.randn(N, n_obs)
+    batches = [np.arange(0, 40), np.arange(40, 45), np.arange(45, 70), np.arange(70, 90)]
+    taper = np.zeros((M, n_obs))
+    for i, b in enumerate(batches):
+        taper[b] = es.bump(rng.rand(n_obs) * (1.1 + 0.3 * i))
+    taper[batches[1]] = 0.0  # a domain without any observation in range
+    a, sa = iles(E, fwd, obs, perturbs, decorr, taper, xStep=0.6, iMax=3, batches=batches, blocked=True)
+    b, sb = iles(E, fwd, obs, perturbs, decorr, taper, xStep=0.6, iMax=3, batches=batches, blocked=False)
+    assert np.abs(a - b).max() < 1e-11 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+    assert np.abs(a[:, 40:45] - E[:, 40:45]).max() < 1e-13 and np.abs(a - E).max() > 1e-2
+    # one step from the identity, weights compared directly
+    plans = []
+    for blocked in (1, 0):
+        plan = IlesPlan(E, batches, np.stack([taper[bb].mean(0) for bb in batches]))
+        plan.set_option("blocked", blocked)
+        Eo = fwd(E) @ decorr
+        plan.step(Eo - Eo.mean(0), (obs - fwd(E) - perturbs) @ decorr, 0.8)
+        plans.append([plan.weights(i) for i in range(len(batches))] + [plan.compose()])
+        plan.close()
+    for x, y in zip(*plans):
+        assert np.abs(x - y).max() < 1e-12 * max(1.0, np.abs(y).max())
+    assert np.array_equal(plans[0][1], np.eye(N))
+    # IES through the one-domain device step at this ensemble size = the host algebra
+    dev, _ = ies(E, fwd, obs, perturbs, decorr, xStep=0.5, iMax=3, subspace="device")
+    host, _ = ies(E, fwd, obs, perturbs, decorr, xStep=0.5, iMax=3, subspace="gram")
+    assert np.abs(dev - host).max() < 1e-10 * max(1.0, np.abs(host).max())
 
 
 def test_device_iles_partitioned_domains():
