@@ -48,7 +48,7 @@ for _ in range(reps):
     ts.append(t1 - t0)
     tc.append(t2 - t1)
 n_loc = int((np.sqrt(taper_b) > 1e-2).sum(1).mean())
-flops = B * (2.0 * N * N * n_loc * 3 + 2.0 / 3 * N ** 3 + 2.0 * N * N * N)  # three products, the LU of W, its solve with N right-hand sides
+flops = B * (2.0 * N * N * n_loc * 3 + 2.0 / 3 * N ** 3 + 2.0 * N * N * n_loc)  # three products, the LU of W, elimination + back substitution of the n_loc right-hand sides
 print(f"ILES device step: N = {N}, state {n} x {n}, {B} domains of {dom} x {dom} cells, {n_obs} observations ({n_loc} in range per domain on average)")
 print(f"   hm_iles_step    {1e3 * min(ts):8.2f} ms  (host call incl. the copy of S, D in; ~{flops / min(ts) / 1e9:.0f} GFLOP/s fp64 of the per-domain algebra)")
 print(f"   hm_iles_compose {1e3 * min(tc):8.2f} ms  (incl. the copy of the {N} x {M} fp64 ensemble out: {N * M * 8 / 1e6:.0f} MB)")
