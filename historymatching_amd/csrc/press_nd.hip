@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(64 * SOL_NW, SOL_OCC) void k_nd_solve(FwdParams p, 
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Nx = p.Nx, Nxy = p.Nxy;
+    const int Nxy = p.Nxy;
     double* P = p.P + (long long)m * Nxy;
     const double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* xe = xe_all[w];
