@@ -885,6 +885,7 @@ static int launch_saturation(hm_fwd* f, int k) {
         if (f->sat_variant != 5) done = launch_saturation_128r(f, Sin, Sout, stride, k);
         if (done < 0) done = launch_saturation_128(f, Sin, Sout, stride, k);
         if (done < 0) done = launch_saturation_128f(f, Sin, Sout, stride, k);  // fp32 twin
+        if (done < 0 && f->sat_variant != 5) done = launch_saturation_256s(f, Sin, Sout, stride, k);  // fp64, grids 256 wide: slabs of 64 rows (workgroup teams), fw in registers
         if (done < 0) done = launch_saturation_128t(f, Sin, Sout, stride, k);  // fp64, grids of 128 x 128 tiles (workgroup teams)
         if (done < 0) done = launch_saturation_128ft(f, Sin, Sout, stride, k); // fp32 twin
     }

@@ -102,3 +102,4 @@ int launch_saturation_128r(hm_fwd* f, const void* S_in, void* S_out, long long S
 int launch_saturation_128f(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // dtype = 32 plans
 int launch_saturation_128t(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // grids of 128 x 128 tiles, fp64
 int launch_saturation_128ft(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // the same, dtype = 32 plans
+int launch_saturation_256s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // grids 256 cells wide, fp64: slabs of 64 rows, fw in registers (sat256s.hip)

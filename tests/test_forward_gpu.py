@@ -426,10 +426,11 @@ def test_cg_solver_reports_non_convergence():
     plan.close()
 
 
-@pytest.mark.parametrize("n,variant", [(20, 1), (128, 1), (128, 0)])
+@pytest.mark.parametrize("n,variant", [(20, 1), (128, 1), (128, 0), (256, 0)])
 def test_general_fluid_parameters_bitexact(n, variant):
     """vw, vo, swc, sor away from the upstream defaults exercise the general RelPerm path (three extra divisions):
-    assembly and saturation sweep stay bit-exact, the pressure solve stays within solver noise."""
+    assembly and saturation sweep stay bit-exact, the pressure solve stays within solver noise.  (256, 0): the slab sweep
+    sat256s.hip in its general-fluid form against the oracle's sweep on the same fluxes."""
     from oracle.ressim import perm_transf, set_perm
 
     om, gm = make_models(n, n)
@@ -627,7 +628,8 @@ def test_streaming_saturation_kernel_bitexact_vs_generic(nx, ny, dtype):
                                                  (256, 256, 3, "default", 32), (384, 256, 2, "edges", 32), (128, 256, 67, "default", 32)])
 def test_multi_tile_saturation_teams_bitexact_vs_tiled(nx, ny, N, wells, dtype):
     """Grids made of 128 x 128 tiles run the saturation sweep as teams of workgroups (sat128t.hip / sat128ft.hip for dtype = 32
-    plans: one workgroup per tile, tile edges exchanged once per sub-step).  Saturations, producer series and sub-step counts are bit-identical to the
+    plans: one workgroup per tile, tile edges exchanged once per sub-step; fp64 grids 256 cells wide by default as slabs of 64 rows
+    with the fractional flow in registers, sat256s.hip: first and last wave of a slab trade one row per sub-step).  Saturations, producer series and sub-step counts are bit-identical to the
     single-workgroup tiled kernel (sat_variant 3).  The default injector sits on a tile corner (its exact fractional flow
     travels in the published edges); "edges" puts wells on every kind of tile border; 67 members = more members than
     teams that fit the chip at once (a second, partial round)."""
@@ -642,7 +644,7 @@ def test_multi_tile_saturation_teams_bitexact_vs_tiled(nx, ny, N, wells, dtype):
         gm.prd_rates = np.ones((4, 1)) / 4
     x = perms(nx, ny, N, seed=37)
     out = {}
-    for sat_variant in (0, 3):
+    for sat_variant in (0, 5, 3):  # 0: the default (fp64 grids 256 wide: slabs, sat256s.hip; else tile teams), 5: tile teams, 3: tiled
         plan = _plan(gm, N, nTime=steps)
         plan.set_variant(0, sat_variant)
         plan.set_inputs(x, transformed=False)
@@ -652,8 +654,9 @@ def test_multi_tile_saturation_teams_bitexact_vs_tiled(nx, ny, N, wells, dtype):
         assert not status.any()
         out[sat_variant] = (w, p, plan.get_field("nts"))
         plan.close()
-    assert np.array_equal(out[0][2], out[3][2]) and out[0][2].min() >= 1
-    assert np.array_equal(out[0][0], out[3][0]) and np.array_equal(out[0][1], out[3][1])
+    for v in (0, 5):
+        assert np.array_equal(out[v][2], out[3][2]) and out[v][2].min() >= 1
+        assert np.array_equal(out[v][0], out[3][0]) and np.array_equal(out[v][1], out[3][1])
     assert out[0][0][:, -1].max() > 0.5  # the front has left the injector
 
 
