@@ -142,10 +142,12 @@ int  hm_fwd_run_to_host(hm_fwd* f, void* wsats_out, void* prods_out, int* status
  *               sweep (fp64: sat128r, fractional flow in registers and scaled fluxes -- 5 names its predecessor sat128 with the
  *               fw image in LDS, which is also what runs when two injectors share a band of 16 rows; fp32: sat128f; all need
  *               uniform porosity and at most one well per 8 x 4 cell patch), else the
- *               tiled sweep from 64 x 64 cells up, the generic one below; grids of 128 x 128 tiles (256^2, 512^2 ...): teams of
- *               workgroups, one per tile (sat128t / sat128ft; a team that gives up waiting for a neighbour -- CUs held by
+ *               tiled sweep from 64 x 64 cells up, the generic one below; fp64 grids 256 cells wide (Nx a multiple of 64:
+ *               256^2): teams of workgroups, one per SLAB of 64 rows, the sweep of sat128r per slab (sat256s; 5 names the tile
+ *               teams below instead); other grids of 128 x 128 tiles (512^2, 256 x 128 ..., and fp32): teams of
+ *               workgroups, one per tile (sat128t / sat128ft); a team that gives up waiting for a neighbour -- CUs held by
  *               someone else -- has its time step redone by the tiled sweep; 4 = take that retry path every step, a test
- *               hook) | pressure 11: two-level CG with the additive preconditioner
+ *               hook | pressure 11: two-level CG with the additive preconditioner
  *               instead of the two-grid cycle */
 int  hm_fwd_set_variant(hm_fwd* f, int pressure_variant, int saturation_variant);
 /* Conjugate-gradient pressure solver (always used when Ny > 128): relative residual target and iteration cap

@@ -9,7 +9,7 @@ from collections import defaultdict
 from pathlib import Path
 
 d, members, Nx, Ny = Path(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-KEYS = ["k_coarse_solve", "k_tg_spmv", "k_tg_update", "k_tg_restrict", "k_tg_correct", "k_tg_postsmooth", "k_tg_direction", "k_sat128t", "k_press128s",
+KEYS = ["k_coarse_solve", "k_tg_spmv", "k_tg_update", "k_tg_restrict", "k_tg_correct", "k_tg_postsmooth", "k_tg_direction", "k_sat128t", "k_sat256s", "k_press128s",
         "k_tl_setup", "k_tl_final"]
 
 
@@ -32,7 +32,7 @@ vec = 8.0 * nxy  # one fp64 cell vector of a member
 alg = {  # algorithmic bytes per member and launch (vector passes of 8 B per cell; the coarse factor: 36 of 64 tiles, two passes)
     "k_coarse_solve": 2 * nxc * 36 * 2048 + 3 * 8.0 * nxc * 128,
     "k_tg_spmv": 4 * vec, "k_tg_update": 7 * vec, "k_tg_restrict": 4 * vec, "k_tg_correct": 2 * vec, "k_tg_postsmooth": 6 * vec,
-    "k_tg_direction": 3 * vec, "k_sat128t": 4 * vec,  # compulsory: S, Vx, Vy in, S out (the edge granules come on top: see DESIGN.md)
+    "k_tg_direction": 3 * vec, "k_sat128t": 4 * vec, "k_sat256s": 4 * vec,  # compulsory: S, Vx, Vy in, S out (the edge granules come on top: see DESIGN.md)
 }
 out = {}
 for k in KEYS:
@@ -42,6 +42,8 @@ for k in KEYS:
         per = members
         if k == "k_sat128t":  # a launch holds one round of teams: at most 8 * (32 / tiles) members
             per = min(members, 8 * (32 // ((Nx // 128) * (Ny // 128))))
+        if k == "k_sat256s":  # teams of Nx / 64 slabs
+            per = min(members, 8 * (32 // (Nx // 64)))
         f, w = f * members / per, w * members / per
         out[k] = {"launches": nf, "members_per_launch": per, "fetch_bytes_raw_per_member": f / members, "write_bytes_per_member": w / members,
                   "hbm_bytes_per_member_raw": (f + w) / members, "hbm_bytes_per_member_fetch_x2": (2 * f + w) / members,
