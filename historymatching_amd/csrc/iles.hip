@@ -369,9 +369,7 @@ __global__ __launch_bounds__(NT) void k_ib_panel(IbArgs a, int kb) {
 #pragma unroll
         for (int c = 0; c < IB_PB; ++c) row[c] = (live && c < pw) ? srcp[c < pw ? c : 0] : 0.0;
     }
-#pragma unroll
-    for (int j = 0; j < IB_PB; ++j) {
-        if (j >= pw) break;
+    for (int j = 0; j < pw; ++j) {  // (not unrolled: the compiler indexes the row registers by j)
         double best = (live && tid >= j) ? fabs(row[j]) : -1.0;
         if (!(best >= 0.0)) best = -1.0;  // NaN: never chosen; a column of NaN ends as "singular" below
         int bi = tid;
