@@ -603,6 +603,37 @@ def test_device_iles_blocked_form_equals_one_workgroup_form():
     assert np.abs(dev - host).max() < 1e-10 * max(1.0, np.abs(host).max())
 
 
+@pytest.mark.parametrize("blocked", [0, 1])
+def test_device_iles_singular_weight_matrix_is_reported_and_left_alone(blocked):
+    """A local domain whose weight matrix has become singular (here: written so by hand through the device pointer) cannot take the
+    Gauss-Newton step (center(W^-1 .) does not exist): the step reports it (error 4, "singular") and leaves that domain's weights as
+    they are, the other domains take their step -- in both forms of the step (one workgroup per domain / blocked elimination)."""
+    import ctypes as C
+
+    from historymatching_amd import _lib
+    from historymatching_amd.update import IlesPlan
+
+    rng = np.random.RandomState(31)
+    N, M, n_obs = 40, 12, 7
+    E = rng.randn(N, M)
+    batches = [np.arange(0, 6), np.arange(6, 12)]
+    plan = IlesPlan(E, batches, np.ones((2, n_obs)), cutoff=0.5)
+    plan.set_option("blocked", blocked)
+    Wbad = np.eye(N)
+    Wbad[5] = 0.0
+    ptr = plan.lib.hm_iles_device_ptr(plan.h, b"W")
+    _lib.check(plan.lib.hm_copy_to_device(plan.ctx.handle, C.c_void_p(ptr + N * N * 8), Wbad.ctypes.data_as(C.c_void_p), Wbad.nbytes), "copy W")
+    S = rng.randn(N, n_obs)
+    S -= S.mean(0)
+    D = rng.randn(N, n_obs)
+    with pytest.raises(_lib.HmError, match="singular"):
+        plan.step(S, D, 0.5)
+    assert np.array_equal(plan.weights(1), Wbad)
+    W0 = plan.weights(0)
+    assert np.isfinite(W0).all() and np.abs(W0 - np.eye(N)).max() > 1e-3
+    plan.close()
+
+
 def test_device_iles_partitioned_domains():
     """The batched form (HistoryMatch.py:802-804, localization.py:95-145): elements of a rectangular domain share one weight
     matrix and the mean of their taper rows.  (a) With a taper that is constant inside every domain the batched run equals the
