@@ -601,6 +601,8 @@ def test_device_iles_blocked_form_equals_one_workgroup_form():
     dev, _ = ies(E, fwd, obs, perturbs, decorr, xStep=0.5, iMax=3, subspace="device")
     host, _ = ies(E, fwd, obs, perturbs, decorr, xStep=0.5, iMax=3, subspace="gram")
     assert np.abs(dev - host).max() < 1e-10 * max(1.0, np.abs(host).max())
+    auto, _ = ies(E, fwd, obs, perturbs, decorr, xStep=0.5, iMax=3)  # the default takes the device step from N = 256 on
+    assert np.array_equal(auto, dev)
 
 
 @pytest.mark.parametrize("blocked", [0, 1])
