@@ -261,7 +261,7 @@ def ies(prior_ens, obs_ens, obs, perturbs, decorr, xStep=1.0, iMax=4, dtype=64, 
     LU solve and an n_obs x n_obs Cholesky factorisation per iterate, fp64; ``"svd"``: the reference's pseudo-inverse + SVD on the host;
     ``"device"``: the same step on the GPU through `IlesPlan` with one domain, weights resident between iterates (from N = 256 members
     on a blocked elimination over the whole device: 8 ms per iterate at N = 1000 against 0.2-0.4 s for the host's LU);
-    ``"auto"`` (default): "device" from N = 256 members on, "gram" below.  The two O(N^2 M) pieces -- centring the prior and
+    ``"auto"`` (default): "device" for 256 <= N <= 1024 members and up to 176 observations, "gram" otherwise.  The two O(N^2 M) pieces -- centring the prior and
     re-composing the ensemble -- and the forward model behind ``obs_ens`` run on the GPU."""
 
     prior_ens = np.asarray(prior_ens, dtype=float)
@@ -271,8 +271,8 @@ def ies(prior_ens, obs_ens, obs, perturbs, decorr, xStep=1.0, iMax=4, dtype=64, 
     Dp = np.asarray(perturbs, float) @ decorr
     W = np.eye(N)
     stats = {"E": [], "Eo": []}
-    if subspace == "auto":
-        subspace = "device" if 256 <= N <= 1024 else "gram"
+    if subspace == "auto":  # (the device step holds the n_obs x n_obs factor in one workgroup's LDS: up to ~190 observations)
+        subspace = "device" if 256 <= N <= 1024 and y.shape[-1] <= 176 else "gram"
     if subspace == "device":
         # The same Gauss-Newton step on the GPU: the localised smoother's device step (hm_iles_step: LU solve with W, n_obs x n_obs
         # Cholesky, the push-through form) with ONE local domain that holds every state element and a taper of ones is this step
