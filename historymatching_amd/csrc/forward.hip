@@ -832,8 +832,13 @@ static int launch_pressure(hm_fwd* f, int k) {
     // in-library cross-check), 9 Jacobi-CG, 7 the 16-wave form of press128s, 12 nested dissection (14: every front eliminated every step), 13 press128s (block elimination,
     // symmetric tiles, 8 waves) also at 128 x 128.  (The first three generations of the 128-wide solver -- rank-1 VALU sweeps, full-tile
     // rank-4 and rank-16 matrix-core panels -- were removed in round 2; their timings are in profiles/README.md.)
+    // 256 x 256 and 512 x 512: nested dissection as well (press_nd256.o / press_nd512.o: the big-front kernels) for variants 0 / 12 / 14;
+    // 15 (and 9, 11) keep the conjugate-gradient solvers there.
     const int pv = f->press_variant;
-    if (pv == 9 || p.Ny > 128) {
+    const bool nd_variant = pv == 0 || pv == 12 || pv == 14;
+    if (nd_variant && pressure_nd_applies256(p)) done = launch_pressure_nd256(f, S, stride, k);
+    else if (nd_variant && pressure_nd_applies512(p)) done = launch_pressure_nd512(f, S, stride, k);
+    else if (pv == 9 || p.Ny > 128) {
         if (f->cg_lazy) {  // CG requested on a small grid: the work vectors were not allocated at creation
             hm_dev_free(f->cg_r); hm_dev_free(f->cg_p);
             int rc2 = hm_dev_alloc(f->cg_r, (size_t)p.N * p.Nxy * 8);
@@ -844,7 +849,7 @@ static int launch_pressure(hm_fwd* f, int k) {
         }
         if (pv != 9 && f->cg_precond == 0 && pressure_two_level_applies(p)) done = launch_pressure_two_level(f, S, stride, k);
         else done = launch_pressure_pcg(f, S, stride, k);
-    } else if ((pv == 0 || pv == 12 || pv == 14) && pressure_nd_applies(p)) done = launch_pressure_nd(f, S, stride, k);  // 128 x 128: nested dissection (14: without reuse across time steps)
+    } else if (nd_variant && pressure_nd_applies(p)) done = launch_pressure_nd(f, S, stride, k);  // 128 x 128: nested dissection (14: without reuse across time steps)
     if (done < 0 && p.Ny <= 128 && pv != 9) {
         if (!f->G.p) {  // every other direct solver keeps its inverse Schur complements
             int rc2 = hm_dev_alloc(f->G, (size_t)p.N * p.Nxy * p.Ny * 8);

@@ -94,6 +94,10 @@ static inline void* fwd_S_ptr(hm_fwd* f, int k, long long* stride) {
 int launch_pressure_128s(hm_fwd* f, const void* S, long long S_stride, int k);  // MFMA panels, symmetric tile storage (default)
 bool pressure_nd_applies(const FwdParams& p);
 int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k);     // nested dissection, 128 x 128 (press_nd.hip)
+bool pressure_nd_applies256(const FwdParams& p);
+int launch_pressure_nd256(hm_fwd* f, const void* S, long long S_stride, int k);  // 256 x 256 (press_nd.hip compiled with -DND_LG=8)
+bool pressure_nd_applies512(const FwdParams& p);
+int launch_pressure_nd512(hm_fwd* f, const void* S, long long S_stride, int k);  // 512 x 512 (-DND_LG=9)
 int launch_pressure_pcg(hm_fwd* f, const void* S, long long S_stride, int k);   // Jacobi-CG, any grid (press_pcg.hip)
 bool pressure_two_level_applies(const FwdParams& p);
 int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int k);  // two-level CG, Ny = 128 c

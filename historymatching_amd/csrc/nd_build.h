@@ -32,18 +32,19 @@ inline void region_cells(std::vector<int>& out, int Ny, int x0, int x1, int y0, 
 }
 
 struct Builder {
-    int Nx, Ny, leaf;
+    int Nx, Ny, leaf, levels;
     std::vector<std::vector<int>> piv, bnd;  // per front id
-    std::vector<int> level, c0, c1, rbox;
+    std::vector<int> level, c0, c1, rbox, rboy;
     bool complete = true;
 
     void dissect(const Region& r, int lv, int idx) {
         const int id = (1 << lv) - 1 + idx;
         if ((int)piv.size() <= id) {
-            piv.resize(id + 1); bnd.resize(id + 1); level.resize(id + 1, -1); c0.resize(id + 1, -1); c1.resize(id + 1, -1); rbox.resize(id + 1, 0);
+            piv.resize(id + 1); bnd.resize(id + 1); level.resize(id + 1, -1); c0.resize(id + 1, -1); c1.resize(id + 1, -1); rbox.resize(id + 1, 0); rboy.resize(id + 1, 0);
         }
         level[id] = lv;
-        rbox[id] = r.x0 | (r.y0 << 8) | (r.x1 << 16) | (r.y1 << 24);
+        rbox[id] = r.x0 | (r.x1 << 16);
+        rboy[id] = r.y0 | (r.y1 << 16);
         std::vector<int>& b = bnd[id];
         if (r.side[0]) region_cells(b, Ny, r.x0 - 1, r.x0, r.y0, r.y1);
         if (r.side[1]) region_cells(b, Ny, r.x1, r.x1 + 1, r.y0, r.y1);
@@ -51,11 +52,11 @@ struct Builder {
         if (r.side[3]) region_cells(b, Ny, r.x0, r.x1, r.y1, r.y1 + 1);
         const int w = r.x1 - r.x0, h = r.y1 - r.y0;
         if (w <= leaf && h <= leaf) {
-            if (lv != ND_LEVELS - 1) complete = false;
+            if (lv != levels - 1) complete = false;
             region_cells(piv[id], Ny, r.x0, r.x1, r.y0, r.y1);
             return;
         }
-        if (lv >= ND_LEVELS - 1) { complete = false; return; }
+        if (lv >= levels - 1) { complete = false; return; }
         Region a = r, c = r;
         if (w >= h) {
             const int xs = r.x0 + (w - 1) / 2;
@@ -79,15 +80,21 @@ struct Builder {
 
 }  // namespace nd_detail
 
-// Returns false (with t.error set) when the grid does not give the complete 11-level tree the kernels are written for.
+// Returns false (with t.error set) when the grid does not give the complete tree the kernels are written for (11 levels at 128 x 128,
+// 13 at 256 x 256, 15 at 512 x 512).
 inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
     using namespace nd_detail;
     Builder B;
     B.Nx = Nx; B.Ny = Ny; B.leaf = 4;
+    int lo = -1;
+    if (Nx == Ny && (Nx == 128 || Nx == 256 || Nx == 512)) lo = Nx == 128 ? 0 : Nx == 256 ? 2 : 4;
+    if (lo < 0) { t.error = "grid does not dissect into the complete tree the kernels are written for (128, 256 or 512 cells a side)"; return false; }
+    const int levels = 11 + lo;
+    B.levels = levels;
     Region root{0, Nx, 0, Ny, {false, false, false, false}};
     B.dissect(root, 0, 0);
-    const int nF = (1 << ND_LEVELS) - 1;
-    if (!B.complete || (int)B.piv.size() != nF) { t.error = "grid does not dissect into the complete 11-level tree"; return false; }
+    const int nF = (1 << levels) - 1;
+    if (!B.complete || (int)B.piv.size() != nF) { t.error = "grid does not dissect into the complete tree"; return false; }
     for (int f = 0; f < nF; ++f)
         if (B.level[f] < 0) { t.error = "missing front"; return false; }
     {  // every cell is a pivot exactly once
@@ -100,9 +107,12 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
     NdInfo& I = t.info;
     I = NdInfo{};
     I.n_fronts = nF;
+    I.levels = levels;
+    I.lo = lo;
+    const int big_top = lo > 0 ? lo + 4 : -1;  // levels 0 .. big_top: big fronts (tile-format updates, no recipes)
     t.fronts.assign((size_t)nF * ND_FRONT_INTS, 0);
     t.cells.clear();
-    long long fact = 0, arena = 0;
+    long long fact = 0, arena = 0, pimg = 0;
     std::vector<int> where((size_t)Nx * Ny, -1);
     for (int f = 0; f < nF; ++f) {
         int* F = &t.fronts[(size_t)f * ND_FRONT_INTS];
@@ -117,18 +127,26 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
         {
             int x0 = Nx, y0 = Ny, x1 = 0, y1 = 0;
             for (int c : B.piv[f]) { x0 = std::min(x0, c / Ny); x1 = std::max(x1, c / Ny + 1); y0 = std::min(y0, c % Ny); y1 = std::max(y1, c % Ny + 1); }
-            F[NDF_PBOX] = x0 | (y0 << 8) | (x1 << 16) | (y1 << 24);
+            F[NDF_PBOX] = x0 | (x1 << 16);
+            F[NDF_PBOY] = y0 | (y1 << 16);
             F[NDF_RBOX] = B.rbox[f];
+            F[NDF_RBOY] = B.rboy[f];
         }
         long long tiles_regs = 0;  // 64-double register rows
         for (int p = 0; p < st; ++p) tiles_regs += (long long)(T - p - 1) * (p == st - 1 ? F[NDF_KREG] : 4);
-        if (lv < ND_LEVELS - 1) fact += tiles_regs * 64;  // (the leaves keep no factor: k_nd_leaf_solve eliminates them again)
-        if ((lv <= ND_ARENA_MAX_LEVEL && lv > 0) || lv == ND_LEVELS - 1) {  // leaves: their updates go from k_nd_leaf to k_nd_sub through the arena
+        if (lv < levels - 1) fact += tiles_regs * 64;  // (the leaves keep no factor: k_nd_leaf_solve eliminates them again)
+        if (fact > 0x7fffffffLL) { t.error = "factor offset exceeds int32"; return false; }
+        F[NDF_PIMG] = -1;
+        if (lv <= big_top) { F[NDF_PIMG] = (int)pimg; pimg += (long long)st * 256; }
+        if (lv == big_top) I.big_fact_doubles = fact;  // (fronts are numbered level by level: the last front of level big_top sets it last)
+        long long upd_n = ((long long)(b + 1) * (b + 2) / 2 + 1) & ~1LL;
+        if (lv <= big_top) upd_n = (long long)bt * (bt + 1) / 2 * 256;  // whole tiles (nd.h)
+        if ((lv - lo <= ND_ARENA_MAX_LEVEL && lv > 0) || lv == levels - 1) {  // leaves: their updates go from k_nd_leaf to k_nd_sub through the arena
             F[NDF_UPD] = (int)arena;
-            long long n = (long long)(b + 1) * (b + 2) / 2;
-            arena += (n + 1) & ~1LL;
+            arena += upd_n;
+            if (arena > 0x7fffffffLL) { t.error = "arena offset exceeds int32"; return false; }
         } else F[NDF_UPD] = -1;
-        I.upd_doubles[lv] = std::max(I.upd_doubles[lv], ((b + 1) * (b + 2) / 2 + 1) & ~1);
+        I.upd_doubles[lv] = std::max(I.upd_doubles[lv], (int)upd_n);
         I.max_bt[lv] = std::max(I.max_bt[lv], bt);
         I.max_st[lv] = std::max(I.max_st[lv], st);
         t.cells.resize(t.cells.size() + (size_t)16 * T, -1);
@@ -140,6 +158,7 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
     I.n_cells = (int)t.cells.size();
     I.fact_doubles = fact;
     I.arena_doubles = arena;
+    I.pimg_doubles = pimg;
     t.cpos.assign((size_t)2 * t.cells.size(), (short)-1);
     for (int f = 0; f < nF; ++f) {
         int* F = &t.fronts[(size_t)f * ND_FRONT_INTS];
@@ -166,21 +185,9 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
     // ---- assembly recipes (nd.h)
     t.rec.clear();
     auto tri = [](int a, int c) { const int hi = a > c ? a : c, lo = a > c ? c : a; return hi * (hi + 1) / 2 + lo; };
-    auto coef_global = [&](int cm, int ck, bool same_pos) -> int {  // index into [dg | -TX | -TY | q], -1 zero, -2 identity
+    auto coef_local = [&](int cm, int ck, bool same_pos, int box, int boy, int plane) -> int {  // offset into the staged LDS planes
         if (ck < 0) return same_pos ? -2 : -1;
-        if (cm == -2) return ND_CF_OQ + ck;
-        if (cm < 0) return -1;
-        const int d = cm - ck;
-        if (d == 0) return ck;
-        if (d == Ny) return ND_CF_OX + ck + Ny;
-        if (d == -Ny) return ND_CF_OX + ck;
-        if (d == 1 && ck % Ny != Ny - 1) return ND_CF_OY + ck + ck / Ny + 1;
-        if (d == -1 && ck % Ny != 0) return ND_CF_OY + ck + ck / Ny;
-        return -1;
-    };
-    auto coef_local = [&](int cm, int ck, bool same_pos, int box, int plane) -> int {  // offset into the staged LDS planes
-        if (ck < 0) return same_pos ? -2 : -1;
-        const int x0 = box & 255, y0 = (box >> 8) & 255, y1 = (box >> 24) & 255, ld = y1 - y0 + 2;
+        const int x0 = box & 0xffff, y0 = boy & 0xffff, y1 = boy >> 16, ld = y1 - y0 + 2;
         const int li = (ck / Ny - x0 + 1) * ld + (ck % Ny - y0 + 1);
         if (cm == -2) return 3 * plane + li;
         if (cm < 0) return -1;
@@ -194,12 +201,12 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
     };
     for (int f = 0; f < nF; ++f) {
         int* F = &t.fronts[(size_t)f * ND_FRONT_INTS];
-        const int lv = F[NDF_LEVEL], b = F[NDF_B], st = F[NDF_ST], bt = F[NDF_BT], T = st + bt;
+        const int lv = F[NDF_LEVEL] - lo, b = F[NDF_B], st = F[NDF_ST], bt = F[NDF_BT], T = st + bt;  // lv: the level in the 128 x 128 tree's numbering
         const int* C = &t.cells[F[NDF_CELLS]];
         const short* P0 = &t.cpos[(size_t)2 * F[NDF_CELLS]];
         const short* P1 = P0 + 16 * T;
         const bool kids = F[NDF_C0] >= 0;
-        F[NDF_REC] = (int)(t.rec.size() / 256);
+        F[NDF_REC] = lv >= 5 ? (int)(t.rec.size() / 256) : -1;
         auto block = [&]() -> size_t { t.rec.resize(t.rec.size() + 256, (short)-1); return t.rec.size() - 256; };
         // (levels >= 5: `base` >= 0 makes the entry a BYTE offset into the wave's LDS block, nd.h, with "none" -> the zero cell)
         auto gather_block = [&](const short* P, int rowpos0, int colpos0, int base = -1) {
@@ -224,25 +231,26 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
                 }
         };
         if (lv >= 5) {
-            int box = F[NDF_PBOX], plane = ND_CF_PLANE_WAVE;
+            int box = F[NDF_PBOX], boy = F[NDF_PBOY], plane = ND_CF_PLANE_WAVE;
             // the wave's LDS block (nd.h): where the children's updates and the coefficient planes lie
             int c0base, c1base, cfbase;
             if (lv >= 8) {
-                const int idx = f - ((1 << lv) - 1), f8 = 255 + (idx >> (lv - 8));
+                const int idx = f - ((1 << (lv + lo)) - 1), f8 = (1 << (8 + lo)) - 1 + (idx >> (lv - 8));
                 box = t.fronts[(size_t)f8 * ND_FRONT_INTS + NDF_RBOX];
+                boy = t.fronts[(size_t)f8 * ND_FRONT_INTS + NDF_RBOY];
                 plane = ND_CF_PLANE_SUB;
-                const int s9 = I.upd_doubles[9], s10 = I.upd_doubles[10];
+                const int s9 = I.upd_doubles[9 + lo], s10 = I.upd_doubles[10 + lo];
                 c0base = lv == 8 ? ND_LDS_DATA : ND_LDS_DATA + 2 * s9;            // level 8 reads the level-9 slots, level 9 the level-10 slots
                 c1base = c0base + (lv == 8 ? s9 : s10);
                 cfbase = ND_LDS_DATA + 2 * (s9 + s10);
             } else {
-                const int chd = I.upd_doubles[lv + 1];
+                const int chd = I.upd_doubles[lv + lo + 1];
                 c0base = ND_LDS_DATA;
                 c1base = ND_LDS_DATA + chd;
                 cfbase = ND_LDS_DATA + 2 * chd;
             }
             {   // the staged planes must hold the box plus its ring
-                const int x0 = box & 255, y0 = (box >> 8) & 255, x1 = (box >> 16) & 255, y1 = (box >> 24) & 255;
+                const int x0 = box & 0xffff, y0 = boy & 0xffff, x1 = box >> 16, y1 = boy >> 16;
                 if ((x1 - x0 + 2) * (y1 - y0 + 2) > plane) { t.error = "coefficient box larger than its LDS plane"; return false; }
             }
             for (int R = 0; R <= bt; ++R) {
@@ -250,7 +258,7 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
                 for (int lane = 0; lane < 64; ++lane)
                     for (int r = 0; r < 4; ++r) {
                         const int k = 4 * r + (lane >> 4), m = 16 * R + (lane & 15);
-                        const int v = coef_local(C[m], C[k], k == m, box, plane);
+                        const int v = coef_local(C[m], C[k], k == m, box, boy, plane);
                         const int off = 8 * (v >= 0 ? cfbase + v : (v == -2 ? ND_LDS_ONE : ND_LDS_ZERO));
                         if (off > 32767) { t.error = "recipe offset exceeds int16"; return false; }
                         B[lane * 4 + r] = (short)off;
@@ -268,27 +276,6 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
                     }
                     out_block(R - 1, Cc - 1);
                 }
-        } else {
-            for (int q = 0; q < st; ++q)
-                for (int R = q; R < T; ++R) {
-                    const size_t lo_at = block();
-                    block();
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int r = 0; r < 4; ++r) {
-                            const int k = 16 * q + 4 * r + (lane >> 4), m = 16 * R + (lane & 15);
-                            const int v = coef_global(C[m], C[k], k == m);
-                            memcpy(&t.rec[lo_at + 2 * (lane * 4 + r)], &v, 4);  // 256 int32 over the two blocks, entry [lane][r]
-                        }
-                    gather_block(P0, 16 * q, 16 * R);
-                    gather_block(P1, 16 * q, 16 * R);
-                }
-            if (b > 0)
-                for (int R = 0; R < bt; ++R)
-                    for (int Cc = 0; Cc <= R; ++Cc) {
-                        gather_block(P0, 16 * (st + R), 16 * (st + Cc));
-                        gather_block(P1, 16 * (st + R), 16 * (st + Cc));
-                        out_block(R, Cc);
-                    }
         }
     }
     if (!t.error.empty()) return false;

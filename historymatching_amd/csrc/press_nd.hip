@@ -39,9 +39,21 @@ __device__ long long hm_nd_prof_buf[64];
 #define NPROF(i)
 #endif
 
+// One source, three objects: -DND_LG=7 (128 x 128, the default object press_nd.o), 8 (256 x 256, press_nd256.o), 9 (512 x 512,
+// press_nd512.o).  Every grid constant below follows from it, so the 128 x 128 object compiles to what it was.
+#ifndef ND_LG
+#define ND_LG 7
+#endif
+
 namespace {
 
-constexpr int NB = 128;
+constexpr int LG = ND_LG;
+constexpr int NB = 1 << LG;        // cells a side
+constexpr int LO = 2 * (LG - 7);   // levels above the 128 x 128 tree's (nd.h)
+constexpr int ND_LEVELS = 11 + LO;
+// first front id of the level that is level `l` of the 128 x 128 tree
+__host__ __device__ constexpr int FID(int l) { return (1 << (l + LO)) - 1; }
+constexpr int NF8 = 256 << LO, NF7 = 128 << LO, NF6 = 64 << LO, NF5 = 32 << LO;  // fronts of levels 8, 7, 6, 5 (128 x 128 numbering)
 
 struct NdDev {
     const int* fronts;
@@ -57,12 +69,19 @@ struct NdDev {
     int top_child_doubles;  // largest child update of a level <= 4 front
     // Reuse across time steps (k_nd_plan): per member the fronts of levels 8..5 that have to be eliminated this step, compacted
     int* work;                   // N x ND_WORK_INTS: [n8, n7, n6, n5 | list8[256] | list7[128] | list6[64] | list5[32] | nt, fronts of levels 4..0]
+                                 // (larger grids: ONE list of every front, shared by all members -- nothing is kept across time steps there)
     unsigned char* cached;       // N x 512: front f (levels 0..8: f = 0..510) holds the results of its all-dry state
     const unsigned char* wells;  // 512: a well somewhere in the front's subtree (its right-hand side rows carry the rates)
     int wells_ok;                // the rates of this time step are those the cached results of such fronts were computed with
     int reuse;                   // 0: every front is eliminated every step
+    // big fronts (levels 0 .. LO + 4 of the larger grids)
+    double* vfac;                // per member: the negated pivot-panel tiles V(p, R) at the factor's offsets (operands of the trailing products)
+    double* pimg;                // per member: the negated inverse pivot tiles, NDF_PIMG + 256 p
+    long long vfac_stride, pimg_stride;
 };
-constexpr int ND_WORK_INTS = 576, ND_W8 = 4, ND_W7 = ND_W8 + 256, ND_W6 = ND_W7 + 128, ND_W5 = ND_W6 + 64, ND_WT = ND_W5 + 32;  // ND_WT: n, then the fronts of levels 4..0 in order
+constexpr int ND_W8 = 4, ND_W7 = ND_W8 + NF8, ND_W6 = ND_W7 + NF7, ND_W5 = ND_W6 + NF6, ND_WT = ND_W5 + NF5;  // ND_WT: n, then the fronts of levels 4..0 in order
+constexpr int ND_WORK_INTS = ND_WT + 64;
+__device__ __forceinline__ const int* nd_work(const NdDev& nd, int m) { return nd.work + (LG == 7 ? (long long)m * ND_WORK_INTS : 0LL); }
 
 struct NdGeo {
     int lane, lc, lq;
@@ -86,8 +105,8 @@ __device__ __forceinline__ double nd_coef_global(const double* __restrict__ cf, 
     off = (cell && d == 0) ? ck : off;
     off = (cell && d == NB) ? CF_OX + ck + NB : off;
     off = (cell && d == -NB) ? CF_OX + ck : off;
-    off = (cell && d == 1) ? CF_OY + ck + (ck >> 7) + 1 : off;
-    off = (cell && d == -1) ? CF_OY + ck + (ck >> 7) : off;
+    off = (cell && d == 1) ? CF_OY + ck + (ck >> LG) + 1 : off;
+    off = (cell && d == -1) ? CF_OY + ck + (ck >> LG) : off;
     off = (ck >= 0 && cm == -2) ? CF_OQ + ck : off;
     const double l = cf[off >= 0 ? off : 0];
     return l * (off >= 0 ? 1.0 : 0.0) + ((ck < 0 && same_pos) ? 1.0 : 0.0);  // padded pivot: identity
@@ -100,8 +119,17 @@ struct NdCfl {
     const double* p;  // LDS
     int plane, ld, x0, y0;
 };
-__device__ __forceinline__ void nd_stage_cf(const double* __restrict__ cf, double* cfl, int plane, int box, int lane, NdCfl& out) {
-    const int x0 = box & 255, y0 = (box >> 8) & 255, x1 = (box >> 16) & 255, y1 = (box >> 24) & 255;
+// a front record's pivot box (slot NDF_PBOX) or region (NDF_RBOX): x range in the slot, y range five slots on (nd.h)
+struct NdBox {
+    int x0, x1, y0, y1;
+};
+__device__ __host__ __forceinline__ NdBox nd_box(const int* F, int slot) {
+    const int bx = F[slot], by = F[slot + (NDF_PBOY - NDF_PBOX)];
+    return NdBox{bx & 0xffff, bx >> 16, by & 0xffff, by >> 16};
+}
+static_assert(NDF_RBOY - NDF_RBOX == NDF_PBOY - NDF_PBOX, "box slots");
+__device__ __forceinline__ void nd_stage_cf(const double* __restrict__ cf, double* cfl, int plane, const NdBox& box, int lane, NdCfl& out) {
+    const int x0 = box.x0, y0 = box.y0, x1 = box.x1, y1 = box.y1;
     const int ld = y1 - y0 + 2, n = (x1 - x0 + 2) * ld;
     for (int i = lane; i < n; i += 64) {
         const int lx = i / ld, ly = i - lx * ld;
@@ -123,7 +151,7 @@ __device__ __forceinline__ void nd_stage_cf(const double* __restrict__ cf, doubl
 // (index arithmetic only and the loaded value used unconditionally: with `if`s the lanes of a wave take up to six divergent paths,
 // each with its own LDS round trip; with a select around the load the compiler sinks the load into a branch and waits there)
 __device__ __forceinline__ double nd_coef_lds(const NdCfl& L, int cm, int ck, bool same_pos) {
-    const int li = ((ck >> 7) - L.x0 + 1) * L.ld + ((ck & 127) - L.y0 + 1);
+    const int li = ((ck >> LG) - L.x0 + 1) * L.ld + ((ck & (NB - 1)) - L.y0 + 1);
     const int d = cm - ck;
     const bool cell = ck >= 0 && cm >= 0;
     int off = -1;
@@ -297,6 +325,7 @@ __device__ __forceinline__ void nd_wave_front(int bt, int kreg, const NdPanelRec
 // wet-cell bitmap the first loop collects by ballots: 0.36 + 0.06 -> 0.24 ms for 1000 members.  Anisotropic K: 1 / (mobility K) through
 // memory as on the other grids (fwd_dev.h), the plan as a launch of its own.
 // ------------------------------------------------------------------------------------------------------------------------
+#if ND_LG == 7
 __device__ __forceinline__ void nd_plan_body(const NdDev& nd, int m, int t, const unsigned long long (*wet)[2], unsigned char* dry, int* wcount);  // below
 
 template <typename TS>
@@ -381,8 +410,8 @@ __global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, con
 __device__ __forceinline__ void nd_plan_body(const NdDev& nd, int m, int t, const unsigned long long (*wet)[2], unsigned char* dry, int* wcount) {
     int* work = nd.work + (long long)m * ND_WORK_INTS;
     unsigned char* cached = nd.cached + (long long)m * 512;
-    auto box_dry = [&](int box) {
-        const int x0 = max((box & 255) - 1, 0), y0 = max(((box >> 8) & 255) - 1, 0), x1 = min(((box >> 16) & 255) + 1, NB), y1 = min(((box >> 24) & 255) + 1, NB);
+    auto box_dry = [&](const NdBox& box) {
+        const int x0 = max(box.x0 - 1, 0), y0 = max(box.y0 - 1, 0), x1 = min(box.x1 + 1, NB), y1 = min(box.y1 + 1, NB);
         // bits [y0, y1) of a 128-bit row
         const unsigned long long lo = y0 < 64 ? (~0ull << y0) & (y1 >= 64 ? ~0ull : ~(~0ull << y1)) : 0ull;
         const unsigned long long hi = y1 > 64 ? (y0 > 64 ? ~0ull << (y0 - 64) : ~0ull) & (y1 == 128 ? ~0ull : ~(~0ull << (y1 - 64))) : 0ull;
@@ -393,12 +422,12 @@ __device__ __forceinline__ void nd_plan_body(const NdDev& nd, int m, int t, cons
     // level 8: the subtree's region; levels 7..5: the separator, and both children
     if (t < 256) {
         const int f = 255 + t;
-        dry[f] = nd.reuse && box_dry(nd.fronts[f * ND_FRONT_INTS + NDF_RBOX]);
+        dry[f] = nd.reuse && box_dry(nd_box(nd.fronts + f * ND_FRONT_INTS, NDF_RBOX));
     }
     __syncthreads();
     for (int lv = 7; lv >= 0; --lv) {
         const int nf = 1 << lv, f = nf - 1 + t;
-        if (t < nf) dry[f] = dry[2 * f + 1] && dry[2 * f + 2] && box_dry(nd.fronts[f * ND_FRONT_INTS + NDF_PBOX]);
+        if (t < nf) dry[f] = dry[2 * f + 1] && dry[2 * f + 2] && box_dry(nd_box(nd.fronts + f * ND_FRONT_INTS, NDF_PBOX));
         __syncthreads();
     }
     // skip = dry and cached; what is computed now is the state of the cache afterwards
@@ -451,6 +480,47 @@ __global__ __launch_bounds__(256) void k_nd_plan(FwdParams p, NdDev nd, const TS
     nd_plan_body(nd, m, t, wet, dry, wcount);
 }
 
+#else  // ND_LG > 7
+// TX, TY (bit-exact: the expressions of fwd_dev.h / the kernel above, operand for operand) and the coefficient block of the larger
+// grids: one thread per cell, one workgroup per grid row, 1 / (mobility K) of the cell and its four neighbours recomputed on the fly
+// (five divisions per cell instead of a 0.5 / 2 MB image per member that no LDS holds).  A cell writes its west and south faces; the
+// last row / column also the zero boundary faces behind them.
+template <typename TS>
+__global__ __launch_bounds__(NB) void k_ndl_assemble(FwdParams p, NdDev nd, const TS* __restrict__ S_base, long long S_stride, int k) {
+    const int m = blockIdx.x % p.N, ix = blockIdx.x / p.N, iy = threadIdx.x;
+    const int Nx = p.Nx, Nxy = p.Nxy;
+    const TS* S = S_base + (long long)m * S_stride;
+    const double* Km = p.K + (long long)m * Nxy;
+    const double* Kym = p.Ky ? p.Ky + (long long)m * Nxy : Km;
+    double* TX = p.TX + (long long)m * (Nx + 1) * NB;
+    double* TY = p.TY + (long long)m * Nx * (NB + 1);
+    double* cf = nd.cf + (long long)m * CF_STRIDE;
+    const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+    const int c = ix * NB + iy;
+    auto linv = [&](int cell, const double* Kf) {  // 1 / (mobility K): the expression of assemble_transmissibilities (fwd_dev.h)
+        double mw, mo;
+        rel_perm<double>(p, (double)S[cell], mw, mo);
+        return 1.0 / ((mw + mo) * Kf[cell]);
+    };
+    const double lxc = linv(c, Km), lyc = Kym == Km ? lxc : linv(c, Kym);
+    const double lw = ix > 0 ? linv(c - NB, Km) : 0.0, le = ix < Nx - 1 ? linv(c + NB, Km) : 0.0;
+    const double ls = iy > 0 ? linv(c - 1, Kym) : 0.0, ln = iy < NB - 1 ? linv(c + 1, Kym) : 0.0;
+    const double tx0 = ix == 0 ? 0.0 : p.cx / (lw + lxc), tx1 = ix == Nx - 1 ? 0.0 : p.cx / (lxc + le);
+    const double ty0 = iy == 0 ? 0.0 : p.cy / (ls + lyc), ty1 = iy == NB - 1 ? 0.0 : p.cy / (lyc + ln);
+    TX[c] = tx0;
+    cf[CF_OX + c] = -tx0;
+    if (ix == Nx - 1) { TX[c + NB] = 0.0; cf[CF_OX + c + NB] = -0.0; }
+    const int fy = ix * (NB + 1) + iy;
+    TY[fy] = ty0;
+    cf[CF_OY + fy] = -ty0;
+    if (iy == NB - 1) { TY[fy + 1] = 0.0; cf[CF_OY + fy + 1] = -0.0; }
+    double d = ty0 + ty1 + tx0 + tx1;
+    if (c == 0) d += Km[0] + Kym[0];  // SPD pin: A[0,0] += Kx[0,0] + Ky[0,0]
+    cf[c] = d;
+    cf[CF_OQ + c] = q[c];
+}
+#endif  // ND_LG
+
 // ------------------------------------------------------------------------------------------------------------------------
 // The leaves (level 10: 3 x 3 .. 4 x 4 cells, at most 12 boundary cells), ONE LANE PER LEAF.  A leaf's pivot block is the five-point
 // matrix of a tiny grid -- banded, bandwidth 4 in the padded 4 x 4 ordering i = 4 lx + ly -- and every boundary cell touches exactly one
@@ -469,8 +539,8 @@ struct NdLeaf {
 
 // band + factorisation of leaf front `f` (per lane); returns false for a non-positive pivot
 __device__ __forceinline__ bool nd_leaf_factor(NdLeaf& Lf, const NdDev& nd, const double* __restrict__ cf, int f) {
-    const int box = nd.fronts[f * ND_FRONT_INTS + NDF_RBOX];
-    const int x0 = box & 255, y0 = (box >> 8) & 255, w = ((box >> 16) & 255) - x0, h = ((box >> 24) & 255) - y0;
+    const NdBox box = nd_box(nd.fronts + f * ND_FRONT_INTS, NDF_RBOX);
+    const int x0 = box.x0, y0 = box.y0, w = box.x1 - x0, h = box.y1 - y0;
     double d[16], e1[16], e4[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -478,7 +548,7 @@ __device__ __forceinline__ bool nd_leaf_factor(NdLeaf& Lf, const NdDev& nd, cons
         const bool alive = lx < w && ly < h;
         const int c = alive ? (x0 + lx) * NB + y0 + ly : 0;
         Lf.cell[i] = alive ? c : -1;
-        const double dg = cf[c], tn = cf[CF_OY + c + (c >> 7) + 1], te = cf[CF_OX + c + NB];
+        const double dg = cf[c], tn = cf[CF_OY + c + (c >> LG) + 1], te = cf[CF_OX + c + NB];
         d[i] = alive ? dg : 1.0;
         e1[i] = (alive && ly + 1 < h) ? tn : 0.0;   // A[i+1][i]: the north face (cf holds -TY)
         e4[i] = (alive && lx + 1 < w) ? te : 0.0;   // A[i+4][i]: the east face (cf holds -TX)
@@ -528,11 +598,12 @@ __device__ __forceinline__ void nd_leaf_solve(const NdLeaf& Lf, double (&v)[16])
 // boundary entry j of the leaf: the local cell it touches and the coefficient A[boundary cell, that cell] (0: no such entry)
 __device__ __forceinline__ void nd_leaf_boundary(const NdDev& nd, const double* __restrict__ cf, int f, int j, int& il, double& t, int& bcell) {
     const int* F = nd.fronts + f * ND_FRONT_INTS;
-    const int box = F[NDF_RBOX], b = F[NDF_B];
-    const int x0 = box & 255, y0 = (box >> 8) & 255, x1 = (box >> 16) & 255, y1 = (box >> 24) & 255;
+    const NdBox box = nd_box(F, NDF_RBOX);
+    const int b = F[NDF_B];
+    const int x0 = box.x0, y0 = box.y0, x1 = box.x1, y1 = box.y1;
     const bool on = j < b;
     const int c = on ? nd.cells[F[NDF_CELLS] + 16 + j] : 0;
-    const int bx = c >> 7, by = c & 127;
+    const int bx = c >> LG, by = c & (NB - 1);
     // the one region cell next to it, and the face between them
     int ix = bx, iy = by, fidx;
     if (bx < x0) { ix = x0; fidx = CF_OX + ix * NB + iy; }                 // west side: the cell's west face
@@ -550,10 +621,10 @@ __global__ __launch_bounds__(256, 2) void k_nd_leaf(FwdParams p, NdDev nd, int k
     const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // the leaves of the level-8 subtrees that are eliminated this step (k_nd_plan's list), four lanes per subtree
-    const int* work = nd.work + (long long)m * ND_WORK_INTS;
+    const int* work = nd_work(nd, m);
     const int e = (bidx * 256 + tid) >> 2;
     if (e >= work[0]) return;  // (no workgroup barrier below)
-    const int f = 1023 + 4 * work[ND_W8 + e] + (tid & 3);
+    const int f = FID(10) + 4 * work[ND_W8 + e] + (tid & 3);
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* out = nd.arena + (long long)m * nd.arena_stride + nd.fronts[f * ND_FRONT_INTS + NDF_UPD];
     const int b = nd.fronts[f * ND_FRONT_INTS + NDF_B];
@@ -599,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void k_nd_leaf(FwdParams p, NdDev nd, int k
 // The last step of the back substitution: the leaves' own cells, with every separator pressure known.
 __global__ __launch_bounds__(256) void k_nd_leaf_solve(FwdParams p, NdDev nd, int k) {
     const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;
-    const int f = 1023 + bidx * 256 + threadIdx.x;
+    const int f = FID(10) + bidx * 256 + threadIdx.x;
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* P = p.P + (long long)m * p.Nxy;
     NdLeaf Lf;
@@ -647,7 +718,7 @@ __global__ __launch_bounds__(64 * SUB_WPB) void k_nd_sub(FwdParams p, NdDev nd, 
     const int mgroups = (p.N + SUB_WPB - 1) / SUB_WPB;
     const int m = SUB_WPB * (blockIdx.x % mgroups) + w, e8 = blockIdx.x / mgroups;
     if (m >= p.N) return;  // (no workgroup barrier below)
-    const int* work = nd.work + (long long)m * ND_WORK_INTS;
+    const int* work = nd_work(nd, m);
     if (e8 >= __builtin_amdgcn_readfirstlane(work[0])) return;  // the member's subtrees that are eliminated this step: k_nd_plan's list
     const int i8 = __builtin_amdgcn_readfirstlane(work[ND_W8 + e8]);
     double* blk = nd_lds + w * nd_sub_lds_doubles(nd);  // the wave's LDS block (nd.h): the recipes' offsets refer to it
@@ -658,7 +729,7 @@ __global__ __launch_bounds__(64 * SUB_WPB) void k_nd_sub(FwdParams p, NdDev nd, 
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* arena = nd.arena + (long long)m * nd.arena_stride;
-    const int f8 = 255 + i8, f9 = 511 + 2 * i8, f10 = 1023 + 4 * i8;
+    const int f8 = FID(8) + i8, f9 = FID(9) + 2 * i8, f10 = FID(10) + 4 * i8;
     int bad = 0;
     NPROF_DECL;
     const int* F8 = nd.fronts + f8 * ND_FRONT_INTS;
@@ -685,7 +756,7 @@ __global__ __launch_bounds__(64 * SUB_WPB) void k_nd_sub(FwdParams p, NdDev nd, 
     double2 lf0 = leaf_d2(0), lf1 = leaf_d2(1), lf2 = leaf_d2(2), lf3 = leaf_d2(3);
     nd_panel_rec_load(pp, recp(F9[0]), btof(F9[0]), g.lane);
     NdCfl L;
-    nd_stage_cf(cf, cfl, SUB_CF_PLANE, F8[NDF_RBOX], g.lane, L);
+    nd_stage_cf(cf, cfl, SUB_CF_PLANE, nd_box(F8, NDF_RBOX), g.lane, L);
     {
         double2* a2 = reinterpret_cast<double2*>(s10);
         double2* b2 = reinterpret_cast<double2*>(s10 + nd.slot10);
@@ -725,7 +796,7 @@ constexpr int WAVE_CF_PLANE = ND_CF_PLANE_WAVE;
 template <int LEVEL, int MAXBT, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int k) {
     extern __shared__ double nd_lds[];
-    constexpr int NF = 1 << LEVEL;
+    constexpr int NF = 1 << (LEVEL + LO);
     const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;
     const int tid = threadIdx.x;
     NdGeo g;
@@ -742,7 +813,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* arena = nd.arena + (long long)m * nd.arena_stride;
-    const int* work = nd.work + (long long)m * ND_WORK_INTS;
+    const int* work = nd_work(nd, m);
     const int e = bidx * WPB + w;
     if (e >= __builtin_amdgcn_readfirstlane(work[8 - LEVEL])) return;  // the level's fronts that are eliminated this step (k_nd_plan); no workgroup barrier below
     const int f = NF - 1 + __builtin_amdgcn_readfirstlane(work[(LEVEL == 7 ? ND_W7 : LEVEL == 6 ? ND_W6 : ND_W5) + e]);
@@ -756,7 +827,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     nd_wave_copy(c0l, arena + F[NDF_UC0], n0, g.lane);
     nd_wave_copy(c1l, arena + F[NDF_UC1], n1, g.lane);
     NdCfl L;
-    nd_stage_cf(cf, cfl, WAVE_CF_PLANE, F[NDF_PBOX], g.lane, L);
+    nd_stage_cf(cf, cfl, WAVE_CF_PLANE, nd_box(F, NDF_PBOX), g.lane, L);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA pieces have landed
     nd_wave_fence();
     int bad = 0;
@@ -774,7 +845,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
 // as register images (lane-major, conflict-free 8-byte reads) and store the factor;  every later tile is updated with
 // Y^T Z products of two published images.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int TOP_NW = 16, TOP_NVS = 3, TOP_NTS = 4, TOP_MAXT = 13;
+constexpr int TOP_NW = 16, TOP_NVS = 3, TOP_NTS = 4, TOP_MAXT = LG == 7 ? 13 : (LG == 8 ? 25 : 49);  // (larger grids: TOP_MAXT sizes the back substitution only)
 
 // A child's packed update matrix (n2 double2), arena -> LDS, by the whole workgroup through LDS-DMA (global_load_lds_dwordx4: no
 // registers, every piece in flight at once, retired by the issuing wave's vmcnt): pieces of 64 double2 = 1 KB, wave w takes pieces
@@ -804,6 +875,7 @@ __device__ __forceinline__ void img_store(double* img, int lane, const d4& v) {
     for (int r = 0; r < 4; ++r) img[r * 64 + lane] = v[r];
 }
 
+#if ND_LG == 7
 __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, int k) {
     extern __shared__ double nd_lds[];
     double* Pimg = nd_lds;                       // 256
@@ -1067,6 +1139,255 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
+#else  // ND_LG > 7
+// ------------------------------------------------------------------------------------------------------------------------
+// The BIG fronts of the larger grids (levels 0 .. LO + 4: up to 25 tile rows at 256 x 256, 49 at 512 x 512 -- 0.65 / 2.5 MB a front,
+// more than a CU's register file).  Same elimination as k_nd_top -- same tiles, same products, same order of additions per tile --
+// but LEFT-LOOKING out of global memory, one WAVE per task, no synchronisation inside a launch:
+//   pivot tile columns are taken in blocks of BIG_PB.  A tile (q, R) of block g (transposed panel tile: pivots of tile column q x front
+//   rows of tile row R) is assembled -- coefficients + the children's update matrices gathered through the position tables -- and
+//   takes the updates of every earlier block at once, V(q, R) += V(p, q)^T W(p, R)^T for p < g BIG_PB, straight from the stored
+//   panels:  `fact` holds +W^T (the factor rows the back substitution reads), `vfac` the NEGATED panel tiles -V(p, R) at the same
+//   offsets, so that (-V)(−Wn) = V Wn is the product of two stored images.
+//     k_big_diag   one wave per front: the block's own BIG_PB x BIG_PB tiles; in-wave inverses of its pivot tiles (-> `pimg`), its
+//                  off-diagonal tiles eliminated in registers
+//     k_big_rows   one wave per row tile R below the block: W(p, R)^T = P(p) V(p, R) for the block's pivot tiles in turn, the later
+//                  tiles of the row updated with the diagonal block's stored tiles
+//     k_big_trail  one wave per 2 x 2 block of trailing tiles: children's updates gathered + the sum over ALL pivot tile columns, written
+//                  as whole tiles (nd.h) for the parent's gathers
+// A launch covers every front of a level and every member; levels run leaves-to-root.  Each tile is assembled, written and read
+// once; what a front costs in memory traffic is its factor (written once, read by the later blocks and the trailing products).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int BIG_PB = 4;
+
+struct BigFront {  // wave-uniform
+    int b, st, bt, T;
+    const int* cl;         // position -> cell
+    const short* cp[2];    // position -> position in child c's boundary list
+    const double* ch[2];   // children's update matrices
+    bool tiles[2];         // ... stored as whole tiles (big children) or packed (children of level LO + 5)
+    bool kids;
+    double* fa;            // factor (+W^T tiles)
+    double* vf;            // -V tiles, same offsets
+    double* pi;            // -inverse pivot tiles
+    double* upd;           // this front's update matrix (whole tiles)
+};
+__device__ __forceinline__ void big_front(BigFront& B, const NdDev& nd, int m, int f) {
+    const int* F = nd.fronts + f * ND_FRONT_INTS;
+    B.b = __builtin_amdgcn_readfirstlane(F[NDF_B]);
+    B.st = __builtin_amdgcn_readfirstlane(F[NDF_ST]);
+    B.bt = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
+    B.T = B.st + B.bt;
+    const int con = __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
+    B.cl = nd.cells + con;
+    B.cp[0] = nd.cpos + 2 * (long long)con;
+    B.cp[1] = B.cp[0] + 16 * B.T;
+    const double* arena = nd.arena + (long long)m * nd.arena_stride;
+    B.ch[0] = arena + __builtin_amdgcn_readfirstlane(F[NDF_UC0]);
+    B.ch[1] = arena + __builtin_amdgcn_readfirstlane(F[NDF_UC1]);
+    const int lv = __builtin_amdgcn_readfirstlane(F[NDF_LEVEL]);
+    B.tiles[0] = B.tiles[1] = lv + 1 <= LO + 4;
+    B.kids = true;  // (every big front has children)
+    const long long fo = __builtin_amdgcn_readfirstlane(F[NDF_FACT]);
+    B.fa = nd.fact + (long long)m * nd.fact_stride + fo;
+    B.vf = nd.vfac + (long long)m * nd.vfac_stride + fo;
+    B.pi = nd.pimg + (long long)m * nd.pimg_stride + __builtin_amdgcn_readfirstlane(F[NDF_PIMG]);
+    B.upd = nd.arena + (long long)m * nd.arena_stride + __builtin_amdgcn_readfirstlane(F[NDF_UPD]);
+}
+// offset (doubles) of the stored tile (p, R), R > p, of a front with T tile rows (every pivot tile of a big front is full: kreg = 4)
+__device__ __forceinline__ int big_img(int T, int p, int R) { return 256 * (p * T - ((p * (p + 1)) >> 1) + (R - p - 1)); }
+// entry (hi, lo), hi >= lo, of an update matrix stored as whole tiles (nd.h)
+__device__ __forceinline__ int big_tile_off(int hi, int lo) {
+    const int R = hi >> 4, C = lo >> 4;
+    return ((((R * (R + 1)) >> 1) + C) << 8) + (((hi & 15) >> 2) << 6) + ((hi & 3) << 4) + (lo & 15);
+}
+__device__ __forceinline__ double big_gather(const double* __restrict__ ch, bool tiles, int a, int c) {
+    const bool ok = a >= 0 && c >= 0;
+    const int hi = a > c ? a : c, lo = a > c ? c : a;
+    const int off = tiles ? big_tile_off(hi, lo) : ((hi * (hi + 1)) >> 1) + lo;
+    const double l = ch[ok ? off : 0];  // (unconditional load, then the mask: see nd_coef_global)
+    return l * (ok ? 1.0 : 0.0);
+}
+// t += the children's entries of the tile whose rows are the front positions rowpos0 + 4 r + lq and whose columns are colpos0 + lc; a child
+// that touches none of them (wave-uniform) costs two table reads
+__device__ __forceinline__ void big_gather_tile(d4& t, const BigFront& B, int rowpos0, int colpos0, const NdGeo& g) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const short* cp = B.cp[c];
+        const int cc = cp[colpos0 + g.lc];
+        int a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = cp[rowpos0 + 4 * r + g.lq];
+        const bool any = cc >= 0 && (a[0] >= 0 || a[1] >= 0 || a[2] >= 0 || a[3] >= 0);
+        if (__ballot(any) == 0ull) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] += big_gather(B.ch[c], B.tiles[c], a[r], cc);
+    }
+}
+// the assembled panel tile (q, R): coefficients of the five-point system + the children
+__device__ __forceinline__ d4 big_assemble_v(const BigFront& B, const double* __restrict__ cf, int q, int R, const NdGeo& g) {
+    d4 t;
+    const int pm = 16 * R + g.lc, cm = B.cl[pm];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int pk = 16 * q + 4 * r + g.lq;
+        t[r] = nd_coef_global(cf, cm, B.cl[pk], pk == pm);
+    }
+    big_gather_tile(t, B, 16 * q, 16 * R, g);
+    return t;
+}
+__device__ __forceinline__ d4 big_mfma4(const d4& Y, const d4& Z, d4 acc) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kk], Z[kk], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ d4 big_neg(const d4& v) { return d4{-v[0], -v[1], -v[2], -v[3]}; }
+
+// The diagonal block of pivot block g0 (grid: members x fronts of the level, one wave each).
+__global__ __launch_bounds__(64) void k_big_diag(FwdParams p, NdDev nd, int level, int g0) {
+    const int m = blockIdx.x % p.N, f = (1 << level) - 1 + blockIdx.x / p.N;
+    NdGeo g;
+    g.lane = threadIdx.x;
+    g.lc = g.lane & 15;
+    g.lq = g.lane >> 4;
+    BigFront B;
+    big_front(B, nd, m, f);
+    const int q0 = g0 * BIG_PB;
+    if (q0 >= B.st) return;
+    const int nq = min(BIG_PB, B.st - q0);
+    const double* cf = nd.cf + (long long)m * CF_STRIDE;
+    d4 D[BIG_PB][BIG_PB];  // D[a][c], a <= c: tile (q0 + a, q0 + c)
+#pragma unroll
+    for (int a = 0; a < BIG_PB; ++a)
+#pragma unroll
+        for (int c = a; c < BIG_PB; ++c)
+            if (c < nq) D[a][c] = big_assemble_v(B, cf, q0 + a, q0 + c, g);
+    for (int pp = 0; pp < q0; ++pp) {  // the earlier blocks' updates
+        d4 Y[BIG_PB], Z[BIG_PB];
+#pragma unroll
+        for (int a = 0; a < BIG_PB; ++a)
+            if (a < nq) {
+                Y[a] = img_load(B.vf + big_img(B.T, pp, q0 + a), g.lane);
+                Z[a] = img_load(B.fa + big_img(B.T, pp, q0 + a), g.lane);
+            }
+#pragma unroll
+        for (int a = 0; a < BIG_PB; ++a)
+#pragma unroll
+            for (int c = a; c < BIG_PB; ++c)
+                if (c < nq) D[a][c] = big_mfma4(Y[a], Z[c], D[a][c]);
+    }
+    int bad = 0;
+#pragma unroll
+    for (int a = 0; a < BIG_PB; ++a) {
+        if (a >= nq) break;
+        const int pp = q0 + a;
+        d4 Pn = D[a][a];
+        sweep16_partial(Pn, g, bad, 4);  // -inverse
+        img_store(B.pi + 256 * pp, g.lane, Pn);
+        d4 W[BIG_PB];
+#pragma unroll
+        for (int c = a + 1; c < BIG_PB; ++c)
+            if (c < nq) {
+                W[c] = big_mfma4(Pn, D[a][c], d4{0.0, 0.0, 0.0, 0.0});  // -W^T
+                img_store(B.fa + big_img(B.T, pp, q0 + c), g.lane, big_neg(W[c]));
+                img_store(B.vf + big_img(B.T, pp, q0 + c), g.lane, big_neg(D[a][c]));
+            }
+#pragma unroll
+        for (int a2 = a + 1; a2 < BIG_PB; ++a2)
+#pragma unroll
+            for (int c = a2; c < BIG_PB; ++c)
+                if (c < nq) D[a2][c] = big_mfma4(D[a][a2], W[c], D[a2][c]);
+    }
+    if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
+}
+
+// The rows below the diagonal block of pivot block g0 (grid: members x fronts x ceil(rows / 4) workgroups of four waves, one row tile each).
+__global__ __launch_bounds__(256) void k_big_rows(FwdParams p, NdDev nd, int level, int g0, int wgs) {
+    const int nf = 1 << level;
+    const int m = blockIdx.x % p.N, rest = blockIdx.x / p.N, f = nf - 1 + rest % nf, wg = rest / nf;
+    NdGeo g;
+    g.lane = threadIdx.x & 63;
+    g.lc = g.lane & 15;
+    g.lq = g.lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    BigFront B;
+    big_front(B, nd, m, f);
+    const int q0 = g0 * BIG_PB;
+    if (q0 >= B.st) return;
+    const int nq = min(BIG_PB, B.st - q0);
+    const int R = q0 + nq + 4 * wg + w;
+    if (R >= B.T) return;
+    const double* cf = nd.cf + (long long)m * CF_STRIDE;
+    d4 V[BIG_PB];
+#pragma unroll
+    for (int a = 0; a < BIG_PB; ++a)
+        if (a < nq) V[a] = big_assemble_v(B, cf, q0 + a, R, g);
+    for (int pp = 0; pp < q0; ++pp) {
+        const d4 Z = img_load(B.fa + big_img(B.T, pp, R), g.lane);
+#pragma unroll
+        for (int a = 0; a < BIG_PB; ++a)
+            if (a < nq) V[a] = big_mfma4(img_load(B.vf + big_img(B.T, pp, q0 + a), g.lane), Z, V[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < BIG_PB; ++a) {
+        if (a >= nq) break;
+        const int pp = q0 + a;
+        const d4 Pn = img_load(B.pi + 256 * pp, g.lane);
+        const d4 W = big_mfma4(Pn, V[a], d4{0.0, 0.0, 0.0, 0.0});  // -W^T
+        const d4 Wp = big_neg(W);
+        img_store(B.fa + big_img(B.T, pp, R), g.lane, Wp);
+        img_store(B.vf + big_img(B.T, pp, R), g.lane, big_neg(V[a]));
+#pragma unroll
+        for (int a2 = a + 1; a2 < BIG_PB; ++a2)
+            if (a2 < nq) V[a2] = big_mfma4(img_load(B.vf + big_img(B.T, pp, q0 + a2), g.lane), Wp, V[a2]);  // (-V)(+W^T) = V (-W^T)
+    }
+    (void)wgs;
+}
+
+// The update matrix (grid: members x fronts x ceil(blocks / 4) workgroups of four waves, one 2 x 2 block of lower tiles each).
+__global__ __launch_bounds__(256) void k_big_trail(FwdParams p, NdDev nd, int level) {
+    const int nf = 1 << level;
+    const int m = blockIdx.x % p.N, rest = blockIdx.x / p.N, f = nf - 1 + rest % nf, wg = rest / nf;
+    NdGeo g;
+    g.lane = threadIdx.x & 63;
+    g.lc = g.lane & 15;
+    g.lq = g.lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    BigFront B;
+    big_front(B, nd, m, f);
+    const int hb = (B.bt + 1) >> 1;
+    int rem = 4 * wg + w, Rb = 0;
+    if (rem >= ((hb * (hb + 1)) >> 1)) return;
+    while (rem > Rb) { rem -= Rb + 1; ++Rb; }
+    const int Cb = rem;
+    const int R0 = B.st + 2 * Rb, C0 = B.st + 2 * Cb;
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+            if (R0 + i < B.T && C0 + j <= R0 + i) big_gather_tile(acc[i][j], B, 16 * (R0 + i), 16 * (C0 + j), g);
+        }
+    const int R1 = R0 + 1 < B.T ? R0 + 1 : R0, C1 = C0 + 1 < B.T ? C0 + 1 : C0;  // (a surplus tile recomputes its neighbour and is not stored)
+    for (int pp = 0; pp < B.st; ++pp) {
+        const d4 Y0 = img_load(B.fa + big_img(B.T, pp, R0), g.lane), Y1 = img_load(B.fa + big_img(B.T, pp, R1), g.lane);
+        const d4 Z0 = img_load(B.vf + big_img(B.T, pp, C0), g.lane), Z1 = img_load(B.vf + big_img(B.T, pp, C1), g.lane);
+        acc[0][0] = big_mfma4(Y0, Z0, acc[0][0]);
+        acc[0][1] = big_mfma4(Y0, Z1, acc[0][1]);
+        acc[1][0] = big_mfma4(Y1, Z0, acc[1][0]);
+        acc[1][1] = big_mfma4(Y1, Z1, acc[1][1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int Rt = R0 + i - B.st, Ct = C0 + j - B.st;
+            if (R0 + i < B.T && Ct <= Rt) img_store(B.upd + ((((Rt * (Rt + 1)) >> 1) + Ct) << 8), g.lane, acc[i][j]);
+        }
+}
+#endif  // ND_LG
+
 // ------------------------------------------------------------------------------------------------------------------------
 // Back substitution, root to leaves: per front and panel (last first)  x1 = -W^T [x of the rows below; -1 for the rhs row],
 // one wave per front, levels separated by workgroup barriers; pressures in P; then the face fluxes.
@@ -1161,8 +1482,8 @@ __global__ __launch_bounds__(64 * SOL_NW, SOL_OCC) void k_nd_solve(FwdParams p, 
     const double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* xe = xe_all[w];
     NPROF_DECL;
-    for (int lv = 0; lv < 8; ++lv) {  // levels 8..10: k_nd_solve_sub
-        const int nf = 1 << lv;
+    for (int lvg = 0; lvg < 8 + LO; ++lvg) {  // levels 8..10 (128 x 128 numbering): k_nd_solve_sub
+        const int nf = 1 << lvg, lv = lvg - LO;
         NPROF(lv < 5 ? 12 : lv - 5);
         if (lv >= 5) {
             if (lv == 5) nd_solve_single<1, 6>(nd, fact, P, nf, w, g);
@@ -1266,12 +1587,12 @@ __global__ __launch_bounds__(256, 4) void k_nd_solve_sub(FwdParams p, NdDev nd, 
     const double* fact = nd.fact + (long long)m * nd.fact_stride;
     const int i8 = 4 * bidx + w;
     constexpr int NFR = 3;  // the level-8 front and its two level-9 children (the leaves: k_nd_leaf_solve)
-    const int fid[NFR] = {255 + i8, 511 + 2 * i8, 512 + 2 * i8};
+    const int fid[NFR] = {FID(8) + i8, FID(9) + 2 * i8, FID(9) + 1 + 2 * i8};
     constexpr int MB[NFR] = {2, 2, 2}, MK[NFR] = {2, 1, 1};  // most boundary tiles / pivot register rows per front
     int bt[NFR], kreg[NFR], cb[NFR][2], cpv[NFR][4];
     double t[NFR][2][4];
-    const int box = nd.fronts[fid[0] * ND_FRONT_INTS + NDF_RBOX];
-    const int x0 = box & 255, y0 = (box >> 8) & 255, x1 = (box >> 16) & 255, y1 = (box >> 24) & 255, ld = y1 - y0 + 2;
+    const NdBox box = nd_box(nd.fronts + fid[0] * ND_FRONT_INTS, NDF_RBOX);
+    const int x0 = box.x0, y0 = box.y0, x1 = box.x1, y1 = box.y1, ld = y1 - y0 + 2;
 #pragma unroll
     for (int i = 0; i < NFR; ++i) {
         const int* F = nd.fronts + fid[i] * ND_FRONT_INTS;
@@ -1288,7 +1609,7 @@ __global__ __launch_bounds__(256, 4) void k_nd_solve_sub(FwdParams p, NdDev nd, 
 #pragma unroll
         for (int r = 0; r < MK[i]; ++r) cpv[i][r] = cl[4 * r + g.lq];
     }
-    auto li = [&](int c) { return ((c >> 7) - x0 + 1) * ld + ((c & 127) - y0 + 1); };
+    auto li = [&](int c) { return ((c >> LG) - x0 + 1) * ld + ((c & (NB - 1)) - y0 + 1); };
     // the ring: the level-8 front's boundary cells, solved by the levels above
 #pragma unroll
     for (int R = 0; R < 2; ++R) {
@@ -1337,36 +1658,54 @@ __global__ __launch_bounds__(1024) void k_nd_flux(FwdParams p) {
 // ------------------------------------------------------------------------------------------------------------------------
 struct hm_nd {
     NdInfo info{};
-    DevBuf fronts, cells, cpos, rec, fact, arena, dg, work, cached, wells;
+    DevBuf fronts, cells, cpos, rec, fact, arena, dg, work, cached, wells, vfac, pimg;
     NdDev dev{};
+    int cap = 0;                // members the per-member buffers hold: larger ensembles are solved in blocks of `cap` members (larger grids)
     long long cached_gen = -1;  // hm_fwd::inputs_gen the cached results belong to
     int cached_q_epoch = -1;    // hm_fwd::q_epoch of the time step the cached results of fronts with wells belong to
 };
 
-bool pressure_nd_applies(const FwdParams& p) { return p.Nx == NB && p.Ny == NB; }
+// the entry points of this object (one per grid size, fwd.h)
+#if ND_LG == 7
+#define ND_ENTRY(name) name
+#elif ND_LG == 8
+#define ND_ENTRY(name) name##256
+#else
+#define ND_ENTRY(name) name##512
+#endif
 
+bool ND_ENTRY(pressure_nd_applies)(const FwdParams& p) { return p.Nx == NB && p.Ny == NB; }
+
+#if ND_LG == 7
 void hm_nd_free(hm_nd* n) {
     if (!n) return;
-    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->rec, &n->fact, &n->arena, &n->dg, &n->work, &n->cached, &n->wells};
+    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->rec, &n->fact, &n->arena, &n->dg, &n->work, &n->cached, &n->wells, &n->vfac, &n->pimg};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     delete n;
 }
+#endif
 
 static int nd_setup(hm_fwd* f) {
     const FwdParams& p = f->p;
     NdTablesHost t;
     HM_REQUIRE(nd_build_tables(p.Nx, p.Ny, t), "nested-dissection tables: %s", t.error.c_str());
-    HM_REQUIRE(t.info.max_bt[10] <= 1 && t.info.max_bt[9] <= 2 && t.info.max_bt[8] <= 2 && t.info.max_bt[7] <= 3 && t.info.max_bt[6] <= 4 &&
-                   t.info.max_bt[5] <= 6, "nested-dissection tables: a wave-level front is larger than the kernels' register arrays");
-    for (int lv = 0; lv <= 4; ++lv) {
+    HM_REQUIRE(t.info.lo == LO && t.info.levels == ND_LEVELS, "nested-dissection tables: %d levels for a kernel family of %d", t.info.levels, ND_LEVELS);
+    const int* mbt = t.info.max_bt + LO;  // by the 128 x 128 tree's level numbers
+    HM_REQUIRE(mbt[10] <= 1 && mbt[9] <= 2 && mbt[8] <= 2 && mbt[7] <= 3 && mbt[6] <= 4 && mbt[5] <= 6,
+               "nested-dissection tables: a wave-level front is larger than the kernels' register arrays");
+    for (int lv = 0; lv <= LO + 4; ++lv) {
         const int T = t.info.max_st[lv] + t.info.max_bt[lv];
         HM_REQUIRE(T <= TOP_MAXT, "nested-dissection tables: a top-level front has %d tile rows (max %d)", T, TOP_MAXT);
     }
-    HM_REQUIRE(t.info.upd_doubles[10] <= 128 && t.info.max_bt[10] == 1, "nested-dissection tables: a leaf has more than 12 boundary cells");
-    for (int lv = 5; lv < ND_LEVELS; ++lv) HM_REQUIRE(t.info.max_st[lv] == 1, "nested-dissection tables: level %d has several pivot tiles", lv);
+    HM_REQUIRE(t.info.upd_doubles[LO + 10] <= 128 && mbt[10] == 1, "nested-dissection tables: a leaf has more than 12 boundary cells");
+    for (int lv = LO + 5; lv < ND_LEVELS; ++lv) HM_REQUIRE(t.info.max_st[lv] == 1, "nested-dissection tables: level %d has several pivot tiles", lv);
     for (int fI = 0; fI < t.info.n_fronts; ++fI) {
         const int* F = &t.fronts[(size_t)fI * ND_FRONT_INTS];
-        if (F[NDF_LEVEL] > 4) continue;
+        if (F[NDF_LEVEL] > LO + 4) continue;
+        if (LO > 0) {
+            HM_REQUIRE(F[NDF_KREG] == 4, "nested-dissection tables: big front %d has a partial last pivot tile", fI);
+            continue;
+        }
         const int st = F[NDF_ST], bt = F[NDF_BT], T = st + bt;
         const int nV = st * T - st * (st - 1) / 2, nT = F[NDF_B] > 0 ? bt * (bt + 1) / 2 : 0;
         HM_REQUIRE(nV <= TOP_NVS * TOP_NW && nT <= TOP_NTS * TOP_NW, "nested-dissection tables: front %d has %d + %d tiles", fI, nV, nT);
@@ -1374,17 +1713,29 @@ static int nd_setup(hm_fwd* f) {
     // the LDS-DMA copies move 16-byte pieces: every update matrix starts on an even double of an even-strided, 16-byte aligned arena
     HM_REQUIRE(t.info.arena_doubles % 2 == 0, "nested dissection: odd arena stride %lld", (long long)t.info.arena_doubles);
     for (int f = 1; f < (int)(t.fronts.size() / ND_FRONT_INTS); ++f)
-        HM_REQUIRE(t.fronts[f * ND_FRONT_INTS + NDF_LEVEL] > ND_ARENA_MAX_LEVEL && t.fronts[f * ND_FRONT_INTS + NDF_LEVEL] != ND_LEVELS - 1
-                       ? true : t.fronts[f * ND_FRONT_INTS + NDF_UPD] % 2 == 0,
+        HM_REQUIRE(t.fronts[f * ND_FRONT_INTS + NDF_UPD] < 0 || t.fronts[f * ND_FRONT_INTS + NDF_UPD] % 2 == 0,
                    "nested dissection: the update matrix of front %d starts on an odd double", f);
     hm_nd* n = new hm_nd();
     n->info = t.info;
     int rc = 0;
-    const size_t N = p.N;
+    // members per block: the whole ensemble where its factor, update matrices and panels fit the budget below (always at 128 x 128:
+    // 9.6 MB a member), else blocks of that many members, one after the other through the same buffers
+    const size_t per_member = (size_t)(t.info.fact_doubles + t.info.arena_doubles + t.info.big_fact_doubles + t.info.pimg_doubles + CF_STRIDE) * 8;
+    size_t cap = p.N;
+    if (LO > 0) {
+        size_t free_b = 0, total_b = 0;
+        HM_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t budget = std::min<size_t>(free_b / 2, (size_t)96 << 30);
+        cap = std::max<size_t>(1, std::min<size_t>(p.N, budget / per_member));
+    }
+    n->cap = (int)cap;
+    const size_t N = cap;
+    const size_t n_cached = (size_t)512 << LO;
     if ((rc = hm_dev_alloc(n->fronts, t.fronts.size() * 4)) || (rc = hm_dev_alloc(n->cells, t.cells.size() * 4)) ||
         (rc = hm_dev_alloc(n->cpos, t.cpos.size() * 2)) || (rc = hm_dev_alloc(n->rec, t.rec.size() * 2)) || (rc = hm_dev_alloc(n->fact, N * t.info.fact_doubles * 8)) ||
         (rc = hm_dev_alloc(n->arena, N * t.info.arena_doubles * 8)) || (rc = hm_dev_alloc(n->dg, N * (size_t)CF_STRIDE * 8)) ||
-        (rc = hm_dev_alloc(n->work, N * (size_t)ND_WORK_INTS * 4)) || (rc = hm_dev_alloc(n->cached, N * (size_t)512)) || (rc = hm_dev_alloc(n->wells, 512))) {
+        (rc = hm_dev_alloc(n->work, (LO > 0 ? 1 : N) * (size_t)ND_WORK_INTS * 4)) || (rc = hm_dev_alloc(n->cached, N * n_cached)) || (rc = hm_dev_alloc(n->wells, n_cached)) ||
+        (LO > 0 && ((rc = hm_dev_alloc(n->vfac, N * (size_t)t.info.big_fact_doubles * 8)) || (rc = hm_dev_alloc(n->pimg, N * (size_t)t.info.pimg_doubles * 8))))) {
         hm_nd_free(n);
         return rc;
     }
@@ -1403,35 +1754,49 @@ static int nd_setup(hm_fwd* f) {
     d.work = (int*)n->work.p;
     d.cached = (unsigned char*)n->cached.p;
     d.wells = (const unsigned char*)n->wells.p;
-    d.reuse = 1;
-    {   // fronts with a well in their subtree: the region of a level-8 subtree, above that the separator and both children (+ 1 ring)
+    d.vfac = (double*)n->vfac.p;
+    d.pimg = (double*)n->pimg.p;
+    d.vfac_stride = t.info.big_fact_doubles;
+    d.pimg_stride = t.info.pimg_doubles;
+    d.reuse = LO == 0;
+    if (LO == 0) {  // fronts with a well in their subtree: the region of a level-8 subtree, above that the separator and both children (+ 1 ring)
         std::vector<unsigned char> wf(512, 0);
         for (int fr = 510; fr >= 0; --fr) {
             if (fr < 255) wf[fr] = wf[2 * fr + 1] | wf[2 * fr + 2];
-            const int box = t.fronts[fr * ND_FRONT_INTS + (fr >= 255 ? NDF_RBOX : NDF_PBOX)];
-            const int x0 = (box & 255) - 1, y0 = ((box >> 8) & 255) - 1, x1 = ((box >> 16) & 255) + 1, y1 = ((box >> 24) & 255) + 1;
+            const NdBox box = nd_box(&t.fronts[fr * ND_FRONT_INTS], fr >= 255 ? NDF_RBOX : NDF_PBOX);
+            const int x0 = box.x0 - 1, y0 = box.y0 - 1, x1 = box.x1 + 1, y1 = box.y1 + 1;
             for (int cell : f->well_cells_host) {
                 const int ix = cell / NB, iy = cell % NB;
                 if (ix >= x0 && ix < x1 && iy >= y0 && iy < y1) wf[fr] = 1;
             }
         }
         HM_HIP(hipMemcpy(n->wells.p, wf.data(), 512, hipMemcpyHostToDevice));
+    } else {  // one list of every front of levels 8..5 (128 x 128 numbering) for all members: nothing is kept across time steps
+        std::vector<int> wk(ND_WORK_INTS, 0);
+        wk[0] = NF8; wk[1] = NF7; wk[2] = NF6; wk[3] = NF5;
+        for (int i = 0; i < NF8; ++i) wk[ND_W8 + i] = i;
+        for (int i = 0; i < NF7; ++i) wk[ND_W7 + i] = i;
+        for (int i = 0; i < NF6; ++i) wk[ND_W6 + i] = i;
+        for (int i = 0; i < NF5; ++i) wk[ND_W5 + i] = i;
+        HM_HIP(hipMemcpy(n->work.p, wk.data(), wk.size() * 4, hipMemcpyHostToDevice));
     }
     d.fact_stride = t.info.fact_doubles;
     d.arena_stride = t.info.arena_doubles;
-    d.slot9 = t.info.upd_doubles[9];
-    d.slot10 = t.info.upd_doubles[10];
-    d.child_doubles[0] = t.info.upd_doubles[8];
-    d.child_doubles[1] = t.info.upd_doubles[7];
-    d.child_doubles[2] = t.info.upd_doubles[6];
+    d.slot9 = t.info.upd_doubles[LO + 9];
+    d.slot10 = t.info.upd_doubles[LO + 10];
+    d.child_doubles[0] = t.info.upd_doubles[LO + 8];
+    d.child_doubles[1] = t.info.upd_doubles[LO + 7];
+    d.child_doubles[2] = t.info.upd_doubles[LO + 6];
+    // dynamic LDS beyond 64 KB must be requested per kernel
+#if ND_LG == 7
     for (int f = 0; f < 31; ++f)
         HM_REQUIRE(t.fronts[f * ND_FRONT_INTS + NDF_CELLS] + 256 <= (int)t.cells.size(), "nested dissection: the table piece of front %d runs past the tables", f);
     d.top_child_doubles = 0;
     for (int lv = 1; lv <= 5; ++lv) d.top_child_doubles = std::max(d.top_child_doubles, t.info.upd_doubles[lv]);
-    // dynamic LDS beyond 64 KB must be requested per kernel
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_top, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_assemble<double>, hipFuncAttributeMaxDynamicSharedMemorySize, NB * NB * 8));
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_assemble<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NB * NB * 8));
+#endif
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<5, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<6, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<7, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1440,28 +1805,12 @@ static int nd_setup(hm_fwd* f) {
     return 0;
 }
 
-// Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
-int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
-    const FwdParams& p = f->p;
-    if (!pressure_nd_applies(p)) return -1;
-    if (!f->nd) {
-        int rc = nd_setup(f);
-        if (rc) return rc;
-    }
+// The launches of one pressure step for the members the parameter block `p` describes (the whole ensemble, or one block of it).
+static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long long S_stride, int k) {
     hipStream_t s = f->ctx->stream;
     NdDev& nd = f->nd->dev;
-    // results kept from earlier time steps are only good for the inputs they were computed from; press_variant 14: no reuse at all; per-member
-    // wells: none either (the well flags are per plan)
-    nd.reuse = f->press_variant != 14 && p.q_mstride == 0 && !f->raw_field_exposed;
-    if (f->nd->cached_gen != f->inputs_gen) {
-        HM_HIP(hipMemsetAsync(f->nd->cached.p, 0, (size_t)p.N * 512, s));
-        f->nd->cached_gen = f->inputs_gen;
-    }
-    {   // the right-hand side rows of fronts with wells in their subtree: kept while the rates stay what they were
-        const int ep = p.q_cols > 1 ? f->q_epoch[k] : 0;
-        nd.wells_ok = ep == f->nd->cached_q_epoch;
-        f->nd->cached_q_epoch = ep;
-    }
+    const size_t lds_sub = (size_t)SUB_WPB * nd_sub_lds_doubles(nd) * 8;
+#if ND_LG == 7
     const bool iso = p.Ky == nullptr;  // isotropic: assembly from an LDS copy of 1 / (mobility K), the plan in the same launch
     const size_t lds_asm = iso ? (size_t)NB * NB * 8 : 0;
     if (f->dtype == 64) {
@@ -1471,20 +1820,82 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
         hipLaunchKernelGGL(k_nd_assemble<float>, dim3(p.N), dim3(1024), lds_asm, s, p, nd, (const float*)S, S_stride, k);
         if (!iso) hipLaunchKernelGGL(k_nd_plan<float>, dim3(p.N), dim3(256), 0, s, p, nd, (const float*)S, S_stride);
     }
-    const size_t lds_sub = (size_t)SUB_WPB * nd_sub_lds_doubles(nd) * 8;
-    hipLaunchKernelGGL(k_nd_leaf, dim3(p.N * 4), dim3(256), 0, s, p, nd, k);
-    hipLaunchKernelGGL(k_nd_sub, dim3(((p.N + SUB_WPB - 1) / SUB_WPB) * 256), dim3(64 * SUB_WPB), lds_sub, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * 32), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * 16), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * 16), dim3(128), (size_t)2 * (ND_LDS_DATA + 2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
+#else
+    if (f->dtype == 64) hipLaunchKernelGGL(k_ndl_assemble<double>, dim3(p.N * p.Nx), dim3(NB), 0, s, p, nd, (const double*)S, S_stride, k);
+    else hipLaunchKernelGGL(k_ndl_assemble<float>, dim3(p.N * p.Nx), dim3(NB), 0, s, p, nd, (const float*)S, S_stride, k);
+#endif
+    hipLaunchKernelGGL(k_nd_leaf, dim3(p.N * (4 << LO)), dim3(256), 0, s, p, nd, k);
+    hipLaunchKernelGGL(k_nd_sub, dim3(((p.N + SUB_WPB - 1) / SUB_WPB) * NF8), dim3(64 * SUB_WPB), lds_sub, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * (NF7 / 4)), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * (NF6 / 4)), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
+    hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * (NF5 / 2)), dim3(128), (size_t)2 * (ND_LDS_DATA + 2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
+#if ND_LG == 7
     const size_t lds_top = (size_t)(256 + 2 * TOP_MAXT * 256 + 256 + top_pad(nd.top_child_doubles)) * 8 + 31 * ND_FRONT_INTS * 4;  // images, 2 KB of tables, children, records
     hipLaunchKernelGGL(k_nd_top, dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k);
     if (hipError_t e_ = hipGetLastError()) { hm_set_error("k_nd_top launch with %zu bytes of LDS: %s", lds_top, hipGetErrorString(e_)); return 1; }
+#else
+    const NdInfo& I = f->nd->info;
+    for (int lv = LO + 4; lv >= 0; --lv) {  // the big fronts, leaves-to-root; per level: pivot blocks in turn, then the update matrix
+        const int nf = 1 << lv, st = I.max_st[lv], bt = I.max_bt[lv], T = st + bt;
+        for (int g0 = 0; g0 * BIG_PB < st; ++g0) {
+            hipLaunchKernelGGL(k_big_diag, dim3(p.N * nf), dim3(64), 0, s, p, nd, lv, g0);
+            const int rows = T - std::min(st, (g0 + 1) * BIG_PB), wgs = (rows + 3) / 4;
+            if (wgs > 0) hipLaunchKernelGGL(k_big_rows, dim3(p.N * nf * wgs), dim3(256), 0, s, p, nd, lv, g0, wgs);
+        }
+        if (lv > 0) {
+            const int hb = (bt + 1) / 2, wgs = (hb * (hb + 1) / 2 + 3) / 4;
+            hipLaunchKernelGGL(k_big_trail, dim3(p.N * nf * wgs), dim3(256), 0, s, p, nd, lv);
+        }
+    }
+#endif
     hipLaunchKernelGGL(k_nd_solve, dim3(p.N), dim3(64 * SOL_NW), 0, s, p, nd, k);
-    hipLaunchKernelGGL(k_nd_solve_sub, dim3(p.N * 64), dim3(256), 0, s, p, nd, k);
-    hipLaunchKernelGGL(k_nd_leaf_solve, dim3(p.N * 4), dim3(256), 0, s, p, nd, k);
+    hipLaunchKernelGGL(k_nd_solve_sub, dim3(p.N * (64 << LO)), dim3(256), 0, s, p, nd, k);
+    hipLaunchKernelGGL(k_nd_leaf_solve, dim3(p.N * (4 << LO)), dim3(256), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_flux, dim3(p.N), dim3(1024), 0, s, p);
     HM_HIP(hipGetLastError());
+    return 0;
+}
+
+// Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
+int ND_ENTRY(launch_pressure_nd)(hm_fwd* f, const void* S, long long S_stride, int k) {
+    const FwdParams& p = f->p;
+    if (!ND_ENTRY(pressure_nd_applies)(p)) return -1;
+    if (!f->nd) {
+        int rc = nd_setup(f);
+        if (rc) return rc;
+    }
+    hipStream_t s = f->ctx->stream;
+    NdDev& nd = f->nd->dev;
+    // results kept from earlier time steps are only good for the inputs they were computed from; press_variant 14: no reuse at all; per-member
+    // wells: none either (the well flags are per plan); the larger grids keep nothing
+    nd.reuse = LO == 0 && f->press_variant != 14 && p.q_mstride == 0 && !f->raw_field_exposed;
+    if (LO == 0 && f->nd->cached_gen != f->inputs_gen) {
+        HM_HIP(hipMemsetAsync(f->nd->cached.p, 0, (size_t)p.N * 512, s));
+        f->nd->cached_gen = f->inputs_gen;
+    }
+    {   // the right-hand side rows of fronts with wells in their subtree: kept while the rates stay what they were
+        const int ep = p.q_cols > 1 ? f->q_epoch[k] : 0;
+        nd.wells_ok = ep == f->nd->cached_q_epoch;
+        f->nd->cached_q_epoch = ep;
+    }
+    const int cap = f->nd->cap;
+    if (p.N <= cap) return nd_launch_block(f, p, S, S_stride, k);
+    for (int m0 = 0; m0 < p.N; m0 += cap) {  // blocks of members through the same factor / update / panel buffers, one after the other
+        FwdParams pb = p;
+        const long long o = m0;
+        pb.N = std::min(cap, p.N - m0);
+        pb.K = p.K + o * p.Nxy;
+        if (p.Ky) pb.Ky = p.Ky + o * p.Nxy;
+        pb.q = p.q + o * p.q_mstride;
+        pb.TX = p.TX + o * (p.Nx + 1) * NB;
+        pb.TY = p.TY + o * p.Nx * (NB + 1);
+        pb.P = p.P + o * p.Nxy;
+        pb.Vx = p.Vx + o * (p.Nx + 1) * NB;
+        pb.Vy = p.Vy + o * p.Nx * (NB + 1);
+        pb.status = p.status + o;
+        const char* Sb = (const char*)S + (size_t)(o * S_stride) * f->esz;
+        if (int rc = nd_launch_block(f, pb, Sb, S_stride, k)) return rc;
+    }
     return 0;
 }
 
@@ -1492,6 +1903,11 @@ int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k) {
 extern "C" int hm_debug_nd_prof(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hm_nd_prof_buf), sizeof(long long) * 64); }
 #endif
 
+#if ND_LG == 7
+// The symbolic phase on the host (no device needed).  info (64 entries): [0] fronts, [1] table entries, [2] factor doubles, [3] arena doubles,
+// [4..6] largest update of levels 8..10 (128 x 128 numbering), [7] recipe blocks, [19] ints per front record, [20] levels, [21] LO,
+// [22] panel-image doubles, [23] pivot-image doubles, [24 + level] max_bt * 64 + max_st; the first 11 levels also at [8 + level] as max_bt * 16 + max_st
+// (the 128 x 128 form of the call).
 extern "C" int hm_debug_nd_tables(int Nx, int Ny, long long* info, int* fronts, int* cells, short* cpos, short* rec) {
     HM_REQUIRE(info, "hm_debug_nd_tables: NULL info");
     NdTablesHost t;
@@ -1499,17 +1915,25 @@ extern "C" int hm_debug_nd_tables(int Nx, int Ny, long long* info, int* fronts, 
         hm_set_error("hm_debug_nd_tables: %s (%d x %d)", t.error.c_str(), Nx, Ny);
         return 2;
     }
+    const int lo = t.info.lo;
     info[0] = t.info.n_fronts;
     info[1] = t.info.n_cells;
     info[2] = t.info.fact_doubles;
     info[3] = t.info.arena_doubles;
-    for (int i = 0; i < 3; ++i) info[4 + i] = t.info.upd_doubles[8 + i];
-    for (int i = 0; i < ND_LEVELS; ++i) info[8 + i] = t.info.max_bt[i] * 16 + t.info.max_st[i];
+    for (int i = 0; i < 3; ++i) info[4 + i] = t.info.upd_doubles[lo + 8 + i];
+    if (lo == 0)
+        for (int i = 0; i < 11; ++i) info[8 + i] = t.info.max_bt[i] * 16 + t.info.max_st[i];
     if (fronts) memcpy(fronts, t.fronts.data(), t.fronts.size() * sizeof(int));
     if (cells) memcpy(cells, t.cells.data(), t.cells.size() * sizeof(int));
     info[7] = t.info.n_rec_blocks;
     info[19] = ND_FRONT_INTS;
+    info[20] = t.info.levels;
+    info[21] = lo;
+    info[22] = t.info.big_fact_doubles;
+    info[23] = t.info.pimg_doubles;
+    for (int i = 0; i < t.info.levels; ++i) info[24 + i] = t.info.max_bt[i] * 64 + t.info.max_st[i];
     if (cpos) memcpy(cpos, t.cpos.data(), t.cpos.size() * sizeof(short));
     if (rec) memcpy(rec, t.rec.data(), t.rec.size() * sizeof(short));
     return 0;
 }
+#endif

@@ -183,7 +183,7 @@ int hm_debug_mfma_f64(hm_ctx* ctx, const double* A, const double* B, double* D);
  * info[4..6] = largest packed update of levels 8..10 (doubles); info[7] = assembly-recipe blocks of 256 int16 (csrc/nd.h);
  * info[8..18] = 16 * boundary tiles + pivot tiles per level; info[19] = ints per front record.
  * fronts (info[0] * info[19] ints), cells (info[1] ints), cpos (2 * info[1] shorts), rec (256 * info[7] shorts) may be NULL (size query). */
-int hm_debug_nd_tables(int Nx, int Ny, long long* info /* 24 */, int* fronts, int* cells, short* cpos, short* rec);
+int hm_debug_nd_tables(int Nx, int Ny, long long* info /* 64 */, int* fronts, int* cells, short* cpos, short* rec);
 
 /* ---- ensemble-smoother update: replaces ens_update0 -------------------------------------------
  * Reference: ens_update0  notebooks/HistoryMatch.py:578-586  (center: tools/utils.py:10-28).

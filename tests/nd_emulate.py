@@ -10,7 +10,7 @@ F_LEVEL, F_S, F_B, F_ST, F_BT, F_C0, F_C1, F_CELLS, F_FACT, F_UPD, F_KREG, F_BC0
 
 
 def tables(lib, Nx, Ny):
-    info = (C.c_longlong * 24)()
+    info = (C.c_longlong * 64)()
     rc = lib.hm_debug_nd_tables(Nx, Ny, info, None, None, None, None)
     if rc:
         raise RuntimeError(lib.hm_last_error().decode())
@@ -43,6 +43,20 @@ def coefficient(tab, dg, TX, TY, cm, ck):
     return 0.0
 
 
+def matrix(tab, dg, TX, TY):
+    """The five-point system as a CSR matrix, entry by entry through `coefficient`'s rules (vectorised)."""
+    import scipy.sparse as sp
+
+    Nx, Ny = tab["Nx"], tab["Ny"]
+    c = np.arange(Nx * Ny)
+    ty = c + c // Ny
+    rows = [c, c[Ny:], c[:-Ny], c[c % Ny != Ny - 1] + 1, c[c % Ny != 0] - 1]
+    cols = [c, c[Ny:] - Ny, c[:-Ny] + Ny, c[c % Ny != Ny - 1], c[c % Ny != 0]]
+    # A[cm, ck]: d = cm - ck = Ny -> -TX[ck + Ny]; -Ny -> -TX[ck]; 1 -> -TY[ty + 1]; -1 -> -TY[ty]
+    vals = [dg[c], -TX[cols[1] + Ny], -TX[cols[2]], -TY[ty[cols[3]] + 1], -TY[ty[cols[4]]]]
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(Nx * Ny, Nx * Ny))
+
+
 def tri(a, b):
     hi, lo = (a, b) if a >= b else (b, a)
     return hi * (hi + 1) // 2 + lo
@@ -52,6 +66,7 @@ def solve(tab, dg, TX, TY, q):
     """Returns (x, factor dict, flops) -- x solves the five-point system with diagonal dg, faces TX/TY, right-hand side q."""
     fronts, cells, cpos = tab["fronts"], tab["cells"], tab["cpos"]
     nF = len(fronts)
+    A = matrix(tab, dg, TX, TY)
     upd = {}
     fact = {}
     order = sorted(range(nF), key=lambda f: -fronts[f][F_LEVEL])  # deepest level first: children before parents
@@ -65,20 +80,18 @@ def solve(tab, dg, TX, TY, q):
         n = 16 * T
         # the whole (padded) front as a dense symmetric matrix; only pivot columns get A entries
         M = np.zeros((n, n))
-        for k in range(16 * st):
-            ck = cl[k]
-            for m in range(n):
-                cm = cl[m]
-                v = 0.0
-                if ck >= 0:
-                    if cm >= 0:
-                        v = coefficient(tab, dg, TX, TY, cm, ck)
-                    elif cm == -2:
-                        v = q[ck]
-                elif m == k:
-                    v = 1.0
-                M[m, k] = v
-                M[k, m] = v
+        piv = cl[:16 * st]
+        pk = np.nonzero(piv >= 0)[0]
+        rows = np.nonzero(cl >= 0)[0]
+        if len(pk):
+            blk = A[cl[rows]][:, piv[pk]].toarray()
+            M[np.ix_(rows, pk)] = blk
+            M[np.ix_(pk, rows)] = blk.T
+            rhs = np.nonzero(cl == -2)[0]
+            M[np.ix_(rhs, pk)] = q[piv[pk]][None, :]
+            M[np.ix_(pk, rhs)] = q[piv[pk]][:, None]
+        pad = np.nonzero(piv < 0)[0]
+        M[pad, pad] = 1.0
         if kids[0] >= 0:
             for c in range(2):
                 U = upd.pop(kids[c])

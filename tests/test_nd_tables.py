@@ -16,11 +16,15 @@ def lib():
     return _lib.load()
 
 
-def test_tables_structure(lib):
-    tab = E.tables(lib, 128, 128)
+@pytest.mark.parametrize("n", [128, 256, 512])
+def test_tables_structure(lib, n):
+    tab = E.tables(lib, n, n)
     f = tab["fronts"]
-    assert len(f) == 2047
-    for lv in range(11):
+    info = tab["info"]
+    levels, lo = info[20], info[21]
+    assert (levels, lo) == {128: (11, 0), 256: (13, 2), 512: (15, 4)}[n]
+    assert len(f) == (1 << levels) - 1
+    for lv in range(levels):
         assert (f[:, E.F_LEVEL] == lv).sum() == 1 << lv
     piv = []
     for F in f:
@@ -30,14 +34,18 @@ def test_tables_structure(lib):
         assert (cl[:s] >= 0).all() and (cl[s:16 * st] == -1).all()
         assert (cl[16 * st:16 * st + b] >= 0).all() and cl[16 * st + b] == -2 and (cl[16 * st + b + 1:] == -1).all()
         piv.append(cl[:s])
-        if F[E.F_LEVEL] >= 5:
-            assert st == 1, "levels 5..10 are single-pivot-tile fronts (one wave each)"
+        if F[E.F_LEVEL] >= lo + 5:
+            assert st == 1, "levels 5..10 (128 x 128 numbering) are single-pivot-tile fronts (one wave each)"
+        elif lo > 0:
+            assert F[10] == 4, "every pivot tile of a big front is full (k_big_*: kreg = 4)"
     piv = np.concatenate(piv)
-    assert np.array_equal(np.sort(piv), np.arange(128 * 128)), "every cell is a pivot exactly once"
-    # sizes the kernels' static register arrays assume (press_nd.hip: nd_setup)
-    info = tab["info"]
-    bt = [info[8 + lv] // 16 for lv in range(11)]
+    assert np.array_equal(np.sort(piv), np.arange(n * n)), "every cell is a pivot exactly once"
+    # sizes the kernels' static register arrays assume (press_nd.hip: nd_setup), by the 128 x 128 tree's level numbers
+    bt = [info[24 + lo + lv] // 64 for lv in range(11)]
     assert bt[10] <= 1 and bt[9] <= 2 and bt[8] <= 2 and bt[7] <= 3 and bt[6] <= 4 and bt[5] <= 6
+    tmax = {128: 13, 256: 25, 512: 49}[n]
+    for lv in range(lo + 5):
+        assert info[24 + lv] // 64 + info[24 + lv] % 64 <= tmax
 
 
 def test_unsupported_grid_is_refused(lib):
@@ -48,8 +56,9 @@ def test_unsupported_grid_is_refused(lib):
     assert b"tree" in lib.hm_last_error()
 
 
-def test_elimination_by_the_tables_solves_the_system(lib):
-    Nx = Ny = 128
+@pytest.mark.parametrize("n", [128, 256])
+def test_elimination_by_the_tables_solves_the_system(lib, n):
+    Nx = Ny = n
     tab = E.tables(lib, Nx, Ny)
     rng = np.random.RandomState(1)
     z = rng.randn(Nx, Ny)
