@@ -134,10 +134,9 @@ def test_config4_analysis_shape_whole_and_row_sharded_vs_oracle():
 
 
 def test_config4_shard_whole_run_properties():
-    """One rank's shard of config 4: 512 members at 256 x 256, all 40 steps, default kernels (two-level CG + tile teams: 8 rounds
-    of 64 teams).  Mass-balance bracket, bounds, monotone producer series, and a sub-ensemble from different team rounds run
-    alone agrees (the CG passes of a member are split over a member-count-dependent number of workgroups, so the two
-    solves may differ at rounding level: bar = the CG tolerance amplified as in the oracle comparisons)."""
+    """One rank's shard of config 4: 512 members at 256 x 256, all 40 steps, default kernels (nested-dissection pressure solve of the
+    larger grids + slab sweep: 8 rounds of 64 teams).  Mass-balance bracket, bounds, monotone producer series, and a sub-ensemble
+    from different team rounds run alone agrees BIT FOR BIT (the direct solver treats every member by itself)."""
     n, N, steps = 256, 512, 40
     _, gm = make_models(n, n)
     from historymatching_amd.forward import ForwardPlan
@@ -149,7 +148,7 @@ def test_config4_shard_whole_run_properties():
     st = plan.sync()
     S_end, prods, status = plan.outputs()
     plan.close()
-    assert not status.any() and 0 < st["mean_n_cg"] < 80 and st["mean_nts"] > 2000
+    assert not status.any() and st["mean_n_cg"] == 0 and st["mean_nts"] > 2000
     assert S_end.min() >= -1e-9 and S_end.max() <= 1 + 1e-9 and np.isfinite(prods).all()
     assert (np.diff(prods, axis=1) >= -1e-9).all()
     fw = lambda s: s * s / (s * s + (1 - s) * (1 - s))  # noqa: E731
@@ -166,12 +165,12 @@ def test_config4_shard_whole_run_properties():
     S_sub, p_sub, st2 = plan.outputs()
     plan.close()
     assert not st2.any()
-    assert np.abs(S_sub - S_end[sub]).max() < 1e-6 and np.abs(p_sub - prods[sub]).max() < 1e-6
+    assert np.array_equal(S_sub, S_end[sub]) and np.array_equal(p_sub, prods[sub])
 
 
 def test_config5_grid_forward_vs_oracle():
-    """512 x 512 (config 5's grid): two members, one time step (9 831 explicit sub-steps), default kernels -- two-level CG
-    pressure solver with its 128-wide coarse direct solve, saturation sweep by teams of 16 tile workgroups -- against the
+    """512 x 512 (config 5's grid): two members, one time step (9 831 explicit sub-steps), default kernels -- nested-dissection
+    pressure solve (press_nd512.o: 15 levels, fronts of up to 49 tile rows), saturation sweep by teams of 16 tile workgroups -- against the
     oracle, within the oracle's own solver noise (second SuperLU ordering: MMD_AT_PLUS_A; NATURAL fills in too much here)."""
     from historymatching_amd.forward import ForwardPlan
 
@@ -185,7 +184,7 @@ def test_config5_grid_forward_vs_oracle():
     w, p, status = plan.outputs()
     nts = plan.get_field("nts")
     plan.close()
-    assert not status.any() and 0 < st["mean_n_cg"] < 200
+    assert not status.any() and st["mean_n_cg"] == 0
     assert (nts[:, 0] == 9831).all()  # ceil(9830.4), SURVEY.md Appendix B: the injector cell sets the CFL limit
     for m, (ref, noise) in enumerate(oracle_sims_and_noise_parallel(n, n, x, DT, 1, permc2="MMD_AT_PLUS_A")):
         err = np.abs(w[m] - ref).max()
