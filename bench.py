@@ -83,7 +83,7 @@ def nd_mfma_count():
     from historymatching_amd import _lib
 
     lib = _lib.load()
-    info = (C.c_longlong * 24)()
+    info = (C.c_longlong * 64)()
     _lib.check(lib.hm_debug_nd_tables(NX, NY, info, None, None, None, None), "hm_debug_nd_tables")
     fronts = np.zeros((int(info[0]), int(info[19])), dtype=np.int32)
     _lib.check(lib.hm_debug_nd_tables(NX, NY, info, fronts.ctypes.data_as(C.POINTER(C.c_int)), None, None, None), "hm_debug_nd_tables")
@@ -261,15 +261,19 @@ def config4_sharded(device, comm, n_total=4096, n_grid=256):
             "collective": "RCCL (hm_upd_run_comm)" if comm.rccl is not None else ("none (one rank)" if comm.world_size == 1 else f"host channel ({comm.rccl_error})")}
 
 
-def config5_sharded(device, comm, n_total=1000, n_grid=512):
+def config5_sharded(device, comm, n_total=1000, n_grid=512, bounded=False):
     """BASELINE.json config 5: N_e = 1000 members at 512 x 512, localised update (taper = bump(dist / 1.2) to the 4 producers x
     40 times, HistoryMatch.py:700-717, 863), fp32 plans, members split over the ranks (strong scaling); one ES-MDA pass = forward
     model of the local members + the localised analysis over the ranks: two all-reduces, per-element solves sharded by state
-    column, all-gather of the weights.  Called by EVERY rank.  Default only at 4 ranks or more (one rank: ~4 min)."""
+    column, all-gather of the weights.  Called by EVERY rank.  The whole ensemble from 4 ranks up (or with --config5: one rank
+    ~2 min); below that `bounded`: ONE GPU's share of the 8-GPU configuration -- 125 members, the same grid, the same localised
+    analysis step on those members -- so that the default line carries a driver-timed figure for this configuration."""
     from historymatching_amd.dist import es_mda_sharded, shard_bounds
     from historymatching_amd.geostat import gaussian_fields_kron
     from historymatching_amd.localization import taper_for_wells
 
+    if bounded:
+        n_total = 125
     lo, hi = shard_bounds(n_total, comm.world_size, comm.rank)
     model = build_model(32, device=device, n=n_grid)
     n_obs = NTIME * 4
@@ -287,6 +291,8 @@ def config5_sharded(device, comm, n_total=1000, n_grid=512):
     upd_ms = comm.all_reduce_max(st["ms_update"] + st.get("ms_comm", 0.0))
     ok = comm.all_reduce_max(0.0 if np.isfinite(post).all() else 1.0) == 0.0
     return {"members_total": n_total, "members_per_rank": hi - lo, "grid": [n_grid, n_grid], "n_ranks": comm.world_size, "scaling": "strong",
+            "sample": ("one GPU's shard of the 8-GPU configuration: 125 of the 1000 members, the whole 512 x 512 grid, one localised ES-MDA pass"
+                       if bounded else "the whole configuration"),
             "passes": 1, "wall_s": wall, "device_ms_forward_max": fwd_ms, "device_ms_localised_update_max": upd_ms,
             "ensemble_steps_per_s_forward": n_total * NTIME / (fwd_ms * 1e-3), "posterior_finite": bool(ok), "dtype": "f32 saturation sweep + fp64 pressure, fp32 matrix-core analysis",
             "collective": "RCCL (hm_upd_run_comm: 2 all-reduces + all-gather of the column-sharded weights)" if comm.rccl is not None
@@ -361,7 +367,8 @@ def main():
     ap.add_argument("--no-host-call", action="store_true", help="skip the PCIe-inclusive leg (the drop-in call with host arrays in and out)")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (N_e=4096 at 256x256 over the ranks)")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the two-stream leg (profiling runs: one kernel shape per name)")
-    ap.add_argument("--config5", action="store_true", help="run the config-5 leg (N_e=1000 at 512x512, localised) also below 4 ranks")
+    ap.add_argument("--config5", action="store_true", help="run the WHOLE config-5 leg (N_e=1000 at 512x512, localised) also below 4 ranks (default there: one GPU's shard of 125 members)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0, help="0 = fastest kernels, 1 = generic kernels")
     ap.add_argument("--dry-run", action="store_true", help="no device work: the ranks rendezvous, agree on a time and rank 0 prints a line (tests of the N-rank launch path)")
@@ -511,8 +518,9 @@ def main():
         dominant = "saturation" if stats["ms_saturation"] >= stats["ms_pressure"] else "pressure"
         isa, isa_src = load_profile_json("isa_counts.json")
         pmc, pmc_src = load_profile_json("pmc_hbm_traffic.json")
-        # the committed counts were taken from particular builds of sat128r.o / press_nd.o: if the objects this process runs
-        # differ, every figure derived from them is stale -- say so and report no fraction
+        # the committed counts (DP instructions per cell and sub-step, executed / algorithmic ratio) were taken from particular builds of
+        # sat128r.o / press_nd.o: if the objects this process runs differ, `stale_inputs` says so (a separate flag -- `frac` is always this
+        # run's launch time priced with those counts; the defaults below are the round-3 census)
         sys.path.insert(0, str(ROOT / "profiles" / "tools"))
         from obj_hash import object_hashes
         built = object_hashes()
@@ -551,7 +559,7 @@ def main():
         prs_bytes = w * (4 * nxy + 2 * ND_FACTOR_DOUBLES + 2 * ND_ARENA_DOUBLES) * n_e  # compulsory + factor write/read + update matrices write/read
         roofline = {
             "bound": bound, "kernel": {"saturation": "k_sat128r", "pressure": "k_nd_* (press_nd.hip: assemble, sub, wave x3, top, solve)"}[dominant] if args.variant == 0 else dominant,
-            "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None if stale else ach / FP64_PEAK_TFLOPS,
+            "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
             "stale_inputs": bool(stale), "stale_inputs_detail": stale or None,
             "inputs_taken_from_objects": recorded, "objects_run": {k: built.get(k) for k in ("sat128r.o", "press_nd.o")},
             "unit_note": "for bound fp64_valu `achieved` is an issue-slot rate: DP lane-instructions/s x 2 (every DP VALU instruction priced as one FMA "
@@ -568,7 +576,7 @@ def main():
                                        "5.4 cycles, not 4 (v_rcp_f64: 16.4; an FMA with three distinct register operands: 6.9) -- "
                                        "historymatching_amd/csrc/diag/valu_rate.hip, profiles/README.md"},
             "avg_launch_ms": {"saturation": sat_ms, "pressure": prs_ms},
-            "per_kernel": {"saturation_fp64_valu_frac": None if stale else 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            "per_kernel": {"saturation_fp64_valu_frac": 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                            # the factorisation's matrix instructions counted from the symbolic tables, every front eliminated: since fronts
                            # whose subtree is still dry are skipped (k_nd_plan) the EXECUTED work is lower -- the counter-based figure below
                            "pressure_fp64_mfma_frac_skip_free_count": prs_flops / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
@@ -576,13 +584,25 @@ def main():
                            # against the nested dissection's 55): this launch time priced at THAT flop count, for comparison across rounds only
                            "pressure_frac_at_block_elimination_flop_count": 2048.0 * 36 * 4 * 8 * NX * n_e / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                            # counter-based: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flop per launch (committed PMC pass) over THIS run's launch time
-                           "pressure_fp64_mfma_frac_from_counters": None if stale or not (f64r or {}).get("pressure_nd") else
+                           "pressure_fp64_mfma_frac_from_counters": None if not (f64r or {}).get("pressure_nd") else
                            f64r["pressure_nd"]["fp64_mfma_flops_per_member_step"] * n_e / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
             "effective_bandwidth_diagnostic": {
                 "note": "SURVEY.md 8d 'effective GB/s' (algorithmic bytes / launch time); exceeds the HBM peak by construction for the register-resident sweep",
                 "saturation_GBps": sat_bytes / (sat_ms * 1e-3) / 1e9, "pressure_GBps": prs_bytes / (prs_ms * 1e-3) / 1e9,
                 "algorithmic_bytes_per_launch": {"saturation": sat_bytes, "pressure": prs_bytes},
                 "compulsory_floor_bytes_per_member_step": 4 * w * nxy},
+            "pressure": {
+                "kernel": "k_nd_* (press_nd.hip)" if args.variant == 0 else "pressure",
+                "avg_launch_ms": prs_ms,
+                # both bounds of the pressure step: matrix flops EXECUTED (counters: fronts still dry are skipped) over the fp64 matrix peak,
+                # and measured HBM traffic over the HBM peak -- it is bound by neither (latency at low occupancy, profiles/README.md)
+                "fp64_mfma_frac": None if not (f64r or {}).get("pressure_nd") else
+                f64r["pressure_nd"]["fp64_mfma_flops_per_member_step"] * n_e / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "fp64_mfma_frac_skip_free_count": prs_flops / (prs_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "hbm_traffic_bytes_per_launch": None if not (pmc and "press_nd" in pmc.get("kernels", {})) else pmc["kernels"]["press_nd"]["hbm_bytes_per_member_corrected"] * n_e,
+                "hbm_frac": None if not (pmc and "press_nd" in pmc.get("kernels", {})) else
+                pmc["kernels"]["press_nd"]["hbm_bytes_per_member_corrected"] * n_e / (prs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "sources": [f64r_src, pmc_src]},
             "mean_nts": nts, "assumes": "2.4 GHz, 256 CUs (the chip holds a lower clock under this load: profiles/rNN/fp64_roofline.json)",
         }
         upd = None if upd_sharded is None else {"sharded": upd_sharded}
@@ -594,6 +614,14 @@ def main():
             if not args.no_esmda:
                 try:
                     upd = dict(upd or {}, es_mda_config3=es_mda_c3(local_rank, perms))
+                    c3 = upd["es_mda_config3"]
+                    # the HEADLINE analysis figure: the step where it is used -- inside the 4-pass assimilation, each step behind a forward pass
+                    # of 40 time steps (cold caches, whatever clocks the device holds there); the back-to-back figure above is the secondary
+                    in_situ = c3["device_ms_update"] / c3["iterations"]
+                    flops = 4.0 * N_E * 160 * NX * NY
+                    upd["in_situ_ms"] = in_situ
+                    upd["mfma_frac_in_situ"] = flops / (in_situ * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS
+                    upd["headline"] = "in_situ_ms / mfma_frac_in_situ (one analysis step inside es_mda_config3); wall_ms / mfma_frac_of_fp32_peak are the same step queued back to back"
                 except Exception as e:
                     upd = dict(upd or {}, es_mda_config3={"error": str(e)})
         cpu = None
@@ -640,8 +668,9 @@ def main():
     if not args.no_config4 and args.members == N_E:
         c4 = guarded(lambda: config4_sharded(local_rank, comm))
     c5 = None
-    if args.members == N_E and (args.config5 or (world >= 4 and not args.no_config4)):
-        c5 = guarded(lambda: config5_sharded(local_rank, comm))
+    if args.members == N_E and not args.no_config5:
+        whole = args.config5 or world >= 4
+        c5 = guarded(lambda: config5_sharded(local_rank, comm, bounded=not whole))
 
     legs_done.set()
     if rank == 0:

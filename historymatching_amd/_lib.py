@@ -51,6 +51,8 @@ SIGNATURES = {
     "hm_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_longlong]),
     "hm_copy_to_device": (C.c_int, [_vp, _vp, _vp, C.c_longlong]),
     "hm_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "hm_comm_probe": (C.c_int, []),
+    "hm_upd_chain_fallbacks": (C.c_int, [_vp]),
     "hm_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(_vp)]),
     "hm_comm_destroy": (None, [_vp]),
     "hm_comm_rank": (C.c_int, [_vp]),

@@ -86,6 +86,10 @@ int nccl_type(int dtype, ncclDataType_t* t) {
 }
 }  // namespace
 
+// librccl opened and its symbols bound, nothing else: what every rank other than 0 checks before anyone enters ncclCommInitRank
+// (ncclGetUniqueId starts a bootstrap listener thread and opens a port: only the rank whose id is used may call it)
+extern "C" int hm_comm_probe(void) { return rccl_load(); }
+
 extern "C" int hm_comm_unique_id(char* id_out) {
     HM_REQUIRE(id_out, "hm_comm_unique_id: NULL argument");
     static_assert(sizeof(ncclUniqueId) == HM_COMM_ID_BYTES, "HM_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");

@@ -953,6 +953,9 @@ extern "C" int hm_fwd_run(hm_fwd* f, int first_step, int n_steps) {
         HM_REQUIRE(first_step == f->cur, "hm_fwd_run: a plan without history continues at time index %d (got first_step %d); "
                    "call hm_fwd_set_inputs* to restart", f->cur, first_step);
     HM_HIP(hipSetDevice(f->ctx->device));
+    // a run from time index 0 is a new forward_model call (HistoryMatch.py:383-387): it does the work a fresh plan does -- nothing the
+    // pressure solve kept from an earlier run's time steps is reused, even where the inputs are the same
+    if (first_step == 0) ++f->inputs_gen;
     int rc = f->t_total.begin(f->ctx->stream);
     if (rc) return rc;
     for (int k = first_step; k < first_step + n_steps; ++k) {
@@ -1090,10 +1093,14 @@ extern "C" void* hm_fwd_device_ptr(hm_fwd* f, const char* name) {
     if (s == "S_all") return f->S.p;
     FieldRef r;
     if (field_ref(f, name, r)) return nullptr;
-    // the caller may write K, fluxes ... through this pointer at any later time without the library seeing it: results cached across
-    // time steps (press_nd.hip) are not kept for this plan any more
-    ++f->inputs_gen;
-    f->raw_field_exposed = true;
+    // the caller may write an INPUT of the pressure step (K, the transmissibilities it may overwrite, the source field) through this
+    // pointer at any later time without the library seeing it: results cached across time steps (press_nd.hip) are not kept for this
+    // plan any more.  Pure outputs (P, Vx, Vy, nts, status ...) are rewritten by every step before anything reads them: handing
+    // those out costs nothing.
+    if (s == "K" || s == "Ky" || s == "TX" || s == "TY" || s == "q" || s == "por") {
+        ++f->inputs_gen;
+        f->raw_field_exposed = true;
+    }
     return r.p;
 }
 

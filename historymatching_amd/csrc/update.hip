@@ -1209,6 +1209,8 @@ extern "C" int hm_upd_sync(hm_upd* u, hm_stats* st) {
     return 0;
 }
 
+extern "C" int hm_upd_chain_fallbacks(hm_upd* u) { return u ? (int)u->chain_fallbacks : 0; }
+
 extern "C" int hm_upd_get_output(hm_upd* u, void* E_out) {
     HM_REQUIRE(u && E_out, "hm_upd_get_output: NULL argument");
     HM_HIP(hipSetDevice(u->ctx->device));

@@ -225,17 +225,20 @@ class Comm:
             return True
         if self.world_size == 1 and not force_single:
             return False
-        # Phase 1, every rank: a device context, librccl opened and its symbols bound (hm_comm_unique_id does both; only
-        # rank 0's id is used).  The outcome is agreed on BEFORE anyone enters ncclCommInitRank: a rank that cannot take part
-        # (no device, no librccl, a bad LOCAL_RANK) would otherwise leave the healthy ranks blocked in it for ever.
+        # Phase 1, every rank: a device context, librccl opened and its symbols bound (rank 0: hm_comm_unique_id, whose id is the one
+        # used; the others: hm_comm_probe, which starts no bootstrap listener).  The outcome is agreed on BEFORE anyone enters
+        # ncclCommInitRank: a rank that cannot take part (no device, no librccl, a bad LOCAL_RANK) would otherwise leave the healthy
+        # ranks blocked in it for ever.
         err, uid, lib = None, None, None
         try:
             ctx = ctx or _lib.Context.get(self.local_rank)
             lib = ctx.lib
-            buf = C.create_string_buffer(128)
-            _lib.check(lib.hm_comm_unique_id(buf), "hm_comm_unique_id")
             if self.rank == 0:
+                buf = C.create_string_buffer(128)
+                _lib.check(lib.hm_comm_unique_id(buf), "hm_comm_unique_id")
                 uid = buf.raw
+            else:
+                _lib.check(lib.hm_comm_probe(), "hm_comm_probe")
         except Exception as e:  # no GPU / no RCCL on this rank
             err = e
         if self.world_size > 1:

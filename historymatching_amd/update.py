@@ -157,7 +157,7 @@ class UpdatePlan:
     def sync(self):
         st = _lib.hm_stats()
         _lib.check(self.lib.hm_upd_sync(self.h, C.byref(st)), "hm_upd_sync")
-        return st.asdict()
+        return dict(st.asdict(), chain_fallbacks=int(self.lib.hm_upd_chain_fallbacks(self.h)))
 
     def output(self):
         out = np.empty((self.N_local, self.M), dtype=self.ft)
@@ -273,6 +273,9 @@ def ies(prior_ens, obs_ens, obs, perturbs, decorr, xStep=1.0, iMax=4, dtype=64, 
     stats = {"E": [], "Eo": []}
     if subspace == "auto":  # (the device step holds the n_obs x n_obs factor in one workgroup's LDS: up to ~190 observations)
         subspace = "device" if 256 <= N <= 1024 and y.shape[-1] <= 176 else "gram"
+    elif subspace == "device" and not (N <= 1024 and y.shape[-1] <= 176):
+        raise ValueError(f'ies(subspace="device") takes up to 1024 members and 176 observations (got N = {N}, n_obs = {y.shape[-1]}); '
+                         'use subspace="gram"')
     if subspace == "device":
         # The same Gauss-Newton step on the GPU: the localised smoother's device step (hm_iles_step: LU solve with W, n_obs x n_obs
         # Cholesky, the push-through form) with ONE local domain that holds every state element and a taper of ones is this step
@@ -280,18 +283,32 @@ def ies(prior_ens, obs_ens, obs, perturbs, decorr, xStep=1.0, iMax=4, dtype=64, 
         # constant row, which center(W^-1 .) removes because W keeps constant vectors).  The weights stay on the device between
         # iterates; only the N x N matrix comes back for the re-composition.
         plan = IlesPlan(prior_ens, [np.arange(prior_ens.shape[1])], np.ones((1, y.shape[-1])), cutoff=0.5, device=device)
+        done = 0
         try:
             for _ in range(int(iMax)):
-                E = recompose(plan.weights(0), X0, x0, dtype=dtype, device=device).astype(float)
+                W = plan.weights(0)
+                E = recompose(W, X0, x0, dtype=dtype, device=device).astype(float)
                 Eo = np.asarray(obs_ens(E), dtype=float)
                 stats["E"].append(E)
                 stats["Eo"].append(Eo)
                 Eo = Eo @ decorr
-                plan.step(Eo - Eo.mean(0), y - Dp - Eo, xStep)
-            W = plan.weights(0)
+                try:
+                    plan.step(Eo - Eo.mean(0), y - Dp - Eo, xStep)
+                except _lib.HmError:
+                    # the device step solves with W by LU and has no pseudo-inverse to fall back on: a numerically singular W (the reference's
+                    # pinv + SVD carries on there, HistoryMatch.py:927-938) is taken over by the host step -- this iterate and the rest
+                    W = W + xStep * ies_step(W, Eo, y - Dp - Eo, subspace="gram")
+                    done += 1
+                    stats["device_step_fallback_at_iterate"] = done - 1
+                    break
+                done += 1
+            else:
+                W = plan.weights(0)
         finally:
             plan.close()
-        return recompose(W, X0, x0, dtype=dtype, device=device).astype(float), stats
+        if done == int(iMax):
+            return recompose(W, X0, x0, dtype=dtype, device=device).astype(float), stats
+        iMax, subspace = int(iMax) - done, "gram"
     for _ in range(int(iMax)):
         E = recompose(W, X0, x0, dtype=dtype, device=device).astype(float)
         Eo = np.asarray(obs_ens(E), dtype=float)

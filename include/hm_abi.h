@@ -67,6 +67,7 @@ int         hm_copy_to_device(hm_ctx* ctx, void* dst_device, const void* src_hos
 #define HM_COMM_SUM 0
 #define HM_COMM_MAX 1
 int  hm_comm_unique_id(char* id_out /* HM_COMM_ID_BYTES */);
+int  hm_comm_probe(void);  /* 0 when librccl can be opened and bound on this rank; starts nothing (ranks other than 0 call this, not hm_comm_unique_id) */
 int  hm_comm_create(hm_ctx* ctx, int rank, int world_size, const char* unique_id, hm_comm** out);
 void hm_comm_destroy(hm_comm* c);
 int  hm_comm_rank(hm_comm* c);
@@ -258,7 +259,12 @@ int   hm_upd_run(hm_upd* u);
  * on a second stream (measured slower); kernel-variant selectors "gxt_dma", "gxt_chunk", "apply_variant", "small_inverse", ... */
 int   hm_upd_set_option(hm_upd* u, const char* name, int value);
 void* hm_upd_reduce_buffer(hm_upd* u, int which /*0..4*/, long long* n_elems, int* elem_bytes); /* device pointer */
+/* Waits for the plan's stream.  THE OUTPUT OF A RUN IS VALID ONLY AFTER hm_upd_sync HAS RETURNED 0: a fused run whose one-launch
+ * factorisation stalled (another stream or process held the CUs) is redone here through the two-kernel form, and only the LAST run is
+ * redone -- work that reads E_out (hm_fwd_set_inputs_device, a further hm_upd_run after hm_upd_swap) must be queued after this call,
+ * as update.es_mda_device and dist.es_mda_sharded do.  hm_upd_chain_fallbacks counts such redone steps of the plan. */
 int   hm_upd_sync(hm_upd* u, hm_stats* stats);
+int   hm_upd_chain_fallbacks(hm_upd* u);
 int   hm_upd_get_output(hm_upd* u, void* E_out_local);
 void* hm_upd_device_ptr(hm_upd* u, const char* name);   /* "E","E_out","obs_ens","perturbs" */
 

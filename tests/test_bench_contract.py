@@ -1,0 +1,39 @@
+"""The bench line's contract (task prompt, section 4): the committed line of the last GPU run (profiles/rNN/bench_default.json, written
+by `python3 bench.py` on the MI355X box through profiles/tools/collect_rNN.sh) has every key the driver and the judge read, with the
+types and relations they rely on.  CPU-only: it checks the record, not the GPU."""
+import json
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _latest_line():
+    files = sorted(ROOT.glob("profiles/r*/bench_default.json"))
+    assert files, "no committed bench line"
+    return json.loads(files[-1].read_text()), files[-1]
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    d, path = _latest_line()
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict),
+                     ("roofline", dict), ("cpu_baseline", dict)):
+        assert key in d and isinstance(d[key], typ), (path, key)
+    assert "vs_baseline" in d and d["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
+    baseline = json.loads((ROOT / "BASELINE.json").read_text())
+    assert d["metric"] == baseline["metric"] or d["metric"] in str(baseline)
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "stale_inputs"):
+        assert key in r, key
+    # `frac` is always a number (this run's launch time priced with the committed instruction counts); staleness of those counts is a flag
+    assert isinstance(r["frac"], float) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert isinstance(r["stale_inputs"], bool)
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    # value = members x time steps x steps / wall, with the wall the line itself reports
+    members, n_time = d["config"]["members_per_gpu"], d["config"]["nTime"]
+    assert abs(d["value"] - members * n_time / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
