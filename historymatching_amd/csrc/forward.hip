@@ -1085,6 +1085,8 @@ extern "C" int hm_fwd_set_field(hm_fwd* f, const char* name, const void* in) {
     return 0;
 }
 
+extern "C" long long hm_fwd_nd_fallbacks(hm_fwd* f) { return f ? f->nd_fallbacks : 0; }
+
 extern "C" void* hm_fwd_device_ptr(hm_fwd* f, const char* name) {
     if (!f || !name) return nullptr;
     std::string s(name);

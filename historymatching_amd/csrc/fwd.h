@@ -63,6 +63,7 @@ struct hm_fwd {
     // two-level CG preconditioner (allocated on first use): coarse transmissibilities, pin, restricted residual, coarse
     // correction, coarse scratch, coarse factor, per-member CG scalars and convergence flags
     DevBuf tl_TXc, tl_TYc, tl_pin, tl_rc, tl_yc, tl_yv, tl_G, tl_cgs, tl_done, tl_ndone, tl_z1, tl_dinv, tl_parts;
+    int tl_n = 0;        // members the two-level buffers were sized for (they grow when a larger member block asks)
     int cg_precond = 0;  // 0 = two-level where it applies, 1 = Jacobi
     DevBuf S;      // keep_history ? N*(nTime+1)*Nxy : 2*N*Nxy (ping-pong)
     DevBuf prods;  // N*nTime*nPrd
@@ -74,6 +75,7 @@ struct hm_fwd {
     std::vector<int> q_epoch;  // per column of q_host: first time step of the run of equal columns it belongs to (build_q)
     DevBuf well_cells;
     DevBuf team_mem;  // synchronisation blocks of the multi-tile saturation sweep (sat128t.hip), allocated on first use
+    long long nd_fallbacks = 0;  // member-steps the direct solver of the larger grids handed to the two-level CG (press_nd.hip: nd_check_and_fall_back)
     long long team_retries = 0, team_retries_seen = 0;  // time steps redone by the tiled sweep after a team gave up waiting
 };
 

@@ -1645,10 +1645,45 @@ __global__ __launch_bounds__(256, 4) void k_nd_solve_sub(FwdParams p, NdDev nd, 
 }
 
 // Face fluxes from the pressures (fwd_dev.h), one workgroup per member.
-__global__ __launch_bounds__(1024) void k_nd_flux(FwdParams p) {
+__global__ __launch_bounds__(1024) void k_nd_flux(FwdParams p, int k) {
     const int m = blockIdx.x, Nx = p.Nx;
-    face_fluxes(p, p.P + (long long)m * p.Nxy, p.TX + (long long)m * (Nx + 1) * NB, p.TY + (long long)m * Nx * (NB + 1),
-                p.Vx + (long long)m * (Nx + 1) * NB, p.Vy + (long long)m * Nx * (NB + 1), threadIdx.x, 1024);
+    double* Vx = p.Vx + (long long)m * (Nx + 1) * NB;
+    double* Vy = p.Vy + (long long)m * Nx * (NB + 1);
+    face_fluxes(p, p.P + (long long)m * p.Nxy, p.TX + (long long)m * (Nx + 1) * NB, p.TY + (long long)m * Nx * (NB + 1), Vx, Vy, threadIdx.x, 1024);
+#if ND_LG > 7
+    // A posteriori check of the direct solve (the larger grids only): the fluxes must reproduce the wells, max |div V - q| <= 1e-7 max |q|.
+    // An elimination without pivoting loses that on the rare member whose permeability spans ten orders of magnitude (cond(A) beyond
+    // 1 / eps: the diagonal of a strongly coupled cluster cancels to nothing; measured on a 256 x 256 member with K = 0.1 ... 1.2e9: fluxes
+    // off by 40 % three steps before the first non-positive pivot shows) -- such a member is flagged like a bad pivot, and the host hands
+    // it to the two-level CG for this step (nd_check_and_fall_back).
+    __shared__ double red[2][16];
+    __syncthreads();
+    const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * p.Nxy;
+    double worst = 0.0, qmax = 0.0;
+    for (int c = threadIdx.x; c < p.Nxy; c += 1024) {
+        const int ix = c >> LG, iy = c & (NB - 1), fy = ix * (NB + 1) + iy;
+        const double div = (Vx[c + NB] - Vx[c]) + (Vy[fy + 1] - Vy[fy]);
+        const double e = fabs(div - q[c]);
+        worst = (e > worst || e != e) ? e : worst;  // (a NaN wins)
+        qmax = fmax(qmax, fabs(q[c]));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double w2 = __shfl_xor(worst, o), q2 = __shfl_xor(qmax, o);
+        worst = (w2 > worst || w2 != w2) ? w2 : worst;
+        qmax = fmax(qmax, q2);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = worst; red[1][threadIdx.x >> 6] = qmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) {
+            worst = (red[0][w] > worst || red[0][w] != red[0][w]) ? red[0][w] : worst;
+            qmax = fmax(qmax, red[1][w]);
+        }
+        if (!(worst <= 1e-7 * qmax)) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
+    }
+#else
+    (void)k;
+#endif
 }
 
 }  // namespace
@@ -1851,10 +1886,57 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
     hipLaunchKernelGGL(k_nd_solve, dim3(p.N), dim3(64 * SOL_NW), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_solve_sub, dim3(p.N * (64 << LO)), dim3(256), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_leaf_solve, dim3(p.N * (4 << LO)), dim3(256), 0, s, p, nd, k);
-    hipLaunchKernelGGL(k_nd_flux, dim3(p.N), dim3(1024), 0, s, p);
+    hipLaunchKernelGGL(k_nd_flux, dim3(p.N), dim3(1024), 0, s, p, k);
     HM_HIP(hipGetLastError());
     return 0;
 }
+
+#if ND_LG > 7
+// The direct solver's safety net on the larger grids.  A member the elimination could not solve -- a non-positive pivot, or fluxes that
+// do not reproduce the wells (k_nd_flux) -- is solved again for this time step by the two-level conjugate-gradient solver
+// (press_pcg.hip: it works on the matrix itself and stops on its residual), as a member block of one.  Members are independent, so nothing
+// else is touched.  Costs one stream synchronisation and a read of the status words per time step (a step is ~25 ms of pressure solve and
+// ~75 ms of sweep per 512 members); a flagged member costs a single-member CG solve (a few ms).  More than ND_MAX_FALLBACK flagged members
+// in one step are a defect of the inputs (K <= 0, NaN), not of conditioning: their flags stay.
+constexpr int ND_MAX_FALLBACK = 32;
+static int nd_check_and_fall_back(hm_fwd* f, const void* S, long long S_stride, int k) {
+    const FwdParams p = f->p;
+    hipStream_t s = f->ctx->stream;
+    std::vector<int> st((size_t)p.N);
+    HM_HIP(hipMemcpyAsync(st.data(), p.status, (size_t)p.N * 4, hipMemcpyDeviceToHost, s));
+    HM_HIP(hipStreamSynchronize(s));
+    std::vector<int> bad;
+    for (int m = 0; m < p.N; ++m)
+        if (st[m] & HM_MEMBER_BAD_PIVOT) bad.push_back(m);
+    if (bad.empty() || (int)bad.size() > ND_MAX_FALLBACK || !pressure_two_level_applies(p)) return 0;
+    int rc = 0;
+    for (int m : bad) {
+        const long long o = m;
+        const int cleared = st[m] & ~HM_MEMBER_BAD_PIVOT;
+        HM_HIP(hipMemcpyAsync(p.status + o, &cleared, 4, hipMemcpyHostToDevice, s));
+        HM_HIP(hipMemsetAsync(p.P + o * p.Nxy, 0, (size_t)p.Nxy * 8, s));  // the CG starts from the pressures it finds: not from a failed solve's
+        HM_HIP(hipStreamSynchronize(s));                                    // (`cleared` leaves scope)
+        FwdParams pb = p;
+        pb.N = 1;
+        pb.K = p.K + o * p.Nxy;
+        if (p.Ky) pb.Ky = p.Ky + o * p.Nxy;
+        pb.q = p.q + o * p.q_mstride;
+        pb.TX = p.TX + o * (p.Nx + 1) * NB;
+        pb.TY = p.TY + o * p.Nx * (NB + 1);
+        pb.P = p.P + o * p.Nxy;
+        pb.Vx = p.Vx + o * (p.Nx + 1) * NB;
+        pb.Vy = p.Vy + o * p.Nx * (NB + 1);
+        pb.status = p.status + o;
+        pb.n_cg = p.n_cg + o * p.nTime;
+        f->p = pb;  // (launch_pressure_two_level reads the plan's parameter block)
+        rc = launch_pressure_two_level(f, (const char*)S + (size_t)(o * S_stride) * f->esz, S_stride, k);
+        f->p = p;
+        if (rc) return rc;
+        f->nd_fallbacks++;
+    }
+    return 0;
+}
+#endif
 
 // Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
 int ND_ENTRY(launch_pressure_nd)(hm_fwd* f, const void* S, long long S_stride, int k) {
@@ -1879,7 +1961,14 @@ int ND_ENTRY(launch_pressure_nd)(hm_fwd* f, const void* S, long long S_stride, i
         f->nd->cached_q_epoch = ep;
     }
     const int cap = f->nd->cap;
+#if ND_LG > 7
+    if (p.N <= cap) {
+        if (int rc = nd_launch_block(f, p, S, S_stride, k)) return rc;
+        return nd_check_and_fall_back(f, S, S_stride, k);
+    }
+#else
     if (p.N <= cap) return nd_launch_block(f, p, S, S_stride, k);
+#endif
     for (int m0 = 0; m0 < p.N; m0 += cap) {  // blocks of members through the same factor / update / panel buffers, one after the other
         FwdParams pb = p;
         const long long o = m0;
@@ -1896,7 +1985,11 @@ int ND_ENTRY(launch_pressure_nd)(hm_fwd* f, const void* S, long long S_stride, i
         const char* Sb = (const char*)S + (size_t)(o * S_stride) * f->esz;
         if (int rc = nd_launch_block(f, pb, Sb, S_stride, k)) return rc;
     }
+#if ND_LG > 7
+    return nd_check_and_fall_back(f, S, S_stride, k);
+#else
     return 0;
+#endif
 }
 
 #ifdef HM_ND_PROF

@@ -573,7 +573,11 @@ int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int 
     hipStream_t s = f->ctx->stream;
     const int c = p.Ny / 128, Nxc = p.Nx / c;
     const size_t n = p.N, nc = (size_t)Nxc * 128;
-    if (!f->tl_TXc.p) {
+    if (!f->tl_TXc.p || f->tl_n < p.N) {  // (first use, or sized for a smaller member block: the fall-back of the direct solver runs single members)
+        DevBuf* bufs[] = {&f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->tl_z1, &f->tl_dinv, &f->tl_parts};
+        if (f->tl_TXc.p) HM_HIP(hipStreamSynchronize(s));
+        for (DevBuf* b : bufs) hm_dev_free(*b);
+        f->tl_n = p.N;
         int rc = 0;
 #define A_(buf, bytes) if (!rc) rc = hm_dev_alloc(f->buf, (bytes))
         A_(tl_TXc, n * (Nxc + 1) * 128 * 8); A_(tl_TYc, n * Nxc * 129 * 8); A_(tl_pin, n * 8); A_(tl_rc, n * nc * 8); A_(tl_yc, n * nc * 8);

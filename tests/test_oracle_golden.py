@@ -209,3 +209,27 @@ def test_rectangular_partitioning_matches_reference_fixture():
         assert sorted(np.concatenate(batches)) == list(range(int(np.prod(shape))))  # a partition of the grid
         c += 1
     assert c == 5
+
+
+def test_npv_accounting_matches_the_reference_fixture(golden):
+    """F10 (oracle/make_golden_npv.py): the ledgers of the reference's OWN `accounting` / `prd_sats` (Optimise.py:170-208, AST-extracted) on
+    six synthetic cases -- shut-in intervals, a late producer, field production above rate0, changing injection rates.  Both the oracle's
+    restatement and the product's accounting reproduce every entry."""
+    from historymatching_amd import opt as popt
+    from oracle import opt as oopt
+
+    f = _load(golden, "f10_npv_accounting.npz")
+    dt, nTime, rate0 = float(f["dt"]), int(f["nTime"]), float(f["rate0"])
+    keys = [str(k) for k in f["ledger_keys"]]
+    price = dict(zip((str(k) for k in f["price_keys"]), f["price_values"]))
+    assert popt.default_prices(dt) == pytest.approx(price) and np.allclose(popt.discounts(dt, nTime), f["discounts"], rtol=0, atol=1e-15)
+    for i in range(int(f["n_cases"])):
+        wsats, cells, inj, prd, ref = f[f"wsats_{i}"], f[f"prd_cells_{i}"], f[f"inj_{i}"], f[f"prd_{i}"], f[f"ledger_{i}"]
+        s = wsats[:, cells]
+        prd_wsats = ((s[:-1] + s[1:]) / 2).T   # prd_sats, Optimise.py:205-208 (the product forms it the same way: opt.py NpvBatch.__call__)
+        assert np.array_equal(prd_wsats, f[f"prd_wsats_{i}"])
+        lo = oopt.accounting(prd_wsats, inj, prd, dt, nTime, rate0)
+        lp = popt.accounting(prd_wsats, inj, prd, dt, popt.default_prices(dt), popt.discounts(dt, nTime), rate0)
+        for k, r in zip(keys, ref):
+            assert abs(lo[k] - r) <= 1e-12 * max(1.0, abs(r)), (i, k, lo[k], r)
+            assert abs(lp[k] - r) <= 1e-12 * max(1.0, abs(r)), (i, k, lp[k], r)
