@@ -956,8 +956,13 @@ extern "C" int hm_fwd_run(hm_fwd* f, int first_step, int n_steps) {
     // a run from time index 0 is a new forward_model call (HistoryMatch.py:383-387): it does the work a fresh plan does -- nothing the
     // pressure solve kept from an earlier run's time steps is reused, even where the inputs are the same
     if (first_step == 0) ++f->inputs_gen;
-    int rc = f->t_total.begin(f->ctx->stream);
-    if (rc) return rc;
+    int rc = 0;
+    {   // one-time set-up of the nested-dissection solver (tables, factor / update buffers): before the run's clock starts
+        const int pv = f->press_variant;
+        if (pv == 0 || pv == 12 || pv == 14)
+            if ((rc = prepare_pressure_nd(f)) || (rc = prepare_pressure_nd256(f)) || (rc = prepare_pressure_nd512(f))) return rc;
+    }
+    if ((rc = f->t_total.begin(f->ctx->stream))) return rc;
     for (int k = first_step; k < first_step + n_steps; ++k) {
         if ((rc = launch_pressure(f, k))) return rc;
         if ((rc = launch_saturation(f, k))) return rc;

@@ -96,6 +96,9 @@ static inline void* fwd_S_ptr(hm_fwd* f, int k, long long* stride) {
 int launch_pressure_128s(hm_fwd* f, const void* S, long long S_stride, int k);  // MFMA panels, symmetric tile storage (default)
 bool pressure_nd_applies(const FwdParams& p);
 int launch_pressure_nd(hm_fwd* f, const void* S, long long S_stride, int k);     // nested dissection, 128 x 128 (press_nd.hip)
+int prepare_pressure_nd(hm_fwd* f);   // tables + buffers before the first launch (outside a run's timed region)
+int prepare_pressure_nd256(hm_fwd* f);
+int prepare_pressure_nd512(hm_fwd* f);
 bool pressure_nd_applies256(const FwdParams& p);
 int launch_pressure_nd256(hm_fwd* f, const void* S, long long S_stride, int k);  // 256 x 256 (press_nd.hip compiled with -DND_LG=8)
 bool pressure_nd_applies512(const FwdParams& p);

@@ -130,7 +130,7 @@ int  hm_fwd_run(hm_fwd* f, int first_step, int n_steps);           /* steps [fir
                                                                      * (grids beyond poll CG convergence on the host)        */
 int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
 /* Member-steps the direct pressure solver of the 256 x 256 / 512 x 512 grids handed to the two-level CG since the plan was created: a
- * member whose elimination met a non-positive pivot, or whose fluxes missed the wells by more than 1e-7 of the largest rate (the
+ * member whose elimination met a non-positive pivot, or whose fluxes missed the wells by more than 1e-4 of the largest rate (the
  * reference's sparse direct solve with partial pivoting, HistoryMatch.py:362, does not fail on such members either). */
 long long hm_fwd_nd_fallbacks(hm_fwd* f);
 int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member);     /* D2H */
