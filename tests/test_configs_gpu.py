@@ -223,6 +223,44 @@ def test_config5_grid_properties_over_steps(dtype):
     assert not st2.any() and np.abs(S_sub.astype(float) - S_end[[3, 1]]).max() < (1e-6 if dtype == 64 else 1e-4)
 
 
+def test_config5_shard_whole_run_properties():
+    """One rank's shard of config 5 as the 8-GPU configuration runs it: 125 members at 512 x 512, all 40 steps, fp32 plans (fp32 tile-team
+    sweep sat128ft, fp64 nested-dissection pressure solve press_nd512.o) -- late-run behaviour included (the tile teams' sweep slows as the
+    grid gets wet).  Mass-balance bracket, bounds, monotone producer series, and a sub-ensemble from different team rounds (16 members a
+    round) run alone agrees bit for bit (the direct solver and the sweep treat every member by itself)."""
+    from historymatching_amd.forward import ForwardPlan
+
+    n, N, steps = 512, 125, 40
+    _, gm = make_models(n, n, dtype=32)
+    x = perms(n, n, N, seed=8)
+    plan = ForwardPlan(gm, N, DT, steps, keep_history=False)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    st = plan.sync()
+    S_end, prods, status = plan.outputs()
+    plan.close()
+    assert not status.any() and st["mean_n_cg"] == 0 and st["nd_fallbacks"] == 0 and st["mean_nts"] > 9000
+    S64, p64 = S_end.astype(float), prods.astype(float)
+    tol = 2e-4
+    assert S64.min() >= -tol and S64.max() <= 1 + tol and np.isfinite(p64).all()
+    assert (np.diff(p64, axis=1) >= -tol).all()
+    fw = lambda s: s * s / (s * s + (1 - s) * (1 - s))  # noqa: E731
+    water = S64.sum(1) * (gm.Lx / n) * (gm.Ly / n)
+    injected = steps * DT * 1.0
+    at_end = DT * 0.25 * fw(p64).sum((1, 2))
+    at_start = DT * 0.25 * fw(np.concatenate([np.zeros((N, 1, 4)), p64[:, :-1]], 1)).sum((1, 2))
+    assert (water >= injected - at_end - 5e-4).all() and (water <= injected - at_start + 5e-4).all()
+    sub = [0, 15, 16, 77, 124]
+    plan = ForwardPlan(gm, len(sub), DT, steps, keep_history=False)
+    plan.set_inputs(x[sub], transformed=False)
+    plan.run()
+    plan.sync()
+    S_sub, p_sub, st2 = plan.outputs()
+    plan.close()
+    assert not st2.any()
+    assert np.array_equal(S_sub, S_end[sub]) and np.array_equal(p_sub, prods[sub])
+
+
 def test_config5_localised_update_at_shard_shape_vs_oracle():
     """Config 5's analysis step at its own size: N = 1000 members in 8 row shards of 125 (one per GPU of the node), M = 512 * 512
     state elements, n_obs = 160, fp32 plans (matrix-core contractions and local analyses), taper = bump(dist / 1.2) from the

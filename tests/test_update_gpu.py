@@ -520,6 +520,29 @@ def test_device_kronecker_prior_sampler_matches_host(nx, ny, N):
     assert np.abs(dev - host).max() <= 1e-12 * max(1.0, np.abs(host).max())
 
 
+def test_device_prior_sampler_has_the_reference_law(golden):
+    """hm_sample_kron against the REFERENCE's prior law (fixture F11: rows of the dense covariance the reference's geostat.py forms on the
+    default 20 x 20 grid, and the 2000-sample covariance of its own sampler): the sample covariance of 40 000 device-drawn fields
+    matches the reference's covariance rows within sampling error (4 standard errors of a covariance estimate at this size: 0.03; the
+    reference's own sampler is 0.11 off at its 2000 samples), their mean is zero and their variance one -- and an oracle-side dense
+    sampler (oracle/geostat.py, the reference's algorithm) gives the same statistics."""
+    from historymatching_amd.geostat import gaussian_fields_kron_device
+    from oracle import geostat as og
+
+    f = np.load(golden / "f11_prior_law.npz")
+    Nx, Ny, Lx, Ly, r, cells = int(f["Nx"]), int(f["Ny"]), float(f["Lx"]), float(f["Ly"]), float(f["r"]), f["cells"]
+    n = 40000
+    dev = gaussian_fields_kron_device(Nx, Ny, Lx, Ly, n, r=r, seed=123)
+    assert dev.shape == (n, Nx * Ny) and np.abs(dev.mean(0)).max() < 5 / np.sqrt(n)
+    X = dev - dev.mean(0)
+    cov_rows = (X[:, cells].T @ X) / (n - 1)
+    assert np.abs(cov_rows - f["cov_rows"]).max() < 0.03
+    assert np.abs(np.abs(f["ref_sample_cov_2000"] - f["cov_rows"]).max() - 0.1) < 0.1   # (what 2000 samples of the reference's own sampler give)
+    dense = og.gaussian_fields(Nx, Ny, Lx, Ly, 4000, r=r, rng=np.random.RandomState(5))
+    Xd = dense - dense.mean(0)
+    assert np.abs((Xd[:, cells].T @ Xd) / (len(Xd) - 1) - f["cov_rows"]).max() < 0.1
+
+
 def test_device_iles_matches_reference_fixture_and_host_twin(golden):
     """the localised iterative smoother with its per-domain subspace algebra on the device (iles.hip: LU
     solve with W, n_loc x n_loc Cholesky, push-through form of the Gauss-Newton step) against
