@@ -74,6 +74,60 @@ def cpu_baseline(members, steps, nproc):
     return members * steps / wall, wall
 
 
+def config1_reference_run(device, nproc):
+    """BASELINE config 1 -- "Reference HistoryMatch.py CPU run: N_e=100, default 2D grid, 1 ES-MDA iteration" -- both ways: the oracle
+    on the host cores parallelised like the reference (utils.py:201-224: one process per core) and the same forward run + one analysis
+    step on the GPU.  Default grid and wells of HistoryMatch.py:97, 177-190 (20 x 20 cells on 2 x 1), nTime = 40."""
+    import scipy.linalg as sla
+
+    from historymatching_amd.forward import ForwardPlan
+    from historymatching_amd.geostat import gaussian_fields_kron
+    from historymatching_amd.update import UpdatePlan
+    from oracle import es as oes
+    from oracle.ressim import ResSim, default_wells, forward_model, make_pool
+
+    n, N = 20, 100
+    x = gaussian_fields_kron(n, n, 2, 1, N, r=0.8, seed=77)
+    R12 = reference_obs_error(160)
+    rng = np.random.RandomState(5)
+    om = default_wells(ResSim(n, n, 2, 1))
+    procs = max(1, min(nproc, N))
+    with make_pool(procs) as pool:
+        forward_model(om, x[:procs], None, DT, 1, pool=pool)  # warm-up
+        t0 = time.perf_counter()
+        _, prods_cpu = forward_model(om, x, None, DT, NTIME, pool=pool)
+        cpu_fwd = time.perf_counter() - t0
+    obs = np.clip(prods_cpu[0].reshape(-1) + R12 @ rng.randn(160), 0, 1)
+    perturbs, decorr = rng.randn(N, 160) @ R12.T, sla.inv(R12.T)
+    t0 = time.perf_counter()
+    post_cpu = oes.ens_update0(x, prods_cpu.reshape(N, -1), obs, perturbs, decorr)
+    cpu_upd = time.perf_counter() - t0
+    model = build_model(64, device=device, n=n)
+    plan = ForwardPlan(model, N, DT, NTIME, keep_history=False, device=device)
+    upd = UpdatePlan(N, N, n * n, 160, dtype=64, device=device)
+    for _ in range(2):  # second pass timed
+        plan.set_inputs(x, None, transformed=False)
+        t0 = time.perf_counter()
+        plan.run()
+        st = plan.sync()
+        gpu_fwd = time.perf_counter() - t0
+    _, prods_gpu, status = plan.outputs(want_wsats=False)
+    upd.set_inputs(x, prods_gpu.reshape(N, -1), obs, perturbs, decorr)
+    upd.run_local()
+    t0 = time.perf_counter()
+    su = upd.run_local()
+    gpu_upd = time.perf_counter() - t0
+    post_gpu = upd.output()
+    plan.close()
+    upd.close()
+    return {"workload": "N_e=100, 20x20 (HistoryMatch.py:97), nTime=40, one forward run + one ens_update0 (fp64)",
+            "cpu": {"kind": "port", "cores": procs, "forward_s": cpu_fwd, "update_s": cpu_upd, "ensemble_steps_per_s": N * NTIME / cpu_fwd},
+            "gpu": {"forward_s": gpu_fwd, "forward_device_ms": st["ms_total"], "update_s": gpu_upd, "update_device_ms": su["ms_update"],
+                    "ensemble_steps_per_s": N * NTIME / gpu_fwd, "status_ok": bool(not status.any())},
+            "max_abs_diff_producer_series": float(np.abs(prods_gpu - prods_cpu).max()),
+            "max_abs_diff_posterior": float(np.abs(post_gpu - post_cpu).max())}
+
+
 def nd_mfma_count():
     """v_mfma_f64_16x16x4 instructions per member and time step of the nested-dissection factorisation (press_nd.hip), from the
     symbolic tables: a front with st pivot tiles and bt boundary tiles runs, per pivot tile p with kreg 4-row groups, kreg matrix
@@ -632,6 +686,10 @@ def main():
             cpu = {"value": v, "unit": "ensemble-steps/s", "cores": nproc, "kind": "port",
                    "sample": f"{members} members x {args.cpu_steps} steps of the same 128x128 workload, "
                              f"{nproc} processes x 1 BLAS thread, {wall:.1f} s wall"}
+            try:
+                cpu["config1"] = config1_reference_run(local_rank, nproc)
+            except Exception as e:
+                cpu["config1"] = {"error": f"{type(e).__name__}: {e}"}
         out = {
             "metric": "ensemble-steps/sec", "value": value, "unit": "ensemble-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,

@@ -384,10 +384,10 @@ def es_mda_sharded(model, prior_local, obs, R12, dt, nTime, n_iter=4, seed=0, co
             err = None
             perturbs = np.sqrt(alpha) * (rng.randn(N, n_obs)[lo:lo + Nl] @ R12.T)  # drawn on every rank, failed or not
             try:
+                upd.set_inputs(perturbs=perturbs)  # (before the pass: nothing of the update waits for the host afterwards)
                 fwd.set_inputs_device(upd.device_ptr("E"), dtype, transformed=False)
                 fwd.run()
                 upd.set_inputs_device(obs_ens_ptr=fwd.device_ptr("prods"), obs_dtype=model.dtype)
-                upd.set_inputs(perturbs=perturbs)
                 ms_fwd += fwd.sync()["ms_total"]
                 _, _, status = fwd.outputs(want_wsats=False)
                 if status.any():
