@@ -6,8 +6,8 @@
 // tree is a complete binary tree: levels 0..9 are separators (128, 64, 64, 32, 32, 16, 16, 8, 8, 4 cells), level 10 the
 // 1024 leaves (3x3 .. 4x4 cells).  Front (level l, index i) has id 2^l - 1 + i; its children are (l+1, 2i) and (l+1, 2i+1).
 // A grid of 128 * 2^h cells a side has 2 h more levels on top (LO = 2 h: 13 levels at 256 x 256, 15 at 512 x 512); its levels
-// LO + 5 .. LO + 10 have the shapes of the 128 x 128 tree's levels 5..10 (same separators, same largest boundaries) and are
-// eliminated by the same kernels; its levels 0 .. LO + 4 are the BIG fronts (up to 25 / 49 tile rows), eliminated tile column by
+// LO + 4 .. LO + 10 have the shapes of the 128 x 128 tree's levels 4..10 (same separators, same largest boundaries) and are
+// eliminated by the same kernels (level LO + 3 by the workgroup kernel as well); its levels 0 .. LO + 2 are the BIG fronts (up to 25 / 49 tile rows), eliminated tile column by
 // tile column out of global memory (press_nd.hip: k_big_*), their update matrices stored as whole 16 x 16 tiles.
 //
 // A front = s pivots (its separator / leaf cells) + b boundary cells (the part of the region's perimeter that is an
@@ -46,7 +46,7 @@
                                // (global memory); level 9's in per-wave LDS slots
 #define ND_WAVE_TOP_LEVEL 5    // levels 10..5: one wave per front;  levels 4..0: one workgroup per front (per member) at 128 x 128,
                                // the big-front kernels on the larger grids
-// Update matrices of the BIG fronts (levels 0 .. LO + 4 of a grid with LO > 0) are stored as whole tiles: tile (R, C), 0 <= C <= R < bt,
+// Update matrices of the BIG fronts (levels 0 .. LO + 2 of a grid with LO > 0) are stored as whole tiles: tile (R, C), 0 <= C <= R < bt,
 // at NDF_UPD + (R (R + 1) / 2 + C) * 256 doubles, entry (i, j) = (16 R + 4 r + lq, 16 C + lc) at [r * 64 + lq * 16 + lc] -- the accumulator
 // layout as it stands in the registers.  All other update matrices are packed lower triangles, entry (i, j) at i (i + 1) / 2 + j.
 
@@ -81,7 +81,7 @@ struct NdInfo {
     int n_cells;              // entries of `cells` (and, twice, of `cpos`)
     int n_rec_blocks;         // blocks of 256 int16 in `rec`
     long long fact_doubles;   // per member
-    long long big_fact_doubles;  // of that, the factor of the big fronts (levels 0 .. lo + 4; they come first): the size of the image scratch
+    long long big_fact_doubles;  // of that, the factor of the big fronts (levels 0 .. lo + 2; they come first): the size of the image scratch
     long long arena_doubles;  // per member
     long long pimg_doubles;   // per member: inverse pivot tiles of the big fronts
     int upd_doubles[ND_MAX_LEVELS];  // largest update matrix per level (packed: (b + 1)(b + 2) / 2 rounded up to even; tiles: bt (bt + 1) / 2 * 256)

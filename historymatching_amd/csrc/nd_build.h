@@ -109,7 +109,7 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
     I.n_fronts = nF;
     I.levels = levels;
     I.lo = lo;
-    const int big_top = lo > 0 ? lo + 4 : -1;  // levels 0 .. big_top: big fronts (tile-format updates, no recipes)
+    const int big_top = lo > 0 ? lo + 2 : -1;  // levels 0 .. big_top: big fronts (tile-format updates); levels lo + 3, lo + 4: k_nd_top's, packed
     t.fronts.assign((size_t)nF * ND_FRONT_INTS, 0);
     t.cells.clear();
     long long fact = 0, arena = 0, pimg = 0;

@@ -845,7 +845,11 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
 // as register images (lane-major, conflict-free 8-byte reads) and store the factor;  every later tile is updated with
 // Y^T Z products of two published images.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int TOP_NW = 16, TOP_NVS = 3, TOP_NTS = 4, TOP_MAXT = LG == 7 ? 13 : (LG == 8 ? 25 : 49);  // (larger grids: TOP_MAXT sizes the back substitution only)
+constexpr int TOP_NW = 16;
+constexpr int TOP_MAXT = LG == 7 ? 13 : (LG == 8 ? 25 : 49);  // tile rows of the largest front of the grid (sizes the back substitution)
+// k_nd_top<TOP_NVS, TOP_NTS, TOPK_MAXT, TOPK_LEVEL>: panel / trailing tiles per wave, tile rows of the largest front it takes, and (larger
+// grids) the one level it eliminates, a workgroup per front.  128 x 128: <3, 4, 13, 4> (levels 4..0 of a member in one workgroup);
+// larger grids: <3, 4, 13, LO + 4> and <2, 6, 15, LO + 3>.
 
 // A child's packed update matrix (n2 double2), arena -> LDS, by the whole workgroup through LDS-DMA (global_load_lds_dwordx4: no
 // registers, every piece in flight at once, retired by the issuing wave's vmcnt): pieces of 64 double2 = 1 KB, wave w takes pieces
@@ -875,16 +879,26 @@ __device__ __forceinline__ void img_store(double* img, int lane, const d4& v) {
     for (int r = 0; r < 4; ++r) img[r * 64 + lane] = v[r];
 }
 
-#if ND_LG == 7
-__global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, int k) {
+// Larger grids (ND_LG > 7): the same kernel eliminates the fronts of level LO + 4 -- the shape of the 128 x 128 tree's level 4: two pivot
+// tiles, up to 8 boundary tiles, children packed by k_nd_wave<5> -- and, with six trailing tiles a wave, those of level LO + 3 (two pivot
+// tiles, up to 13 boundary tiles), ONE FRONT PER WORKGROUP (grid: members x fronts of the level); the levels above are the big fronts
+// (k_big_*).  As big fronts the 64 / 256 fronts of level LO + 4 cost 3.0 ms per 512 members at 256 x 256 (one wave per tile row or 2 x 2
+// tiles, every operand through L2); here 1.4.
+template <int TOP_NVS, int TOP_NTS, int TOPK_MAXT, int TOPK_LEVEL>
+__global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, int k, int top_child_doubles) {
     extern __shared__ double nd_lds[];
     double* Pimg = nd_lds;                       // 256
-    double* Wimg = Pimg + 256;                   // TOP_MAXT x 256
-    double* Vimg = Wimg + TOP_MAXT * 256;        // TOP_MAXT x 256
-    int* cl_s = reinterpret_cast<int*>(Vimg + TOP_MAXT * 256);  // 16 T ints (<= 832 B) in one DMA piece of 1 KB
+    double* Wimg = Pimg + 256;                   // TOPK_MAXT x 256
+    double* Vimg = Wimg + TOPK_MAXT * 256;       // TOPK_MAXT x 256
+    int* cl_s = reinterpret_cast<int*>(Vimg + TOPK_MAXT * 256);  // 16 T ints (<= 832 B) in one DMA piece of 1 KB
     short* cp_s0 = reinterpret_cast<short*>(cl_s + 256);        // 16 T shorts for child 0, then 16 T for child 1, as in memory: one piece
     double* chl = reinterpret_cast<double*>(cp_s0 + 512);       // the children's packed updates
-    const int m = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+#if ND_LG == 7
+    const int m = blockIdx.x;
+#else
+    const int m = blockIdx.x % p.N;
+#endif
     NdGeo g;
     g.lane = tid & 63;
     g.lc = g.lane & 15;
@@ -897,13 +911,23 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
     NPROF_DECL;
     // the records of fronts 0..30 in LDS, read once (they carry their children's sizes and offsets): per front they would otherwise
     // cost two dependent round trips to memory (the front's record, then its children's) before anything else can start
-    const int chl_cap = top_pad(nd.top_child_doubles);  // doubles: whole DMA pieces
+    const int chl_cap = top_pad(top_child_doubles);  // doubles: whole DMA pieces
     int* frec = reinterpret_cast<int*>(chl + chl_cap);  // 31 records behind the child buffer
+#if ND_LG == 7
     for (int i = tid; i < 31 * ND_FRONT_INTS; i += 64 * TOP_NW) frec[i] = nd.fronts[i];
     __syncthreads();
     // the fronts of levels 4..0 that are eliminated this step, in order (k_nd_plan: those whose subtree is still dry keep the results they have)
     const int* tlist = nd.work + (long long)m * ND_WORK_INTS + ND_WT;
     const int nt = __builtin_amdgcn_readfirstlane(tlist[0]);
+#else
+    // one front: its record at frec[0] (the code below indexes the records by front id: `frec - f0 * ND_FRONT_INTS` makes that this one)
+    const int f0 = (1 << TOPK_LEVEL) - 1 + blockIdx.x / p.N;
+    if (tid < ND_FRONT_INTS) frec[tid] = nd.fronts[f0 * ND_FRONT_INTS + tid];
+    __syncthreads();
+    frec -= f0 * ND_FRONT_INTS;
+    const int tlist[3] = {1, f0, 0};
+    const int nt = 1;
+#endif
     bool prefetched = false;  // (wave-uniform) this front's tables and children were issued during the previous front's panels
     {
         for (int idx = 0; idx < nt; ++idx) {
@@ -1139,9 +1163,9 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
-#else  // ND_LG > 7
+#if ND_LG > 7
 // ------------------------------------------------------------------------------------------------------------------------
-// The BIG fronts of the larger grids (levels 0 .. LO + 4: up to 25 tile rows at 256 x 256, 49 at 512 x 512 -- 0.65 / 2.5 MB a front,
+// The BIG fronts of the larger grids (levels 0 .. LO + 2: up to 25 tile rows at 256 x 256, 49 at 512 x 512 -- 0.65 / 2.5 MB a front,
 // more than a CU's register file).  Same elimination as k_nd_top -- same tiles, same products, same order of additions per tile --
 // but LEFT-LOOKING out of global memory, one WAVE per task, no synchronisation inside a launch:
 //   pivot tile columns are taken in blocks of BIG_PB.  A tile (q, R) of block g (transposed panel tile: pivots of tile column q x front
@@ -1186,7 +1210,7 @@ __device__ __forceinline__ void big_front(BigFront& B, const NdDev& nd, int m, i
     B.ch[0] = arena + __builtin_amdgcn_readfirstlane(F[NDF_UC0]);
     B.ch[1] = arena + __builtin_amdgcn_readfirstlane(F[NDF_UC1]);
     const int lv = __builtin_amdgcn_readfirstlane(F[NDF_LEVEL]);
-    B.tiles[0] = B.tiles[1] = lv + 1 <= LO + 4;
+    B.tiles[0] = B.tiles[1] = lv + 1 <= LO + 2;  // (levels LO + 3, LO + 4: packed by k_nd_top)
     B.kids = true;  // (every big front has children)
     const long long fo = __builtin_amdgcn_readfirstlane(F[NDF_FACT]);
     B.fa = nd.fact + (long long)m * nd.fact_stride + fo;
@@ -1318,6 +1342,8 @@ __global__ __launch_bounds__(256) void k_big_rows(FwdParams p, NdDev nd, int lev
     const int R = q0 + nq + 4 * wg + w;
     if (R >= B.T) return;
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
+    // (requesting the diagonal block's tiles up front instead of inside the elimination below was measured: 200 instead of 128 registers,
+    // two waves per SIMD instead of four, 6.3 against 5.0 ms per time step over the levels)
     d4 V[BIG_PB];
 #pragma unroll
     for (int a = 0; a < BIG_PB; ++a)
@@ -1361,6 +1387,11 @@ __global__ __launch_bounds__(256) void k_big_trail(FwdParams p, NdDev nd, int le
     while (rem > Rb) { rem -= Rb + 1; ++Rb; }
     const int Cb = rem;
     const int R0 = B.st + 2 * Rb, C0 = B.st + 2 * Cb;
+    const int R1 = R0 + 1 < B.T ? R0 + 1 : R0, C1 = C0 + 1 < B.T ? C0 + 1 : C0;  // (a surplus tile recomputes its neighbour and is not stored)
+    // the first panel's images are requested before the children's entries are gathered (two dependent round trips to memory: position
+    // tables, then the entries), every later panel's while the previous one's products run
+    d4 Y0 = img_load(B.fa + big_img(B.T, 0, R0), g.lane), Y1 = img_load(B.fa + big_img(B.T, 0, R1), g.lane);
+    d4 Z0 = img_load(B.vf + big_img(B.T, 0, C0), g.lane), Z1 = img_load(B.vf + big_img(B.T, 0, C1), g.lane);
     d4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1369,14 +1400,15 @@ __global__ __launch_bounds__(256) void k_big_trail(FwdParams p, NdDev nd, int le
             acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
             if (R0 + i < B.T && C0 + j <= R0 + i) big_gather_tile(acc[i][j], B, 16 * (R0 + i), 16 * (C0 + j), g);
         }
-    const int R1 = R0 + 1 < B.T ? R0 + 1 : R0, C1 = C0 + 1 < B.T ? C0 + 1 : C0;  // (a surplus tile recomputes its neighbour and is not stored)
     for (int pp = 0; pp < B.st; ++pp) {
-        const d4 Y0 = img_load(B.fa + big_img(B.T, pp, R0), g.lane), Y1 = img_load(B.fa + big_img(B.T, pp, R1), g.lane);
-        const d4 Z0 = img_load(B.vf + big_img(B.T, pp, C0), g.lane), Z1 = img_load(B.vf + big_img(B.T, pp, C1), g.lane);
+        const int pn = pp + 1 < B.st ? pp + 1 : pp;
+        const d4 Y0n = img_load(B.fa + big_img(B.T, pn, R0), g.lane), Y1n = img_load(B.fa + big_img(B.T, pn, R1), g.lane);
+        const d4 Z0n = img_load(B.vf + big_img(B.T, pn, C0), g.lane), Z1n = img_load(B.vf + big_img(B.T, pn, C1), g.lane);
         acc[0][0] = big_mfma4(Y0, Z0, acc[0][0]);
         acc[0][1] = big_mfma4(Y0, Z1, acc[0][1]);
         acc[1][0] = big_mfma4(Y1, Z0, acc[1][0]);
         acc[1][1] = big_mfma4(Y1, Z1, acc[1][1]);
+        Y0 = Y0n; Y1 = Y1n; Z0 = Z0n; Z1 = Z1n;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1422,12 +1454,13 @@ __device__ __forceinline__ void nd_solve_idx(NdSolveIdx<UNR, MAXBT>& I, const Nd
     }
 }
 template <int UNR, int MAXBT>
-__device__ __forceinline__ void nd_solve_single(const NdDev& nd, const double* __restrict__ fact, double* P, int nf, int w, const NdGeo& g) {
+__device__ __forceinline__ void nd_solve_single(const NdDev& nd, const double* __restrict__ fact, double* P, int nf, int w_in, const NdGeo& g, int nwaves = SOL_NW) {
+    const int w = w_in;  // this wave's index among the `nwaves` waves that share the level's fronts (one workgroup, or several: k_nd_solve_level)
     // software pipeline: the cell indices of batch i + 1 are requested before batch i's values are waited for, so a batch costs one
     // round trip to memory, not two
     NdSolveIdx<UNR, MAXBT> I, In;
     nd_solve_idx(I, nd, fact, nf, w * UNR < nf ? w * UNR : 0, g);
-    for (int fi0 = w * UNR; fi0 < nf; fi0 += SOL_NW * UNR) {
+    for (int fi0 = w * UNR; fi0 < nf; fi0 += nwaves * UNR) {
         double xv[UNR][MAXBT], t[UNR][MAXBT][4];
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
@@ -1444,7 +1477,7 @@ __device__ __forceinline__ void nd_solve_single(const NdDev& nd, const double* _
                 for (int r = 0; r < 4; ++r) t[u][R][r] = I.fa[u][(Rc * I.kreg[u] + (r < I.kreg[u] ? r : 0)) * 64 + g.lane];
 #endif
             }
-        const int fin = fi0 + SOL_NW * UNR;
+        const int fin = fi0 + nwaves * UNR;
         nd_solve_idx(In, nd, fact, nf, fin < nf ? fin : fi0, g);
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -1482,7 +1515,7 @@ __global__ __launch_bounds__(64 * SOL_NW, SOL_OCC) void k_nd_solve(FwdParams p, 
     const double* fact = nd.fact + (long long)m * nd.fact_stride;
     double* xe = xe_all[w];
     NPROF_DECL;
-    for (int lvg = 0; lvg < 8 + LO; ++lvg) {  // levels 8..10 (128 x 128 numbering): k_nd_solve_sub
+    for (int lvg = 0; lvg < (LO == 0 ? 8 : LO + 5); ++lvg) {  // levels 8..10 (128 x 128 numbering): k_nd_solve_sub; larger grids: levels 5..7 by k_nd_solve_level
         const int nf = 1 << lvg, lv = lvg - LO;
         NPROF(lv < 5 ? 12 : lv - 5);
         if (lv >= 5) {
@@ -1566,6 +1599,28 @@ __global__ __launch_bounds__(64 * SOL_NW, SOL_OCC) void k_nd_solve(FwdParams p, 
         for (int i = 0; i < 16; ++i) hm_nd_prof_buf[32 + i] = prof_acc[i];
 #endif
 }
+
+#if ND_LG > 7
+// Larger grids: the back substitution of one of the levels 5, 6, 7 (128 x 128 numbering) as a launch of its own, SOLL_WGS workgroups of four
+// waves per member sharing the level's fronts (a member has 4 / 16 times the fronts of the 128 x 128 tree there: inside k_nd_solve's one
+// workgroup per member they were 1.1 of its 1.9 ms at 256 x 256).
+constexpr int SOLL_WGS = 4;
+template <int LV>
+__global__ __launch_bounds__(256, SOL_OCC) void k_nd_solve_level(FwdParams p, NdDev nd) {
+    const int m = blockIdx.x % p.N, wg = blockIdx.x / p.N, tid = threadIdx.x;
+    NdGeo g;
+    g.lane = tid & 63;
+    g.lc = g.lane & 15;
+    g.lq = g.lane >> 4;
+    const int w = wg * 4 + __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* P = p.P + (long long)m * p.Nxy;
+    const double* fact = nd.fact + (long long)m * nd.fact_stride;
+    constexpr int nf = 1 << (LV + LO);
+    if (LV == 5) nd_solve_single<1, 6>(nd, fact, P, nf, w, g, 4 * SOLL_WGS);
+    else if (LV == 6) nd_solve_single<2, 4>(nd, fact, P, nf, w, g, 4 * SOLL_WGS);
+    else nd_solve_single<2, 3>(nd, fact, P, nf, w, g, 4 * SOLL_WGS);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Back substitution of levels 8..10: one wave per level-8 subtree (the workgroups of k_nd_sub), top-down.  Every factor row of the
@@ -1741,13 +1796,15 @@ static int nd_setup(hm_fwd* f) {
     for (int fI = 0; fI < t.info.n_fronts; ++fI) {
         const int* F = &t.fronts[(size_t)fI * ND_FRONT_INTS];
         if (F[NDF_LEVEL] > LO + 4) continue;
-        if (LO > 0) {
+        if (LO > 0 && F[NDF_LEVEL] <= LO + 2) {
             HM_REQUIRE(F[NDF_KREG] == 4, "nested-dissection tables: big front %d has a partial last pivot tile", fI);
             continue;
         }
+        const int top_nts = LO > 0 && F[NDF_LEVEL] == LO + 3 ? 6 : 4, top_nvs = LO > 0 && F[NDF_LEVEL] == LO + 3 ? 2 : 3, top_maxt = LO > 0 && F[NDF_LEVEL] == LO + 3 ? 15 : 13;
+        HM_REQUIRE(F[NDF_ST] + F[NDF_BT] <= top_maxt, "nested-dissection tables: front %d has %d tile rows (k_nd_top takes %d)", fI, F[NDF_ST] + F[NDF_BT], top_maxt);
         const int st = F[NDF_ST], bt = F[NDF_BT], T = st + bt;
         const int nV = st * T - st * (st - 1) / 2, nT = F[NDF_B] > 0 ? bt * (bt + 1) / 2 : 0;
-        HM_REQUIRE(nV <= TOP_NVS * TOP_NW && nT <= TOP_NTS * TOP_NW, "nested-dissection tables: front %d has %d + %d tiles", fI, nV, nT);
+        HM_REQUIRE(nV <= top_nvs * TOP_NW && nT <= top_nts * TOP_NW, "nested-dissection tables: front %d has %d + %d tiles", fI, nV, nT);
     }
     // the LDS-DMA copies move 16-byte pieces: every update matrix starts on an even double of an even-strided, 16-byte aligned arena
     HM_REQUIRE(t.info.arena_doubles % 2 == 0, "nested dissection: odd arena stride %lld", (long long)t.info.arena_doubles);
@@ -1828,12 +1885,15 @@ static int nd_setup(hm_fwd* f) {
     d.child_doubles[1] = t.info.upd_doubles[LO + 7];
     d.child_doubles[2] = t.info.upd_doubles[LO + 6];
     // dynamic LDS beyond 64 KB must be requested per kernel
-#if ND_LG == 7
-    for (int f = 0; f < 31; ++f)
+    for (int f = LO == 0 ? 0 : (1 << (LO + 3)) - 1; f < (2 << (LO + 4)) - 1; ++f)  // (k_nd_top's fronts: their 1 KB table pieces)
         HM_REQUIRE(t.fronts[f * ND_FRONT_INTS + NDF_CELLS] + 256 <= (int)t.cells.size(), "nested dissection: the table piece of front %d runs past the tables", f);
     d.top_child_doubles = 0;
-    for (int lv = 1; lv <= 5; ++lv) d.top_child_doubles = std::max(d.top_child_doubles, t.info.upd_doubles[lv]);
-    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (int lv = LO == 0 ? 1 : LO + 5; lv <= LO + 5; ++lv) d.top_child_doubles = std::max(d.top_child_doubles, t.info.upd_doubles[lv]);
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<3, 4, 13, LO + 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#if ND_LG > 7
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<2, 6, 15, LO + 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
+#if ND_LG == 7
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_assemble<double>, hipFuncAttributeMaxDynamicSharedMemorySize, NB * NB * 8));
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_assemble<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NB * NB * 8));
 #endif
@@ -1869,13 +1929,18 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
     hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * (NF7 / 4)), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * (NF6 / 4)), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * (NF5 / 2)), dim3(128), (size_t)2 * (ND_LDS_DATA + 2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
-#if ND_LG == 7
-    const size_t lds_top = (size_t)(256 + 2 * TOP_MAXT * 256 + 256 + top_pad(nd.top_child_doubles)) * 8 + 31 * ND_FRONT_INTS * 4;  // images, 2 KB of tables, children, records
-    hipLaunchKernelGGL(k_nd_top, dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k);
+    const size_t lds_top = (size_t)(256 + 2 * 13 * 256 + 256 + top_pad(nd.top_child_doubles)) * 8 + 31 * ND_FRONT_INTS * 4;  // images, 2 KB of tables, children, records
+    hipLaunchKernelGGL((k_nd_top<3, 4, 13, LO + 4>), dim3(LO == 0 ? p.N : p.N << (LO + 4)), dim3(64 * TOP_NW), lds_top, s, p, nd, k, nd.top_child_doubles);  // (larger grids: one front of level LO + 4 per workgroup)
     if (hipError_t e_ = hipGetLastError()) { hm_set_error("k_nd_top launch with %zu bytes of LDS: %s", lds_top, hipGetErrorString(e_)); return 1; }
-#else
+#if ND_LG > 7
     const NdInfo& I = f->nd->info;
-    for (int lv = LO + 4; lv >= 0; --lv) {  // the big fronts, leaves-to-root; per level: pivot blocks in turn, then the update matrix
+    {   // level LO + 3: one front per workgroup as well, six trailing tiles a wave; its children (level LO + 4) staged one after the other
+        const int chd = I.upd_doubles[LO + 4];
+        const size_t lds3 = (size_t)(256 + 2 * 15 * 256 + 256 + top_pad(chd)) * 8 + 31 * ND_FRONT_INTS * 4;
+        hipLaunchKernelGGL((k_nd_top<2, 6, 15, LO + 3>), dim3(p.N << (LO + 3)), dim3(64 * TOP_NW), lds3, s, p, nd, k, chd);
+        if (hipError_t e_ = hipGetLastError()) { hm_set_error("k_nd_top<level LO + 3> launch with %zu bytes of LDS: %s", lds3, hipGetErrorString(e_)); return 1; }
+    }
+    for (int lv = LO + 2; lv >= 0; --lv) {  // the big fronts, leaves-to-root; per level: pivot blocks in turn, then the update matrix
         const int nf = 1 << lv, st = I.max_st[lv], bt = I.max_bt[lv], T = st + bt;
         for (int g0 = 0; g0 * BIG_PB < st; ++g0) {
             hipLaunchKernelGGL(k_big_diag, dim3(p.N * nf), dim3(64), 0, s, p, nd, lv, g0);
@@ -1889,6 +1954,11 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
     }
 #endif
     hipLaunchKernelGGL(k_nd_solve, dim3(p.N), dim3(64 * SOL_NW), 0, s, p, nd, k);
+#if ND_LG > 7
+    hipLaunchKernelGGL(k_nd_solve_level<5>, dim3(p.N * SOLL_WGS), dim3(256), 0, s, p, nd);
+    hipLaunchKernelGGL(k_nd_solve_level<6>, dim3(p.N * SOLL_WGS), dim3(256), 0, s, p, nd);
+    hipLaunchKernelGGL(k_nd_solve_level<7>, dim3(p.N * SOLL_WGS), dim3(256), 0, s, p, nd);
+#endif
     hipLaunchKernelGGL(k_nd_solve_sub, dim3(p.N * (64 << LO)), dim3(256), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_leaf_solve, dim3(p.N * (4 << LO)), dim3(256), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_flux, dim3(p.N), dim3(1024), 0, s, p, k);
