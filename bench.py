@@ -190,7 +190,7 @@ def es_update_timing(device):
         # 0.1 s of untimed batches, then fifteen batches of ten, the median batch.  After an idle spell (the host-synchronised steps
         # above, the set-up of the inputs) the device needs 15-20 ms of work -- on some boxes of this pool several times that -- to
         # get back to the clocks it holds behind a forward pass: first batches 0.171 ms, settled 0.158 ms at config 3's shape
-        # (historymatching_amd/csrc/diag/upd_ramp.py, upd_after_forward.py).
+        # (profiles/diag/upd_ramp.py, upd_after_forward.py).
         reps, batches = 10, []
         t_warm = time.perf_counter()
         while time.perf_counter() - t_warm < 0.1:
@@ -628,7 +628,7 @@ def main():
             "frac_if_skipped_dry_bands_counted_as_work": 2 * sat_lane_instr_algorithmic / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             "measured_issue_ceiling": {"frac_of_peak": 0.74, "note": "at this kernel's two waves per SIMD a SIMD issues one simple DP instruction per "
                                        "5.4 cycles, not 4 (v_rcp_f64: 16.4; an FMA with three distinct register operands: 6.9) -- "
-                                       "historymatching_amd/csrc/diag/valu_rate.hip, profiles/README.md"},
+                                       "profiles/diag/valu_rate.hip, profiles/README.md"},
             "avg_launch_ms": {"saturation": sat_ms, "pressure": prs_ms},
             "per_kernel": {"saturation_fp64_valu_frac": 2 * sat_lane_instr / (sat_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                            # the factorisation's matrix instructions counted from the symbolic tables, every front eliminated: since fronts

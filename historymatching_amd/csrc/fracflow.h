@@ -4,7 +4,7 @@
 // the correctly rounded IEEE one.  The compiler's IEEE division is 11 instructions: two v_div_scale (operand pre-scaling for
 // quotients near the ends of the exponent range), v_rcp + two Newton steps, the quotient + one residual correction (v_div_fmas,
 // which undoes the scaling) and v_div_fixup (NaN / infinity / zero operands): ~60 cycles of a SIMD per wave, a third of the sweep
-// (diag/valu_rate.hip).  For the upstream fluid (vw = vo = 1, swc = sor = 0: n = S^2, d = S^2 + (1-S)^2) the three scaling / fix-up
+// (profiles/diag/valu_rate.hip).  For the upstream fluid (vw = vo = 1, swc = sor = 0: n = S^2, d = S^2 + (1-S)^2) the three scaling / fix-up
 // instructions never do anything, so `div_unscaled` runs the same sequence without them -- 8 instructions, same bits:
 //   * 2^-480 <= |S| < 2^500: d >= 0.5 is normal, n >= 2^-960 is far above v_div_scale's thresholds (numerator exponent <= 53,
 //     denormal quotient), the quotient is normal: both v_div_scale return their operand, VCC = 0 makes v_div_fmas a v_fma,

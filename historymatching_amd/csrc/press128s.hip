@@ -2,7 +2,7 @@
 //
 // Block elimination (block-Thomas along ix, every 128x128 Schur complement
 // inverted explicitly by blocked symmetric Gauss-Jordan sweeps with rank-16 panels), re-laid-out around two
-// measured facts of gfx950 (diag/inv16.hip):
+// measured facts of gfx950 (profiles/diag/inv16.hip):
 //   * fp64 MFMA and the VALU share the SIMD's double-precision lanes: a wave's VALU instruction waits for every
 //     in-flight v_mfma_f64 of the co-resident waves (64 cycles each).  The in-wave 16x16 pivot sweep (2.5k cycles
 //     alone) takes 11k-19k cycles next to one or two MFMA streams, so it cannot be hidden under matrix-core work on

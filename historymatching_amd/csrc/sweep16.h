@@ -8,7 +8,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------------------
 // In-wave symmetric sweep of one 16x16 tile held in the accumulator layout (lane (lq, lc), reg r <-> entry
 // (lq + 4r, lc)): 16 pivots, on return t = -inv(tile).  One wave is issue bound (~6 cycles per instruction), so the
-// step is written for instruction count (diag/inv16.hip: 156 cycles per pivot against 296 with the pivot column
+// step is written for instruction count (profiles/diag/inv16.hip: 156 cycles per pivot against 296 with the pivot column
 // staged through LDS):
 //   * pivot column to the lanes of each row:   v_mov_b64_dpp row_newbcast:K                     (4 instructions)
 //   * pivot row to the 4 lane-rows:            ds_bpermute (the only cross-row move; symmetric tile).  Tried instead: one

@@ -1,7 +1,7 @@
 """Analysis-step timing at BASELINE config 3 size (N=1000, M=128*128, n_obs=160): device time of the three update
 phases (HIP events), MFMA rate of the two state-dimension contractions by the SURVEY 8d flop count 4*N*n_obs*M."""
 import os, sys, json
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 from historymatching_amd.update import UpdatePlan
 

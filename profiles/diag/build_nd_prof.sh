@@ -1,7 +1,7 @@
 #!/bin/bash
 # A second copy of the library with press_nd.hip compiled with cycle stamps (-DHM_ND_PROF):  -> build_prof/libhm_ndprof.so
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../historymatching_amd/csrc"
 out=../../build_prof
 mkdir -p $out
 make -s

@@ -1,9 +1,9 @@
 #!/bin/bash
 # A second copy of the library with press128s.hip compiled with extra flags, without touching the in-tree objects:
-#   historymatching_amd/csrc/diag/build_press_prof.sh [name [flags]]   ->  build_prof/libhm_<name>.so   (remove build_prof/ afterwards)
+#   profiles/diag/build_press_prof.sh [name [flags]]   ->  build_prof/libhm_<name>.so   (remove build_prof/ afterwards)
 # default: name = prof, flags = -DHM_PRESS_PROF  (the cycle stamps diag/press_prof.py reads)
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../historymatching_amd/csrc"
 name=${1:-prof}
 flags=${2:--DHM_PRESS_PROF}
 out=../../build_prof

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A second copy of the library with sat128r.hip compiled with cycle stamps (-DHM_SAT_PROF):  -> build_prof/libhm_satprof.so
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../historymatching_amd/csrc"
 out=../../build_prof
 mkdir -p $out
 make -s

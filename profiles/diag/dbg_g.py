@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__file__), '..', '..'))
 from historymatching_amd.forward import ForwardPlan
 from historymatching_amd import _lib
 from tests.helpers import make_models, perms

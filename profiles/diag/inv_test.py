@@ -1,5 +1,5 @@
 import sys, ctypes as C, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__file__), '..', '..'))
 from historymatching_amd import _lib
 ctx = _lib.Context.get(0); lib = _lib.load()
 rng = np.random.RandomState(0)

@@ -1,11 +1,11 @@
 """Cycle stamps of the nested-dissection pressure kernels (block 0, wave 0).  Build first: diag/build_nd_prof.sh, then
-     HM_AMD_LIB=build_prof/libhm_ndprof.so python historymatching_amd/csrc/diag/nd_prof.py [N=1000]"""
+     HM_AMD_LIB=build_prof/libhm_ndprof.so python profiles/diag/nd_prof.py [N=1000]"""
 import ctypes as C
 import sys
 from pathlib import Path
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
-sys.path.insert(0, str(Path(__file__).resolve().parents[3] / "tests"))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "tests"))
 from helpers import make_models, perms  # noqa: E402
 from historymatching_amd import _lib  # noqa: E402
 from historymatching_amd.forward import ForwardPlan  # noqa: E402

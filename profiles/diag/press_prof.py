@@ -1,13 +1,13 @@
 """Cycle breakdown of k_press128m (workgroup 0, thread 0).  Build the instrumented library first:
      make -C historymatching_amd/csrc clean && make -C historymatching_amd/csrc EXTRA=-DHM_PRESS_PROF TARGET=/tmp/libhm_prof.so
-   then  HM_AMD_LIB=/tmp/libhm_prof.so python historymatching_amd/csrc/diag/press_prof.py"""
+   then  HM_AMD_LIB=/tmp/libhm_prof.so python profiles/diag/press_prof.py"""
 import ctypes as C
 import sys
 from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import bench  # noqa: E402
 from historymatching_amd import _lib  # noqa: E402
 from historymatching_amd.forward import ForwardPlan  # noqa: E402

@@ -1,12 +1,12 @@
 """Cycle stamps of the register-resident saturation sweep (k_sat128r, workgroup 0, every wave), one launch per time step of a forward run.
 Build first: diag/build_sat_prof.sh, then
-     HM_AMD_LIB=build_prof/libhm_satprof.so python historymatching_amd/csrc/diag/sat_prof.py [sat_variant=7] [steps=0,5,20,39] [N=256]"""
+     HM_AMD_LIB=build_prof/libhm_satprof.so python profiles/diag/sat_prof.py [sat_variant=7] [steps=0,5,20,39] [N=256]"""
 import ctypes as C
 import sys
 from pathlib import Path
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
-sys.path.insert(0, str(Path(__file__).resolve().parents[3] / "tests"))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "tests"))
 from helpers import make_models, perms  # noqa: E402
 from historymatching_amd import _lib  # noqa: E402
 from historymatching_amd.forward import ForwardPlan  # noqa: E402

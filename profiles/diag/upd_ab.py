@@ -1,6 +1,6 @@
 """Back-to-back analysis step at config 3's shape for the values of an option given on the command line: option v1 v2 ... (5 rounds each, interleaved)."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 import scipy.linalg as sla
 from historymatching_amd import _lib

@@ -1,6 +1,6 @@
 """Does a forward run earlier in the process slow the analysis step down?  (scratch memory on the queue / clocks)"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 import scipy.linalg as sla
 import bench

@@ -1,12 +1,12 @@
 """One analysis step at config 3's shape with the small fp64 chain on a second stream: run under
-   rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python3 historymatching_amd/csrc/diag/upd_overlap_trace.py [overlap kc small]
+   rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python3 profiles/diag/upd_overlap_trace.py [overlap kc small]
 and print the kernels' start / end times of the last step with  --report DIR."""
 import csv
 import glob
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 
 if len(sys.argv) > 2 and sys.argv[1] == "--report":
     f = glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True)[0]

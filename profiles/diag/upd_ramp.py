@@ -1,6 +1,6 @@
 """Analysis step at config 3's shape, batches of 10 back-to-back steps right after plan set-up: how long until the times settle."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 import scipy.linalg as sla
 from historymatching_amd import _lib

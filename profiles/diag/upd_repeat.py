@@ -1,6 +1,6 @@
 """Race check of the flag-synchronised chain kernels: the same analysis step many times, every output bit-identical to the first."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 import scipy.linalg as sla
 from historymatching_amd.obs import obs_error_model

@@ -1,7 +1,7 @@
 """Settled time of the analysis step at config 3's shape: 60 batches of 10 back-to-back steps, median of the last 30 (for A/B runs
 with HM_AMD_LIB=...)."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 import scipy.linalg as sla
 from historymatching_amd import _lib

@@ -18,10 +18,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   cp "$(find $W/$C -name '*counter_collection.csv' | head -1)" $OUT/pmc_${C}_counter_collection.csv
 done
 python3 profiles/tools/pmc_to_json.py $OUT 256 > $OUT/pmc_hbm_traffic.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $W/upd -o upd -- python3 historymatching_amd/csrc/diag/bench_update.py > $OUT/bench_update.txt 2> $W/upd.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/upd -o upd -- python3 profiles/diag/bench_update.py > $OUT/bench_update.txt 2> $W/upd.err
 cp "$(find $W/upd -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_update.csv
 # 5. matrix-core counters of the update kernels (own pass, counters only)
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $W/mf -o mf -- python3 historymatching_amd/csrc/diag/bench_update.py > /dev/null 2> $W/mf.err
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $W/mf -o mf -- python3 profiles/diag/bench_update.py > /dev/null 2> $W/mf.err
 f=$(find $W/mf -name '*counter_collection.csv' | head -1)
 if [ -n "$f" ]; then
   (head -1 $f; grep -E "gxt|apply|dgemm|spd_inverse" $f) > $OUT/pmc_mfma_update_counter_collection.csv

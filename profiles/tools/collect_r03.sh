@@ -30,7 +30,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   (head -1 $f; grep -E "k_nd_|k_press|k_sat|k_perm|k_pressure|k_saturation" $f) > $OUT/pmc_${C}_counter_collection.csv
 done
 python3 profiles/tools/pmc_to_json.py $OUT 256 > $OUT/pmc_hbm_traffic.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $W/upd -o upd -- python3 historymatching_amd/csrc/diag/bench_update.py > $OUT/bench_update.txt 2> $W/upd.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/upd -o upd -- python3 profiles/diag/bench_update.py > $OUT/bench_update.txt 2> $W/upd.err
 cp "$(find $W/upd -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_update.csv
 python3 - <<PY > $OUT/isa_counts.json
 import json, subprocess, sys

@@ -3,7 +3,7 @@ W=/tmp/pmcu; rm -rf $W; mkdir -p $W
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_MFMA_MOPS_F32" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_FLAT GRBM_GUI_ACTIVE SQ_WAIT_INST_VMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d $W/p$i -o p -- python3 historymatching_amd/csrc/diag/upd_ramp.py > /dev/null 2> $W/p$i.err
+  rocprofv3 --pmc $C --output-format csv -d $W/p$i -o p -- python3 profiles/diag/upd_ramp.py > /dev/null 2> $W/p$i.err
   f=$(find $W/p$i -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && (head -1 $f; grep -E "k_gxt_dma|k_apply_dma" $f) > $W/p$i.csv || tail -3 $W/p$i.err
 done

@@ -16,14 +16,17 @@ for i, r in enumerate(rows):
         continue
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     if s == "k_center_gram":
-        prev = rows[i - 1]["Kernel_Name"] if i else ""
-        cur = {"after": "forward pass" if ("k_sat" in prev or "k_cast" in prev or "k_nd" in prev) else "update", "t0": int(r["Start_Timestamp"])}
+        # right behind a forward pass: a sweep or pressure kernel ended within 200 us before this step's first kernel (runtime fill / copy /
+        # cast kernels may sit in between)
+        t0 = int(r["Start_Timestamp"])
+        near = [q for q in rows[max(0, i - 8):i] if t0 - int(q["End_Timestamp"]) < 200000 and ("k_sat" in q["Kernel_Name"] or "k_nd" in q["Kernel_Name"])]
+        cur = {"after": "forward pass" if near else "update", "t0": t0}
         steps.append(cur)
     if cur is not None and s != "k_cast":
         cur[s] = dur
         cur["t1"] = int(r["End_Timestamp"])
 for kind in ("forward pass", "update"):
-    sel = [s for s in steps if s["after"] == kind and all(k in s for k in names[:4])]
+    sel = [s for s in steps if s["after"] == kind and all(k in s for k in names[:4]) and s["k_gxt_dma"] < 100.0]  # (config 3's shape)
     if not sel:
         continue
     sel = sel[-40:] if kind == "update" else sel

@@ -257,7 +257,7 @@ def test_fp32_matrix_core_path_matches_generic_and_oracle(N, M, n_obs, localized
 def test_fused_run_is_bit_reproducible():
     """The chain in front of the apply hands tiles from wave to wave and from workgroup to workgroup through flags (spdinv.hip:
     sweeper, pivot wave, tile waves; the gain's workgroups taking block columns as they are published): every sum has a fixed
-    order, so repeated runs of one plan give the same bits (300 repeats at three shapes: csrc/diag/upd_repeat.py)."""
+    order, so repeated runs of one plan give the same bits (300 repeats at three shapes: profiles/diag/upd_repeat.py)."""
     from historymatching_amd.update import UpdatePlan
     from oracle import es
 

@@ -1,4 +1,4 @@
-# timing of sat256s.hip variants (build_ab/libhm_<name>.so from csrc/diag/build_src_ab.sh): bash tests/tools/ab_slab.sh name...
+# timing of sat256s.hip variants (build_ab/libhm_<name>.so from profiles/diag/build_src_ab.sh): bash tests/tools/ab_slab.sh name...
 cd $GRAFT_REPO_ROOT
 for v in base "$@"; do
   if [ $v = base ]; then unset HM_AMD_LIB; else export HM_AMD_LIB=$GRAFT_REPO_ROOT/build_ab/libhm_$v.so; fi
