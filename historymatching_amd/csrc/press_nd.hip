@@ -69,19 +69,24 @@ struct NdDev {
     int top_child_doubles;  // largest child update of a level <= 4 front
     // Reuse across time steps (k_nd_plan): per member the fronts of levels 8..5 that have to be eliminated this step, compacted
     int* work;                   // N x ND_WORK_INTS: [n8, n7, n6, n5 | list8[256] | list7[128] | list6[64] | list5[32] | nt, fronts of levels 4..0]
-                                 // (larger grids: ONE list of every front, shared by all members -- nothing is kept across time steps there)
-    unsigned char* cached;       // N x 512: front f (levels 0..8: f = 0..510) holds the results of its all-dry state
-    const unsigned char* wells;  // 512: a well somewhere in the front's subtree (its right-hand side rows carry the rates)
+                                 // (larger grids: the lists are 4 / 16 times as long; the fronts of levels <= LO + 4 have `todo` bytes instead)
+    unsigned char* cached;       // N x NCACHE (512 at 128 x 128): front f (levels 0..8: f = 0..510) holds the results of its all-dry state
+    const unsigned char* wells;  // NCACHE: a well somewhere in the front's subtree (its right-hand side rows carry the rates)
     int wells_ok;                // the rates of this time step are those the cached results of such fronts were computed with
     int reuse;                   // 0: every front is eliminated every step
     // big fronts (levels 0 .. LO + 4 of the larger grids)
+    unsigned long long* wet;     // per member: wet-cell bitmap, NB rows x NB / 64 words (k_ndl_assemble -> k_ndl_plan)
+    unsigned char* todo;         // per member: NTODO bytes, front f of levels 0 .. LO + 4 is eliminated this step (k_ndl_plan)
     double* vfac;                // per member: the negated pivot-panel tiles V(p, R) at the factor's offsets (operands of the trailing products)
     double* pimg;                // per member: the negated inverse pivot tiles, NDF_PIMG + 256 p
     long long vfac_stride, pimg_stride;
 };
 constexpr int ND_W8 = 4, ND_W7 = ND_W8 + NF8, ND_W6 = ND_W7 + NF7, ND_W5 = ND_W6 + NF6, ND_WT = ND_W5 + NF5;  // ND_WT: n, then the fronts of levels 4..0 in order
 constexpr int ND_WORK_INTS = ND_WT + 64;
-__device__ __forceinline__ const int* nd_work(const NdDev& nd, int m) { return nd.work + (LG == 7 ? (long long)m * ND_WORK_INTS : 0LL); }
+constexpr int NCACHE = 512 << LO;              // >= fronts of levels 0 .. LO + 8
+constexpr int NTODO = 32 << LO;                // >= fronts of levels 0 .. LO + 4
+constexpr int WETW = NB / 64;                  // 64-bit words of a grid row's wet-cell bitmap
+__device__ __forceinline__ const int* nd_work(const NdDev& nd, int m) { return nd.work + (long long)m * ND_WORK_INTS; }
 
 struct NdGeo {
     int lane, lc, lq;
@@ -497,6 +502,10 @@ __global__ __launch_bounds__(NB) void k_ndl_assemble(FwdParams p, NdDev nd, cons
     double* cf = nd.cf + (long long)m * CF_STRIDE;
     const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
     const int c = ix * NB + iy;
+    {   // the row's wet-cell bitmap (one bit per cell: S != 0; -0.0 == 0: dry), a word per wave, for the plan of the time step
+        const unsigned long long bits = __ballot(S[c] != (TS)0);
+        if ((iy & 63) == 0) nd.wet[((long long)m * NB + ix) * WETW + (iy >> 6)] = bits;
+    }
     auto linv = [&](int cell, const double* Kf) {  // 1 / (mobility K): the expression of assemble_transmissibilities (fwd_dev.h)
         double mw, mo;
         rel_perm<double>(p, (double)S[cell], mw, mo);
@@ -518,6 +527,76 @@ __global__ __launch_bounds__(NB) void k_ndl_assemble(FwdParams p, NdDev nd, cons
     if (c == 0) d += Km[0] + Kym[0];  // SPD pin: A[0,0] += Kx[0,0] + Ky[0,0]
     cf[c] = d;
     cf[CF_OQ + c] = q[c];
+}
+
+// What has to be eliminated this time step on the larger grids: the plan of the 128 x 128 tree (nd_plan_body above: a front is skipped while
+// its box + ring is dry, its children are skipped, the rates of the wells in its subtree are unchanged and its stored results were
+// computed from such a state since the inputs last changed) for 4 / 16 times the fronts.  One workgroup of 1024 threads per member; the
+// lists of levels 8..5 (128 x 128 numbering) as there, one `todo` byte per front of levels 0 .. LO + 4 (k_nd_top's and the big fronts'
+// launches are indexed by front: a skipped front's workgroups return at once).  Only where the whole ensemble is one member block (the
+// factor and update matrices of every member stay in memory); else, and for press_variant 14, nd.reuse = 0 makes every front due.
+__global__ __launch_bounds__(1024) void k_ndl_plan(FwdParams p, NdDev nd) {
+    extern __shared__ unsigned long long plan_lds[];
+    unsigned long long* wet = plan_lds;                                             // [NB][WETW]
+    unsigned char* dry = reinterpret_cast<unsigned char*>(plan_lds + NB * WETW);     // by front id, levels 0 .. LO + 8
+    __shared__ int wcount[16];
+    const int m = blockIdx.x, t = threadIdx.x;
+    int* work = nd.work + (long long)m * ND_WORK_INTS;
+    unsigned char* cached = nd.cached + (long long)m * NCACHE;
+    for (int i = t; i < NB * WETW; i += 1024) wet[i] = nd.wet[(long long)m * NB * WETW + i];
+    __syncthreads();
+    auto box_dry = [&](const NdBox& box) {
+        const int x0 = max(box.x0 - 1, 0), y0 = max(box.y0 - 1, 0), x1 = min(box.x1 + 1, NB), y1 = min(box.y1 + 1, NB);
+        unsigned long long any = 0ull;
+        for (int wd = y0 >> 6; wd <= (y1 - 1) >> 6; ++wd) {
+            const int lo = max(y0 - 64 * wd, 0), hi = min(y1 - 64 * wd, 64);  // bits [lo, hi) of word wd
+            const unsigned long long msk = (hi == 64 ? ~0ull : ~(~0ull << hi)) & (~0ull << lo);
+            for (int ix = x0; ix < x1; ++ix) any |= wet[ix * WETW + wd] & msk;
+        }
+        return any == 0ull;
+    };
+    for (int i = t; i < NF8; i += 1024) {
+        const int f = FID(8) + i;
+        dry[f] = nd.reuse && box_dry(nd_box(nd.fronts + f * ND_FRONT_INTS, NDF_RBOX));
+    }
+    __syncthreads();
+    for (int lv = LO + 7; lv >= 0; --lv) {
+        const int nf = 1 << lv;
+        for (int i = t; i < nf; i += 1024) {
+            const int f = nf - 1 + i;
+            dry[f] = dry[2 * f + 1] && dry[2 * f + 2] && box_dry(nd_box(nd.fronts + f * ND_FRONT_INTS, NDF_PBOX));
+        }
+        __syncthreads();
+    }
+    auto due = [&](int f) {  // skip = dry and cached; what is computed now is the state of the cache afterwards
+        const bool todo = !(dry[f] && cached[f] && (nd.wells_ok || !nd.wells[f]));
+        cached[f] = dry[f];
+        return todo;
+    };
+    for (int lvp = 8; lvp >= 5; --lvp) {  // order-preserving compaction, 1024 fronts at a time
+        const int nf = 1 << (lvp + LO);
+        const int base = lvp == 8 ? ND_W8 : lvp == 7 ? ND_W7 : lvp == 6 ? ND_W6 : ND_W5;
+        int running = 0;
+        for (int c0 = 0; c0 < nf; c0 += 1024) {
+            const int i = c0 + t;
+            const bool todo = i < nf && due(nf - 1 + i);
+            const unsigned long long mask = __ballot(todo);
+            const int w = t >> 6, lane = t & 63;
+            if (lane == 0) wcount[w] = __popcll(mask);
+            __syncthreads();
+            int off = running, tot = 0;
+            for (int qq = 0; qq < 16; ++qq) {
+                off += qq < w ? wcount[qq] : 0;
+                tot += wcount[qq];
+            }
+            if (todo) work[base + off + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+            running += tot;
+            __syncthreads();
+        }
+        if (t == 0) work[8 - lvp] = running;
+    }
+    unsigned char* todo_b = nd.todo + (long long)m * NTODO;
+    for (int f = t; f < (2 << (LO + 4)) - 1; f += 1024) todo_b[f] = due(f);
 }
 #endif  // ND_LG
 
@@ -922,6 +1001,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
 #else
     // one front: its record at frec[0] (the code below indexes the records by front id: `frec - f0 * ND_FRONT_INTS` makes that this one)
     const int f0 = (1 << TOPK_LEVEL) - 1 + blockIdx.x / p.N;
+    if (!nd.todo[(long long)m * NTODO + f0]) return;  // (k_ndl_plan: the front keeps the results it has; the whole workgroup leaves)
     if (tid < ND_FRONT_INTS) frec[tid] = nd.fronts[f0 * ND_FRONT_INTS + tid];
     __syncthreads();
     frec -= f0 * ND_FRONT_INTS;
@@ -1274,6 +1354,7 @@ __global__ __launch_bounds__(64) void k_big_diag(FwdParams p, NdDev nd, int leve
     g.lane = threadIdx.x;
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
+    if (!nd.todo[(long long)m * NTODO + f]) return;  // (k_ndl_plan)
     BigFront B;
     big_front(B, nd, m, f);
     const int q0 = g0 * BIG_PB;
@@ -1334,6 +1415,7 @@ __global__ __launch_bounds__(256) void k_big_rows(FwdParams p, NdDev nd, int lev
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (!nd.todo[(long long)m * NTODO + f]) return;  // (k_ndl_plan)
     BigFront B;
     big_front(B, nd, m, f);
     const int q0 = g0 * BIG_PB;
@@ -1379,6 +1461,7 @@ __global__ __launch_bounds__(256) void k_big_trail(FwdParams p, NdDev nd, int le
     g.lc = g.lane & 15;
     g.lq = g.lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (!nd.todo[(long long)m * NTODO + f]) return;  // (k_ndl_plan)
     BigFront B;
     big_front(B, nd, m, f);
     const int hb = (B.bt + 1) >> 1;
@@ -1752,7 +1835,7 @@ __global__ __launch_bounds__(1024) void k_nd_flux(FwdParams p, int k) {
 // ------------------------------------------------------------------------------------------------------------------------
 struct hm_nd {
     NdInfo info{};
-    DevBuf fronts, cells, cpos, rec, fact, arena, dg, work, cached, wells, vfac, pimg;
+    DevBuf fronts, cells, cpos, rec, fact, arena, dg, work, cached, wells, vfac, pimg, wet, todo;
     NdDev dev{};
     int cap = 0;                // members the per-member buffers hold: larger ensembles are solved in blocks of `cap` members (larger grids)
     long long cached_gen = -1;  // hm_fwd::inputs_gen the cached results belong to
@@ -1773,7 +1856,7 @@ bool ND_ENTRY(pressure_nd_applies)(const FwdParams& p) { return p.Nx == NB && p.
 #if ND_LG == 7
 void hm_nd_free(hm_nd* n) {
     if (!n) return;
-    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->rec, &n->fact, &n->arena, &n->dg, &n->work, &n->cached, &n->wells, &n->vfac, &n->pimg};
+    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->rec, &n->fact, &n->arena, &n->dg, &n->work, &n->cached, &n->wells, &n->vfac, &n->pimg, &n->wet, &n->todo};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     delete n;
 }
@@ -1827,12 +1910,13 @@ static int nd_setup(hm_fwd* f) {
     }
     n->cap = (int)cap;
     const size_t N = cap;
-    const size_t n_cached = (size_t)512 << LO;
+    const size_t n_cached = NCACHE;
     if ((rc = hm_dev_alloc(n->fronts, t.fronts.size() * 4)) || (rc = hm_dev_alloc(n->cells, t.cells.size() * 4)) ||
         (rc = hm_dev_alloc(n->cpos, t.cpos.size() * 2)) || (rc = hm_dev_alloc(n->rec, t.rec.size() * 2)) || (rc = hm_dev_alloc(n->fact, N * t.info.fact_doubles * 8)) ||
         (rc = hm_dev_alloc(n->arena, N * t.info.arena_doubles * 8)) || (rc = hm_dev_alloc(n->dg, N * (size_t)CF_STRIDE * 8)) ||
-        (rc = hm_dev_alloc(n->work, (LO > 0 ? 1 : N) * (size_t)ND_WORK_INTS * 4)) || (rc = hm_dev_alloc(n->cached, N * n_cached)) || (rc = hm_dev_alloc(n->wells, n_cached)) ||
-        (LO > 0 && ((rc = hm_dev_alloc(n->vfac, N * (size_t)t.info.big_fact_doubles * 8)) || (rc = hm_dev_alloc(n->pimg, N * (size_t)t.info.pimg_doubles * 8))))) {
+        (rc = hm_dev_alloc(n->work, N * (size_t)ND_WORK_INTS * 4)) || (rc = hm_dev_alloc(n->cached, N * n_cached)) || (rc = hm_dev_alloc(n->wells, n_cached)) ||
+        (LO > 0 && ((rc = hm_dev_alloc(n->vfac, N * (size_t)t.info.big_fact_doubles * 8)) || (rc = hm_dev_alloc(n->pimg, N * (size_t)t.info.pimg_doubles * 8)) ||
+                    (rc = hm_dev_alloc(n->wet, N * (size_t)NB * WETW * 8)) || (rc = hm_dev_alloc(n->todo, N * (size_t)NTODO))))) {
         hm_nd_free(n);
         return rc;
     }
@@ -1853,30 +1937,28 @@ static int nd_setup(hm_fwd* f) {
     d.wells = (const unsigned char*)n->wells.p;
     d.vfac = (double*)n->vfac.p;
     d.pimg = (double*)n->pimg.p;
+    d.wet = (unsigned long long*)n->wet.p;
+    d.todo = (unsigned char*)n->todo.p;
     d.vfac_stride = t.info.big_fact_doubles;
     d.pimg_stride = t.info.pimg_doubles;
-    d.reuse = LO == 0;
-    if (LO == 0) {  // fronts with a well in their subtree: the region of a level-8 subtree, above that the separator and both children (+ 1 ring)
-        std::vector<unsigned char> wf(512, 0);
-        for (int fr = 510; fr >= 0; --fr) {
-            if (fr < 255) wf[fr] = wf[2 * fr + 1] | wf[2 * fr + 2];
-            const NdBox box = nd_box(&t.fronts[fr * ND_FRONT_INTS], fr >= 255 ? NDF_RBOX : NDF_PBOX);
+    d.reuse = 1;
+    {   // fronts with a well in their subtree: the region of a level-8 subtree, above that the separator and both children (+ 1 ring)
+        std::vector<unsigned char> wf(NCACHE, 0);
+        for (int fr = FID(9) - 1; fr >= 0; --fr) {
+            if (fr < FID(8)) wf[fr] = wf[2 * fr + 1] | wf[2 * fr + 2];
+            const NdBox box = nd_box(&t.fronts[fr * ND_FRONT_INTS], fr >= FID(8) ? NDF_RBOX : NDF_PBOX);
             const int x0 = box.x0 - 1, y0 = box.y0 - 1, x1 = box.x1 + 1, y1 = box.y1 + 1;
             for (int cell : f->well_cells_host) {
                 const int ix = cell / NB, iy = cell % NB;
                 if (ix >= x0 && ix < x1 && iy >= y0 && iy < y1) wf[fr] = 1;
             }
         }
-        HM_HIP(hipMemcpy(n->wells.p, wf.data(), 512, hipMemcpyHostToDevice));
-    } else {  // one list of every front of levels 8..5 (128 x 128 numbering) for all members: nothing is kept across time steps
-        std::vector<int> wk(ND_WORK_INTS, 0);
-        wk[0] = NF8; wk[1] = NF7; wk[2] = NF6; wk[3] = NF5;
-        for (int i = 0; i < NF8; ++i) wk[ND_W8 + i] = i;
-        for (int i = 0; i < NF7; ++i) wk[ND_W7 + i] = i;
-        for (int i = 0; i < NF6; ++i) wk[ND_W6 + i] = i;
-        for (int i = 0; i < NF5; ++i) wk[ND_W5 + i] = i;
-        HM_HIP(hipMemcpy(n->work.p, wk.data(), wk.size() * 4, hipMemcpyHostToDevice));
+        HM_HIP(hipMemcpy(n->wells.p, wf.data(), NCACHE, hipMemcpyHostToDevice));
     }
+    HM_HIP(hipMemset(n->cached.p, 0, N * n_cached));
+#if ND_LG > 7
+    HM_HIP(hipFuncSetAttribute((const void*)k_ndl_plan, hipFuncAttributeMaxDynamicSharedMemorySize, NB * WETW * 8 + NCACHE));
+#endif
     d.fact_stride = t.info.fact_doubles;
     d.arena_stride = t.info.arena_doubles;
     d.slot9 = t.info.upd_doubles[LO + 9];
@@ -1923,6 +2005,7 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
 #else
     if (f->dtype == 64) hipLaunchKernelGGL(k_ndl_assemble<double>, dim3(p.N * p.Nx), dim3(NB), 0, s, p, nd, (const double*)S, S_stride, k);
     else hipLaunchKernelGGL(k_ndl_assemble<float>, dim3(p.N * p.Nx), dim3(NB), 0, s, p, nd, (const float*)S, S_stride, k);
+    hipLaunchKernelGGL(k_ndl_plan, dim3(p.N), dim3(1024), (size_t)NB * WETW * 8 + NCACHE, s, p, nd);
 #endif
     hipLaunchKernelGGL(k_nd_leaf, dim3(p.N * (4 << LO)), dim3(256), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_sub, dim3(((p.N + SUB_WPB - 1) / SUB_WPB) * NF8), dim3(64 * SUB_WPB), lds_sub, s, p, nd, k);
@@ -2031,10 +2114,10 @@ int ND_ENTRY(launch_pressure_nd)(hm_fwd* f, const void* S, long long S_stride, i
     hipStream_t s = f->ctx->stream;
     NdDev& nd = f->nd->dev;
     // results kept from earlier time steps are only good for the inputs they were computed from; press_variant 14: no reuse at all; per-member
-    // wells: none either (the well flags are per plan); the larger grids keep nothing
-    nd.reuse = LO == 0 && f->press_variant != 14 && p.q_mstride == 0 && !f->raw_field_exposed;
-    if (LO == 0 && f->nd->cached_gen != f->inputs_gen) {
-        HM_HIP(hipMemsetAsync(f->nd->cached.p, 0, (size_t)p.N * 512, s));
+    // wells: none either (the well flags are per plan); an ensemble solved in several member blocks through the same buffers keeps nothing
+    nd.reuse = f->press_variant != 14 && p.q_mstride == 0 && !f->raw_field_exposed && p.N <= f->nd->cap;
+    if (f->nd->cached_gen != f->inputs_gen) {
+        HM_HIP(hipMemsetAsync(f->nd->cached.p, 0, (size_t)std::min(p.N, f->nd->cap) * NCACHE, s));
         f->nd->cached_gen = f->inputs_gen;
     }
     {   // the right-hand side rows of fronts with wells in their subtree: kept while the rates stay what they were

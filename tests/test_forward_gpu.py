@@ -827,14 +827,15 @@ def test_nested_dissection_pressure_whole_run():
         assert np.abs(res[12][0][m] - ref).max() <= 10 * noise + 1e-9, (m, np.abs(res[12][0][m] - ref).max(), noise)
 
 
-@pytest.mark.parametrize("rates", ["constant", "time_varying", "piecewise_constant"])
-def test_nested_dissection_reuse_of_dry_fronts_is_bit_identical(rates):
+@pytest.mark.parametrize("n,rates", [(128, "constant"), (128, "time_varying"), (128, "piecewise_constant"), (256, "constant"), (256, "piecewise_constant")])
+def test_nested_dissection_reuse_of_dry_fronts_is_bit_identical(n, rates):
     """press_nd.hip does not eliminate a front again while its whole subtree is still dry and the rates of the wells in it are unchanged
     (k_nd_plan): the stored factor rows and update matrix are what it would recompute.  Whole runs with the reuse (press_variant 12, the default) and without (14) give
     array_equal saturations, producer series, sub-step counts and final pressures; so does a second run on the SAME plan from other
     permeabilities (the cache dies with the inputs it was computed from) and a pressure solve after a saturation field was written
-    into the plan by hand."""
-    n, N, steps = 128, 4, 14
+    into the plan by hand.  256 x 256: the same plan for the 13-level tree (k_ndl_plan: lists for the wave-level fronts, `todo` bytes for the
+    workgroup-level and big fronts)."""
+    N, steps = 4, 14
     _, gm = make_models(n, n)
     if rates != "constant":
         # the right-hand side rows of a front with a well in its subtree are kept only over runs of time steps with equal rates
@@ -1064,3 +1065,28 @@ def test_direct_solver_hands_an_ill_conditioned_member_to_the_cg():
     plan.close()
     assert not status1.any() and st1["nd_fallbacks"] == 0
     assert np.array_equal(S1[0], S_end[1])
+
+
+def test_nested_dissection_in_member_blocks_is_bit_identical(monkeypatch):
+    """An ensemble whose factor / update / panel buffers would exceed the memory budget is solved in blocks of members through the same
+    buffers (hm_nd::cap; BASELINE config 4 whole on one GPU: 4096 members at 256 x 256).  Forced here with HM_ND_CAP = 3 on 7 members: blocks
+    of 3, 3 and 1 give what the whole ensemble in one block gives, bit for bit (nothing is kept across time steps in the blocked form)."""
+    n, N, steps = 256, 7, 4
+    _, gm = make_models(n, n)
+    x = perms(n, n, N, seed=41)
+    out = []
+    for cap in (None, "3"):
+        if cap is None:
+            monkeypatch.delenv("HM_ND_CAP", raising=False)
+        else:
+            monkeypatch.setenv("HM_ND_CAP", cap)
+        plan = _plan(gm, N, nTime=steps)
+        plan.set_inputs(x, transformed=False)
+        plan.run()
+        st = plan.sync()
+        w, p, status = plan.outputs()
+        assert not status.any() and st["mean_n_cg"] == 0
+        out.append((w.copy(), p.copy(), plan.get_field("P").copy(), plan.get_field("Vx").copy()))
+        plan.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
