@@ -1346,6 +1346,19 @@ __device__ __forceinline__ d4 big_mfma4(const d4& Y, const d4& Z, d4 acc) {
     return acc;
 }
 __device__ __forceinline__ d4 big_neg(const d4& v) { return d4{-v[0], -v[1], -v[2], -v[3]}; }
+// Workgroup -> (member, front of the level, workgroup of the front), XCD-aware: workgroups are dealt round-robin to the 8 XCDs, each with an L2
+// of its own, and the `wgs` workgroups of one (member, front) read the same panel tiles (a trailing tile's operands are shared by a whole tile
+// row / column of the front) -- so they get CONSECUTIVE slots of ONE XCD: they run at the same time behind the same L2.  (Member-fastest
+// order put a front's workgroups N x fronts apart: every task fetched its operands from HBM -- k_big_trail moved 15 MB per member-step.)
+__device__ __forceinline__ bool big_task(int N, int nf, int wgs, int& m, int& fi, int& wg) {
+    const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    wg = t % wgs;
+    const int pr = (t / wgs) * 8 + xcd;
+    m = pr % N;
+    fi = pr / N;
+    return pr < N * nf;
+}
+__host__ inline unsigned big_grid(int N, int nf, int wgs) { return 8u * (unsigned)((N * nf + 7) / 8) * (unsigned)wgs; }
 
 // The diagonal block of pivot block g0 (grid: members x fronts of the level, one wave each).
 __global__ __launch_bounds__(64) void k_big_diag(FwdParams p, NdDev nd, int level, int g0) {
@@ -1409,7 +1422,9 @@ __global__ __launch_bounds__(64) void k_big_diag(FwdParams p, NdDev nd, int leve
 // The rows below the diagonal block of pivot block g0 (grid: members x fronts x ceil(rows / 4) workgroups of four waves, one row tile each).
 __global__ __launch_bounds__(256) void k_big_rows(FwdParams p, NdDev nd, int level, int g0, int wgs) {
     const int nf = 1 << level;
-    const int m = blockIdx.x % p.N, rest = blockIdx.x / p.N, f = nf - 1 + rest % nf, wg = rest / nf;
+    int m, fi, wg;
+    if (!big_task(p.N, nf, wgs, m, fi, wg)) return;
+    const int f = nf - 1 + fi;
     NdGeo g;
     g.lane = threadIdx.x & 63;
     g.lc = g.lane & 15;
@@ -1449,13 +1464,14 @@ __global__ __launch_bounds__(256) void k_big_rows(FwdParams p, NdDev nd, int lev
         for (int a2 = a + 1; a2 < BIG_PB; ++a2)
             if (a2 < nq) V[a2] = big_mfma4(img_load(B.vf + big_img(B.T, pp, q0 + a2), g.lane), Wp, V[a2]);  // (-V)(+W^T) = V (-W^T)
     }
-    (void)wgs;
 }
 
 // The update matrix (grid: members x fronts x ceil(blocks / 4) workgroups of four waves, one 2 x 2 block of lower tiles each).
-__global__ __launch_bounds__(256) void k_big_trail(FwdParams p, NdDev nd, int level) {
+__global__ __launch_bounds__(256) void k_big_trail(FwdParams p, NdDev nd, int level, int wgs) {
     const int nf = 1 << level;
-    const int m = blockIdx.x % p.N, rest = blockIdx.x / p.N, f = nf - 1 + rest % nf, wg = rest / nf;
+    int m, fi, wg;
+    if (!big_task(p.N, nf, wgs, m, fi, wg)) return;
+    const int f = nf - 1 + fi;
     NdGeo g;
     g.lane = threadIdx.x & 63;
     g.lc = g.lane & 15;
@@ -2028,11 +2044,11 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
         for (int g0 = 0; g0 * BIG_PB < st; ++g0) {
             hipLaunchKernelGGL(k_big_diag, dim3(p.N * nf), dim3(64), 0, s, p, nd, lv, g0);
             const int rows = T - std::min(st, (g0 + 1) * BIG_PB), wgs = (rows + 3) / 4;
-            if (wgs > 0) hipLaunchKernelGGL(k_big_rows, dim3(p.N * nf * wgs), dim3(256), 0, s, p, nd, lv, g0, wgs);
+            if (wgs > 0) hipLaunchKernelGGL(k_big_rows, dim3(big_grid(p.N, nf, wgs)), dim3(256), 0, s, p, nd, lv, g0, wgs);
         }
         if (lv > 0) {
             const int hb = (bt + 1) / 2, wgs = (hb * (hb + 1) / 2 + 3) / 4;
-            hipLaunchKernelGGL(k_big_trail, dim3(p.N * nf * wgs), dim3(256), 0, s, p, nd, lv);
+            hipLaunchKernelGGL(k_big_trail, dim3(big_grid(p.N, nf, wgs)), dim3(256), 0, s, p, nd, lv, wgs);
         }
     }
 #endif
