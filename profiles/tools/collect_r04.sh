@@ -57,6 +57,9 @@ python3 tests/tools/nd_residual_stats.py 256 1024 1000 > $OUT/nd_residual_stats.
 rm -rf $W/upd; rocprofv3 --kernel-trace --stats --output-format csv -d $W/upd -o upd -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-config4 --no-config5 --no-two-streams --no-host-call > $OUT/bench_update_legs.json 2> $W/upd.err
 cp "$(find $W/upd -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_update.csv
 python3 profiles/tools/upd_in_situ.py $W/upd > $OUT/upd_in_situ.txt
-# 7. the default bench line of this build
+# 7. the default bench line of this build (it prices its launch times with the newest committed counts under profiles/rNN/: this round's go there first,
+#    so that the line's `stale_inputs` refers to the objects that ran)
+mkdir -p profiles/$R
+cp $OUT/isa_counts.json $OUT/fp64_roofline.json $OUT/pmc_hbm_traffic.json profiles/$R/
 python3 bench.py > $OUT/bench_default.json 2> $W/bench.err
 ls -la $OUT
