@@ -168,6 +168,32 @@ def test_config4_shard_whole_run_properties():
     assert np.array_equal(S_sub, S_end[sub]) and np.array_equal(p_sub, prods[sub])
 
 
+def test_config4_grid_whole_run_vs_oracle():
+    """256 x 256 (config 4's grid), two members, ALL 40 time steps (2 458 explicit sub-steps each) through the default kernels -- nested
+    dissection of the 13-level tree with its dry-front reuse, slab sweep -- against the oracle: within the oracle's own solver noise at every
+    stored step (second SuperLU ordering: MMD_AT_PLUS_A), the sub-step count the CFL of the injector cell gives, the producer gather.  The
+    whole-run companion of the one-solve comparison in test_assembly_bitexact_and_pressure_within_solver_noise[(256, 0)]."""
+    from historymatching_amd.forward import ForwardPlan
+
+    n, N, steps = 256, 2, 40
+    om, gm = make_models(n, n)
+    x = perms(n, n, N, seed=31)
+    plan = ForwardPlan(gm, N, DT, steps)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    st = plan.sync()
+    w, p, status = plan.outputs()
+    nts = plan.get_field("nts")
+    plan.close()
+    assert not status.any() and st["mean_n_cg"] == 0 and st["nd_fallbacks"] == 0
+    assert (nts == 2458).all()  # ceil(2457.6), SURVEY.md Appendix B
+    for m, (ref, noise) in enumerate(oracle_sims_and_noise_parallel(n, n, x, DT, steps, permc2="MMD_AT_PLUS_A")):
+        err = np.abs(w[m] - ref).max()
+        assert err <= 10 * noise + 1e-9, (m, err, noise)
+        assert err < 1e-4
+        assert np.array_equal(p[m], w[m][1:, om.xy2ind(*om.prd_xy.T)])
+
+
 def test_config5_grid_forward_vs_oracle():
     """512 x 512 (config 5's grid): two members, one time step (9 831 explicit sub-steps), default kernels -- nested-dissection
     pressure solve (press_nd512.o: 15 levels, fronts of up to 49 tile rows), saturation sweep by teams of 16 tile workgroups -- against the
