@@ -1700,6 +1700,86 @@ __global__ __launch_bounds__(64 * SOL_NW, SOL_OCC) void k_nd_solve(FwdParams p, 
 }
 
 #if ND_LG > 7
+// Larger grids: the back substitution of ONE of the levels 0 .. LO + 4 as a launch of its own (inside k_nd_solve's one workgroup per member the
+// 4 waves took a level's fronts in turn: 256 fronts of level 8 at 512 x 512 are 64 rounds, and 125 members are 125 workgroups on 256 CUs).
+// WPF = 4: the four waves of a workgroup share one front, each taking every fourth tile of a panel's row (the fronts of levels 0 .. LO + 2:
+// up to 48 tiles a panel, 32 panels); WPF = 1: a front per wave.  Every pivot tile of these levels is full (kreg = 4, checked by nd_setup).
+template <int WPF>
+__global__ __launch_bounds__(256) void k_nd_solve_front(FwdParams p, NdDev nd, int level) {
+    __shared__ double xe_all[WPF == 4 ? 1 : 4][16 * TOP_MAXT];
+    __shared__ double part[4][16];
+    const int nf = 1 << level, tid = threadIdx.x;
+    const int m = blockIdx.x % p.N, b = blockIdx.x / p.N;
+    NdGeo g;
+    g.lane = tid & 63;
+    g.lc = g.lane & 15;
+    g.lq = g.lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = WPF == 4 ? b : 4 * b + w;
+    if (fi >= nf) return;  // (WPF = 4: the whole workgroup; WPF = 1: no workgroup barrier below)
+    double* P = p.P + (long long)m * p.Nxy;
+    const double* fact = nd.fact + (long long)m * nd.fact_stride;
+    double* xe = xe_all[WPF == 4 ? 0 : w];
+    const int* F = nd.fronts + (nf - 1 + fi) * ND_FRONT_INTS;
+    const int st = __builtin_amdgcn_readfirstlane(F[NDF_ST]);
+    const int T = st + __builtin_amdgcn_readfirstlane(F[NDF_BT]);
+    const int* cl = nd.cells + __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
+    const double* fa = fact + F[NDF_FACT];
+    // boundary values (ancestors' pivots, already known), -1 on the right-hand-side row
+    for (int pos = 16 * st + (WPF == 4 ? tid : g.lane); pos < 16 * T; pos += WPF == 4 ? 256 : 64) {
+        const int c = cl[pos];
+        xe[pos] = c >= 0 ? P[c] : (c == -2 ? -1.0 : 0.0);
+    }
+    if (WPF == 4) __syncthreads();
+    else nd_wave_fence();
+    for (int pp = st - 1; pp >= 0; --pp) {
+        const long long fo = 4LL * (pp * T - ((pp * (pp + 1)) >> 1));  // register rows in front of panel pp (big_img)
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int R = pp + 1 + (WPF == 4 ? w : 0); R < T; R += WPF) {
+            const double xv = xe[16 * R + g.lc];
+            const double* tl = fa + (fo + (R - pp - 1) * 4) * 64 + g.lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fma(tl[r * 64], xv, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = acc[r];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            acc[r] = v;
+        }
+        if (WPF == 4) {
+            if (g.lc == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[w][4 * r + g.lq] = acc[r];
+            }
+            __syncthreads();
+            if (tid < 16) {  // (fixed order of the four partial sums)
+                const double v = -(((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]);
+                const int pos = 16 * pp + tid, c = cl[pos];
+                const double x = c >= 0 ? v : 0.0;
+                xe[pos] = x;
+                if (c >= 0) P[c] = x;
+            }
+            __syncthreads();
+        } else {
+            if (g.lc == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pos = 16 * pp + 4 * r + g.lq, c = cl[pos];
+                    const double x = c >= 0 ? -acc[r] : 0.0;
+                    xe[pos] = x;
+                    if (c >= 0) P[c] = x;
+                }
+            }
+            nd_wave_fence();
+        }
+    }
+}
+
 // Larger grids: the back substitution of one of the levels 5, 6, 7 (128 x 128 numbering) as a launch of its own, SOLL_WGS workgroups of four
 // waves per member sharing the level's fronts (a member has 4 / 16 times the fronts of the 128 x 128 tree there: inside k_nd_solve's one
 // workgroup per member they were 1.1 of its 1.9 ms at 256 x 256).
@@ -1895,10 +1975,8 @@ static int nd_setup(hm_fwd* f) {
     for (int fI = 0; fI < t.info.n_fronts; ++fI) {
         const int* F = &t.fronts[(size_t)fI * ND_FRONT_INTS];
         if (F[NDF_LEVEL] > LO + 4) continue;
-        if (LO > 0 && F[NDF_LEVEL] <= LO + 2) {
-            HM_REQUIRE(F[NDF_KREG] == 4, "nested-dissection tables: big front %d has a partial last pivot tile", fI);
-            continue;
-        }
+        if (LO > 0) HM_REQUIRE(F[NDF_KREG] == 4, "nested-dissection tables: front %d of the top levels has a partial last pivot tile", fI);
+        if (LO > 0 && F[NDF_LEVEL] <= LO + 2) continue;
         const int top_nts = LO > 0 && F[NDF_LEVEL] == LO + 3 ? 6 : 4, top_nvs = LO > 0 && F[NDF_LEVEL] == LO + 3 ? 2 : 3, top_maxt = LO > 0 && F[NDF_LEVEL] == LO + 3 ? 15 : 13;
         HM_REQUIRE(F[NDF_ST] + F[NDF_BT] <= top_maxt, "nested-dissection tables: front %d has %d tile rows (k_nd_top takes %d)", fI, F[NDF_ST] + F[NDF_BT], top_maxt);
         const int st = F[NDF_ST], bt = F[NDF_BT], T = st + bt;
@@ -2052,8 +2130,13 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
         }
     }
 #endif
+#if ND_LG == 7
     hipLaunchKernelGGL(k_nd_solve, dim3(p.N), dim3(64 * SOL_NW), 0, s, p, nd, k);
-#if ND_LG > 7
+#else
+    for (int lv = 0; lv <= LO + 4; ++lv) {  // root to leaves, a launch per level
+        if (lv <= LO + 2) hipLaunchKernelGGL(k_nd_solve_front<4>, dim3(p.N << lv), dim3(256), 0, s, p, nd, lv);
+        else hipLaunchKernelGGL(k_nd_solve_front<1>, dim3(p.N * (((1 << lv) + 3) / 4)), dim3(256), 0, s, p, nd, lv);
+    }
     hipLaunchKernelGGL(k_nd_solve_level<5>, dim3(p.N * SOLL_WGS), dim3(256), 0, s, p, nd);
     hipLaunchKernelGGL(k_nd_solve_level<6>, dim3(p.N * SOLL_WGS), dim3(256), 0, s, p, nd);
     hipLaunchKernelGGL(k_nd_solve_level<7>, dim3(p.N * SOLL_WGS), dim3(256), 0, s, p, nd);
