@@ -2165,6 +2165,10 @@ static int nd_check_and_fall_back(hm_fwd* f, const void* S, long long S_stride, 
     std::vector<int> bad;
     for (int m = 0; m < p.N; ++m)
         if (st[m] & HM_MEMBER_BAD_PIVOT) bad.push_back(m);
+    if (const char* e = getenv("HM_ND_FORCE_FALLBACK")) {  // (tests: member e takes the hand-over every time step, whatever its solve was like)
+        const int m = atoi(e);
+        if (m >= 0 && m < p.N && !(st[m] & HM_MEMBER_BAD_PIVOT)) bad.push_back(m);
+    }
     if (bad.empty() || (int)bad.size() > ND_MAX_FALLBACK || !pressure_two_level_applies(p)) return 0;
     int rc = 0;
     for (int m : bad) {
