@@ -310,6 +310,7 @@ def config4_sharded(device, comm, n_total=4096, n_grid=256):
     ok = comm.all_reduce_max(0.0 if np.isfinite(post).all() else 1.0) == 0.0
     return {"members_total": n_total, "members_per_rank": hi - lo, "grid": [n_grid, n_grid], "n_ranks": comm.world_size, "scaling": "strong",
             "passes": 1, "wall_s": wall, "device_ms_forward_max": fwd_ms, "device_ms_update_max": upd_ms,
+            "member_steps_handed_to_the_cg": int(comm.all_reduce_max(float(st.get("nd_fallbacks", 0)))),  # (direct solver's a-posteriori check; max over ranks)
             "ensemble_steps_per_s_forward": n_total * NTIME / (fwd_ms * 1e-3), "ensemble_steps_per_s_incl_update_and_setup": n_total * NTIME / wall,
             "posterior_finite": bool(ok),
             "collective": "RCCL (hm_upd_run_comm)" if comm.rccl is not None else ("none (one rank)" if comm.world_size == 1 else f"host channel ({comm.rccl_error})")}
@@ -348,6 +349,7 @@ def config5_sharded(device, comm, n_total=1000, n_grid=512, bounded=False):
             "sample": ("one GPU's shard of the 8-GPU configuration: 125 of the 1000 members, the whole 512 x 512 grid, one localised ES-MDA pass"
                        if bounded else "the whole configuration"),
             "passes": 1, "wall_s": wall, "device_ms_forward_max": fwd_ms, "device_ms_localised_update_max": upd_ms,
+            "member_steps_handed_to_the_cg": int(comm.all_reduce_max(float(st.get("nd_fallbacks", 0)))),
             "ensemble_steps_per_s_forward": n_total * NTIME / (fwd_ms * 1e-3), "posterior_finite": bool(ok), "dtype": "f32 saturation sweep + fp64 pressure, fp32 matrix-core analysis",
             "collective": "RCCL (hm_upd_run_comm: 2 all-reduces + all-gather of the column-sharded weights)" if comm.rccl is not None
                           else ("none (one rank)" if comm.world_size == 1 else f"host channel ({comm.rccl_error})")}

@@ -370,6 +370,7 @@ def es_mda_sharded(model, prior_local, obs, R12, dt, nTime, n_iter=4, seed=0, co
         device = comm.ctx.device
     fwd = upd = None
     ms_fwd = ms_upd = ms_comm = 0.0
+    nd_fallbacks = 0
     alpha = float(n_iter)
     try:
         err = None
@@ -388,7 +389,9 @@ def es_mda_sharded(model, prior_local, obs, R12, dt, nTime, n_iter=4, seed=0, co
                 fwd.set_inputs_device(upd.device_ptr("E"), dtype, transformed=False)
                 fwd.run()
                 upd.set_inputs_device(obs_ens_ptr=fwd.device_ptr("prods"), obs_dtype=model.dtype)
-                ms_fwd += fwd.sync()["ms_total"]
+                st_f = fwd.sync()
+                ms_fwd += st_f["ms_total"]
+                nd_fallbacks = st_f["nd_fallbacks"]  # (cumulative over the plan's life)
                 _, _, status = fwd.outputs(want_wsats=False)
                 if status.any():
                     raise _lib.HmError(f"forward model failed for members {(lo + np.flatnonzero(status))[:8].tolist()} "
@@ -409,5 +412,5 @@ def es_mda_sharded(model, prior_local, obs, R12, dt, nTime, n_iter=4, seed=0, co
         if upd is not None:
             upd.close()
     if stats is not None:
-        stats.update(ms_forward=ms_fwd, ms_update=ms_upd, ms_comm=ms_comm)
+        stats.update(ms_forward=ms_fwd, ms_update=ms_upd, ms_comm=ms_comm, nd_fallbacks=nd_fallbacks)
     return out.astype(float)
