@@ -1,25 +1,29 @@
-// press_nd.hip -- fp64 pressure step of the 128 x 128 grid by NESTED DISSECTION (multifrontal), SURVEY.md A.3's system.
+// press_nd.hip -- fp64 pressure step of the 128 x 128, 256 x 256 and 512 x 512 grids by NESTED DISSECTION (multifrontal), SURVEY.md A.3's system.
 //
-// Replaces the sparse direct solve inside ResSim.sim (notebooks/HistoryMatch.py:362; TPFA-ResSim) for
-// Nx = Ny = 128: the block elimination along ix of press128s.hip costs 302 Mflop per member and time step and has a serial
-// chain of 1024 pivot tiles; the geometric dissection of the grid (nd.h) needs about 70 Mflop (profiles/tools/nd_flops.py) and
-// a chain of 24.  Numerically it is a block L D L^T factorisation in another elimination order: same pin, same pivot-tile
-// inverses (sweep16.h), same fp64 matrix-core products.
+// Replaces the sparse direct solve inside ResSim.sim (notebooks/HistoryMatch.py:362; TPFA-ResSim): the block
+// elimination along ix of press128s.hip costs 302 Mflop per member and time step at 128 x 128 and has a serial chain of 1024 pivot tiles;
+// the geometric dissection of the grid (nd.h) needs about 55 Mflop and a chain of 24 (0.45 Gflop at 256 x 256, 3.6 at 512 x 512, where the
+// alternative was 26 / 48 iterations of a two-level CG).  Numerically it is a block L D L^T factorisation in another elimination order:
+// same pin, same pivot-tile inverses (sweep16.h), same fp64 matrix-core products.  One source, one object per grid size (ND_LG below).
 //
-// Data flow per member and time step (four launches):
-//   k_nd_assemble   TX, TY (bit-exact with the oracle, fwd_dev.h) and the matrix diagonal dg
-//   k_nd_sub        levels 10..7: ONE WAVE per level-7 subtree (8 x 16 cells, 15 fronts in post-order).  A front with one
-//                   pivot tile lives entirely in the wave's registers: with the pivot panel held TRANSPOSED (V_R = F21_R^T,
-//                   16 pivots x 16 front rows, accumulator layout) every product the factorisation needs has the form
-//                   Y^T Z of two register tiles, which v_mfma_f64_16x16x4_f64 computes straight from the accumulator
-//                   layout (register kk of Y as A operand = Y^T's k-slice, register kk of Z as B operand):
+// Data flow per member and time step (level numbers of the 128 x 128 tree; a larger grid's levels are LO = 2 / 4 higher):
+//   k_nd_assemble / k_ndl_assemble   TX, TY (bit-exact with the oracle, fwd_dev.h), the coefficient block [dg | -TX | -TY | q]; the plan of the
+//                   time step (which fronts keep the results they have: k_nd_plan / k_ndl_plan)
+//   k_nd_leaf       level 10: one LANE per leaf, banded L D L^T in registers
+//   k_nd_sub        levels 9, 8: ONE WAVE per level-8 subtree.  A front with one pivot tile lives entirely in the wave's registers: with
+//                   the pivot panel held TRANSPOSED (V_R = F21_R^T, 16 pivots x 16 front rows, accumulator layout) every product the
+//                   factorisation needs has the form Y^T Z of two register tiles, which v_mfma_f64_16x16x4_f64 computes straight from the
+//                   accumulator layout (register kk of Y as A operand = Y^T's k-slice, register kk of Z as B operand):
 //                       W_R^T = P V_R  (P = inverse pivot tile, symmetric),   F22[R, C] -= (W_R^T)^T V_C.
-//                   No operand staging through LDS at all.  Children's update matrices (packed lower triangles, levels 8..10
-//                   in per-wave LDS slots) are GATHERED into the parent's tiles through the position tables.
-//   k_nd_wave       levels 6 and 5: one wave per front, children and update in the member's arena (global memory)
-//   k_nd_top        levels 4..0: one WORKGROUP per member; fronts with 2..8 pivot tiles, their tiles dealt to the waves'
-//                   registers, the current panel (W^T and V per row tile, register images) broadcast through LDS
-//   k_nd_solve      back substitution root -> leaves, x1 = -W^T [x2; -1] per panel, then the face fluxes
+//                   No operand staging through LDS at all.  Children's update matrices (packed lower triangles) are GATHERED into the
+//                   parent's tiles through host-built recipes.
+//   k_nd_wave       levels 7, 6, 5: one wave per front, children staged from the member's arena into LDS
+//   k_nd_top        128 x 128: levels 4..0, one WORKGROUP per member; fronts with 2..8 pivot tiles, their tiles dealt to the waves' registers,
+//                   the current panel (W^T and V per row tile, register images) broadcast through LDS.  Larger grids: levels LO + 4 and
+//                   LO + 3, one front per workgroup
+//   k_big_*         larger grids, levels LO + 2 .. 0: fronts of up to 25 / 49 tile rows, eliminated left-looking out of global memory
+//   k_nd_solve*     back substitution root -> leaves, x1 = -W^T [x2; -1] per panel, then the face fluxes (k_nd_flux; on the larger grids
+//                   with the a-posteriori check of the solve)
 // The right-hand side rides along as one extra boundary row of every front (its W^T column is z1 = P r1; the (rhs, boundary)
 // entries of the update are the reduced right-hand side), so forward elimination costs nothing extra.
 #include "fwd_dev.h"
@@ -74,7 +78,7 @@ struct NdDev {
     const unsigned char* wells;  // NCACHE: a well somewhere in the front's subtree (its right-hand side rows carry the rates)
     int wells_ok;                // the rates of this time step are those the cached results of such fronts were computed with
     int reuse;                   // 0: every front is eliminated every step
-    // big fronts (levels 0 .. LO + 4 of the larger grids)
+    // larger grids: the plan's inputs / outputs, and the big fronts' (levels 0 .. LO + 2) panel images
     unsigned long long* wet;     // per member: wet-cell bitmap, NB rows x NB / 64 words (k_ndl_assemble -> k_ndl_plan)
     unsigned char* todo;         // per member: NTODO bytes, front f of levels 0 .. LO + 4 is eliminated this step (k_ndl_plan)
     double* vfac;                // per member: the negated pivot-panel tiles V(p, R) at the factor's offsets (operands of the trailing products)
