@@ -21,7 +21,11 @@ constexpr int REC_FLOATS = 8;          // S, cE, cN, cC, cS, cW, fid, fw
 constexpr int MAX_WELLS = 16;
 constexpr int REC_BASE = FW_FLOATS;                             // float indices
 constexpr int EDGE_BASE = REC_BASE + (MAX_WELLS + 2) * REC_FLOATS;  // south halo column [128], north halo column [128]
-constexpr int MISC_BASE = EDGE_BASE + 2 * TS;                   // team CFL minima (32 doubles)
+constexpr int CC_BASE = EDGE_BASE + 2 * TS;                     // the diagonal coefficient c_C, thread-private: chunk i of thread t at CC_BASE + (i * NT + t) * 4
+                                                                // (consecutive lanes, consecutive 16-byte chunks: conflict-free b128) -- 64 KB of the
+                                                                // LDS the tile does not otherwise use, for 32 registers of a register-full loop
+                                                                // (round 4: 264 -> 255 ms per 125-member step at 512 x 512)
+constexpr int MISC_BASE = CC_BASE + PX * NT * PY;               // team CFL minima (32 doubles)
 constexpr int LDS_BYTES = MISC_BASE * 4 + MAX_TILES * 8;
 static_assert(MISC_BASE % 2 == 0, "double alignment");
 
@@ -153,7 +157,8 @@ __global__ __launch_bounds__(NT) void k_sat128ft(FwdParams p, const float* __res
     const double d = bad ? 0.0 : (p.dt / (double)Nts) / pv;
 
     // upwind coefficients of the own cells: fp64 arithmetic on the fp64 fluxes, rounded to fp32 once (= the generic kernel)
-    float cE[PX][PY], cN[PX][PY], cC[PX][PY], cS[PX][PY], cW[PX][PY];
+    float cE[PX][PY], cN[PX][PY], cS[PX][PY], cW[PX][PY];
+    float* ccl = fwf + CC_BASE + tid * PY;
 #pragma unroll
     for (int i = 0; i < PX; ++i)
 #pragma unroll
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(NT) void k_sat128ft(FwdParams p, const float* __res
             const double vxw = gVx[ix * Ny + iy], vxe = gVx[(ix + 1) * Ny + iy];
             const double vys = gVy[ix * (Ny + 1) + iy], vyn = gVy[ix * (Ny + 1) + iy + 1];
             const double x1 = fmin(vxw, 0.0), x2 = fmax(vxe, 0.0), y1 = fmin(vys, 0.0), y2 = fmax(vyn, 0.0);
-            cC[i][j] = (float)(d * (0.0 + x1 - x2 + y1 - y2));
+            ccl[i * NT * PY + j] = (float)(d * (0.0 + x1 - x2 + y1 - y2));
             cW[i][j] = (float)(d * fmax(vxw, 0.0));
             cE[i][j] = (float)(d * (-fmin(vxe, 0.0)));
             cS[i][j] = (float)(d * fmax(vys, 0.0));
@@ -241,6 +246,8 @@ __global__ __launch_bounds__(NT) void k_sat128ft(FwdParams p, const float* __res
         for (int i = 0; i < PX; ++i) {
             load_row(i + 1 < PX ? ix0 + i + 1 : ixE, fn);
             const float eh = edge_row0[i];
+            const float4 cc4 = *reinterpret_cast<const float4*>(ccl + i * NT * PY);
+            const float cC[PY] = {cc4.x, cc4.y, cc4.z, cc4.w};
             const float fSd = prev_lane(fc[PY - 1]);  // fw(ix, iy0 - 1): its coefficient is 0 on the boundary
             const float fNd = next_lane(fc[0]);       // fw(ix, iy0 + PY)
             const float fS = isS ? eh : fSd;
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(NT) void k_sat128ft(FwdParams p, const float* __res
                 const float fnn = j + 1 < PY ? fc[j + 1 < PY ? j + 1 : 0] : fN;
                 float acc = cE[i][j] * fn[j];
                 acc = acc + cN[i][j] * fnn;
-                acc = acc + cC[i][j] * fc[j];
+                acc = acc + cC[j] * fc[j];
                 acc = acc + cS[i][j] * fs;
                 acc = acc + cW[i][j] * fp[j];
                 S[i][j] = S[i][j] + acc;
