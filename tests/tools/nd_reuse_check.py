@@ -1,7 +1,7 @@
 """Nested-dissection pressure solve with and without the reuse of dry fronts across time steps (press_variant 12 / 14): whole runs must be
 array_equal (saturation histories, producer series, sub-step counts); then the launch average of the pressure step over a whole run of
 N members for both.
-    python tests/tools/nd_reuse_check.py [N=1000] [members=8] [steps=40]"""
+    python tests/tools/nd_reuse_check.py [N=1000] [members=8] [steps=40] [grid=128]"""
 import sys
 from pathlib import Path
 
@@ -16,7 +16,7 @@ from historymatching_amd.forward import ForwardPlan  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 nT = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-n = 128
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 128
 _, gm = make_models(n, n)
 x = perms(n, n, M, seed=3)
 res = {}
