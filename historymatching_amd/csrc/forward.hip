@@ -833,7 +833,8 @@ static int launch_pressure(hm_fwd* f, int k) {
     // symmetric tiles, 8 waves) also at 128 x 128.  (The first three generations of the 128-wide solver -- rank-1 VALU sweeps, full-tile
     // rank-4 and rank-16 matrix-core panels -- were removed in round 2; their timings are in profiles/README.md.)
     // 256 x 256 and 512 x 512: nested dissection as well (press_nd256.o / press_nd512.o: the big-front kernels) for variants 0 / 12 / 14;
-    // 15 (and 9, 11) keep the conjugate-gradient solvers there.
+    // 15 (and 9, 11) keep the conjugate-gradient solvers there.  On these grids 0 (and 14) check every solve a posteriori and hand a member
+    // the elimination cannot solve to the CG (one stream synchronisation per time step); 12 does not: hm_fwd_run stays asynchronous.
     const int pv = f->press_variant;
     const bool nd_variant = pv == 0 || pv == 12 || pv == 14;
     if (nd_variant && pressure_nd_applies256(p)) done = launch_pressure_nd256(f, S, stride, k);

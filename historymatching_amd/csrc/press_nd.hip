@@ -2161,6 +2161,8 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
 // in one step are a defect of the inputs (K <= 0, NaN), not of conditioning: their flags stay.
 constexpr int ND_MAX_FALLBACK = 32;
 static int nd_check_and_fall_back(hm_fwd* f, const void* S, long long S_stride, int k) {
+    if (f->press_variant == 12) return 0;  // the fully asynchronous form: no host synchronisation per time step; a member the elimination
+                                           // cannot solve keeps its HM_MEMBER_BAD_PIVOT flag (the behaviour of the 128 x 128 solver)
     const FwdParams p = f->p;
     hipStream_t s = f->ctx->stream;
     std::vector<int> st((size_t)p.N);
