@@ -278,6 +278,85 @@ class ResSim:
             S = S + (acc + fid)
         return S.ravel()
 
+    # ---- the build's fp32 forward mode (NOT in the reference, which is fp64 end to end: HistoryMatch.py:362) ----
+    F32_FOLD = 64
+
+    def saturation_step_stencil_f32c(self, S32, q, Vx, Vy, T, compensated=True):
+        """Specification of the saturation step of ``dtype=32`` plans (historymatching_amd/csrc/sat32.h), operation for
+        operation in NumPy float32 -- the HIP kernels are compared with it bit for bit.  The reference has no such mode; its
+        accuracy against `saturation_step_upwind` is what the parity tests bound (<= 1e-3 on S over a whole run).
+
+        Pressure, fluxes, the CFL bound, `Nts` and `d = dtx` are fp64 (as in the fp64 mode: the sub-step count is a
+        discontinuity).  The five coefficients and `fi*d` are formed in fp64 and rounded to float32 ONCE; the fractional flow,
+        its five products and their sum are float32.  The saturation is carried as a float32 pair (base, dS), `S = base + dS`:
+        a sub-step adds its increment to dS only, whose ulp is that of the change since the last fold, not that of S -- a plain
+        float32 accumulator loses every increment below half an ulp of S (2.6e-4 / 2.3e-3 / > 1e-2 of drift at 128^2 / 256^2 /
+        512^2 over 40 steps, profiles/r05/fp32_drift_*_before.txt).  Every `F32_FOLD` sub-steps dS is folded into base by an
+        exact two-sum (the rounding error stays in dS); the stored state of a time step is `base + dS` rounded once.
+        `compensated=False`: the plain float32 accumulator of rounds 1-4 (kept to measure what the pair buys)."""
+        f32 = np.float32
+        Nx, Ny = self.shape
+        Nts, dtx, fi = self.cfl_substeps(Vx, Vy, q, T)
+        fp = q.clip(max=0).reshape(Nx, Ny)
+        d = dtx.reshape(Nx, Ny)
+        XN, XP = Vx.clip(max=0), Vx.clip(min=0)
+        YN, YP = Vy.clip(max=0), Vy.clip(min=0)
+        x1, x2, y1, y2 = XN[:-1, :], XP[1:, :], YN[:, :-1], YP[:, 1:]
+        cC = (d * (fp + x1 - x2 + y1 - y2)).astype(f32)
+        cW = (d * XP[:-1, :]).astype(f32)
+        cE = (d * (-XN[1:, :])).astype(f32)
+        cS = (d * YP[:, :-1]).astype(f32)
+        cN = (d * (-YN[:, 1:])).astype(f32)
+        fid = (fi * dtx).reshape(Nx, Ny).astype(f32)
+        base = np.asarray(S32, dtype=f32).reshape(Nx, Ny).copy()
+        dS = np.zeros((Nx, Ny), dtype=f32)
+        one = f32(1)
+        default = self.vw == 1 and self.vo == 1 and self.swc == 0 and self.sor == 0
+        fpad = np.zeros((Nx + 2, Ny + 2), dtype=f32)
+        for it in range(Nts):
+            s = base + dS
+            if default:
+                mw = s * s
+                o = one - s
+                mo = o * o
+            else:  # rel_perm<float> of fwd_dev.h
+                den = f32((1.0 - self.swc) - self.sor)
+                Sn = (s - f32(self.swc)) / den
+                mw = (Sn * Sn) / f32(self.vw)
+                o = one - Sn
+                mo = (o * o) / f32(self.vo)
+            f = mw / (mw + mo)
+            fpad[1:-1, 1:-1] = f
+            acc = cE * fpad[2:, 1:-1]
+            acc = acc + cN * fpad[1:-1, 2:]
+            acc = acc + cC * f
+            acc = acc + cS * fpad[1:-1, :-2]
+            acc = acc + cW * fpad[:-2, 1:-1]
+            if not compensated:
+                base = base + (acc + fid)
+                continue
+            dS = dS + (acc + fid)
+            if (it & (self.F32_FOLD - 1)) == self.F32_FOLD - 1:  # exact two-sum: base + dS == t + e
+                t = base + dS
+                bb = t - base
+                dS = (base - (t - bb)) + (dS - bb)
+                base = t
+            assert dS.dtype == f32 and base.dtype == f32
+        return (base + dS).ravel()
+
+    def sim_f32c(self, dt, nTime, wsat0, compensated=True):
+        """`sim` in the build's fp32 mode: fp64 pressure step on the float32 state, `saturation_step_stencil_f32c`."""
+        wsats = np.zeros((nTime + 1, self.Nxy), dtype=np.float32)
+        wsats[0] = wsat0
+        self._trace = []
+        for k in range(nTime):
+            q, _, _ = self.source_field(k)
+            _, Vx, Vy = self.pressure_step(wsats[k].astype(np.float64), q)
+            wsats[k + 1] = self.saturation_step_stencil_f32c(wsats[k], q, Vx, Vy, dt, compensated)
+        self.nts_trace = np.array([t[0] for t in self._trace], dtype=np.int64)
+        self._trace = None
+        return wsats
+
 
 def perm_transf(x):
     """HistoryMatch.py:137-138."""
