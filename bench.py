@@ -260,7 +260,7 @@ def es_mda_c3(device, perms, n_iter=4):
     from historymatching_amd.forward import ForwardPlan
     from historymatching_amd.update import es_mda_device
 
-    model = build_model(32, device=device)  # config 3 is the fp32 configuration: fp32 saturation sweep (sat128f), fp64 pressure
+    model = build_model(32, device=device)  # config 3 is the fp32 configuration: fp32 saturation sweep (sat32s, compensated state), fp64 pressure
     n_obs = NTIME * 4
     rng = np.random.RandomState(4)
     R12 = reference_obs_error(n_obs)

@@ -14,7 +14,9 @@
 // NumPy does; FMAs appear only where written explicitly (inside the pressure solve, which is not a
 // bit-exact path).
 #include "fwd_dev.h"
+#include "sat32.h"
 #include <algorithm>
+#include <type_traits>
 #include <chrono>
 
 // ------------------------------------------------------------------------------------------------
@@ -214,6 +216,8 @@ __global__ void k_saturation_generic(FwdParams p, const T* __restrict__ Sin_base
     T* cE = (T*)p.coef + (long long)m * 6 * Nxy;
     T *cN = cE + Nxy, *cC = cN + Nxy, *cS = cC + Nxy, *cW = cS + Nxy, *fid = cW + Nxy;
     T* fw = (T*)p.fw + (long long)m * Nxy;
+    constexpr bool F32 = std::is_same<T, float>::value;  // dtype = 32 plans: S[] is `base`, dSa[] the running change (sat32.h)
+    float* dSa = F32 ? p.comp + (long long)m * Nxy : nullptr;
 
     // --- CFL: pm = min(pv / (Vi + fi))
     double lmin = INFINITY;
@@ -252,13 +256,16 @@ __global__ void k_saturation_generic(FwdParams p, const T* __restrict__ Sin_base
         cN[j] = (T)(d * (-fmin(vyn, 0.0)));
         fid[j] = (T)(fi * d);
         S[j] = Sin[j];
+        if constexpr (F32) dSa[j] = 0.0f;
     }
     __syncthreads();
     // --- explicit sub-steps
     for (int it = 0; it < Nts; ++it) {
         for (int j = tid; j < Nxy; j += NT) {
             T mw, mo;
-            rel_perm<T>(p, S[j], mw, mo);
+            T s = S[j];
+            if constexpr (F32) s = s + dSa[j];
+            rel_perm<T>(p, s, mw, mo);
             fw[j] = mw / (mw + mo);
         }
         __syncthreads();
@@ -269,8 +276,21 @@ __global__ void k_saturation_generic(FwdParams p, const T* __restrict__ Sin_base
             acc = acc + cC[j] * fw[j];
             if (iy > 0) acc = acc + cS[j] * fw[j - 1];
             if (ix > 0) acc = acc + cW[j] * fw[j - Ny];
-            S[j] = S[j] + (acc + fid[j]);
+            if constexpr (F32) {
+                float b = S[j], e = dSa[j] + (acc + fid[j]);
+                if ((it & (F32_FOLD - 1)) == F32_FOLD - 1) {
+                    fold32(b, e);
+                    S[j] = b;
+                }
+                dSa[j] = e;
+            } else {
+                S[j] = S[j] + (acc + fid[j]);
+            }
         }
+        __syncthreads();
+    }
+    if constexpr (F32) {  // the stored state of the next time step: fl(base + dS)
+        for (int j = tid; j < Nxy; j += NT) S[j] = S[j] + dSa[j];
         __syncthreads();
     }
     // --- checks + producer observations
@@ -327,8 +347,18 @@ __global__ void k_saturation_stream(FwdParams p, const T* __restrict__ Sin_base,
         p.nts[(long long)m * p.nTime + k] = Nts;
         if (bad) atomicOr(&p.status[m], HM_MEMBER_BAD_CFL);
     }
+    // dtype = 32 plans (sat32.h): the images of the ping-pong hold s = fl(base + dS), what the neighbours' fractional flow is formed
+    // from; base and dS themselves are private to their cell's thread and live in two more arrays
+    constexpr bool F32 = std::is_same<T, float>::value;
+    float* basea = F32 ? p.comp + (long long)m * Nxy : nullptr;
+    float* dSa = F32 ? p.comp + ((long long)p.N + m) * Nxy : nullptr;
+    if constexpr (F32)
+        for (int j = tid; j < Nxy; j += NT) {
+            basea[j] = Sin[j];
+            dSa[j] = 0.0f;
+        }
     if (Nts == 0) {
-        for (int j = tid; j < Nxy; j += NT) Sout[j] = Sin[j];
+        for (int j = tid; j < Nxy; j += NT) Sout[j] = F32 ? Sin[j] + T(0) : Sin[j];
         __syncthreads();
     }
     auto fwf = [&](T s) {
@@ -361,7 +391,17 @@ __global__ void k_saturation_stream(FwdParams p, const T* __restrict__ Sin_base,
             acc = acc + cC * fwf(sc);
             if (iy > 0) acc = acc + cS * fwf(src[j - 1]);
             if (ix > 0) acc = acc + cW * fwf(src[j - Ny]);
-            dst[j] = sc + (acc + fid);
+            if constexpr (F32) {
+                float b = basea[j], e = dSa[j] + (acc + fid);
+                if ((it & (F32_FOLD - 1)) == F32_FOLD - 1) {
+                    fold32(b, e);
+                    basea[j] = b;
+                }
+                dSa[j] = e;
+                dst[j] = b + e;
+            } else {
+                dst[j] = sc + (acc + fid);
+            }
         }
         __syncthreads();
     }
@@ -414,8 +454,16 @@ __global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T*
         p.nts[(long long)m * p.nTime + k] = Nts;
         if (bad) atomicOr(&p.status[m], HM_MEMBER_BAD_CFL);
     }
+    constexpr bool F32 = std::is_same<T, float>::value;  // dtype = 32 plans: as in k_saturation_stream
+    float* basea = F32 ? p.comp + (long long)m * Nxy : nullptr;
+    float* dSa = F32 ? p.comp + ((long long)p.N + m) * Nxy : nullptr;
+    if constexpr (F32)
+        for (int j = tid; j < Nxy; j += NT) {
+            basea[j] = Sin[j];
+            dSa[j] = 0.0f;
+        }
     if (Nts == 0) {
-        for (int j = tid; j < Nxy; j += NT) Sout[j] = Sin[j];
+        for (int j = tid; j < Nxy; j += NT) Sout[j] = F32 ? Sin[j] + T(0) : Sin[j];
         __syncthreads();
     }
     auto fwf = [&](T s) {
@@ -477,7 +525,17 @@ __global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T*
                     acc = acc + cC * f[0];
                     if (iy > 0) acc = acc + cS * f[-1];
                     if (ix > 0) acc = acc + cW * f[-LW];
-                    dst[j] = sc + (acc + fid);
+                    if constexpr (F32) {
+                        float b = basea[j], e = dSa[j] + (acc + fid);
+                        if ((it & (F32_FOLD - 1)) == F32_FOLD - 1) {
+                            fold32(b, e);
+                            basea[j] = b;
+                        }
+                        dSa[j] = e;
+                        dst[j] = b + e;
+                    } else {
+                        dst[j] = sc + (acc + fid);
+                    }
                 };
                 for (int li = tx; li < th; li += 16) {
                     const int ix = x0 + li;
@@ -632,7 +690,7 @@ extern "C" int hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, doub
     p.cg_rtol = 1e-12; p.cg_max_iter = 40 * (Nx > Ny ? Nx : Ny) + 1000;
     f->cg_lazy = direct;
     p.por = porosity ? (double*)f->por.p : nullptr;
-    p.coef = nullptr; p.fw = nullptr;
+    p.coef = nullptr; p.fw = nullptr; p.comp = nullptr;
     hipStream_t s = ctx->stream;
     HM_HIP(hipMemcpyAsync(f->q.p, f->q_host.data(), f->q_host.size() * 8, hipMemcpyHostToDevice, s));
     HM_HIP(hipMemcpyAsync(f->prd_ind.p, prd_ind, (size_t)nPrd * 4, hipMemcpyHostToDevice, s));
@@ -655,7 +713,7 @@ extern "C" void hm_fwd_destroy(hm_fwd* f) {
     (void)hipStreamSynchronize(f->ctx->stream);
     DevBuf* bufs[] = {&f->K, &f->por, &f->q, &f->prd_ind, &f->TX, &f->TY, &f->G, &f->yv, &f->P, &f->Vx,
                       &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells, &f->cg_r, &f->cg_p, &f->n_cg,
-                      &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->tl_z1, &f->tl_dinv, &f->tl_parts, &f->team_mem, &f->Ky};
+                      &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->tl_z1, &f->tl_dinv, &f->tl_parts, &f->team_mem, &f->Ky, &f->comp};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     hm_nd_free(f->nd);
     f->t_total.destroy(); f->t_press.destroy(); f->t_sat.destroy();
@@ -812,6 +870,10 @@ static int ensure_generic_sat_scratch(hm_fwd* f, bool need_coef) {
         if ((rc = hm_dev_alloc(f->fw, n * f->esz))) return rc;
         f->p.fw = f->fw.p;
     }
+    if (f->dtype == 32 && !f->comp.p) {  // the compensated pair of dtype = 32 plans (sat32.h): base and dS images
+        if ((rc = hm_dev_alloc(f->comp, 2 * n * 4))) return rc;
+        f->p.comp = (float*)f->comp.p;
+    }
     return 0;
 }
 
@@ -890,13 +952,12 @@ static int launch_saturation(hm_fwd* f, int k) {
         // fp64, register/LDS resident: fw in registers, scaled fluxes (sat128r.hip); sat_variant 5: fw image in LDS (sat128.hip)
         if (f->sat_variant != 5) done = launch_saturation_128r(f, Sin, Sout, stride, k);
         if (done < 0) done = launch_saturation_128(f, Sin, Sout, stride, k);
-        if (done < 0) done = launch_saturation_128f(f, Sin, Sout, stride, k);  // fp32 twin
+        if (done < 0) done = launch_saturation_32s(f, Sin, Sout, stride, k);  // dtype = 32 plans, grids 128 / 256 / 512 wide: slabs (workgroup teams), fw in registers
         if (done < 0 && f->sat_variant != 5) done = launch_saturation_256s(f, Sin, Sout, stride, k);  // fp64, grids 256 wide: slabs of 64 rows (workgroup teams), fw in registers
         if (done < 0) done = launch_saturation_128t(f, Sin, Sout, stride, k);  // fp64, grids of 128 x 128 tiles (workgroup teams)
-        if (done < 0) done = launch_saturation_128ft(f, Sin, Sout, stride, k); // fp32 twin
     }
     if (done > 0) return done;
-    if (done == 0 && p.Ny > 128 && f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
+    if (done == 0 && p.Nxy > 128 * 128 && f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
         // The tile-team sweeps spin on their neighbours' edges, which needs every workgroup of a team resident at once; the
         // launch is sized for an otherwise idle GPU (one workgroup per CU).  If something else held CUs (another process, a
         // masked device), a team can be partly resident: its workgroups give up after a bounded spin and flag the member
@@ -916,7 +977,7 @@ static int launch_saturation(hm_fwd* f, int k) {
             done = -1;  // fall through to the tiled kernel below
         }
     }
-    const bool retry_tiled = done < 0 && p.Ny > 128 && f->team_retries_seen != f->team_retries;
+    const bool retry_tiled = done < 0 && p.Nxy > 128 * 128 && f->team_retries_seen != f->team_retries;
     f->team_retries_seen = f->team_retries;
     if (done < 0) {
         // sat_variant 1: generic (coefficient arrays + fw image); 2: streaming; 3: tiled; otherwise (no 128 x 128 specialisation

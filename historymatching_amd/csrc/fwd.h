@@ -33,6 +33,7 @@ struct FwdParams {
     // generic saturation scratch (dtype of the saturation arithmetic)
     void* coef;               // 6*N*Nxy : cE,cN,cC,cS,cW,fid
     void* fw;                 // N*Nxy
+    float* comp;              // 2*N*Nxy (dtype = 32 plans): base and dS of the compensated float32 state (sat32.h)
     int* status;              // N
     int* nts;                 // N*nTime
     // conjugate-gradient pressure solver (grids with Ny > 128, or press_variant 9)
@@ -74,6 +75,7 @@ struct hm_fwd {
     std::vector<int> well_cells_host;
     std::vector<int> q_epoch;  // per column of q_host: first time step of the run of equal columns it belongs to (build_q)
     DevBuf well_cells;
+    DevBuf comp;      // base / dS images of the generic fp32 sweeps (sat32.h), allocated on first use
     DevBuf team_mem;  // synchronisation blocks of the multi-tile saturation sweep (sat128t.hip), allocated on first use
     long long nd_fallbacks = 0;  // member-steps the direct solver of the larger grids handed to the two-level CG (press_nd.hip: nd_check_and_fall_back)
     long long team_retries = 0, team_retries_seen = 0;  // time steps redone by the tiled sweep after a team gave up waiting
@@ -108,7 +110,6 @@ bool pressure_two_level_applies(const FwdParams& p);
 int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int k);  // two-level CG, Ny = 128 c
 int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);
 int launch_saturation_128r(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // fw in registers, scaled fluxes (sat128r.hip)
-int launch_saturation_128f(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // dtype = 32 plans
+int launch_saturation_32s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // dtype = 32 plans, grids 128 / 256 / 512 wide (sat32s.hip)
 int launch_saturation_128t(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // grids of 128 x 128 tiles, fp64
-int launch_saturation_128ft(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // the same, dtype = 32 plans
 int launch_saturation_256s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // grids 256 cells wide, fp64: slabs of 64 rows, fw in registers (sat256s.hip)

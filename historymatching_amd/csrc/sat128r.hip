@@ -58,18 +58,21 @@ __device__ __forceinline__ double prev_lane(double v) {  // value of lane - 1
     return __hiloint2double(hi, lo);
 }
 
-// max(a, z) / min(a, z) as the one instruction they are.  fmax() / fmin() compile to the same instruction behind a canonicalising
-// v_max_f64 x, x of every operand the compiler cannot prove free of signalling NaNs -- here every flux, because they live in
-// registers across the sub-step loop's back edge: 78 extra instructions per thread and sub-step.  Same result for every operand that
-// is not a signalling NaN.  z is the loop's opaque zero (an SGPR pair).
-__device__ __forceinline__ double vmax(double a, double z) {
+// c f for an off-diagonal upwind coefficient c = max(+-v, 0) of a scaled face flux v = d V: ONE instruction, the product with the VOP3
+// `clamp` output modifier (and the `neg` input modifier): clamp(x) = min(max(x, +0), 1), every product of the sweep is below 1 (the CFL
+// bound keeps the coefficients below 1/3, f <= 1), f >= +0, so  max(v, 0) f == max(v f, +0) == clamp(v f)  bit for bit, denormal products
+// included (profiles/r05/fp32_rate.txt, clamp_f64.txt).  Where the reference's coefficient is -0 (-min of a positive flux) the product here
+// is +0 instead of -0: the sum of the five terms is the same -- a zero sum is +0 either way because the c_S and c_W terms are never -0 --
+// and nothing else sees the term.  (Rounds 2-4 formed the coefficient first, one v_max_f64 / v_min_f64 each: 4 of the 26 instructions per
+// cell and sub-step.)
+__device__ __forceinline__ double mulc(double v, double f) {
     double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(z));
+    asm("v_mul_f64 %0, %1, %2 clamp" : "=v"(r) : "v"(v), "v"(f));
     return r;
 }
-__device__ __forceinline__ double vmin(double a, double z) {
+__device__ __forceinline__ double nmulc(double v, double f) {
     double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(z));
+    asm("v_mul_f64 %0, -%1, %2 clamp" : "=v"(r) : "v"(v), "v"(f));
     return r;
 }
 
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(NT) void k_sat128r(FwdParams p, const double* __res
         for (int i = 0; i < PX; ++i)
 #pragma unroll
             for (int j = 0; j < PY; ++j) bits |= (unsigned long long)__double_as_longlong(S[i][j]) << 1;  // -0.0 counts as zero
-        dry = __ballot(bits != 0ull || inj) == 0ull;
+        dry = p.swc == 0.0 && __ballot(bits != 0ull || inj) == 0ull;  // swc > 0: fw(0) != 0, nothing is dry
     }
     auto ff4 = [&](const double (&s)[PY], double (&f)[PY]) {
 #pragma unroll
@@ -233,10 +236,6 @@ __global__ __launch_bounds__(NT) void k_sat128r(FwdParams p, const double* __res
 #endif
     // ---------------- explicit sub-steps
     for (int it = 0; it < Nts; ++it) {
-        // the coefficients are pure functions of the fluxes: without an opaque operand the compiler hoists them out of the loop
-        // (four more cell-sized arrays) and spills
-        double z = 0.0;
-        asm volatile("" : "+s"(z));
         double fc[PY], fm[PY], fn[PY];
         {
             double f7[PY], te[PY];
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(NT) void k_sat128r(FwdParams p, const double* __res
                 for (int j = 0; j < PY; ++j) fc[j] = f7[j] = 0.0;
             }
 #pragma unroll
-            for (int j = 0; j < PY; ++j) te[j] = (-vmin(Vx[0][j], z)) * fc[j];  // c_E f_E of the cell above, (ix0 - 1, iy0 + j)
+            for (int j = 0; j < PY; ++j) te[j] = nmulc(Vx[0][j], fc[j]);  // c_E f_E of the cell above, (ix0 - 1, iy0 + j)
             if (px > 0) st4(pubE, te);
             st4(pubW, f7);
         }
@@ -283,14 +282,13 @@ __global__ __launch_bounds__(NT) void k_sat128r(FwdParams p, const double* __res
 #pragma unroll
                 for (int j = 0; j < PY; ++j) {
                     const double vyn = j + 1 < PY ? Vy[i][j + 1 < PY ? j + 1 : 0] : vyn3;
-                    const double cW = vmax(Vx[i][j], z), cS = vmax(Vy[i][j], z), cN = -vmin(vyn, z);
                     const double fs = j > 0 ? fc[j > 0 ? j - 1 : 0] : fS;
                     const double fnn = j + 1 < PY ? fc[j + 1 < PY ? j + 1 : 0] : fN;
-                    double a = i + 1 < PX ? (-vmin(Vx[i + 1 < PX ? i + 1 : 0][j], z)) * fn[j] : fn[j];
-                    a = a + cN * fnn;
+                    double a = i + 1 < PX ? nmulc(Vx[i + 1 < PX ? i + 1 : 0][j], fn[j]) : fn[j];  // c_E f_E = max(-d Vx_e, 0) f_E
+                    a = a + nmulc(vyn, fnn);       // c_N f_N
                     a = a + ar[j] * fc[j];
-                    a = a + cS * fs;
-                    acc[j] = a + cW * fm[j];
+                    a = a + mulc(Vy[i][j], fs);    // c_S f_S = max(d Vy, 0) f_S
+                    acc[j] = a + mulc(Vx[i][j], fm[j]);
                 }
 #ifndef HM_SAT_NOWELL
                 // the injector's row (wave-uniform): its lane adds fi d in its column before S is updated.  A scalar branch inside the

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NT) void k_sat128t(FwdParams p, const double* __res
         for (int i = 0; i < PX; ++i)
 #pragma unroll
             for (int j = 0; j < PY; ++j) bits |= (unsigned long long)__double_as_longlong(S[i][j]) << 1;  // -0.0 counts as zero
-        dry = __ballot(bits != 0ull || (has_well && (wq > 0.0 || Sin[wcell] != 0.0))) == 0ull;
+        dry = p.swc == 0.0 && __ballot(bits != 0ull || (has_well && (wq > 0.0 || Sin[wcell] != 0.0))) == 0ull;  // swc > 0: fw(0) != 0, nothing is dry
     }
     const int wave_well = __builtin_amdgcn_readfirstlane(__ballot(has_well) != 0ull);
 #ifdef HM_SAT_PROF

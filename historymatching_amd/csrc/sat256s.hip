@@ -62,15 +62,21 @@ __device__ __forceinline__ double prev_lane(double v) {  // value of lane - 1
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-// max / min as the one instruction they are (sat128r.hip)
-__device__ __forceinline__ double vmax(double a, double z) {
+// c f for an off-diagonal upwind coefficient c = max(+-v, 0) of a scaled face flux v = d V: ONE instruction, the product with the VOP3
+// `clamp` output modifier (and the `neg` input modifier): clamp(x) = min(max(x, +0), 1), every product of the sweep is below 1 (the CFL
+// bound keeps the coefficients below 1/3, f <= 1), f >= +0, so  max(v, 0) f == max(v f, +0) == clamp(v f)  bit for bit, denormal products
+// included (profiles/r05/fp32_rate.txt, clamp_f64.txt).  Where the reference's coefficient is -0 (-min of a positive flux) the product here
+// is +0 instead of -0: the sum of the five terms is the same -- a zero sum is +0 either way because the c_S and c_W terms are never -0 --
+// and nothing else sees the term.  (Rounds 2-4 formed the coefficient first, one v_max_f64 / v_min_f64 each: 4 of the 26 instructions per
+// cell and sub-step.)
+__device__ __forceinline__ double mulc(double v, double f) {
     double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(z));
+    asm("v_mul_f64 %0, %1, %2 clamp" : "=v"(r) : "v"(v), "v"(f));
     return r;
 }
-__device__ __forceinline__ double vmin(double a, double z) {
+__device__ __forceinline__ double nmulc(double v, double f) {
     double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(z));
+    asm("v_mul_f64 %0, -%1, %2 clamp" : "=v"(r) : "v"(v), "v"(f));
     return r;
 }
 
@@ -103,6 +109,7 @@ __device__ __forceinline__ void get4(const u64* slot, int lane, double (&v)[PY],
 #pragma unroll
     for (int j = 0; j < PY; ++j) v[j] = __hiloint2double((int)(unsigned)g[2 * j + 1], (int)(unsigned)g[2 * j]);
 }
+
 
 template <bool FD>
 __global__ __launch_bounds__(NT) void k_sat256s(FwdParams p, const double* __restrict__ Sin_base, double* __restrict__ Sout_base,
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(NT) void k_sat256s(FwdParams p, const double* __res
         for (int i = 0; i < PX; ++i)
 #pragma unroll
             for (int j = 0; j < PY; ++j) bits |= (unsigned long long)__double_as_longlong(S[i][j]) << 1;  // -0.0 counts as zero
-        dry = __ballot(bits != 0ull || inj) == 0ull;
+        dry = p.swc == 0.0 && __ballot(bits != 0ull || inj) == 0ull;  // swc > 0: fw(0) != 0, nothing is dry
     }
     auto ff4 = [&](const double (&s)[PY], double (&f)[PY]) {
 #pragma unroll
@@ -287,8 +294,6 @@ __global__ __launch_bounds__(NT) void k_sat256s(FwdParams p, const double* __res
 
     // ---------------- explicit sub-steps
     for (int it = 0; it < Nts; ++it) {
-        double z = 0.0;
-        asm volatile("" : "+s"(z));
         const unsigned tag = (unsigned)it + 2u;
         const int par = it & 1;
         double fc[PY], fm[PY], fn[PY];
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(NT) void k_sat256s(FwdParams p, const double* __res
                 for (int j = 0; j < PY; ++j) fc[j] = f7[j] = 0.0;
             }
 #pragma unroll
-            for (int j = 0; j < PY; ++j) te[j] = (-vmin(Vx[0][j], z)) * fc[j];  // c_E f_E of the cell above, (gx0 - 1, iy0 + j)
+            for (int j = 0; j < PY; ++j) te[j] = nmulc(Vx[0][j], fc[j]);  // c_E f_E of the cell above, (gx0 - 1, iy0 + j)
             if (px > 0) st4(pubE, te);
             st4(pubW, f7);
             if (first) put4(slot(slab, par, 1), py, te, tag);             // up: the previous slab's last wave wants them
@@ -340,14 +345,13 @@ __global__ __launch_bounds__(NT) void k_sat256s(FwdParams p, const double* __res
 #pragma unroll
                 for (int j = 0; j < PY; ++j) {
                     const double vyn = j + 1 < PY ? Vy[i][j + 1 < PY ? j + 1 : 0] : vyn3;
-                    const double cW = vmax(Vx[i][j], z), cS = vmax(Vy[i][j], z), cN = -vmin(vyn, z);
                     const double fs = j > 0 ? fc[j > 0 ? j - 1 : 0] : fS;
                     const double fnn = j + 1 < PY ? fc[j + 1 < PY ? j + 1 : 0] : fN;
-                    double a = i + 1 < PX ? (-vmin(Vx[i + 1 < PX ? i + 1 : 0][j], z)) * fn[j] : fn[j];
-                    a = a + cN * fnn;
+                    double a = i + 1 < PX ? nmulc(Vx[i + 1 < PX ? i + 1 : 0][j], fn[j]) : fn[j];  // c_E f_E = max(-d Vx_e, 0) f_E
+                    a = a + nmulc(vyn, fnn);       // c_N f_N
                     a = a + ar[j] * fc[j];
-                    a = a + cS * fs;
-                    acc[j] = a + cW * fm[j];
+                    a = a + mulc(Vy[i][j], fs);    // c_S f_S = max(d Vy, 0) f_S
+                    acc[j] = a + mulc(Vx[i][j], fm[j]);
                 }
                 // the injector's row (wave-uniform): a scalar branch inside the asm, as in sat128r.hip
                 asm volatile("s_cmp_lg_u32 %[ir], %[i]\n\t"

@@ -1,0 +1,443 @@
+// sat32s.hip -- float32 explicit upwind saturation sweep of dtype = 32 plans on grids 128, 256 or 512 cells wide,
+// fractional flow in registers, the saturation as the compensated pair of sat32.h: the register-window sweep of sat128r.hip /
+// sat256s.hip re-cut for single precision.
+//
+// A thread owns a 4 (ix) x 8 (iy) patch; the NY / 8 lanes of a patch row span the grid WIDTH (16 / 32 / 64 lanes: four, two or one patch
+// rows per wave), a workgroup of 8 waves is a SLAB of 128 / 64 / 32 rows = 16 384 cells, and the Nx / SLAB slabs of a member form a
+// TEAM of workgroups, all resident at once (128 x 128: a team of one, no traffic between workgroups at all).  Per cell the registers
+// hold base and dS (sat32.h), the SCALED west- and south-face fluxes fx = (float)(d Vx), fy = (float)(d Vy) and the diagonal coefficient
+// c_C: five words, 160 of the 256 registers -- the four off-diagonal coefficients are not stored.  The reference's
+//     c_W f_W,   c_W = (float)(d max(Vx, 0))         is      clamp(fx f_W)       (the VOP3 `clamp` output modifier: one v_mul_f32)
+//     c_E f_E,   c_E = (float)(d (-min(Vx_e, 0)))    is      clamp(-fx_e f_E)    (`neg` input modifier)
+// bit for bit: d > 0 and rounding are sign-symmetric and monotone, so max(.., 0) commutes with the scaling and the conversion; f >= +0,
+// so it commutes with the product as well; every product of the sweep is below 1, where clamp(x) == max(x, +0) including denormals
+// (profiles/r05/fp32_rate.txt).  Where the reference's coefficient is -0 (a positive flux under -min) the product here is +0: the
+// sign of a zero term never reaches the state (dS starts at +0; (+-0) + x = x; base + (+0)).  c_C = (float)(d ((((fp + x1) - x2) +
+// y1) - y2)) is not a function of the rounded fluxes: it is formed once per launch in fp64 as the reference does and kept as data.
+// A sub-step:  fw of the patch's rows 0 and 3 from s = base + dS; row 3's fw (the west halo of the patch below) and the east TERMS
+// clamp(-fx[0] f[0]) of the row above are published in LDS (32 bytes each per thread; two parities, so ONE workgroup barrier per
+// sub-step); then the four rows in turn with a rolling window of three fw rows (row i+1's fw from its not-yet-updated state), the
+// iy-neighbours by DPP wave shifts (past a patch row's end the shift brings the neighbouring row's value against a zero boundary flux).
+// Between slabs the first and the last patch row trade the same two 8-value records per sub-step as GRANULES (sat_team.h: 8-byte
+// {tag, float} words, write-through stores, polled until the tag matches); the last row polls right before its row 3, behind three
+// rows of work.  Wells: a producer's rate is part of c_C; the injector's lane adds fi d in a scalar branch inside asm (sat128r.hip).
+// Dry waves (every base and dS of the wave zero, no injector) publish zeros and skip the sweep until something non-zero arrives.
+// Arithmetic per cell and sub-step: 23 VALU instructions (s, fw: 12, 5 products, 4 + 1 sums) + 0.6 DPP moves.
+// Bit-identical to k_saturation_generic<float> / _stream / _tiled and to oracle/ressim.py:saturation_step_stencil_f32c.
+// Spins are bounded: on a timeout the member is flagged HM_MEMBER_SYNC_TIMEOUT and the host redoes the step with the single-workgroup
+// tiled sweep (forward.hip).  Compiled with -ffp-contract=off.
+#include "sat_team.h"
+#include "fracflow.h"
+#include "sat32.h"
+
+namespace {
+
+using sat_team::u64;
+
+constexpr int PX = 4, PY = 8;
+constexpr int NW = 8;                  // waves per workgroup
+constexpr int NT = NW * 64;            // 512 threads
+constexpr int CHUNK = NT * 16;         // one 16-byte chunk per thread: consecutive lanes, consecutive chunks (conflict-free b128)
+// LDS: per parity [HW chunk 0, 1 | HE chunk 0, 1]; then the edge slots of the first / last patch row (what they polled, or zeros)
+constexpr int HALO_BYTES = 2 * 4 * CHUNK;       // 64 KB
+constexpr int EDGE_BASE = HALO_BYTES;           // [W | E][parity][chunk][64 lanes] x 16 bytes
+constexpr int LDS_BYTES = EDGE_BASE + 2 * 2 * 2 * 64 * 16;  // 72 KB
+constexpr int MAX_WELLS = 16;
+constexpr int MAX_SLABS = 32;
+constexpr int SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ float next_lane(float v) {  // value of lane + 1; 0 beyond the wave
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float prev_lane(float v) {  // value of lane - 1
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+// clamp(a b) and clamp(-a b): max(+-a b, +0) for products below 1 (see the header)
+__device__ __forceinline__ float mulc(float a, float b) {
+    float r;
+    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float nmulc(float a, float b) {
+    float r;
+    asm("v_mul_f32_e64 %0, -%1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// team block: CFL granules [T][2] (padded to 512 B), then per slab [2 parities][2 directions: 0 = down (fw of the last row), 1 = up (east terms)][8 values][NY / 8 lanes]
+__host__ __device__ inline size_t team_pub_off() { return 512; }
+__host__ __device__ inline size_t team_bytes(int T, int NY) { return team_pub_off() + (size_t)T * 2 * 2 * NY * 8; }
+
+template <int LPR>
+__device__ __forceinline__ void put8(u64* slot, int py, const float (&v)[PY], unsigned tag) {
+#pragma unroll
+    for (int j = 0; j < PY; ++j) sat_team::put_granule(slot + j * LPR + py, __float_as_uint(v[j]), tag);
+}
+// poll until all eight carry `tag` (the active lanes leave together); `failed`: a wait of this thread's wave has timed out -- no more waiting
+template <int LPR>
+__device__ __forceinline__ void get8(const u64* slot, int py, float (&v)[PY], unsigned tag, int& failed) {
+    u64 g[PY];
+    for (int spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < PY; ++j) {
+            g[j] = __hip_atomic_load(slot + j * LPR + py, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (unsigned)(g[j] >> 32) == tag;
+        }
+        if (__all(ok) || failed) break;
+        if (spins > SPIN_LIMIT) { failed = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int j = 0; j < PY; ++j) v[j] = __uint_as_float((unsigned)g[j]);
+}
+
+template <int NY, bool FD>
+__global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restrict__ Sin_base, float* __restrict__ Sout_base,
+                                               long long S_stride, float* __restrict__ prods, int k, char* team_mem, int T, int first_member) {
+    constexpr int LPR = NY / PY;          // lanes per patch row
+    constexpr int NROWS = NT / LPR;       // patch rows per slab
+    constexpr int SLAB = NROWS * PX;      // grid rows per slab
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    int team, slab;
+    sat_team::team_of_block(T, team, slab);
+    const int m = first_member + team;
+    if (m >= p.N) return;
+    const int py = tid % LPR, prow = tid / LPR;
+    const int gx0 = slab * SLAB + prow * PX, iy0 = py * PY;  // global row / column of the patch's first cell
+    const bool hasPrev = slab > 0, hasNext = slab + 1 < T;
+    const bool first = prow == 0 && hasPrev, last = prow == NROWS - 1 && hasNext;  // the patch rows that talk to a neighbouring slab
+
+    char* tm = team_mem + (size_t)team * team_bytes(T, NY);
+    u64* cflg = reinterpret_cast<u64*>(tm);
+    u64* pub = reinterpret_cast<u64*>(tm + team_pub_off());
+    auto slot = [&](int sl, int par, int dir) { return pub + (((size_t)sl * 2 + par) * 2 + dir) * NY; };
+    int failed = 0;
+
+    const float* Sin = Sin_base + (long long)m * S_stride;
+    float* Sout = Sout_base + (long long)m * S_stride;
+    const double* gVx = p.Vx + (long long)m * (p.Nx + 1) * NY;
+    const double* gVy = p.Vy + (long long)m * p.Nx * (NY + 1);
+    const double* q = p.q + (long long)(p.q_cols > 1 ? k : 0) * p.Nxy;
+
+    // ---------------- the (at most one) well of this patch
+    int wcell = -1;
+    double wq = 0.0;
+    const int nWl = min(p.nInj + p.nPrd, MAX_WELLS);
+    for (int w = 0; w < nWl; ++w) {
+        const int cell = p.well_cells[w];
+        const int r = cell / NY - gx0;
+        if (r >= 0 && r < PX && ((cell % NY) >> 3) == py && q[cell] != 0.0) {
+            wcell = cell;
+            wq = q[cell];
+        }
+    }
+    const bool has_well = wcell >= 0;
+    const int wrow = has_well ? wcell / NY - gx0 : -1, wcol = wcell & (PY - 1);
+    const double fpq = fmin(wq, 0.0), fiq = fmax(wq, 0.0);
+
+    // ---------------- CFL: pm = min over cells of pv / (Vi + fi), over the whole member = the team, in fp64      
+    const double pv = p.h2 * 1.0;
+    double lmin = INFINITY;
+#pragma unroll
+    for (int i = 0; i < PX; ++i)
+#pragma unroll
+        for (int j = 0; j < PY; ++j) {
+            const long long ix = gx0 + i, iy = iy0 + j;
+            const double Vi = fmax(gVx[ix * NY + iy], 0.0) + fmax(gVy[ix * (NY + 1) + iy], 0.0) - fmin(gVx[(ix + 1) * NY + iy], 0.0) -
+                              fmin(gVy[ix * (NY + 1) + iy + 1], 0.0);
+            lmin = fmin(lmin, pv / (Vi + ((wrow == i && wcol == j) ? fiq : 0.0)));
+        }
+    double* red = reinterpret_cast<double*>(lds);
+    red[tid] = lmin;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmin(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    if (T > 1) {
+        if (tid == 0) sat_team::put_double(cflg + slab * 2, cflg + slab * 2 + 1, red[0], 1u);
+        if (tid < 64) {  // wave 0: lane t collects slab t's minimum
+            const int t = tid < T ? tid : 0;
+            u64 x = 0, y = 0;
+            for (int spins = 0;; ++spins) {
+                x = __hip_atomic_load(cflg + t * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                y = __hip_atomic_load(cflg + t * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((unsigned)(x >> 32) == 1u && (unsigned)(y >> 32) == 1u)) break;
+                if (spins > SPIN_LIMIT) { failed = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            double v = failed ? INFINITY : __hiloint2double((int)(unsigned)y, (int)(unsigned)x);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+            if (tid == 0) red[NT] = v;
+        }
+        __syncthreads();
+    }
+    const double pm = T > 1 ? red[NT] : red[0];
+    __syncthreads();
+    const double sat = p.swc + p.sor;
+    const double cfl = ((1.0 - sat) / 3.0) * pm;
+    const double ntsd = ceil(p.dt / cfl);
+    const bool bad = !(ntsd >= 1.0 && ntsd <= 1.0e7);
+    const int Nts = bad ? 0 : (int)ntsd;
+    if (tid == 0 && slab == 0) {
+        p.nts[(long long)m * p.nTime + k] = Nts;
+        if (bad) atomicOr(&p.status[m], HM_MEMBER_BAD_CFL);
+    }
+    const double d = bad ? 0.0 : (p.dt / (double)Nts) / pv;
+
+    // ---------------- the state and its coefficients: fp64 arithmetic on the fp64 fluxes, rounded to float32 once (= the generic kernel)
+    float base[PX][PY], dS[PX][PY], fx[PX][PY], fy[PX][PY], cC[PX][PY];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const long long ix = gx0 + i;
+        const float4 u = *reinterpret_cast<const float4*>(Sin + ix * NY + iy0), v = *reinterpret_cast<const float4*>(Sin + ix * NY + iy0 + 4);
+        base[i][0] = u.x; base[i][1] = u.y; base[i][2] = u.z; base[i][3] = u.w;
+        base[i][4] = v.x; base[i][5] = v.y; base[i][6] = v.z; base[i][7] = v.w;
+#pragma unroll
+        for (int j = 0; j < PY; ++j) {
+            const long long iy = iy0 + j;
+            const double vxw = gVx[ix * NY + iy], vxe = gVx[(ix + 1) * NY + iy];
+            const double vys = gVy[ix * (NY + 1) + iy], vyn = gVy[ix * (NY + 1) + iy + 1];
+            const double x1 = fmin(vxw, 0.0), x2 = fmax(vxe, 0.0), y1 = fmin(vys, 0.0), y2 = fmax(vyn, 0.0);
+            cC[i][j] = (float)(d * (((wrow == i && wcol == j) ? fpq : 0.0) + x1 - x2 + y1 - y2));
+            fx[i][j] = (float)(d * vxw);
+            fy[i][j] = (float)(d * vys);
+            dS[i][j] = 0.0f;
+        }
+    }
+
+    // halo slots: HW = fw of this patch's row 3 (read by the patch row below as its west halo), HE = east terms for the row above this
+    // patch (read by the patch row above).  The first / last patch row of the slab read their halo from an edge slot instead: what they
+    // polled from the neighbouring slab, or (at the domain boundary) zeros -- against a zero boundary flux.
+    char* own = lds + tid * 16;
+    const char* getW = prow > 0 ? own - LPR * 16 : lds + EDGE_BASE + py * 16;
+    const char* getE = prow + 1 < NROWS ? own + 2 * CHUNK + LPR * 16 : lds + EDGE_BASE + 4 * 1024 + py * 16;
+    constexpr int PAR_W = 4 * CHUNK;  // parity stride of the halo slots
+    constexpr int PAR_E = 2 * 1024;   // ... of the edge slots (chunk stride there: 1024)
+    if (tid < 64)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *reinterpret_cast<float4*>(lds + EDGE_BASE + c * 1024 + tid * 16) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int cstrW = prow > 0 ? CHUNK : 1024, cstrE = prow + 1 < NROWS ? CHUNK : 1024;
+    const int pstrW = prow > 0 ? PAR_W : PAR_E, pstrE = prow + 1 < NROWS ? PAR_W : PAR_E;
+
+    // the injector of this wave (the host admits at most one per wave): its patch row and the eight per-column addends
+    // (fi d in the injector's column, 0.0 elsewhere) are wave-uniform, its lane is a mask
+    const bool inj = has_well && wq > 0.0;
+    const unsigned long long injb = __ballot(inj);
+    const int injl = injb ? __ffsll((long long)injb) - 1 : 0;
+    const int irow = injb ? __builtin_amdgcn_readlane(wrow, injl) : -1, icol = __builtin_amdgcn_readlane(wcol, injl);
+    const float fid = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)(fiq * d)), injl));
+    float fi[PY];
+#pragma unroll
+    for (int j = 0; j < PY; ++j) fi[j] = icol == j ? fid : 0.0f;
+    int dry;
+    {
+        unsigned bits = 0u;
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+#pragma unroll
+            for (int j = 0; j < PY; ++j) bits |= __float_as_uint(base[i][j]) << 1;  // -0.0 counts as zero
+        dry = p.swc == 0.0 && __ballot(bits != 0u || inj) == 0ull;  // swc > 0: fw(0) != 0, nothing is dry
+    }
+    auto ff8 = [&](const float (&b)[PY], const float (&e)[PY], float (&f)[PY]) {
+#pragma unroll
+        for (int j = 0; j < PY; ++j) f[j] = frac_flow<FD>(p, b[j] + e[j]);
+    };
+    auto ld8 = [&](const char* a, int cstr, float (&f)[PY]) {
+        const float4 u = *reinterpret_cast<const float4*>(a), v = *reinterpret_cast<const float4*>(a + cstr);
+        f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w; f[4] = v.x; f[5] = v.y; f[6] = v.z; f[7] = v.w;
+    };
+    auto st8 = [&](char* a, int cstr, const float (&f)[PY]) {
+        *reinterpret_cast<float4*>(a) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(a + cstr) = make_float4(f[4], f[5], f[6], f[7]);
+    };
+    __syncthreads();
+
+    // ---------------- explicit sub-steps
+    for (int it = 0; it < Nts; ++it) {
+        const unsigned tag = (unsigned)it + 2u;
+        const int par = it & 1;
+        float fc[PY], fm[PY], fn[PY];
+        {
+            float f3[PY], te[PY];
+            if (!dry) {
+                ff8(base[0], dS[0], fc);
+                ff8(base[PX - 1], dS[PX - 1], f3);
+            } else {
+#pragma unroll
+                for (int j = 0; j < PY; ++j) fc[j] = f3[j] = 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < PY; ++j) te[j] = nmulc(fx[0][j], fc[j]);  // c_E f_E of the cell above, (gx0 - 1, iy0 + j)
+            st8(own + par * PAR_W, CHUNK, f3);
+            st8(own + par * PAR_W + 2 * CHUNK, CHUNK, te);
+            if (first) put8<LPR>(slot(slab, par, 1), py, te, tag);   // up: the previous slab's last patch row wants them
+            if (last) put8<LPR>(slot(slab, par, 0), py, f3, tag);    // down: the next slab's first patch row wants them
+        }
+        __syncthreads();
+        if (first) {  // the previous slab's last fw row -> this patch row's edge slot (thread-private)
+            float hw[PY];
+            get8<LPR>(slot(slab - 1, par, 0), py, hw, tag, failed);
+            st8(lds + EDGE_BASE + par * PAR_E + py * 16, 1024, hw);
+        }
+        ld8(getW + par * pstrW, cstrW, fm);
+        if (dry) {  // the band only changes once something non-zero arrives from just outside it
+            float he[PY];
+            if (last) {  // (a band that wakes up polls the same record again before its row 3: same tag, same values)
+                get8<LPR>(slot(slab + 1, par, 1), py, he, tag, failed);
+                st8(lds + EDGE_BASE + 4 * 1024 + par * PAR_E + py * 16, 1024, he);
+            }
+            ld8(getE + par * pstrE, cstrE, he);
+            unsigned o = 0u;
+#pragma unroll
+            for (int j = 0; j < PY; ++j) o |= __float_as_uint(fm[j]) | __float_as_uint(he[j]);  // fw >= +0, east terms >= +0: bit test
+            dry = __ballot(o != 0u) == 0ull;
+        }
+        if (!dry) {
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                if (i + 2 < PX) ff8(base[i + 1], dS[i + 1], fn);
+                else if (i + 2 == PX) ld8(own + par * PAR_W, CHUNK, fn);  // this thread's own row 3, as published
+                else {
+                    if (last) {  // the next slab's east terms for this patch row's row 3, polled behind three rows of work
+                        float he[PY];
+                        get8<LPR>(slot(slab + 1, par, 1), py, he, tag, failed);
+                        st8(lds + EDGE_BASE + 4 * 1024 + par * PAR_E + py * 16, 1024, he);
+                    }
+                    ld8(getE + par * pstrE, cstrE, fn);  // row 3: the east TERMS, not fw
+                }
+                const float fS = prev_lane(fc[PY - 1]);  // f(ix, iy0 - 1): its flux is 0 on the boundary
+                const float fN = next_lane(fc[0]);       // f(ix, iy0 + PY)
+                const float fyn = next_lane(fy[i][0]);   // the north face of column 7
+                float acc[PY];
+#pragma unroll
+                for (int j = 0; j < PY; ++j) {
+                    float a = i + 1 < PX ? nmulc(fx[i + 1 < PX ? i + 1 : 0][j], fn[j]) : fn[j];
+                    a = a + nmulc(j + 1 < PY ? fy[i][j + 1 < PY ? j + 1 : 0] : fyn, j + 1 < PY ? fc[j + 1 < PY ? j + 1 : 0] : fN);
+                    a = a + cC[i][j] * fc[j];
+                    a = a + mulc(fy[i][j], j > 0 ? fc[j > 0 ? j - 1 : 0] : fS);
+                    acc[j] = a + mulc(fx[i][j], fm[j]);
+                }
+                // the injector's row (wave-uniform): its lane adds fi d in its column before the state is updated.  A scalar branch inside
+                // the asm: a branch the compiler sees costs the loop its register allocation (sat128r.hip).
+                asm volatile("s_cmp_lg_u32 %[ir], %[i]\n\t"
+                             "s_cbranch_scc1 .Lsat32s_noinj_%=\n\t"
+                             "s_mov_b64 exec, %[m]\n\t"
+                             "v_add_f32 %[a0], %[f0], %[a0]\n\t"
+                             "v_add_f32 %[a1], %[f1], %[a1]\n\t"
+                             "v_add_f32 %[a2], %[f2], %[a2]\n\t"
+                             "v_add_f32 %[a3], %[f3], %[a3]\n\t"
+                             "v_add_f32 %[a4], %[f4], %[a4]\n\t"
+                             "v_add_f32 %[a5], %[f5], %[a5]\n\t"
+                             "v_add_f32 %[a6], %[f6], %[a6]\n\t"
+                             "v_add_f32 %[a7], %[f7], %[a7]\n\t"
+                             "s_mov_b64 exec, -1\n"
+                             ".Lsat32s_noinj_%=:"
+                             : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),
+                               [a6] "+v"(acc[6]), [a7] "+v"(acc[7])
+                             : [ir] "s"(irow), [i] "s"(i), [m] "s"(injb), [f0] "s"(fi[0]), [f1] "s"(fi[1]), [f2] "s"(fi[2]), [f3] "s"(fi[3]),
+                               [f4] "s"(fi[4]), [f5] "s"(fi[5]), [f6] "s"(fi[6]), [f7] "s"(fi[7])
+                             : "scc");
+#pragma unroll
+                for (int j = 0; j < PY; ++j) dS[i][j] = dS[i][j] + acc[j];
+#pragma unroll
+                for (int j = 0; j < PY; ++j) { fm[j] = fc[j]; fc[j] = fn[j]; }
+            }
+            if ((it & (F32_FOLD - 1)) == F32_FOLD - 1) {
+#pragma unroll
+                for (int i = 0; i < PX; ++i)
+#pragma unroll
+                    for (int j = 0; j < PY; ++j) fold32(base[i][j], dS[i][j]);
+            }
+        }
+    }
+
+    // ---------------- write back: the state of the next time step is fl(base + dS)
+    int nonfinite = 0;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        float s[PY];
+#pragma unroll
+        for (int j = 0; j < PY; ++j) {
+            s[j] = base[i][j] + dS[i][j];
+            nonfinite |= !isfinite(s[j]);
+        }
+        float* o = Sout + (long long)(gx0 + i) * NY + iy0;
+        *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(s[4], s[5], s[6], s[7]);
+    }
+    if (nonfinite) atomicOr(&p.status[m], HM_MEMBER_NONFINITE);
+    if (__ballot(failed) != 0ull && (tid & 63) == 0) atomicOr(&p.status[m], HM_MEMBER_SYNC_TIMEOUT);
+    __threadfence_block();
+    __syncthreads();
+    if (tid < p.nPrd) {
+        const int cell = p.prd_ind[tid];
+        if (cell / NY >= slab * SLAB && cell / NY < (slab + 1) * SLAB) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = Sout[cell];
+    }
+}
+
+template <int NY, bool FD>
+int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, int T, int max_teams) {
+    const FwdParams& p = f->p;
+    const size_t need = T > 1 ? team_bytes(T, NY) * (size_t)max_teams : 0;  // a team of one trades nothing
+    if (f->team_mem.bytes < need) {
+        hm_dev_free(f->team_mem);
+        int rc = hm_dev_alloc(f->team_mem, need);
+        if (rc) return rc;
+    }
+    hipStream_t s = f->ctx->stream;
+    auto kern = k_sat32s<NY, FD>;
+    HM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    if (T > 1) {
+        int resident = 0;  // the runtime's own answer: can a workgroup of this kernel be resident on a CU at all?
+        HM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, NT, LDS_BYTES));
+        if (resident < 1) return -1;
+    }
+    for (int first = 0; first < p.N; first += max_teams) {  // rounds of members whose teams are all resident at once
+        const int nteams = std::min(max_teams, p.N - first);
+        const int used_per_xcd = (nteams + 7) / 8;
+        if (T > 1) HM_HIP(hipMemsetAsync(f->team_mem.p, 0, team_bytes(T, NY) * (size_t)nteams, s));  // tags restart at 0 every launch
+        hipLaunchKernelGGL(kern, dim3(8 * used_per_xcd * T), dim3(NT), LDS_BYTES, s, f->p, (const float*)S_in, (float*)S_out, S_stride,
+                           (float*)f->prods.p, k, (char*)f->team_mem.p, T, first);
+    }
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
+int launch_saturation_32s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
+    const FwdParams& p = f->p;
+    if (p.q_mstride != 0) return -1;  // per-member wells: the well cells come from one shared well list
+    if (f->dtype != 32 || p.por != nullptr) return -1;
+    if (p.Ny != 128 && p.Ny != 256 && p.Ny != 512) return -1;
+    const int slab = 16384 / p.Ny;  // rows per workgroup
+    if (p.Nx % slab != 0) return -1;
+    const int T = p.Nx / slab, slots = f->ctx->num_cu / 8;
+    if (T > MAX_SLABS || (T > 1 && T > slots)) return -1;
+    const int max_teams = T > 1 ? 8 * (slots / T) : p.N;  // a team of one needs nobody resident beside it
+    if ((int)f->well_cells_host.size() > MAX_WELLS) return -1;
+    // at most one well per 4 x 8 patch; at most one injector (a well with q > 0 in this time column) per wave = per band of 4 * (512 / Ny) rows
+    const double* qk = f->q_host.data() + (size_t)(p.q_cols > 1 ? k : 0) * p.Nxy;
+    std::vector<long long> patches;
+    std::vector<int> bands;
+    for (int cell : f->well_cells_host) {
+        const long long id = (long long)((cell / p.Ny) >> 2) * 100000 + ((cell % p.Ny) >> 3);
+        for (long long s : patches)
+            if (s == id) return -1;
+        patches.push_back(id);
+        if (qk[cell] > 0.0) {
+            const int band = (cell / p.Ny) / (PX * 512 / p.Ny);
+            for (int b : bands)
+                if (b == band) return -1;
+            bands.push_back(band);
+        }
+    }
+#define HM_SAT32S(NYV) (p.fluid_default ? launch<NYV, true>(f, S_in, S_out, S_stride, k, T, max_teams) : launch<NYV, false>(f, S_in, S_out, S_stride, k, T, max_teams))
+    return p.Ny == 128 ? HM_SAT32S(128) : p.Ny == 256 ? HM_SAT32S(256) : HM_SAT32S(512);
+#undef HM_SAT32S
+}

@@ -145,12 +145,15 @@ int  hm_fwd_run_to_host(hm_fwd* f, void* wsats_out, void* prods_out, int* status
  *               Ny = 128 c, Nx = c Nx_c, else Jacobi-CG)
  *   saturation: 1 generic (coefficient + fw images) | 2 streaming | 3 LDS-tiled | 0: at 128 x 128 the register/LDS-resident
  *               sweep (fp64: sat128r, fractional flow in registers and scaled fluxes -- 5 names its predecessor sat128 with the
- *               fw image in LDS, which is also what runs when two injectors share a band of 16 rows; fp32: sat128f; all need
+ *               fw image in LDS, which is also what runs when two injectors share a band of 16 rows; all need
  *               uniform porosity and at most one well per 8 x 4 cell patch), else the
  *               tiled sweep from 64 x 64 cells up, the generic one below; fp64 grids 256 cells wide (Nx a multiple of 64:
  *               256^2): teams of workgroups, one per SLAB of 64 rows, the sweep of sat128r per slab (sat256s; 5 names the tile
- *               teams below instead); other grids of 128 x 128 tiles (512^2, 256 x 128 ..., and fp32): teams of
- *               workgroups, one per tile (sat128t / sat128ft); a team that gives up waiting for a neighbour -- CUs held by
+ *               teams below instead); other fp64 grids of 128 x 128 tiles (512^2, 256 x 128 ...): teams of
+ *               workgroups, one per tile (sat128t); dtype = 32 plans on grids 128 / 256 / 512 cells wide: the float32 register
+ *               sweep on slabs of 16 384 cells (sat32s: teams of Nx Ny / 16 384 workgroups; at most one well per 4 x 8 patch);
+ *               every dtype = 32 sweep carries the saturation as a compensated float32 pair (csrc/sat32.h: <= 1e-3 of the
+ *               fp64 mode over a whole run at every grid); a team that gives up waiting for a neighbour -- CUs held by
  *               someone else -- has its time step redone by the tiled sweep; 4 = take that retry path every step, a test
  *               hook | pressure 11: two-level CG with the additive preconditioner
  *               instead of the two-grid cycle */

@@ -104,3 +104,46 @@ def oracle_update_loc_columns(E_cols, obs_ens, obs, perturbs, decorr, taper_rows
     with mp.get_context("spawn").Pool(len(tasks)) as pool:  # spawn: the parent may hold a HIP context
         res = pool.map(_oracle_loc_task, tasks, chunksize=1)
     return np.concatenate(res, axis=1)
+
+
+def fp32_vs_fp64_drift(grid, N, steps=40, every=1, seed=1, sat_variant32=0, dt=0.025, nTime=40, report=None):
+    """dtype=32 plan against dtype=64 plan on the same inputs, advanced side by side without history (GPU).  After every `every`-th
+    time step: max, 99.9-percentile and mean |S32 - S64| over all members and cells, the largest producer-series difference, the
+    water-in-place difference per member (mean saturation = water in place / pore volume; max and min over members) and whether both
+    modes took the same sub-step counts.  Returns the list of rows (dicts); `report(row)` is called as they come."""
+    from historymatching_amd.forward import ForwardPlan
+
+    _, g64 = make_models(grid, grid, dtype=64)
+    _, g32 = make_models(grid, grid, dtype=32)
+    x = perms(grid, grid, N, seed=seed)
+    p64 = ForwardPlan(g64, N, dt, nTime, keep_history=False)
+    p32 = ForwardPlan(g32, N, dt, nTime, keep_history=False)
+    p32.set_variant(0, sat_variant32)
+    p64.set_inputs(x, None, transformed=False)
+    p32.set_inputs(x, None, transformed=False)
+    rows = []
+    try:
+        for k in range(steps):
+            p64.run(k, 1)
+            p32.run(k, 1)
+            if (k + 1) % every and k + 1 != steps:
+                continue
+            S64 = p64.get_field("S").reshape(N, -1)
+            S32 = p32.get_field("S").reshape(N, -1).astype(np.float64)
+            d = np.abs(S32 - S64)
+            wip = S64.mean(axis=1) - S32.mean(axis=1)
+            _, pr64, st64 = p64.outputs(want_wsats=False)
+            _, pr32, st32 = p32.outputs(want_wsats=False)
+            flat = d.reshape(-1)
+            kth = int(0.999 * (flat.size - 1))
+            row = dict(step=k + 1, max=float(d.max()), p999=float(np.partition(flat, kth)[kth]), mean=float(d.mean()),
+                       prod=float(np.abs(pr32[:, :k + 1].astype(np.float64) - pr64[:, :k + 1]).max()), wip_max=float(wip.max()), wip_min=float(wip.min()),
+                       same_nts=bool(np.array_equal(p64.get_field("nts")[:, :k + 1], p32.get_field("nts")[:, :k + 1])),
+                       status=int(max(st64.max(), st32.max())), s_max=float(S32.max()), s_min=float(S32.min()))
+            rows.append(row)
+            if report:
+                report(row)
+    finally:
+        p64.close()
+        p32.close()
+    return rows
