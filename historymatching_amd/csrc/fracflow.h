@@ -5,7 +5,7 @@
 // quotients near the ends of the exponent range), v_rcp + two Newton steps, the quotient + one residual correction (v_div_fmas,
 // which undoes the scaling) and v_div_fixup (NaN / infinity / zero operands): ~60 cycles of a SIMD per wave, a third of the sweep
 // (profiles/diag/valu_rate.hip).  For the upstream fluid (vw = vo = 1, swc = sor = 0: n = S^2, d = S^2 + (1-S)^2) the three scaling / fix-up
-// instructions never do anything, so `div_unscaled` runs the same sequence without them -- 8 instructions, same bits:
+// instructions never do anything, so `div_unscaled` runs the same sequence without them -- 8 instructions, same bits (7 since round 5, below):
 //   * 2^-480 <= |S| < 2^500: d >= 0.5 is normal, n >= 2^-960 is far above v_div_scale's thresholds (numerator exponent <= 53,
 //     denormal quotient), the quotient is normal: both v_div_scale return their operand, VCC = 0 makes v_div_fmas a v_fma,
 //     v_div_fixup returns its first operand -- instruction for instruction the same values;
@@ -40,11 +40,15 @@ __device__ __forceinline__ double frac_flow_ieee(const FwdParams& p, double s) {
 }
 
 // n / d by the compiler's own sequence minus operand scaling and fix-up (see the header comment for when that is exact)
+// Round 5: the reciprocal is refined by ONE cubic step r (1 + e + e^2), e = 1 - d r (three FMAs) instead of the compiler's two quadratic
+// ones (four).  What the quotient's final correction needs of r is |r d - 1| <= 2^-53 (1 + tiny): q0 = RN(n r) is then within an ulp of
+// n / d, the residual n - d q0 is exact, and RN(q0 + (n - d q0) r) = RN(n / d + (n / d - q0) eps) with a perturbation of 2^-53 ulp at
+// most -- the same bound for both refinements (the seed's relative error is below 2^-20, its cube far below 2^-53; the quadratic pair
+// ends at 2^-104, which this step does not use).  Same bits on every division of the parity tests (adversarial operands, whole runs).
 __device__ __forceinline__ double div_unscaled(double n, double d) {
     double r = __builtin_amdgcn_rcp(d);
     double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d, r, 1.0);
+    e = __builtin_fma(e, e, e);
     r = __builtin_fma(r, e, r);
     const double q = n * r;
     e = __builtin_fma(-d, q, n);

@@ -276,16 +276,15 @@ __global__ __launch_bounds__(NT) void k_sat128r(FwdParams p, const double* __res
                 double ar[PY];
                 ld4(arr + (2 * i) * CHUNK, ar);
                 const double fS = prev_lane(fc[PY - 1]);  // f(ix, iy0 - 1): its coefficient is 0 on the boundary
-                const double fN = next_lane(fc[0]);       // f(ix, iy0 + PY)
-                const double vyn3 = next_lane(Vy[i][0]);
+                // c_N f_N of column 3 has both operands in the NEXT lane (its column 0: the south face flux and the fw): that lane forms the
+                // product (same operands, same instruction) and the product is shifted -- 2 DPP moves instead of 4
+                const double tN3 = next_lane(nmulc(Vy[i][0], fc[0]));
                 double acc[PY];
 #pragma unroll
                 for (int j = 0; j < PY; ++j) {
-                    const double vyn = j + 1 < PY ? Vy[i][j + 1 < PY ? j + 1 : 0] : vyn3;
                     const double fs = j > 0 ? fc[j > 0 ? j - 1 : 0] : fS;
-                    const double fnn = j + 1 < PY ? fc[j + 1 < PY ? j + 1 : 0] : fN;
                     double a = i + 1 < PX ? nmulc(Vx[i + 1 < PX ? i + 1 : 0][j], fn[j]) : fn[j];  // c_E f_E = max(-d Vx_e, 0) f_E
-                    a = a + nmulc(vyn, fnn);       // c_N f_N
+                    a = a + (j + 1 < PY ? nmulc(Vy[i][j + 1 < PY ? j + 1 : 0], fc[j + 1 < PY ? j + 1 : 0]) : tN3);  // c_N f_N
                     a = a + ar[j] * fc[j];
                     a = a + mulc(Vy[i][j], fs);    // c_S f_S = max(d Vy, 0) f_S
                     acc[j] = a + mulc(Vx[i][j], fm[j]);
