@@ -120,7 +120,13 @@ __global__ __launch_bounds__(NT) void k_sat256s(FwdParams p, const double* __res
     sat_team::team_of_block(T, team, slab);
     const int m = first_member + team;
     if (m >= p.N) return;
-    const int py = tid & (NPY - 1), px = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The slab's LAST band (it hands its row 7 down to the next slab) is swept by hardware wave 1, not 7: of the two waves on a SIMD the
+    // earlier-dispatched one wins the issue arbitration and finishes its rows well before its partner, so the record leaves earlier by
+    // about the latency of a granule hand-off (sat32s.hip; profiles/r05/sat32_prof_128.txt).  Geometry and LDS slots follow `lt`.
+    const int hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = hw == 0 ? 0 : hw == 1 ? NW - 1 : hw - 1;
+    const int lt = px * 64 + (tid & 63);
+    const int py = tid & (NPY - 1);
     const int gx0 = slab * SLAB + px * PX, iy0 = py * PY;  // global row of the patch's first row
     const bool hasPrev = slab > 0, hasNext = slab + 1 < T;
 
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(NT) void k_sat256s(FwdParams p, const double* __res
     const double d = bad ? 0.0 : (p.dt / (double)Nts) / pv;
 
     // ---------------- c_C -> LDS (thread-private), then the fluxes are scaled in place
-    char* arr = lds + tid * 16;
+    char* arr = lds + lt * 16;
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
         double a[PY];
@@ -252,8 +258,8 @@ __global__ __launch_bounds__(NT) void k_sat256s(FwdParams p, const double* __res
     // halo slots inside the slab as in sat128r.hip.  The first wave's HE slots are read by the LAST wave as the east terms of its row 7:
     // the next slab's (wave 7 parks what it polled there) or, at the end of the domain, (-0) x fw = -0.  The first wave's own west halo:
     // the previous slab's (polled into registers) or, at the start of the domain, its own HW slot (any finite fw against max(0, 0)).
-    char* pubW = lds + HW_BASE + tid * 16;
-    char* pubE = lds + HE_BASE + tid * 16;
+    char* pubW = lds + HW_BASE + lt * 16;
+    char* pubE = lds + HE_BASE + lt * 16;
     const char* getW = px > 0 ? pubW - NPY * 16 : pubW;
     char* edgeE = lds + HE_BASE + py * 16;  // the first wave's HE slot of this lane
     const char* getE = px + 1 < NW ? pubE + NPY * 16 : edgeE;

@@ -22,13 +22,20 @@
 // {tag, float} words, write-through stores, polled until the tag matches); the last row polls right before its row 3, behind three
 // rows of work.  Wells: a producer's rate is part of c_C; the injector's lane adds fi d in a scalar branch inside asm (sat128r.hip).
 // Dry waves (every base and dS of the wave zero, no injector) publish zeros and skip the sweep until something non-zero arrives.
-// Arithmetic per cell and sub-step: 23 VALU instructions (s, fw: 12, 5 products, 4 + 1 sums) + 0.6 DPP moves.
+// Arithmetic per cell and sub-step: 23 VALU instructions (s, fw: 12, 5 products, 4 + 1 sums) + 0.25 DPP moves.
 // Bit-identical to k_saturation_generic<float> / _stream / _tiled and to oracle/ressim.py:saturation_step_stencil_f32c.
 // Spins are bounded: on a timeout the member is flagged HM_MEMBER_SYNC_TIMEOUT and the host redoes the step with the single-workgroup
 // tiled sweep (forward.hip).  Compiled with -ffp-contract=off.
 #include "sat_team.h"
 #include "fracflow.h"
 #include "sat32.h"
+
+#ifdef HM_SAT_PROF
+__device__ long long hm_sat32_prof_buf[64];  // workgroup 0: [wave][publish, barrier, halo (polls), sweep, fold, loop cycles, dry sub-steps, Nts]
+#define SPROF(slot) do { const long long t_ = clock64(); sprof[slot] += t_ - sprof_t; sprof_t = t_; } while (0)
+#else
+#define SPROF(slot) do { } while (0)
+#endif
 
 namespace {
 
@@ -104,7 +111,13 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
     sat_team::team_of_block(T, team, slab);
     const int m = first_member + team;
     if (m >= p.N) return;
-    const int py = tid % LPR, prow = tid / LPR;
+    // Which wave takes which band of the slab: the slab's LAST band (it hands its row 3 down to the next slab) goes to hardware wave 1,
+    // not 7.  Of the two waves on a SIMD the earlier-dispatched one (0..3) wins the issue arbitration and is through its rows in 2.7 k of
+    // the sub-step's 6.2 k cycles (profiles/r05/sat32_prof_128.txt; waves 4..7: 4.6 k), so its next record leaves two thousand cycles
+    // earlier -- about the latency of a granule hand-off, which the next slab's first band otherwise waits out every sub-step.
+    const int lw = (tid >> 6) == 0 ? 0 : (tid >> 6) == 1 ? NW - 1 : (tid >> 6) - 1;  // logical wave: position of this wave's band in the slab
+    const int lt = lw * 64 + (tid & 63);                                             // logical thread id: geometry and LDS slots follow it
+    const int py = lt % LPR, prow = lt / LPR;
     const int gx0 = slab * SLAB + prow * PX, iy0 = py * PY;  // global row / column of the patch's first cell
     const bool hasPrev = slab > 0, hasNext = slab + 1 < T;
     const bool first = prow == 0 && hasPrev, last = prow == NROWS - 1 && hasNext;  // the patch rows that talk to a neighbouring slab
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
     // halo slots: HW = fw of this patch's row 3 (read by the patch row below as its west halo), HE = east terms for the row above this
     // patch (read by the patch row above).  The first / last patch row of the slab read their halo from an edge slot instead: what they
     // polled from the neighbouring slab, or (at the domain boundary) zeros -- against a zero boundary flux.
-    char* own = lds + tid * 16;
+    char* own = lds + lt * 16;
     const char* getW = prow > 0 ? own - LPR * 16 : lds + EDGE_BASE + py * 16;
     const char* getE = prow + 1 < NROWS ? own + 2 * CHUNK + LPR * 16 : lds + EDGE_BASE + 4 * 1024 + py * 16;
     constexpr int PAR_W = 4 * CHUNK;  // parity stride of the halo slots
@@ -256,6 +269,11 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
     };
     __syncthreads();
 
+#ifdef HM_SAT_PROF
+    long long sprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long sprof_t = clock64();
+    const long long sprof_c0 = sprof_t;
+#endif
     // ---------------- explicit sub-steps
     for (int it = 0; it < Nts; ++it) {
         const unsigned tag = (unsigned)it + 2u;
@@ -263,21 +281,28 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
         float fc[PY], fm[PY], fn[PY];
         {
             float f3[PY], te[PY];
-            if (!dry) {
-                ff8(base[0], dS[0], fc);
-                ff8(base[PX - 1], dS[PX - 1], f3);
-            } else {
+            // (the record that leaves the workgroup is formed and sent first: its flight overlaps the rest of this phase)
+            if (!dry) ff8(base[PX - 1], dS[PX - 1], f3);
+            else
 #pragma unroll
-                for (int j = 0; j < PY; ++j) fc[j] = f3[j] = 0.0f;
-            }
+                for (int j = 0; j < PY; ++j) f3[j] = 0.0f;
+            if (last) put8<LPR>(slot(slab, par, 0), py, f3, tag);    // down: the next slab's first patch row wants them
+            if (!dry) ff8(base[0], dS[0], fc);
+            else
+#pragma unroll
+                for (int j = 0; j < PY; ++j) fc[j] = 0.0f;
 #pragma unroll
             for (int j = 0; j < PY; ++j) te[j] = nmulc(fx[0][j], fc[j]);  // c_E f_E of the cell above, (gx0 - 1, iy0 + j)
+            if (first) put8<LPR>(slot(slab, par, 1), py, te, tag);   // up: the previous slab's last patch row wants them
             st8(own + par * PAR_W, CHUNK, f3);
             st8(own + par * PAR_W + 2 * CHUNK, CHUNK, te);
-            if (first) put8<LPR>(slot(slab, par, 1), py, te, tag);   // up: the previous slab's last patch row wants them
-            if (last) put8<LPR>(slot(slab, par, 0), py, f3, tag);    // down: the next slab's first patch row wants them
         }
+        SPROF(0);
         __syncthreads();
+        SPROF(1);
+#ifdef HM_SAT_PROF
+        sprof[6] += dry;
+#endif
         if (first) {  // the previous slab's last fw row -> this patch row's edge slot (thread-private)
             float hw[PY];
             get8<LPR>(slot(slab - 1, par, 0), py, hw, tag, failed);
@@ -296,6 +321,7 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
             for (int j = 0; j < PY; ++j) o |= __float_as_uint(fm[j]) | __float_as_uint(he[j]);  // fw >= +0, east terms >= +0: bit test
             dry = __ballot(o != 0u) == 0ull;
         }
+        SPROF(2);
         if (!dry) {
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
@@ -310,13 +336,12 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
                     ld8(getE + par * pstrE, cstrE, fn);  // row 3: the east TERMS, not fw
                 }
                 const float fS = prev_lane(fc[PY - 1]);  // f(ix, iy0 - 1): its flux is 0 on the boundary
-                const float fN = next_lane(fc[0]);       // f(ix, iy0 + PY)
-                const float fyn = next_lane(fy[i][0]);   // the north face of column 7
+                const float tN7 = next_lane(nmulc(fy[i][0], fc[0]));  // c_N f_N of column 7: both operands live in the next lane (its column 0)
                 float acc[PY];
 #pragma unroll
                 for (int j = 0; j < PY; ++j) {
                     float a = i + 1 < PX ? nmulc(fx[i + 1 < PX ? i + 1 : 0][j], fn[j]) : fn[j];
-                    a = a + nmulc(j + 1 < PY ? fy[i][j + 1 < PY ? j + 1 : 0] : fyn, j + 1 < PY ? fc[j + 1 < PY ? j + 1 : 0] : fN);
+                    a = a + (j + 1 < PY ? nmulc(fy[i][j + 1 < PY ? j + 1 : 0], fc[j + 1 < PY ? j + 1 : 0]) : tN7);
                     a = a + cC[i][j] * fc[j];
                     a = a + mulc(fy[i][j], j > 0 ? fc[j > 0 ? j - 1 : 0] : fS);
                     acc[j] = a + mulc(fx[i][j], fm[j]);
@@ -346,14 +371,23 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
 #pragma unroll
                 for (int j = 0; j < PY; ++j) { fm[j] = fc[j]; fc[j] = fn[j]; }
             }
+            SPROF(3);
             if ((it & (F32_FOLD - 1)) == F32_FOLD - 1) {
 #pragma unroll
                 for (int i = 0; i < PX; ++i)
 #pragma unroll
                     for (int j = 0; j < PY; ++j) fold32(base[i][j], dS[i][j]);
             }
+            SPROF(4);
         }
     }
+#ifdef HM_SAT_PROF
+    if (blockIdx.x == HM_SAT_PROF && (tid & 63) == 0) {
+        sprof[5] = clock64() - sprof_c0;
+        sprof[7] = Nts;
+        for (int i = 0; i < 8; ++i) hm_sat32_prof_buf[(tid >> 6) * 8 + i] = sprof[i];
+    }
+#endif
 
     // ---------------- write back: the state of the next time step is fl(base + dS)
     int nonfinite = 0;
@@ -408,6 +442,10 @@ int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, 
 }
 
 }  // namespace
+
+#ifdef HM_SAT_PROF
+extern "C" int hm_debug_sat32_prof(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hm_sat32_prof_buf), sizeof(long long) * 64); }
+#endif
 
 // Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
 int launch_saturation_32s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
