@@ -421,10 +421,23 @@ __global__ void k_saturation_stream(FwdParams p, const T* __restrict__ Sin_base,
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T* __restrict__ Sin_base, T* __restrict__ Sout_base,
-                                                           long long S_stride, T* __restrict__ prods, int k) {
+                                                           long long S_stride, T* __restrict__ prods, int k, int only_timed_out) {
     constexpr int TH = 64, TW = 256, LW = TW + 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    if (only_timed_out) {
+        // The retry of the workgroup-team sweeps, decided on the device: this launch follows every team launch and redoes the time step
+        // of exactly those members whose team gave up waiting for a neighbour (HM_MEMBER_SYNC_TIMEOUT: its workgroups were not all
+        // resident -- CUs held by someone else).  S_in is untouched by the team sweep (it writes the other time slot), the result is
+        // bit-identical; a member without the flag costs this workgroup one load.  No host synchronisation (round 4 read the flags back).
+        __shared__ int go;
+        if (tid == 0) {
+            go = (p.status[m] & HM_MEMBER_SYNC_TIMEOUT) != 0;
+            if (go) atomicAnd(&p.status[m], ~HM_MEMBER_SYNC_TIMEOUT);
+        }
+        __syncthreads();
+        if (!go) return;
+    }
     const int Nx = p.Nx, Ny = p.Ny, Nxy = p.Nxy;
     double* red = smem;                          // NT doubles
     T* fwt = reinterpret_cast<T*>(smem + 1024);  // (TH + 2) x LW
@@ -571,6 +584,11 @@ __global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T*
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+__global__ void k_or_status(int* status, int n, int bits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicOr(&status[i], bits);
+}
+
 template <typename T>
 __global__ void k_fill(T* p, T v, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -958,41 +976,42 @@ static int launch_saturation(hm_fwd* f, int k) {
     }
     if (done > 0) return done;
     if (done == 0 && p.Nxy > 128 * 128 && f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
-        // The tile-team sweeps spin on their neighbours' edges, which needs every workgroup of a team resident at once; the
-        // launch is sized for an otherwise idle GPU (one workgroup per CU).  If something else held CUs (another process, a
-        // masked device), a team can be partly resident: its workgroups give up after a bounded spin and flag the member
-        // HM_MEMBER_SYNC_TIMEOUT.  Large grids already synchronise with the host every time step (CG convergence), so the
-        // flags are read here and the step is redone for everyone by the single-workgroup tiled sweep, which needs no
-        // co-residency and is bit-identical (S_in is untouched: the sweep writes the other time slot).
-        std::vector<int> st(p.N);
-        HM_HIP(hipStreamSynchronize(s));
-        HM_HIP(hipMemcpy(st.data(), f->status.p, (size_t)p.N * 4, hipMemcpyDeviceToHost));
-        bool timed_out = false;
-        for (int& v : st)
-            if (v & HM_MEMBER_SYNC_TIMEOUT) { timed_out = true; v &= ~HM_MEMBER_SYNC_TIMEOUT; }
-        if (f->sat_variant == 4) timed_out = true;  // test hook: take the retry path although nobody timed out
-        if (timed_out) {
-            HM_HIP(hipMemcpy(f->status.p, st.data(), (size_t)p.N * 4, hipMemcpyHostToDevice));
+        // The team sweeps spin on their neighbours' rows, which needs every workgroup of a team resident at once; the launch is sized for
+        // an otherwise idle GPU (one workgroup per CU).  If something else held CUs (another process, a masked device), a team can be
+        // partly resident: its workgroups give up after a bounded spin and flag the member HM_MEMBER_SYNC_TIMEOUT.  The single-workgroup
+        // tiled sweep needs no co-residency and is bit-identical: it follows every team launch as a GATED launch -- a workgroup per
+        // member that returns at once unless its member carries the flag (k_saturation_tiled, only_timed_out).  sat_variant 4 (a test hook)
+        // flags every member first, so the retry path runs on all of them every step.
+        rc = ensure_generic_sat_scratch(f, false);
+        if (rc) return rc;
+        if (f->sat_variant == 4) {
+            hipLaunchKernelGGL(k_or_status, dim3((p.N + 255) / 256), dim3(256), 0, s, (int*)f->status.p, p.N, (int)HM_MEMBER_SYNC_TIMEOUT);
             f->team_retries++;
-            done = -1;  // fall through to the tiled kernel below
         }
+        const size_t lds = (size_t)1024 * 8 + (size_t)66 * 258 * f->esz;
+        if (f->dtype == 64) {
+            HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_saturation_tiled<double>, dim3(p.N), dim3(1024), lds, s, f->p, (const double*)Sin, (double*)Sout, stride, (double*)f->prods.p, k, 1);
+        } else {
+            HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_saturation_tiled<float>, dim3(p.N), dim3(1024), lds, s, f->p, (const float*)Sin, (float*)Sout, stride, (float*)f->prods.p, k, 1);
+        }
+        HM_HIP(hipGetLastError());
     }
-    const bool retry_tiled = done < 0 && p.Nxy > 128 * 128 && f->team_retries_seen != f->team_retries;
-    f->team_retries_seen = f->team_retries;
     if (done < 0) {
         // sat_variant 1: generic (coefficient arrays + fw image); 2: streaming; 3: tiled; otherwise (no 128 x 128 specialisation
         // applies: other sizes, porosity field, two wells in one patch) tiled from 64 x 64 cells up (67.9 vs 124 ms per launch at
         // 128 x 128, N = 1000), generic below
-        const bool tiled = retry_tiled || f->sat_variant == 3 || (f->sat_variant != 1 && f->sat_variant != 2 && p.Nxy >= 64 * 64);
+        const bool tiled = f->sat_variant == 3 || (f->sat_variant != 1 && f->sat_variant != 2 && p.Nxy >= 64 * 64);
         const bool stream = f->sat_variant == 2;
         rc = ensure_generic_sat_scratch(f, !(stream || tiled));
         if (rc) return rc;
         int T = tiled ? 1024 : (p.Nxy >= 4096 ? 1024 : 256);
         size_t lds = tiled ? (size_t)1024 * 8 + (size_t)66 * 258 * f->esz : (size_t)T * 8;
-#define SAT(KERN, TT) hipLaunchKernelGGL(KERN<TT>, dim3(p.N), dim3(T), lds, s, f->p, (const TT*)Sin, (TT*)Sout, stride, (TT*)f->prods.p, k)
+#define SAT(KERN, TT, ...) hipLaunchKernelGGL(KERN<TT>, dim3(p.N), dim3(T), lds, s, f->p, (const TT*)Sin, (TT*)Sout, stride, (TT*)f->prods.p, k, ##__VA_ARGS__)
         if (tiled) {
-            if (f->dtype == 64) { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, double); }
-            else { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, float); }
+            if (f->dtype == 64) { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, double, 0); }
+            else { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, float, 0); }
         } else if (stream) { if (f->dtype == 64) SAT(k_saturation_stream, double); else SAT(k_saturation_stream, float); }
         else { if (f->dtype == 64) SAT(k_saturation_generic, double); else SAT(k_saturation_generic, float); }
 #undef SAT
@@ -1153,6 +1172,17 @@ extern "C" int hm_fwd_set_field(hm_fwd* f, const char* name, const void* in) {
 }
 
 extern "C" long long hm_fwd_nd_fallbacks(hm_fwd* f) { return f ? f->nd_fallbacks : 0; }
+
+extern "C" int hm_fwd_set_debug(hm_fwd* f, const char* key, long long value) {
+    HM_REQUIRE(f && key, "hm_fwd_set_debug: NULL argument");
+    const std::string k(key);
+    if (k == "nd_force_fallback") f->dbg_nd_force_fallback = (int)value;
+    else if (k == "nd_cap") {
+        HM_REQUIRE(!f->nd, "hm_fwd_set_debug: \"nd_cap\" must be set before the plan's first run");
+        f->dbg_nd_cap = (int)value;
+    } else HM_REQUIRE(false, "hm_fwd_set_debug: unknown key \"%s\"", key);
+    return 0;
+}
 
 extern "C" void* hm_fwd_device_ptr(hm_fwd* f, const char* name) {
     if (!f || !name) return nullptr;

@@ -28,6 +28,7 @@
 // entries of the update are the reduced right-hand side), so forward elimination costs nothing extra.
 #include "fwd_dev.h"
 #include "nd_build.h"
+#include "nd_plan.h"
 #include "sweep16.h"
 
 #ifdef HM_ND_PROF
@@ -59,32 +60,6 @@ constexpr int ND_LEVELS = 11 + LO;
 __host__ __device__ constexpr int FID(int l) { return (1 << (l + LO)) - 1; }
 constexpr int NF8 = 256 << LO, NF7 = 128 << LO, NF6 = 64 << LO, NF5 = 32 << LO;  // fronts of levels 8, 7, 6, 5 (128 x 128 numbering)
 
-struct NdDev {
-    const int* fronts;
-    const int* cells;
-    const short* cpos;
-    const short* rec;  // assembly recipes (nd.h), blocks of 256 int16
-    double* fact;
-    double* arena;
-    double* cf;  // per member: [dg | -TX | -TY | q], CF_STRIDE doubles
-    long long fact_stride, arena_stride;
-    int slot9, slot10;      // doubles per LDS update slot of levels 9, 10 (k_nd_sub)
-    int child_doubles[3];   // largest child update of a level-7 / 6 / 5 front (k_nd_wave's LDS staging)
-    int top_child_doubles;  // largest child update of a level <= 4 front
-    // Reuse across time steps (k_nd_plan): per member the fronts of levels 8..5 that have to be eliminated this step, compacted
-    int* work;                   // N x ND_WORK_INTS: [n8, n7, n6, n5 | list8[256] | list7[128] | list6[64] | list5[32] | nt, fronts of levels 4..0]
-                                 // (larger grids: the lists are 4 / 16 times as long; the fronts of levels <= LO + 4 have `todo` bytes instead)
-    unsigned char* cached;       // N x NCACHE (512 at 128 x 128): front f (levels 0..8: f = 0..510) holds the results of its all-dry state
-    const unsigned char* wells;  // NCACHE: a well somewhere in the front's subtree (its right-hand side rows carry the rates)
-    int wells_ok;                // the rates of this time step are those the cached results of such fronts were computed with
-    int reuse;                   // 0: every front is eliminated every step
-    // larger grids: the plan's inputs / outputs, and the big fronts' (levels 0 .. LO + 2) panel images
-    unsigned long long* wet;     // per member: wet-cell bitmap, NB rows x NB / 64 words (k_ndl_assemble -> k_ndl_plan)
-    unsigned char* todo;         // per member: NTODO bytes, front f of levels 0 .. LO + 4 is eliminated this step (k_ndl_plan)
-    double* vfac;                // per member: the negated pivot-panel tiles V(p, R) at the factor's offsets (operands of the trailing products)
-    double* pimg;                // per member: the negated inverse pivot tiles, NDF_PIMG + 256 p
-    long long vfac_stride, pimg_stride;
-};
 constexpr int ND_W8 = 4, ND_W7 = ND_W8 + NF8, ND_W6 = ND_W7 + NF7, ND_W5 = ND_W6 + NF6, ND_WT = ND_W5 + NF5;  // ND_WT: n, then the fronts of levels 4..0 in order
 constexpr int ND_WORK_INTS = ND_WT + 64;
 constexpr int NCACHE = 512 << LO;              // >= fronts of levels 0 .. LO + 8
@@ -1902,10 +1877,13 @@ __global__ __launch_bounds__(1024) void k_nd_flux(FwdParams p, int k) {
     __syncthreads();
     const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * p.Nxy;
     double worst = 0.0, qmax = 0.0;
+    const double pin0 = (p.K[(long long)m * p.Nxy] + (p.Ky ? p.Ky : p.K)[(long long)m * p.Nxy]) * p.P[(long long)m * p.Nxy];
     for (int c = threadIdx.x; c < p.Nxy; c += 1024) {
         const int ix = c >> LG, iy = c & (NB - 1), fy = ix * (NB + 1) + iy;
         const double div = (Vx[c + NB] - Vx[c]) + (Vy[fy + 1] - Vy[fy]);
-        const double e = fabs(div - q[c]);
+        // (cell 0 carries the SPD pin, A[0,0] += Kx[0] + Ky[0]: the system solved is div V + pin P[0] = q there -- without the term rates
+        // with |sum q| > 1e-4 max |q|, which the reference accepts up to np.isclose, would flag every member)
+        const double e = fabs(div - q[c] + (c == 0 ? pin0 : 0.0));
         worst = (e > worst || e != e) ? e : worst;  // (a NaN wins)
         qmax = fmax(qmax, fabs(q[c]));
     }
@@ -1933,15 +1911,6 @@ __global__ __launch_bounds__(1024) void k_nd_flux(FwdParams p, int k) {
 // ------------------------------------------------------------------------------------------------------------------------
 // Host side: tables built once per plan, buffers sized by the builder.
 // ------------------------------------------------------------------------------------------------------------------------
-struct hm_nd {
-    NdInfo info{};
-    DevBuf fronts, cells, cpos, rec, fact, arena, dg, work, cached, wells, vfac, pimg, wet, todo;
-    NdDev dev{};
-    int cap = 0;                // members the per-member buffers hold: larger ensembles are solved in blocks of `cap` members (larger grids)
-    long long cached_gen = -1;  // hm_fwd::inputs_gen the cached results belong to
-    int cached_q_epoch = -1;    // hm_fwd::q_epoch of the time step the cached results of fronts with wells belong to
-};
-
 // the entry points of this object (one per grid size, fwd.h)
 #if ND_LG == 7
 #define ND_ENTRY(name) name
@@ -2002,9 +1971,14 @@ static int nd_setup(hm_fwd* f) {
     if (LO > 0) {
         size_t free_b = 0, total_b = 0;
         HM_HIP(hipMemGetInfo(&free_b, &total_b));
-        const size_t budget = std::min<size_t>(free_b / 2, (size_t)64 << 30);  // (no faster with larger blocks: 23.3 ms per 512 members at 512, 1024 or 2048 a block)
+        // Blocks of members through the same buffers are no faster when larger (23.3 ms per 512 members at 512, 1024 or 2048 a block) --
+        // but an ensemble that is ONE block keeps the results of its dry fronts from step to step (16.0 instead of 22.6 ms per 512 members
+        // at 256 x 256).  So: the whole ensemble where its buffers fit the free memory with 16 GB to spare (BASELINE config 4 whole on one
+        // GPU: 4096 x 58 MB = 238 GB of the 288), else blocks within 64 GB.
+        const size_t whole = (size_t)p.N * per_member, spare = (size_t)16 << 30;
+        const size_t budget = whole + spare <= free_b ? whole : std::min<size_t>(free_b / 2, (size_t)64 << 30);
         cap = std::max<size_t>(1, std::min<size_t>(p.N, budget / per_member));
-        if (const char* e = getenv("HM_ND_CAP")) cap = std::max<size_t>(1, std::min<size_t>(cap, (size_t)atoi(e)));  // (experiments)
+        if (f->dbg_nd_cap > 0) cap = std::max<size_t>(1, std::min<size_t>(cap, (size_t)f->dbg_nd_cap));  // (hm_fwd_set_debug "nd_cap": tests, experiments)
     }
     n->cap = (int)cap;
     const size_t N = cap;
@@ -2171,8 +2145,8 @@ static int nd_check_and_fall_back(hm_fwd* f, const void* S, long long S_stride, 
     std::vector<int> bad;
     for (int m = 0; m < p.N; ++m)
         if (st[m] & HM_MEMBER_BAD_PIVOT) bad.push_back(m);
-    if (const char* e = getenv("HM_ND_FORCE_FALLBACK")) {  // (tests: member e takes the hand-over every time step, whatever its solve was like)
-        const int m = atoi(e);
+    {   // (hm_fwd_set_debug "nd_force_fallback": a test makes one member take the hand-over every time step, whatever its solve was like)
+        const int m = f->dbg_nd_force_fallback;
         if (m >= 0 && m < p.N && !(st[m] & HM_MEMBER_BAD_PIVOT)) bad.push_back(m);
     }
     if (bad.empty() || (int)bad.size() > ND_MAX_FALLBACK || !pressure_two_level_applies(p)) return 0;

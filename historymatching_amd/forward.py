@@ -83,6 +83,11 @@ class ForwardPlan:
         """0 = fastest applicable kernel, 1 = generic kernels (the in-library correctness baseline)."""
         _lib.check(self.lib.hm_fwd_set_variant(self.h, int(pressure), int(saturation)), "hm_fwd_set_variant")
 
+    def set_debug(self, key, value):
+        """Test / experiment knobs (hm_fwd_set_debug): "nd_force_fallback" = member handed to the CG every step (-1 off), "nd_cap" =
+        members per block of the larger grids' direct solver (before the first run)."""
+        _lib.check(self.lib.hm_fwd_set_debug(self.h, key.encode(), int(value)), "hm_fwd_set_debug")
+
     def set_solver(self, rtol=1e-12, max_iter=None):
         """Conjugate-gradient pressure solver (always used when Ny > 128; pressure variant 9 elsewhere)."""
         if max_iter is None:

@@ -133,6 +133,13 @@ int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
  * member whose elimination met a non-positive pivot, or whose fluxes missed the wells by more than 1e-4 of the largest rate (the
  * reference's sparse direct solve with partial pivoting, HistoryMatch.py:362, does not fail on such members either). */
 long long hm_fwd_nd_fallbacks(hm_fwd* f);
+/* Test and experiment knobs of a plan (not part of the reference's surface; nothing reads the environment).  Keys:
+ *   "nd_force_fallback"  value = member index: on the larger grids that member is handed to the two-level CG at EVERY time step, whatever
+ *                        its direct solve was like (exercises the hand-over deterministically); -1 (default) = off
+ *   "nd_cap"             value = members per block of the larger grids' direct solver (0, the default: automatic -- the whole ensemble
+ *                        where its buffers fit the device, else blocks within 64 GB); must be set before the plan's first run
+ * Returns nonzero for an unknown key. */
+int  hm_fwd_set_debug(hm_fwd* f, const char* key, long long value);
 int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member);     /* D2H */
 /* All nTime steps from the inputs set, then sync + outputs in one call -- what forward_model(perms) -> [wsats, prods]
  * (HistoryMatch.py:383-387) needs.  From 256 MB of saturation history on, time index k of every member is copied to
