@@ -583,7 +583,7 @@ def main():
         # saturation sweep (k_sat128r): member state register/LDS resident, bound by the CU's double-precision VALU.  Work per
         # launch = DP VALU instructions of the sub-step loop (counted from the built object: profiles/tools/isa_count.py) x
         # cells x sub-steps x members, in lane-instructions; the peak is one DP lane-instruction per lane-slot.
-        dp_per_cell = (isa or {}).get("k_sat128r", {}).get("dp_valu_per_cell_substep", 26.0)
+        dp_per_cell = (isa or {}).get("k_sat128r", {}).get("dp_valu_per_cell_substep", 21.0)
         # dry bands are skipped (sat128r.hip): the instructions actually executed are fewer than cells x sub-steps x count; the
         # ratio is measured (SQ_INSTS_VALU over the same workload, profiles/rNN/fp64_roofline.json) -- `frac` uses EXECUTED work
         f64r, f64r_src = load_profile_json("fp64_roofline.json")
@@ -616,6 +616,11 @@ def main():
         roofline = {
             "bound": bound, "kernel": {"saturation": "k_sat128r", "pressure": "k_nd_* (press_nd.hip: assemble, sub, wave x3, top, solve)"}[dominant] if args.variant == 0 else dominant,
             "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+            # `frac` prices THIS run's launch time with the committed instruction counts (ISA census, executed / algorithmic ratio from a
+            # counter pass): `frac_valid` says whether those counts were taken from the very objects that ran (sha256); when they were not
+            # (`stale_inputs`), `frac` is a number priced with another build's counts -- kept, but flagged.  The executed / algorithmic
+            # ratio is a committed measurement (profiles/rNN/fp64_roofline.json), not re-measured in this run.
+            "frac_valid": not stale, "executed_ratio_measured_in_this_run": False,
             "stale_inputs": bool(stale), "stale_inputs_detail": stale or None,
             "inputs_taken_from_objects": recorded, "objects_run": {k: built.get(k) for k in ("sat128r.o", "press_nd.o")},
             "unit_note": "for bound fp64_valu `achieved` is an issue-slot rate: DP lane-instructions/s x 2 (every DP VALU instruction priced as one FMA "

@@ -67,7 +67,7 @@ def hot_loop(body, barriers=None):
     (the compiler places cold blocks at the end of the function that jump BACK into the body: those regions span
     several loops and are told apart by their barrier count)."""
     addr_index = {a: i for i, (a, _, _) in enumerate(body)}
-    best = None
+    best = best_key = None
     for i, (a, op, args) in enumerate(body):
         if not op.startswith("s_cbranch") and op != "s_branch":
             continue
@@ -84,8 +84,12 @@ def hot_loop(body, barriers=None):
             j = addr_index[target]
             if barriers is not None and sum(1 for _, o, _ in body[j:i + 1] if o == "s_barrier") != barriers:
                 continue
-            if best is None or (i - j) > (best[1] - best[0]):
-                best = (j, i)
+            # a region that reloads spilled registers is not the steady-state loop: where a wave wakes up from its dry phase the compiler
+            # re-enters the loop through a block of scratch loads (and the prologue's flux scaling) that a back edge also spans
+            scratch = any(o.startswith("scratch_") for _, o, _ in body[j:i + 1])
+            cand = (not scratch, i - j)
+            if best is None or cand > best_key:
+                best, best_key = (j, i), cand
     return best
 
 

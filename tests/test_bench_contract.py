@@ -30,6 +30,8 @@ def test_committed_bench_line_has_the_contract_keys():
     # `frac` is always a number (this run's launch time priced with the committed instruction counts); staleness of those counts is a flag
     assert isinstance(r["frac"], float) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
     assert isinstance(r["stale_inputs"], bool)
+    if "frac_valid" in r:  # (lines from round 5 on) the committed line must be priced with counts taken from the objects that ran
+        assert r["frac_valid"] is True and r["stale_inputs"] is False, (path, r.get("stale_inputs_detail"))
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

@@ -219,6 +219,31 @@ def test_config5_grid_forward_vs_oracle():
         assert np.array_equal(p[m], w[m][1:, om.xy2ind(*om.prd_xy.T)])
 
 
+def test_config5_grid_fp64_five_steps_vs_oracle():
+    """512 x 512 over FIVE time steps (49 155 explicit sub-steps; the water front has crossed the leaf and subtree boundaries of the
+    15-level tree around the injector and dry-front results are being reused): one member, default fp64 kernels, against the oracle within
+    its own solver noise (second SuperLU ordering MMD_AT_PLUS_A), every stored step; same sub-step counts."""
+    from historymatching_amd.forward import ForwardPlan
+
+    n, steps = 512, 5
+    om, gm = make_models(n, n)
+    x = perms(n, n, 1, seed=29)
+    plan = ForwardPlan(gm, 1, DT, steps)
+    plan.set_inputs(x, transformed=False)
+    plan.run()
+    st = plan.sync()
+    w, p, status = plan.outputs()
+    nts = plan.get_field("nts")
+    plan.close()
+    assert not status.any() and st["mean_n_cg"] == 0 and st["nd_fallbacks"] == 0
+    assert (nts[0, :steps] == 9831).all()
+    (ref, noise), = oracle_sims_and_noise_parallel(n, n, x, DT, steps, permc2="MMD_AT_PLUS_A")
+    err = np.abs(w[0] - ref).max(axis=1)
+    assert err.max() <= 10 * noise + 1e-9, (err, noise)
+    assert err.max() < 1e-4
+    assert np.array_equal(p[0], w[0][1:, om.xy2ind(*om.prd_xy.T)])
+
+
 def test_config5_grid_fp32_forward_vs_oracle():
     """512 x 512 in the mode config 5 runs in: dtype=32 plans (slab teams of 16 workgroups, sat32s.hip; fp64 nested-dissection pressure
     solve), two members, three time steps = 29 493 explicit sub-steps, against the fp64 oracle: <= 1e-3 on S (a plain
@@ -304,11 +329,24 @@ def test_config5_shard_whole_run_properties():
     x = perms(n, n, N, seed=8)
     plan = ForwardPlan(gm, N, DT, steps, keep_history=False)
     plan.set_inputs(x, transformed=False)
-    plan.run()
+    om, _ = make_models(n, n)
+    q = om.source_field(0)[0]
+    worst = 0.0
+    for k0 in range(0, steps, 8):  # the direct solver's divergence residual, what its a-posteriori check sees, at steps 8, 16, ... 40
+        plan.run(k0, 8)
+        plan.sync()
+        Vx, Vy = plan.get_field("Vx"), plan.get_field("Vy")
+        for m0 in range(0, N, 25):
+            div = (Vx[m0:m0 + 25, 1:] - Vx[m0:m0 + 25, :-1]) + (Vy[m0:m0 + 25, :, 1:] - Vy[m0:m0 + 25, :, :-1])
+            worst = max(worst, float(np.abs(div.reshape(len(div), -1) - q).max()))
+        del Vx, Vy
     st = plan.sync()
     S_end, prods, status = plan.outputs()
     plan.close()
     assert not status.any() and st["mean_n_cg"] == 0 and st["nd_fallbacks"] == 0 and st["mean_nts"] > 9000
+    # the check's threshold is 1e-4 max |q| = 1e-4; a healthy solve leaves T eps |p| there (1e-13 ... 1e-5 over config 4's prior at
+    # 256 x 256, profiles/r04/nd_residual_stats.txt): a factor 3 of margin over a whole run at this grid
+    assert worst < 3e-5, worst
     S64, p64 = S_end.astype(float), prods.astype(float)
     tol = 1e-6
     assert S64.min() >= -tol and S64.max() <= 1 + 1e-4 and np.isfinite(p64).all()  # (the injector's cell holds fw = 1 to a float32 ulp)

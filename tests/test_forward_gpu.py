@@ -878,15 +878,16 @@ def test_nested_dissection_pressure_whole_run():
         assert np.abs(res[12][0][m] - ref).max() <= 10 * noise + 1e-9, (m, np.abs(res[12][0][m] - ref).max(), noise)
 
 
-@pytest.mark.parametrize("n,rates", [(128, "constant"), (128, "time_varying"), (128, "piecewise_constant"), (256, "constant"), (256, "piecewise_constant")])
+@pytest.mark.parametrize("n,rates", [(128, "constant"), (128, "time_varying"), (128, "piecewise_constant"), (256, "constant"), (256, "piecewise_constant"),
+                                     (512, "constant")])
 def test_nested_dissection_reuse_of_dry_fronts_is_bit_identical(n, rates):
     """press_nd.hip does not eliminate a front again while its whole subtree is still dry and the rates of the wells in it are unchanged
     (k_nd_plan): the stored factor rows and update matrix are what it would recompute.  Whole runs with the reuse (press_variant 12, the default) and without (14) give
     array_equal saturations, producer series, sub-step counts and final pressures; so does a second run on the SAME plan from other
     permeabilities (the cache dies with the inputs it was computed from) and a pressure solve after a saturation field was written
-    into the plan by hand.  256 x 256: the same plan for the 13-level tree (k_ndl_plan: lists for the wave-level fronts, `todo` bytes for the
-    workgroup-level and big fronts)."""
-    N, steps = 4, 14
+    into the plan by hand.  256 x 256 / 512 x 512: the same plan for the 13- / 15-level tree (k_ndl_plan: lists for the wave-level fronts,
+    `todo` bytes for the workgroup-level and big fronts)."""
+    N, steps = (4, 14) if n < 512 else (3, 8)
     _, gm = make_models(n, n)
     if rates != "constant":
         # the right-hand side rows of a front with a well in its subtree are kept only over runs of time steps with equal rates
@@ -1140,6 +1141,39 @@ def test_direct_solver_survives_an_ill_conditioned_member():
     plan.close()
     assert not status1.any() and st1["nd_fallbacks"] == 0
     assert np.array_equal(S1[0], S_end[1])
+
+
+def test_large_grid_run_is_asynchronous_without_the_a_posteriori_check():
+    """press_variant 12 at 256 x 256 (the direct solver without its per-step check) queues the whole run and returns: nothing in
+    hm_fwd_run waits for the device -- the team sweeps' time-out retry is a device-gated launch since round 5 (forward.hip:
+    launch_saturation), the solver's buffers are set up before the run.  The call returns in a small fraction of the time the device then
+    needs; the default variant (0) reads the status words back once per time step (the hand-over to the two-level CG is a host decision:
+    a device-side single-workgroup CG would cost 0.4-0.5 s per member-step, profiles/r05/pcg_on_hard_member.txt) and so takes as long as
+    the run.  Same results from both."""
+    import time
+
+    n, N, steps = 256, 64, 12
+    _, gm = make_models(n, n)
+    x = perms(n, n, N, seed=19)
+    out = {}
+    for variant in (12, 0):
+        plan = _plan(gm, N, nTime=steps, keep_history=False)
+        plan.set_variant(variant, 0)
+        plan.set_inputs(x, transformed=False)
+        plan.run(0, 1)  # first step: buffers, tables
+        plan.sync()
+        t0 = time.perf_counter()
+        plan.run(1, steps - 1)
+        t_call = time.perf_counter() - t0
+        plan.sync()
+        t_all = time.perf_counter() - t0
+        S, p, status = plan.outputs()
+        plan.close()
+        assert not status.any()
+        out[variant] = (S, p, t_call, t_all)
+    assert out[12][2] < 0.25 * out[12][3], (out[12][2], out[12][3])   # queued, not waited for
+    assert out[0][2] > 0.8 * out[0][3]                                  # the default: one read-back per time step
+    assert np.array_equal(out[12][0], out[0][0]) and np.array_equal(out[12][1], out[0][1])
 
 
 def _config4_member_2086(n=256):
