@@ -77,6 +77,7 @@ struct hm_fwd {
     DevBuf well_cells;
     DevBuf comp;      // base / dS images of the generic fp32 sweeps (sat32.h), allocated on first use
     DevBuf team_mem;  // synchronisation blocks of the multi-tile saturation sweep (sat128t.hip), allocated on first use
+    int dbg_threads_pressure = 0, dbg_threads_saturation = 0;  // hm_fwd_set_debug: workgroup sizes of the generic kernels (experiments)
     int dbg_nd_force_fallback = -1, dbg_nd_cap = 0;  // hm_fwd_set_debug: test / experiment knobs of the larger grids' direct solver (press_nd.hip)
     long long nd_fallbacks = 0;  // member-steps the direct solver of the larger grids handed to the two-level CG (press_nd.hip: nd_check_and_fall_back)
     long long team_retries = 0, team_retries_seen = 0;  // time steps redone by the tiled sweep after a team gave up waiting
@@ -113,4 +114,5 @@ int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_
 int launch_saturation_128r(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // fw in registers, scaled fluxes (sat128r.hip)
 int launch_saturation_32s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // dtype = 32 plans, grids 128 / 256 / 512 wide (sat32s.hip)
 int launch_saturation_128t(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // grids of 128 x 128 tiles, fp64
+int launch_small_forward(hm_fwd* f, int first_step, int n_steps);  // small grids: the whole run as one launch, a wave per member (small.hip)
 int launch_saturation_256s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // grids 256 cells wide, fp64: slabs of 64 rows, fw in registers (sat256s.hip)

@@ -1,0 +1,364 @@
+// small.hip -- the whole forward run of a SMALL grid (the reference's own default case: 20 x 20, HistoryMatch.py:97; up to Nx Ny^2 of about
+// 9 000) as ONE launch: one workgroup of 256 threads per member runs all time steps -- pressure step and explicit
+// saturation sweep (A.4) -- out of LDS and registers.
+//
+// Round 4 measured BASELINE config 1 (N_e = 100, 20 x 20, 40 steps) at 11.05 ms of device time per forward pass on the generic kernels: 80
+// launches, and inside them 223 us per pressure step (k_pressure_generic: 400 Gauss-Jordan sweep steps, each behind two workgroup
+// barriers and an update out of LDS) + 37 us per sweep -- not launch-bound: 260 of the 276 us a step are kernel time.  This is the size the
+// reference's own iterative smoothers call forward_model at, ten times per assimilation (HistoryMatch.py:958-961).  Here the Schur block
+// being inverted lives in registers (two entries per thread; only the pivot row goes through LDS, two buffers in turn: one barrier per
+// sweep step), the inverse blocks, right-hand sides, transmissibilities, fluxes, the fractional-flow image and the upwind coefficients
+// stay in LDS for the whole run, and nothing is launched per step: 8.7 ms per pass (profiles/r05/config1_timing.txt), asynchronous.  What
+// bounds it now is the chain itself: 400 dependent pivots per pressure step at ~0.45 us each (pivot row through LDS, a barrier, an IEEE
+// division).  Fewer, fatter steps -- a tile-banded elimination on the matrix cores with sweep16.h's in-register pivot inverse -- would
+// not be the generic kernels' arithmetic any more; not built.
+//
+// THE ARITHMETIC IS THE GENERIC KERNELS', operation for operation: the same block elimination along ix with explicit inverse Schur
+// complements by symmetric sweeps (same pivot reciprocal 1.0 / d, same fma per entry), the same partial sums of the block mat-vecs in the
+// same order (k_pressure_generic sums rows r = g, g + G, ... per thread group g and then the G partial sums in order, G = its thread
+// groups), transmissibilities and fluxes by the shared expressions of fwd_dev.h, the sweep of k_saturation_generic (CFL count in fp64,
+// coefficients rounded once, E N C S W summation order; dtype = 32: the compensated pair of sat32.h).  So a run through this kernel is
+// BIT-IDENTICAL to the same run through the generic kernels (pressure / saturation variant 1), which are themselves checked against
+// oracle/ressim.py -- tests/test_forward_gpu.py::test_small_grid_single_launch_run_is_bit_identical.
+// Compiled with -ffp-contract=off.
+#include "fwd_dev.h"
+#include "sat32.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int WV = 256;  // threads per member
+constexpr int MAXR = 4;   // rows of the Schur block a thread holds (Ny <= 32 with eight row groups)
+
+struct SmallGeo {
+    int gw;       // row groups of the workgroup: threads [g Ny, (g + 1) Ny) hold rows g, g + gw, ...
+    int groupsG;  // thread groups of k_pressure_generic at this Ny (the order of its partial sums)
+};
+
+// doubles of LDS: [G: Nx Ny Ny | yv: Nxy | xs: Nxy | tx: (Nx + 1) Ny | ty: Nx (Ny + 1) | red: groupsG Ny | row: 2 Ny | ycur: Ny | yprev: Ny |
+//                  S: Nxy | dS: Nxy | fw: Nxy | coef: 6 Nxy | vx: (Nx + 1) Ny | vy: Nx (Ny + 1)]
+__host__ __device__ inline size_t small_lds_doubles(int Nx, int Ny, int groupsG) {
+    const size_t nxy = (size_t)Nx * Ny;
+    return (size_t)Nx * Ny * Ny + 2 * nxy + 2 * ((size_t)(Nx + 1) * Ny + (size_t)Nx * (Ny + 1)) + (size_t)groupsG * Ny + 4 * Ny + 3 * nxy + 6 * nxy;
+}
+
+template <typename TS>
+__global__ __launch_bounds__(WV) void k_small_forward(FwdParams p, SmallGeo geo, TS* __restrict__ S_all, int keep_history, TS* __restrict__ prods,
+                                                      int first_step, int n_steps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr bool F32 = std::is_same<TS, float>::value;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int Nx = p.Nx, Ny = p.Ny, Nxy = p.Nxy;
+    const int gw = geo.gw, groupsG = geo.groupsG, npl = groupsG / gw;  // npl: partial sums a lane carries
+    const int g = tid / Ny, c = tid - g * Ny;
+    const bool act = g < gw;                       // lanes beyond gw Ny idle in the block phases
+    const int nr = act ? (Ny - g + gw - 1) / gw : 0;  // rows of this lane: r = g + gw jj
+
+    double* G = lds;
+    double* yv = G + (size_t)Nx * Ny * Ny;
+    double* xs = yv + Nxy;
+    double* tx = xs + Nxy;
+    double* ty = tx + (Nx + 1) * Ny;
+    double* red = ty + Nx * (Ny + 1);
+    double* rowbuf = red + groupsG * Ny;  // two pivot rows
+    double* ycur = rowbuf + 2 * Ny;
+    double* yprev = ycur + Ny;
+    double* Sl = yprev + Ny;
+    double* dSl = Sl + Nxy;   // (dtype = 32 only; float values held as doubles' storage would waste nothing that matters here)
+    double* fwl = dSl + Nxy;
+    double* cf = fwl + Nxy;   // cE, cN, cC, cS, cW, fid
+    double* vx = cf + 6 * Nxy;
+    double* vy = vx + (Nx + 1) * Ny;
+
+    const double* Km = p.K + (long long)m * Nxy;
+    const double* Kym = p.Ky ? p.Ky + (long long)m * Nxy : Km;
+    double* TXg = p.TX + (long long)m * (Nx + 1) * Ny;
+    double* TYg = p.TY + (long long)m * Nx * (Ny + 1);
+    double* Pg = p.P + (long long)m * Nxy;
+    double* Vxg = p.Vx + (long long)m * (Nx + 1) * Ny;
+    double* Vyg = p.Vy + (long long)m * Nx * (Ny + 1);
+    auto S_of = [&](int k) -> TS* {  // fwd.h: fwd_S_ptr
+        return keep_history ? S_all + ((long long)m * (p.nTime + 1) + k) * Nxy : S_all + ((long long)(k & 1) * p.N + m) * Nxy;
+    };
+    int bad = 0;
+
+    for (int k = first_step; k < first_step + n_steps; ++k) {
+        const TS* Sin = S_of(k);
+        TS* Sout = S_of(k + 1);
+        const double* q = p.q + (long long)m * p.q_mstride + (long long)(p.q_cols > 1 ? k : 0) * Nxy;
+
+        // ================= pressure step: transmissibilities (shared with every other kernel: bit-exact with the oracle)
+        assemble_transmissibilities<TS>(p, Sin, Km, Kym, xs /* scratch for L */, TXg, TYg, tid, WV);
+        __threadfence_block();
+        __syncthreads();
+        for (int f = tid; f < (Nx + 1) * Ny; f += WV) tx[f] = TXg[f];
+        for (int f = tid; f < Nx * (Ny + 1); f += WV) ty[f] = TYg[f];
+        __syncthreads();
+
+        // ---- forward block elimination along ix (k_pressure_generic): Schur block in registers a[jj] = A[g + gw jj][c]
+        double a[MAXR];
+#pragma unroll
+        for (int jj = 0; jj < MAXR; ++jj) a[jj] = 0.0;
+        // y = G v for the block whose inverse is in a[] (regs) or in LDS (Gl != nullptr): the generic kernel's partial sums, in its order
+        auto matvec = [&](const double* Gl, const double* v) {
+            if (act) {
+                for (int qq = 0; qq < npl; ++qq) {  // generic thread group gG = g + gw qq: rows gG, gG + groupsG, ...
+                    const int gG = g + gw * qq;
+                    double part = 0.0;
+                    if (Gl) {
+                        for (int r = gG; r < Ny; r += groupsG) part = fma(Gl[r * Ny + c], v[r], part);
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < MAXR; ++jj) {  // rows of this lane in increasing order; those of group gG are r = gG (mod groupsG)
+                            const int r = g + gw * jj;
+                            if (jj < nr && (r - gG) % groupsG == 0 && r >= gG) part = fma(a[jj], v[r], part);
+                        }
+                    }
+                    red[gG * Ny + c] = part;
+                }
+            }
+            __syncthreads();
+            double t = 0.0;
+            if (tid < Ny)
+                for (int gg = 0; gg < groupsG; ++gg) t += red[gg * Ny + tid];
+            __syncthreads();
+            return t;
+        };
+        for (int i = 0; i < Nx; ++i) {
+            const double* e = tx + i * Ny;  // coupling to block i - 1: E = -diag(e)
+            if (i > 0) {
+                const double t = matvec(nullptr, yprev);
+                if (tid < Ny) ycur[tid] = q[i * Ny + tid] + e[tid] * t;
+                if (act) {
+                    const double ec = e[c];
+#pragma unroll
+                    for (int jj = 0; jj < MAXR; ++jj)
+                        if (jj < nr) a[jj] = -(e[g + gw * jj] * a[jj] * ec);
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < MAXR; ++jj) a[jj] = 0.0;
+                if (tid < Ny) ycur[tid] = q[tid];
+            }
+            // add the tridiagonal block D_i
+            if (act) {
+#pragma unroll
+                for (int jj = 0; jj < MAXR; ++jj) {
+                    const int r = g + gw * jj;
+                    if (jj < nr) {
+                        if (r == c) {
+                            const double y1 = ty[i * (Ny + 1) + c], y2 = ty[i * (Ny + 1) + c + 1];
+                            const double x1 = tx[i * Ny + c], x2 = tx[(i + 1) * Ny + c];
+                            double dg = y1 + y2 + x1 + x2;
+                            if (i == 0 && c == 0) dg += Km[0] + Kym[0];  // SPD pin: A[0,0] += Kx[0,0] + Ky[0,0]
+                            a[jj] += dg;
+                        } else if (c == r + 1) {
+                            a[jj] -= ty[i * (Ny + 1) + r + 1];
+                        } else if (r == c + 1) {
+                            a[jj] -= ty[i * (Ny + 1) + c + 1];
+                        }
+                    }
+                }
+            }
+            // symmetric sweeps: A <- -inv(A).  Pivot kk = gk + gw jk: its row sits in register jk of row group gk.
+#pragma unroll
+            for (int jk = 0; jk < MAXR; ++jk) {
+                for (int gk = 0; gk < gw; ++gk) {
+                    const int kk = gk + gw * jk;
+                    if (kk >= Ny) break;
+                    // (two pivot-row buffers in turn: ONE barrier per sweep step -- a thread writes the buffer of step kk + 1 only after the
+                    // barrier of step kk, which every thread reaches after its reads of step kk - 1)
+                    double* row = rowbuf + (kk & 1) * Ny;
+                    if (act && g == gk) row[c] = a[jk];
+                    __syncthreads();
+                    const double d = row[kk];
+                    if (!(d > 0.0) || !isfinite(d)) bad = 1;
+                    const double pinv = 1.0 / d;
+                    if (act) {
+                        const double tc = row[c] * pinv;
+#pragma unroll
+                        for (int jj = 0; jj < MAXR; ++jj) {
+                            const int r = g + gw * jj;
+                            if (jj < nr) {
+                                double v;
+                                if (r == kk) v = (c == kk) ? -pinv : tc;
+                                else if (c == kk) v = row[r] * pinv;
+                                else v = fma(-row[r], tc, a[jj]);
+                                a[jj] = v;
+                            }
+                        }
+                    }
+                }
+            }
+            // A <- -A = G_i; keep G_i and y_i
+            if (act) {
+#pragma unroll
+                for (int jj = 0; jj < MAXR; ++jj)
+                    if (jj < nr) {
+                        a[jj] = -a[jj];
+                        G[((size_t)i * Ny + g + gw * jj) * Ny + c] = a[jj];
+                    }
+            }
+            if (tid < Ny) {
+                yv[i * Ny + tid] = ycur[tid];
+                yprev[tid] = ycur[tid];
+            }
+            __syncthreads();
+        }
+        // ---- back substitution: x_i = G_i (y_i + e_{i+1} x_{i+1})
+        for (int i = Nx - 1; i >= 0; --i) {
+            if (tid < Ny) {
+                double v = yv[i * Ny + tid];
+                if (i < Nx - 1) v += tx[(i + 1) * Ny + tid] * ycur[tid];  // ycur holds x_{i+1}
+                yprev[tid] = v;
+            }
+            __syncthreads();
+            const double t = matvec(G + (size_t)i * Ny * Ny, yprev);
+            if (tid < Ny) {
+                ycur[tid] = t;
+                xs[i * Ny + tid] = t;
+            }
+            __syncthreads();
+        }
+        for (int j = tid; j < Nxy; j += WV) Pg[j] = xs[j];
+        // ---- face fluxes (fwd_dev.h: face_fluxes, from the LDS copies)
+        for (int f = tid; f < (Nx + 1) * Ny; f += WV) {
+            const int ix = f / Ny, iy = f % Ny;
+            const double v = (ix == 0 || ix == Nx) ? 0.0 : (xs[(ix - 1) * Ny + iy] - xs[ix * Ny + iy]) * tx[f];
+            vx[f] = v;
+            Vxg[f] = v;
+        }
+        for (int f = tid; f < Nx * (Ny + 1); f += WV) {
+            const int ix = f / (Ny + 1), iy = f % (Ny + 1);
+            const double v = (iy == 0 || iy == Ny) ? 0.0 : (xs[ix * Ny + iy - 1] - xs[ix * Ny + iy]) * ty[f];
+            vy[f] = v;
+            Vyg[f] = v;
+        }
+        __syncthreads();
+
+        // ================= saturation step (k_saturation_generic)
+        double lmin = INFINITY;
+        for (int j = tid; j < Nxy; j += WV) {
+            const int ix = j / Ny, iy = j % Ny;
+            const double xp = fmax(vx[ix * Ny + iy], 0.0), yp = fmax(vy[ix * (Ny + 1) + iy], 0.0);
+            const double xn = fmin(vx[(ix + 1) * Ny + iy], 0.0), yn = fmin(vy[ix * (Ny + 1) + iy + 1], 0.0);
+            const double Vi = xp + yp - xn - yn;
+            const double fi = fmax(q[j], 0.0);
+            const double pv = p.h2 * (p.por ? p.por[j] : 1.0);
+            lmin = fmin(lmin, pv / (Vi + fi));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lmin = fmin(lmin, __shfl_xor(lmin, off));  // (a minimum: any order)
+        if ((tid & 63) == 0) red[tid >> 6] = lmin;
+        __syncthreads();
+        const double pm = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+        __syncthreads();
+        const double sat = p.swc + p.sor;
+        const double cfl = ((1.0 - sat) / 3.0) * pm;
+        const double ntsd = ceil(p.dt / cfl);
+        const int badc = !(ntsd >= 1.0 && ntsd <= 1.0e7);
+        const int Nts = badc ? 0 : (int)ntsd;
+        if (tid == 0) {
+            p.nts[(long long)m * p.nTime + k] = Nts;
+            if (badc) atomicOr(&p.status[m], HM_MEMBER_BAD_CFL);
+        }
+        TS* cE = reinterpret_cast<TS*>(cf);
+        TS *cN = cE + Nxy, *cC = cN + Nxy, *cS = cC + Nxy, *cW = cS + Nxy, *fid = cW + Nxy;
+        TS* Sx = reinterpret_cast<TS*>(Sl);
+        TS* fw = reinterpret_cast<TS*>(fwl);
+        float* dSa = reinterpret_cast<float*>(dSl);
+        for (int j = tid; j < Nxy; j += WV) {
+            const int ix = j / Ny, iy = j % Ny;
+            const double pv = p.h2 * (p.por ? p.por[j] : 1.0);
+            const double d = badc ? 0.0 : (p.dt / (double)Nts) / pv;
+            const double vxw = vx[ix * Ny + iy], vxe = vx[(ix + 1) * Ny + iy];
+            const double vys = vy[ix * (Ny + 1) + iy], vyn = vy[ix * (Ny + 1) + iy + 1];
+            const double fp = fmin(q[j], 0.0), fi = fmax(q[j], 0.0);
+            const double x1 = fmin(vxw, 0.0), x2 = fmax(vxe, 0.0), y1 = fmin(vys, 0.0), y2 = fmax(vyn, 0.0);
+            cC[j] = (TS)(d * (fp + x1 - x2 + y1 - y2));
+            cW[j] = (TS)(d * fmax(vxw, 0.0));
+            cE[j] = (TS)(d * (-fmin(vxe, 0.0)));
+            cS[j] = (TS)(d * fmax(vys, 0.0));
+            cN[j] = (TS)(d * (-fmin(vyn, 0.0)));
+            fid[j] = (TS)(fi * d);
+            Sx[j] = Sin[j];
+            if constexpr (F32) dSa[j] = 0.0f;
+        }
+        __syncthreads();
+        for (int it = 0; it < Nts; ++it) {
+            for (int j = tid; j < Nxy; j += WV) {
+                TS mw, mo;
+                TS s = Sx[j];
+                if constexpr (F32) s = s + dSa[j];
+                rel_perm<TS>(p, s, mw, mo);
+                fw[j] = mw / (mw + mo);
+            }
+            __syncthreads();
+            for (int j = tid; j < Nxy; j += WV) {
+                const int ix = j / Ny, iy = j % Ny;
+                TS acc = (ix + 1 < Nx) ? cE[j] * fw[j + Ny] : TS(0);
+                if (iy + 1 < Ny) acc = acc + cN[j] * fw[j + 1];
+                acc = acc + cC[j] * fw[j];
+                if (iy > 0) acc = acc + cS[j] * fw[j - 1];
+                if (ix > 0) acc = acc + cW[j] * fw[j - Ny];
+                if constexpr (F32) {
+                    float b = Sx[j], e = dSa[j] + (acc + fid[j]);
+                    if ((it & (F32_FOLD - 1)) == F32_FOLD - 1) {
+                        fold32(b, e);
+                        Sx[j] = b;
+                    }
+                    dSa[j] = e;
+                } else {
+                    Sx[j] = Sx[j] + (acc + fid[j]);
+                }
+            }
+            __syncthreads();
+        }
+        int nonfinite = 0;
+        for (int j = tid; j < Nxy; j += WV) {
+            TS s = Sx[j];
+            if constexpr (F32) s = s + dSa[j];
+            Sout[j] = s;
+            Sx[j] = s;
+            if (!isfinite((double)s)) nonfinite = 1;
+        }
+        if (nonfinite) atomicOr(&p.status[m], HM_MEMBER_NONFINITE);
+        __syncthreads();
+        if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = Sx[p.prd_ind[m * p.prd_mstride + tid]];
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
+}
+
+int generic_threads_of(int Ny) {  // forward.hip: generic_threads
+    const int maxT = Ny > 32 ? 1024 : 256;
+    return Ny * (maxT / Ny);
+}
+
+}  // namespace
+
+// The whole run [first_step, first_step + n_steps) of a small grid as one launch.  Returns 0 if launched, >0 on error, -1 if this path does
+// not apply (grid too large for the LDS image, kernel variants chosen by hand).
+int launch_small_forward(hm_fwd* f, int first_step, int n_steps) {
+    const FwdParams& p = f->p;
+    if (f->press_variant != 0 || f->sat_variant != 0) return -1;
+    if (p.Ny > 32 || p.Ny < 2 || p.Nxy > 1024) return -1;
+    SmallGeo geo;
+    geo.groupsG = generic_threads_of(p.Ny) / p.Ny;
+    geo.gw = WV / p.Ny;
+    while (geo.gw > 1 && geo.groupsG % geo.gw) --geo.gw;  // the generic kernel's partial sums must split evenly over the wave's row groups
+    if ((p.Ny + geo.gw - 1) / geo.gw > MAXR) return -1;
+    const size_t bytes = small_lds_doubles(p.Nx, p.Ny, geo.groupsG) * 8;
+    if (bytes > 160 * 1024) return -1;
+    hipStream_t s = f->ctx->stream;
+    if (f->dtype == 64) {
+        HM_HIP(hipFuncSetAttribute((const void*)k_small_forward<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(k_small_forward<double>, dim3(p.N), dim3(WV), bytes, s, p, geo, (double*)f->S.p, f->keep_history, (double*)f->prods.p, first_step, n_steps);
+    } else {
+        HM_HIP(hipFuncSetAttribute((const void*)k_small_forward<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(k_small_forward<float>, dim3(p.N), dim3(WV), bytes, s, p, geo, (float*)f->S.p, f->keep_history, (float*)f->prods.p, first_step, n_steps);
+    }
+    HM_HIP(hipGetLastError());
+    return 0;
+}

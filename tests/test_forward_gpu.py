@@ -561,6 +561,45 @@ def test_nonuniform_porosity_uses_generic_path_and_matches():
     assert abs(out[-1] @ (por.ravel() * om.h2) - 8 * DT) < 1e-9  # injected volume = water in place
 
 
+@pytest.mark.parametrize("nx,ny,dtype,extras", [(20, 20, 64, ""), (20, 20, 32, ""), (16, 16, 64, "fluid"), (12, 20, 64, "porosity"), (25, 10, 64, ""),
+                                                 (20, 20, 64, "chunks"), (8, 32, 64, "")])
+def test_small_grid_single_launch_run_is_bit_identical(nx, ny, dtype, extras):
+    """Small grids (the reference's default 20 x 20, HistoryMatch.py:97) run the whole forward pass as ONE launch, a wave per member
+    (csrc/small.hip).  The kernel restates the generic kernels' arithmetic operation for operation (same sweeps, same order of the
+    mat-vec partial sums), so a run through it equals the run through the generic kernels (variant 1 / 1) to the last bit: saturation
+    history, producer series, sub-step counts, final pressures and fluxes; fp32 plans, a general fluid, a porosity field, non-square
+    grids, a run continued in chunks from its own state."""
+    N, steps = 5, 12
+    _, gm = make_models(nx, ny, dtype=dtype)
+    if extras == "fluid":
+        gm.vw, gm.vo, gm.swc, gm.sor = 0.7, 1.9, 0.05, 0.1
+    if extras == "porosity":
+        gm.por = 0.2 + 0.3 * np.random.RandomState(3).rand(nx, ny)
+    x = perms(nx, ny, N, seed=55)
+    out = {}
+    for variant in (1, 0):
+        plan = _plan(gm, N, nTime=steps)
+        plan.set_variant(variant, variant)
+        w0 = np.full((N, nx * ny), 0.05, dtype=np.float64 if dtype == 64 else np.float32) if extras == "fluid" else None
+        plan.set_inputs(x, w0, transformed=False)
+        if extras == "chunks" and variant == 0:
+            plan.run(0, 5)
+            plan.run(5, 1)
+            plan.run(6, steps - 6)
+        else:
+            plan.run()
+        st = plan.sync()
+        w, p, status = plan.outputs()
+        assert not status.any()
+        out[variant] = (w, p, plan.get_field("nts"), plan.get_field("P"), plan.get_field("Vx"), plan.get_field("Vy"), plan.get_field("TX"))
+        if variant == 0:
+            assert st["ms_pressure"] == 0 and st["n_pressure_launches"] == steps  # one launch: no per-step kernels ran
+        plan.close()
+    assert out[0][0][:, -1].max() > 0.5
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a, b), np.abs(a.astype(float) - b.astype(float)).max()
+
+
 def test_fp32_saturation_mode_tolerance():
     """dtype=32: saturation arithmetic and storage in fp32, pressure and Nts in fp64; <= 1e-3 abs on S."""
     from oracle.ressim import forward_model as oracle_forward
