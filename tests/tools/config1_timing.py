@@ -11,6 +11,7 @@ from tests.helpers import make_models, perms  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+generic = len(sys.argv) > 3 and sys.argv[3] == "generic"   # the per-step generic kernels (pressure / saturation variant 1) instead of the single launch
 _, gm = make_models(20, 20)
 x = perms(20, 20, N, seed=1)
 fm = make_forward_model(gm, 0.025, 40)
@@ -20,6 +21,8 @@ for _ in range(reps):
     w, p = fm(x)
 t_host = (time.perf_counter() - t0) / reps
 plan = ForwardPlan(gm, N, 0.025, 40, keep_history=True)
+if generic:
+    plan.set_variant(1, 1)
 plan.set_inputs(x, None, transformed=False)
 plan.run()
 plan.sync()
@@ -29,7 +32,7 @@ for _ in range(reps):
     plan.run()
     st = plan.sync()
 t_plan = (time.perf_counter() - t0) / reps
-print(f"config 1 forward (N = {N}, 20 x 20, 40 steps): drop-in call {t_host * 1e3:.2f} ms, device-resident plan {t_plan * 1e3:.2f} ms per pass; "
+print(f"config 1 forward (N = {N}, 20 x 20, 40 steps{', generic per-step kernels' if generic else ''}): drop-in call {t_host * 1e3:.2f} ms, device-resident plan {t_plan * 1e3:.2f} ms per pass; "
       f"device: total {st['ms_total']:.2f} ms, pressure {st['ms_pressure'] / max(1, st['n_pressure_launches']) * 1e3:.1f} us / launch, "
       f"saturation {st['ms_saturation'] / max(1, st['n_saturation_launches']) * 1e3:.1f} us / launch")
 plan.close()
