@@ -8,7 +8,7 @@ configuration is invalid (a well outside the domain, unbalanced rates) is worth 
 Optimise.py:119-124).  Here the members run as ONE device batch with a different source field per member
 (``hm_fwd_set_member_wells``); the accounting stays NumPy on the (N, nTime+1, nPrd) producer saturations.
 
-The number of wells is the same for every member of a batch; permeability is the base model's (or one field per member).
+Members of a batch may differ in their wells -- positions, rates and their NUMBER; permeability is the base model's (or one field per member).
 Rates are taken as given: the upstream simulator's ``actual_rates`` (its rate controller) is not part of the reference
 repository (parity unpinned for everything inside ``TPFA_ResSim``).
 """
@@ -128,11 +128,9 @@ class NpvBatch:
                 valid[n] = False
                 cfg = None
             cfgs.append(cfg)
-            if cfg is not None:
-                if nInj is None:
-                    nInj, nPrd = len(cfg[0]), len(cfg[2])
-                elif (nInj, nPrd) != (len(cfg[0]), len(cfg[2])):
-                    raise ValueError("all members of a batch must have the same number of injectors and producers")
+            if cfg is not None:  # members may differ in their number of wells (Optimise.py:736-767 varies the wells per member): the device
+                nInj = max(nInj or 0, len(cfg[0]))  # sees a source FIELD per member; the plan is shaped for the largest counts
+                nPrd = max(nPrd or 0, len(cfg[2]))
         values = np.zeros(N)
         if not valid.any():
             return values
@@ -146,7 +144,8 @@ class NpvBatch:
             inj_ind, inj, prd_ind, prd = cfg
             np.add.at(q_all[n], (slice(None), inj_ind), inj.T[:cols])      # q[inj] += rate
             np.subtract.at(q_all[n], (slice(None), prd_ind), prd.T[:cols])  # q[prd] -= rate
-            prd_all[n] = prd_ind
+            prd_all[n, :len(prd_ind)] = prd_ind
+            prd_all[n, len(prd_ind):] = prd_ind[0]  # (a member with fewer producers: its spare gather slots repeat one of its cells; unused)
         key = (N, nInj, nPrd)
         if self._plan is None or self._plan_key != key:
             self.close()

@@ -59,6 +59,32 @@ def test_npv_batch_matches_per_member_oracle(n):
     np.testing.assert_allclose(again, ref[[7, 3, 2, 1, 0, 5, 6, 0]], rtol=1e-7, atol=1e-7)
 
 
+def test_npv_batch_members_with_different_numbers_of_wells():
+    """Optimise.py:736-767 varies the wells per member; one batch may hold members with two, three or four producers and one or two
+    injectors (the device sees a source field per member): values equal the per-member oracle, and the values each member gets in a
+    batch of its own kind."""
+    from historymatching_amd.opt import NpvBatch
+    from oracle.opt import npv as oracle_npv
+
+    n = 20
+    om, gm = _models(n)
+    params = [
+        {},
+        {"prd_xy": [[0.2, 0.2], [1.8, 0.8], [1.0, 0.9]], "prd_rates": 1.5 * np.array([[0.5], [0.3], [0.2]])},
+        {"prd_xy": [[0.2, 0.8], [1.8, 0.2]], "prd_rates": 1.5 * np.array([[0.5], [0.5]])},
+        {"inj_xy": [[0.6, 0.5], [1.4, 0.5]], "inj_rates": 1.5 * np.array([[0.7], [0.3]])},
+        {"inj_xy": [[0.6, 0.5], [1.4, 0.5]], "inj_rates": 1.5 * np.array([[0.5], [0.5]]),
+         "prd_xy": [[0.1, 0.1], [1.9, 0.9], [1.0, 0.1]], "prd_rates": 1.5 * np.ones((3, 1)) / 3},
+    ]
+    batch = NpvBatch(gm, DT, NT)
+    values = batch(params)
+    ref = np.array([oracle_npv(om, DT, NT, np.zeros(n * n), **p)[0] for p in params])
+    assert np.all(np.abs(ref) > 1) and len(set(np.round(ref, 6))) == len(ref)
+    np.testing.assert_allclose(values, ref, rtol=1e-7, atol=1e-7)
+    for k, p in enumerate(params):
+        np.testing.assert_allclose(NpvBatch(gm, DT, NT)([p])[0], values[k], rtol=1e-12, atol=1e-12)
+
+
 def test_npv_batch_one_permeability_per_member():
     """Robust objective: the same controls over an ensemble of permeability fields (Optimise.py:1006)."""
     from historymatching_amd.opt import NpvBatch
