@@ -126,8 +126,13 @@ int  hm_fwd_set_perm_y(hm_fwd* f, const void* perm_y, int perm_is_transformed);
 /* Device-resident chaining (forward -> update -> forward without PCIe): permeability input from a device buffer
  * (fp64 or fp32), initial saturation zero.  Asynchronous on the context's stream. */
 int  hm_fwd_set_inputs_device(hm_fwd* f, const void* perm_dev, int perm_dtype, int perm_is_transformed);
-int  hm_fwd_run(hm_fwd* f, int first_step, int n_steps);           /* steps [first, first+n); asynchronous for Ny <= 128
-                                                                     * (grids beyond poll CG convergence on the host)        */
+/* Steps [first, first + n) of every member (ResSim.sim's time loop, HistoryMatch.py:362, for the whole ensemble).  Asynchronous on the
+ * context's stream for grids up to 128 x 128.  256 x 256 / 512 x 512: the default pressure variant reads the members' status words back once
+ * per time step (its hand-over of a failed direct solve to the two-level CG is a host decision, hm_fwd_nd_fallbacks); pressure variant 12 does
+ * not and is asynchronous as well; other grids beyond 128 poll the CG's convergence on the host.  Small grids (the reference's default
+ * 20 x 20; Nx Ny^2 up to about 9 000) run the whole call as ONE launch (small.hip): hm_stats then reports the step counts with zero
+ * per-kernel times, the total in ms_total. */
+int  hm_fwd_run(hm_fwd* f, int first_step, int n_steps);
 int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
 /* Member-steps the direct pressure solver of the 256 x 256 / 512 x 512 grids handed to the two-level CG since the plan was created: a
  * member whose elimination met a non-positive pivot, or whose fluxes missed the wells by more than 1e-4 of the largest rate (the
