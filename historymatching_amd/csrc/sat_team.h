@@ -1,5 +1,5 @@
-// sat_team.h -- hand-off primitives shared by the multi-tile saturation sweeps (sat128t.hip fp64, sat128ft.hip fp32):
-// teams of workgroups, one per 128 x 128 tile of a member, exchanging tile edges once per explicit sub-step.
+// sat_team.h -- hand-off primitives shared by the workgroup-team saturation sweeps (sat128t.hip: one workgroup per 128 x 128 tile; sat256s.hip,
+// sat32s.hip: one per slab of rows): the workgroups of a member exchange tile edges / border rows once per explicit sub-step.
 //
 // Everything exchanged is a GRANULE: a naturally aligned 8-byte word {tag = event number + 1 (high half), 32 payload bits
 // (low half)} written by one write-through (sc1) store and polled with sc1 loads until the tag matches -- the data is its
