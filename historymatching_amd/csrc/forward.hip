@@ -941,7 +941,7 @@ static int launch_pressure(hm_fwd* f, int k) {
     }
     if (done > 0) return done;
     if (done < 0) {
-        int T = f->dbg_threads_pressure > 0 ? p.Ny * std::max(1, f->dbg_threads_pressure / p.Ny) : generic_threads(p.Ny);
+        int T = generic_threads(p.Ny);
         size_t lds = ((size_t)p.Ny * (p.Ny | 1) + 3 * p.Ny + T) * 8;
         if (f->dtype == 64) {
             HM_HIP(hipFuncSetAttribute((const void*)k_pressure_generic<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1007,7 +1007,6 @@ static int launch_saturation(hm_fwd* f, int k) {
         rc = ensure_generic_sat_scratch(f, !(stream || tiled));
         if (rc) return rc;
         int T = tiled ? 1024 : (p.Nxy >= 4096 ? 1024 : 256);
-        if (!tiled && f->dbg_threads_saturation > 0) T = f->dbg_threads_saturation;
         size_t lds = tiled ? (size_t)1024 * 8 + (size_t)66 * 258 * f->esz : (size_t)T * 8;
 #define SAT(KERN, TT, ...) hipLaunchKernelGGL(KERN<TT>, dim3(p.N), dim3(T), lds, s, f->p, (const TT*)Sin, (TT*)Sout, stride, (TT*)f->prods.p, k, ##__VA_ARGS__)
         if (tiled) {
@@ -1189,8 +1188,6 @@ extern "C" int hm_fwd_set_debug(hm_fwd* f, const char* key, long long value) {
     HM_REQUIRE(f && key, "hm_fwd_set_debug: NULL argument");
     const std::string k(key);
     if (k == "nd_force_fallback") f->dbg_nd_force_fallback = (int)value;
-    else if (k == "threads_pressure") f->dbg_threads_pressure = (int)value;
-    else if (k == "threads_saturation") f->dbg_threads_saturation = (int)value;
     else if (k == "nd_cap") {
         HM_REQUIRE(!f->nd, "hm_fwd_set_debug: \"nd_cap\" must be set before the plan's first run");
         f->dbg_nd_cap = (int)value;

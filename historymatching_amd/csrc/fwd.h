@@ -77,7 +77,6 @@ struct hm_fwd {
     DevBuf well_cells;
     DevBuf comp;      // base / dS images of the generic fp32 sweeps (sat32.h), allocated on first use
     DevBuf team_mem;  // synchronisation blocks of the multi-tile saturation sweep (sat128t.hip), allocated on first use
-    int dbg_threads_pressure = 0, dbg_threads_saturation = 0;  // hm_fwd_set_debug: workgroup sizes of the generic kernels (experiments)
     int dbg_nd_force_fallback = -1, dbg_nd_cap = 0;  // hm_fwd_set_debug: test / experiment knobs of the larger grids' direct solver (press_nd.hip)
     long long nd_fallbacks = 0;  // member-steps the direct solver of the larger grids handed to the two-level CG (press_nd.hip: nd_check_and_fall_back)
     long long team_retries = 0, team_retries_seen = 0;  // time steps redone by the tiled sweep after a team gave up waiting

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(WV) void k_small_forward(FwdParams p, SmallGeo geo,
     double* ycur = rowbuf + 2 * Ny;
     double* yprev = ycur + Ny;
     double* Sl = yprev + Ny;
-    double* dSl = Sl + Nxy;   // (dtype = 32 only; float values held as doubles' storage would waste nothing that matters here)
+    double* dSl = Sl + Nxy;   // dtype = 32 plans: the running change dS of sat32.h (float32 values in the first half of this image)
     double* fwl = dSl + Nxy;
     double* cf = fwl + Nxy;   // cE, cN, cC, cS, cW, fid
     double* vx = cf + 6 * Nxy;
