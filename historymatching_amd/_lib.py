@@ -76,6 +76,8 @@ SIGNATURES = {
     "hm_fwd_run": (C.c_int, [_vp, C.c_int, C.c_int]),
     "hm_fwd_sync": (C.c_int, [_vp, C.POINTER(hm_stats)]),
     "hm_fwd_nd_fallbacks": (C.c_longlong, [_vp]),
+    "hm_fwd_team_retries": (C.c_longlong, [_vp]),
+    "hm_fwd_slab_redos": (C.c_longlong, [_vp]),
     "hm_fwd_set_debug": (C.c_int, [_vp, C.c_char_p, C.c_longlong]),
     "hm_fwd_get_outputs": (C.c_int, [_vp, _vp, _vp, _ip]),
     "hm_fwd_run_to_host": (C.c_int, [_vp, _vp, _vp, _ip, C.POINTER(hm_stats)]),

@@ -421,7 +421,7 @@ __global__ void k_saturation_stream(FwdParams p, const T* __restrict__ Sin_base,
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T* __restrict__ Sin_base, T* __restrict__ Sout_base,
-                                                           long long S_stride, T* __restrict__ prods, int k, int only_timed_out) {
+                                                           long long S_stride, T* __restrict__ prods, int k, int only_timed_out, int* retried) {
     constexpr int TH = 64, TW = 256, LW = TW + 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -433,7 +433,10 @@ __global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T*
         __shared__ int go;
         if (tid == 0) {
             go = (p.status[m] & HM_MEMBER_SYNC_TIMEOUT) != 0;
-            if (go) atomicAnd(&p.status[m], ~HM_MEMBER_SYNC_TIMEOUT);
+            if (go) {
+                atomicAnd(&p.status[m], ~HM_MEMBER_SYNC_TIMEOUT);
+                if (retried) atomicAdd(retried, 1);  // hm_fwd_team_retries
+            }
         }
         __syncthreads();
         if (!go) return;
@@ -731,7 +734,7 @@ extern "C" void hm_fwd_destroy(hm_fwd* f) {
     (void)hipStreamSynchronize(f->ctx->stream);
     DevBuf* bufs[] = {&f->K, &f->por, &f->q, &f->prd_ind, &f->TX, &f->TY, &f->G, &f->yv, &f->P, &f->Vx,
                       &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells, &f->cg_r, &f->cg_p, &f->n_cg,
-                      &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->tl_z1, &f->tl_dinv, &f->tl_parts, &f->team_mem, &f->Ky, &f->comp};
+                      &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->tl_z1, &f->tl_dinv, &f->tl_parts, &f->team_mem, &f->Ky, &f->comp, &f->slab_wet, &f->retried};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     hm_nd_free(f->nd);
     f->t_total.destroy(); f->t_press.destroy(); f->t_sat.destroy();
@@ -984,6 +987,10 @@ static int launch_saturation(hm_fwd* f, int k) {
         // flags every member first, so the retry path runs on all of them every step.
         rc = ensure_generic_sat_scratch(f, false);
         if (rc) return rc;
+        if (!f->retried.p) {
+            if ((rc = hm_dev_alloc(f->retried, 8))) return rc;
+            HM_HIP(hipMemsetAsync(f->retried.p, 0, 8, s));
+        }
         if (f->sat_variant == 4) {
             hipLaunchKernelGGL(k_or_status, dim3((p.N + 255) / 256), dim3(256), 0, s, (int*)f->status.p, p.N, (int)HM_MEMBER_SYNC_TIMEOUT);
             f->team_retries++;
@@ -991,10 +998,10 @@ static int launch_saturation(hm_fwd* f, int k) {
         const size_t lds = (size_t)1024 * 8 + (size_t)66 * 258 * f->esz;
         if (f->dtype == 64) {
             HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_saturation_tiled<double>, dim3(p.N), dim3(1024), lds, s, f->p, (const double*)Sin, (double*)Sout, stride, (double*)f->prods.p, k, 1);
+            hipLaunchKernelGGL(k_saturation_tiled<double>, dim3(p.N), dim3(1024), lds, s, f->p, (const double*)Sin, (double*)Sout, stride, (double*)f->prods.p, k, 1, (int*)f->retried.p);
         } else {
             HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_saturation_tiled<float>, dim3(p.N), dim3(1024), lds, s, f->p, (const float*)Sin, (float*)Sout, stride, (float*)f->prods.p, k, 1);
+            hipLaunchKernelGGL(k_saturation_tiled<float>, dim3(p.N), dim3(1024), lds, s, f->p, (const float*)Sin, (float*)Sout, stride, (float*)f->prods.p, k, 1, (int*)f->retried.p);
         }
         HM_HIP(hipGetLastError());
     }
@@ -1010,8 +1017,8 @@ static int launch_saturation(hm_fwd* f, int k) {
         size_t lds = tiled ? (size_t)1024 * 8 + (size_t)66 * 258 * f->esz : (size_t)T * 8;
 #define SAT(KERN, TT, ...) hipLaunchKernelGGL(KERN<TT>, dim3(p.N), dim3(T), lds, s, f->p, (const TT*)Sin, (TT*)Sout, stride, (TT*)f->prods.p, k, ##__VA_ARGS__)
         if (tiled) {
-            if (f->dtype == 64) { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, double, 0); }
-            else { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, float, 0); }
+            if (f->dtype == 64) { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, double, 0, (int*)nullptr); }
+            else { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, float, 0, (int*)nullptr); }
         } else if (stream) { if (f->dtype == 64) SAT(k_saturation_stream, double); else SAT(k_saturation_stream, float); }
         else { if (f->dtype == 64) SAT(k_saturation_generic, double); else SAT(k_saturation_generic, float); }
 #undef SAT
@@ -1081,6 +1088,13 @@ extern "C" int hm_fwd_sync(hm_fwd* f, hm_stats* st) {
     HM_REQUIRE(f, "hm_fwd_sync: NULL plan");
     HM_HIP(hipSetDevice(f->ctx->device));
     HM_HIP(hipStreamSynchronize(f->ctx->stream));
+    if (f->retried.p && !f->dbg_team_rounds) {
+        // a team of the one-launch slab sweep gave up waiting (sat32s.hip: its workgroups were not started in grid order, or CUs were held by
+        // someone else): from now on this plan launches its teams in rounds of co-resident ones, which rely on neither
+        int n = 0;
+        HM_HIP(hipMemcpy(&n, f->retried.p, 4, hipMemcpyDeviceToHost));
+        if (n > 0) f->dbg_team_rounds = 1;
+    }
     if (st) {
         memset(st, 0, sizeof(*st));
         st->ms_total = f->t_total.total_ms();
@@ -1184,10 +1198,21 @@ extern "C" int hm_fwd_set_field(hm_fwd* f, const char* name, const void* in) {
 
 extern "C" long long hm_fwd_nd_fallbacks(hm_fwd* f) { return f ? f->nd_fallbacks : 0; }
 
+static long long fwd_counter(hm_fwd* f, int which) {
+    if (!f || !f->retried.p) return 0;
+    int n[2] = {0, 0};
+    if (hipSetDevice(f->ctx->device) != hipSuccess || hipStreamSynchronize(f->ctx->stream) != hipSuccess ||
+        hipMemcpy(n, f->retried.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n[which];
+}
+extern "C" long long hm_fwd_team_retries(hm_fwd* f) { return fwd_counter(f, 0); }
+extern "C" long long hm_fwd_slab_redos(hm_fwd* f) { return fwd_counter(f, 1); }
+
 extern "C" int hm_fwd_set_debug(hm_fwd* f, const char* key, long long value) {
     HM_REQUIRE(f && key, "hm_fwd_set_debug: NULL argument");
     const std::string k(key);
     if (k == "nd_force_fallback") f->dbg_nd_force_fallback = (int)value;
+    else if (k == "team_rounds") f->dbg_team_rounds = (int)value;
     else if (k == "nd_cap") {
         HM_REQUIRE(!f->nd, "hm_fwd_set_debug: \"nd_cap\" must be set before the plan's first run");
         f->dbg_nd_cap = (int)value;
@@ -1198,9 +1223,11 @@ extern "C" int hm_fwd_set_debug(hm_fwd* f, const char* key, long long value) {
 extern "C" void* hm_fwd_device_ptr(hm_fwd* f, const char* name) {
     if (!f || !name) return nullptr;
     std::string s(name);
-    if (s == "S") { long long st; return fwd_S_ptr(f, f->cur, &st); }
+    // (the saturation may be written through these pointers without the library seeing it: the float32 slab sweep then keeps no record of
+    // which slabs are dry from one step to the next -- sat32s.hip)
+    if (s == "S") { long long st; f->raw_state_exposed = true; return fwd_S_ptr(f, f->cur, &st); }
     if (s == "prods") return f->prods.p;
-    if (s == "S_all") return f->S.p;
+    if (s == "S_all") { f->raw_state_exposed = true; return f->S.p; }
     FieldRef r;
     if (field_ref(f, name, r)) return nullptr;
     // the caller may write an INPUT of the pressure step (K, the transmissibilities it may overwrite, the source field) through this

@@ -55,6 +55,7 @@ struct hm_fwd {
     int dtype = 64;
     int keep_history = 0;
     int press_variant = 0, sat_variant = 0;
+    bool raw_state_exposed = false;  // a device pointer to the saturation was handed out: nothing about it is remembered from step to step
     bool raw_field_exposed = false;  // a device pointer to K / TX / ... was handed out (hm_fwd_device_ptr): no caching across time steps
     long long inputs_gen = 0;  // bumped by every call that can change K, wells, rates or kernel selection: results cached across time steps (press_nd.hip) die with it
     bool cg_lazy = true;  // CG work vectors not allocated yet
@@ -76,6 +77,11 @@ struct hm_fwd {
     std::vector<int> q_epoch;  // per column of q_host: first time step of the run of equal columns it belongs to (build_q)
     DevBuf well_cells;
     DevBuf comp;      // base / dS images of the generic fp32 sweeps (sat32.h), allocated on first use
+    DevBuf retried;   // two ints: member-steps redone by the gated tiled sweep (hm_fwd_team_retries), by the slab sweep's redo launch (hm_fwd_slab_redos)
+    DevBuf slab_wet;  // sat32s.hip: which slabs of which member hold water, two images in turn (written by the launch of step k, read by that of k + 1)
+    int slab_wet_step = -1;       // time index whose launch may read the record
+    long long slab_wet_gen = -1;  // inputs_gen the record belongs to
+    int dbg_team_rounds = 0;      // hm_fwd_set_debug "team_rounds": 1 = the slab teams in rounds of co-resident teams (round 4's form)
     DevBuf team_mem;  // synchronisation blocks of the multi-tile saturation sweep (sat128t.hip), allocated on first use
     int dbg_nd_force_fallback = -1, dbg_nd_cap = 0;  // hm_fwd_set_debug: test / experiment knobs of the larger grids' direct solver (press_nd.hip)
     long long nd_fallbacks = 0;  // member-steps the direct solver of the larger grids handed to the two-level CG (press_nd.hip: nd_check_and_fall_back)

@@ -101,7 +101,8 @@ __device__ __forceinline__ void get8(const u64* slot, int py, float (&v)[PY], un
 
 template <int NY, bool FD>
 __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restrict__ Sin_base, float* __restrict__ Sout_base,
-                                               long long S_stride, float* __restrict__ prods, int k, char* team_mem, int T, int first_member) {
+                                               long long S_stride, float* __restrict__ prods, int k, char* team_mem, int T, int first_member,
+                                               const unsigned char* __restrict__ wet_in, unsigned char* __restrict__ wet_out, int all_active, int* counters) {
     constexpr int LPR = NY / PY;          // lanes per patch row
     constexpr int NROWS = NT / LPR;       // patch rows per slab
     constexpr int SLAB = NROWS * PX;      // grid rows per slab
@@ -111,6 +112,11 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
     sat_team::team_of_block(T, team, slab);
     const int m = first_member + team;
     if (m >= p.N) return;
+    // all_active == 2: the REDO launch that follows every launch in which slabs may sit out -- only the members flagged HM_MEMBER_REDO_STEP
+    // (water reached a slab that sat the step out), all their slabs; everybody else leaves here.  The flag is cleared by slab 0 once every
+    // workgroup of the member has published its CFL minimum, i.e. has read it.
+    const bool redo = all_active == 2;
+    if (redo && !(p.status[m] & HM_MEMBER_REDO_STEP)) return;
     // Which wave takes which band of the slab: the slab's LAST band (it hands its row 3 down to the next slab) goes to hardware wave 1,
     // not 7.  Of the two waves on a SIMD the earlier-dispatched one (0..3) wins the issue arbitration and is through its rows in 2.7 k of
     // the sub-step's 6.2 k cycles (profiles/r05/sat32_prof_128.txt; waves 4..7: 4.6 k), so its next record leaves two thousand cycles
@@ -119,7 +125,34 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
     const int lt = lw * 64 + (tid & 63);                                             // logical thread id: geometry and LDS slots follow it
     const int py = lt % LPR, prow = lt / LPR;
     const int gx0 = slab * SLAB + prow * PX, iy0 = py * PY;  // global row / column of the patch's first cell
-    const bool hasPrev = slab > 0, hasNext = slab + 1 < T;
+    // ACTIVE slabs.  A slab whose cells are all dry, with dry neighbouring slabs and no injector, cannot change within one time step (the
+    // front would have to cross a whole slab of 16 384 / Ny rows): its workgroup contributes its cells to the CFL bound, writes zeros and
+    // LEAVES -- the CU goes to the next workgroup of the launch, so a launch costs what its wet slabs cost (at 512 x 512 the injector's slab
+    // is wet from the first step, the outer ones only late in a run).  What is wet is recorded per member and slab at the end of every
+    // launch (wet_out) and read by the next (wet_in; all_active: the record is not valid -- first step of a run, inputs changed).
+    // Every workgroup of a member evaluates the same rule on the same record, so neighbours agree on who takes part; towards an inactive
+    // neighbour a slab behaves as at the domain boundary (zero halo), and checks at the end that its border row is still dry.  It need
+    // not be: ahead of the visible front the saturation decays doubly exponentially but stays bitwise non-zero down to 1e-45, and in a
+    // high-flux channel that frontier of denormal values can run a hundred cells within the 9 831 sub-steps of one time step (observed on 1
+    // of 125 members of config 5's prior for six steps in a row).  Such a member is flagged HM_MEMBER_REDO_STEP and its step redone with
+    // every slab by the REDO launch that follows (below): 26 ms, bit-identical.
+    const unsigned char* wet = wet_in + (size_t)m * T;
+    auto slab_has_injector = [&](int sl) {
+        bool any = false;
+        const int nW0 = min(p.nInj + p.nPrd, MAX_WELLS);
+        for (int w = 0; w < nW0; ++w) {
+            const int cell = p.well_cells[w];
+            any = any || (cell / NY / SLAB == sl && p.q[(long long)(p.q_cols > 1 ? k : 0) * p.Nxy + cell] > 0.0);
+        }
+        return any;
+    };
+    auto slab_active = [&](int sl) {
+        if (sl < 0 || sl >= T) return false;
+        if (all_active || T == 1) return true;  // (1: record void; 2: the redo launch)
+        return wet[sl] != 0 || (sl > 0 && wet[sl - 1] != 0) || (sl + 1 < T && wet[sl + 1] != 0) || slab_has_injector(sl);
+    };
+    const bool active = slab_active(slab);
+    const bool hasPrev = slab_active(slab - 1), hasNext = slab_active(slab + 1);  // (an active neighbour: the one this slab trades rows with)
     const bool first = prow == 0 && hasPrev, last = prow == NROWS - 1 && hasNext;  // the patch rows that talk to a neighbouring slab
 
     char* tm = team_mem + (size_t)team * team_bytes(T, NY);
@@ -171,6 +204,15 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
     }
     if (T > 1) {
         if (tid == 0) sat_team::put_double(cflg + slab * 2, cflg + slab * 2 + 1, red[0], 1u);
+        if (!active && slab != 0) {  // (slab 0 records the member's sub-step count: it stays for the team minimum)
+            for (int i = tid; i < SLAB * NY / 4; i += NT) reinterpret_cast<float4*>(Sout + (long long)slab * SLAB * NY)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (tid < p.nPrd) {
+                const int cell = p.prd_ind[tid];
+                if (cell / NY >= slab * SLAB && cell / NY < (slab + 1) * SLAB) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = 0.0f;
+            }
+            if (tid == 0) wet_out[(size_t)m * T + slab] = 0;
+            return;
+        }
         if (tid < 64) {  // wave 0: lane t collects slab t's minimum
             const int t = tid < T ? tid : 0;
             u64 x = 0, y = 0;
@@ -198,6 +240,20 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
     if (tid == 0 && slab == 0) {
         p.nts[(long long)m * p.nTime + k] = Nts;
         if (bad) atomicOr(&p.status[m], HM_MEMBER_BAD_CFL);
+        if (redo) {
+            atomicAnd(&p.status[m], ~HM_MEMBER_REDO_STEP);
+            if (counters) atomicAdd(counters + 1, 1);  // hm_fwd_slab_redos
+        }
+    }
+    if (!active) {  // slab 0, inactive: as above
+        for (int i = tid; i < SLAB * NY / 4; i += NT) reinterpret_cast<float4*>(Sout)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (tid < p.nPrd) {
+            const int cell = p.prd_ind[tid];
+            if (cell / NY < SLAB) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = 0.0f;
+        }
+        if (tid == 0) wet_out[(size_t)m * T] = 0;
+        if (__ballot(failed) != 0ull && (tid & 63) == 0) atomicOr(&p.status[m], HM_MEMBER_SYNC_TIMEOUT);
+        return;
     }
     const double d = bad ? 0.0 : (p.dt / (double)Nts) / pv;
 
@@ -404,6 +460,25 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
         *reinterpret_cast<float4*>(o + 4) = make_float4(s[4], s[5], s[6], s[7]);
     }
     if (nonfinite) atomicOr(&p.status[m], HM_MEMBER_NONFINITE);
+    {   // what the next launch reads: is anything in this slab wet; and towards an inactive neighbour the border row must still be dry
+        unsigned wbits = 0u, border = 0u;
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+#pragma unroll
+            for (int j = 0; j < PY; ++j) {
+                const unsigned b = __float_as_uint(base[i][j] + dS[i][j]) << 1;
+                wbits |= b;
+                if ((i == 0 && prow == 0 && slab > 0 && !hasPrev) || (i == PX - 1 && prow == NROWS - 1 && slab + 1 < T && !hasNext)) border |= b;
+            }
+        if (__ballot(border != 0u) != 0ull && (tid & 63) == 0) atomicOr(&p.status[m], HM_MEMBER_REDO_STEP);  // water reached a slab that sat the step out
+        int* wsum = reinterpret_cast<int*>(lds);
+        __syncthreads();
+        if (tid == 0) wsum[0] = 0;
+        __syncthreads();
+        if (__ballot(wbits != 0u) != 0ull && (tid & 63) == 0) atomicOr(wsum, 1);
+        __syncthreads();
+        if (tid == 0) wet_out[(size_t)m * T + slab] = (unsigned char)wsum[0];
+    }
     if (__ballot(failed) != 0ull && (tid & 63) == 0) atomicOr(&p.status[m], HM_MEMBER_SYNC_TIMEOUT);
     __threadfence_block();
     __syncthreads();
@@ -416,12 +491,36 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
 template <int NY, bool FD>
 int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, int T, int max_teams) {
     const FwdParams& p = f->p;
-    const size_t need = T > 1 ? team_bytes(T, NY) * (size_t)max_teams : 0;  // a team of one trades nothing
+    // One launch for the whole ensemble (teams of more than one slab): workgroups of slabs that sit the step out leave at once, so the
+    // launch costs what the wet slabs cost.  A team's workgroups have consecutive places in their XCD's share of the grid (sat_team.h:
+    // team_of_block); with workgroups started in grid order -- observed, not promised by HIP -- a resident workgroup only ever waits for
+    // workgroups that are resident or next in line, whatever the number of teams.  Should that order not hold, the bounded spins end the
+    // wait, the member is flagged and its step redone by the gated tiled sweep (forward.hip): slower, never wrong.  hm_fwd_set_debug
+    // "team_rounds" = 1 restores round 4's form: rounds of as many teams as are resident at once whatever the order.
+    const bool rounds = T > 1 && f->dbg_team_rounds != 0;
+    const int per_launch = T > 1 && rounds ? max_teams : p.N;
+    const size_t need = T > 1 ? team_bytes(T, NY) * (size_t)per_launch : 0;  // a team of one trades nothing
     if (f->team_mem.bytes < need) {
         hm_dev_free(f->team_mem);
         int rc = hm_dev_alloc(f->team_mem, need);
         if (rc) return rc;
     }
+    if (!f->retried.p) {
+        int rc = hm_dev_alloc(f->retried, 8);
+        if (rc) return rc;
+        HM_HIP(hipMemsetAsync(f->retried.p, 0, 8, f->ctx->stream));
+    }
+    const size_t nflags = (size_t)p.N * T;
+    if (f->slab_wet.bytes < 2 * nflags) {
+        hm_dev_free(f->slab_wet);
+        int rc = hm_dev_alloc(f->slab_wet, 2 * nflags);
+        if (rc) return rc;
+        f->slab_wet_step = -1;
+    }
+    // the record of wet slabs written by the launch of time index k - 1 is good for this one if nothing touched the plan's inputs or state since
+    const int all_active = !(f->slab_wet_step == k && f->slab_wet_gen == f->inputs_gen) || p.swc != 0.0 || f->raw_state_exposed;  // (swc > 0: fw(0) != 0, no slab is inert)
+    const unsigned char* wet_in = (const unsigned char*)f->slab_wet.p + (size_t)(k & 1) * nflags;
+    unsigned char* wet_out = (unsigned char*)f->slab_wet.p + (size_t)((k + 1) & 1) * nflags;
     hipStream_t s = f->ctx->stream;
     auto kern = k_sat32s<NY, FD>;
     HM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
@@ -430,14 +529,25 @@ int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, 
         HM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, NT, LDS_BYTES));
         if (resident < 1) return -1;
     }
-    for (int first = 0; first < p.N; first += max_teams) {  // rounds of members whose teams are all resident at once
-        const int nteams = std::min(max_teams, p.N - first);
+    for (int first = 0; first < p.N; first += per_launch) {
+        const int nteams = std::min(per_launch, p.N - first);
         const int used_per_xcd = (nteams + 7) / 8;
         if (T > 1) HM_HIP(hipMemsetAsync(f->team_mem.p, 0, team_bytes(T, NY) * (size_t)nteams, s));  // tags restart at 0 every launch
         hipLaunchKernelGGL(kern, dim3(8 * used_per_xcd * T), dim3(NT), LDS_BYTES, s, f->p, (const float*)S_in, (float*)S_out, S_stride,
-                           (float*)f->prods.p, k, (char*)f->team_mem.p, T, first);
+                           (float*)f->prods.p, k, (char*)f->team_mem.p, T, first, wet_in, wet_out, all_active, (int*)f->retried.p);
+    }
+    if (T > 1 && !all_active) {  // slabs may have sat out: the gated redo launch (only flagged members do anything)
+        for (int first = 0; first < p.N; first += per_launch) {
+            const int nteams = std::min(per_launch, p.N - first);
+            const int used_per_xcd = (nteams + 7) / 8;
+            HM_HIP(hipMemsetAsync(f->team_mem.p, 0, team_bytes(T, NY) * (size_t)nteams, s));
+            hipLaunchKernelGGL(kern, dim3(8 * used_per_xcd * T), dim3(NT), LDS_BYTES, s, f->p, (const float*)S_in, (float*)S_out, S_stride,
+                               (float*)f->prods.p, k, (char*)f->team_mem.p, T, first, wet_in, wet_out, 2, (int*)f->retried.p);
+        }
     }
     HM_HIP(hipGetLastError());
+    f->slab_wet_step = k + 1;
+    f->slab_wet_gen = f->inputs_gen;
     return 0;
 }
 

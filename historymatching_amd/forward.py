@@ -107,7 +107,8 @@ class ForwardPlan:
     def sync(self):
         st = _lib.hm_stats()
         _lib.check(self.lib.hm_fwd_sync(self.h, C.byref(st)), "hm_fwd_sync")
-        return dict(st.asdict(), nd_fallbacks=int(self.lib.hm_fwd_nd_fallbacks(self.h)))
+        return dict(st.asdict(), nd_fallbacks=int(self.lib.hm_fwd_nd_fallbacks(self.h)), team_retries=int(self.lib.hm_fwd_team_retries(self.h)),
+                    slab_redos=int(self.lib.hm_fwd_slab_redos(self.h)))
 
     def run_to_host(self, out=None):
         """All steps, then ``(wsats, prods, status, stats)`` on the host; a large saturation history is copied out time index

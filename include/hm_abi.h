@@ -110,6 +110,7 @@ int hm_forward_batched(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,
 #define HM_MEMBER_NONFINITE     4   /* NaN/Inf in the saturation                                    */
 #define HM_MEMBER_NO_CONVERGENCE 8  /* CG pressure solver hit max_iter before ||r|| <= rtol ||q||   */
 #define HM_MEMBER_SYNC_TIMEOUT   16  /* a tile workgroup of the multi-tile saturation sweep gave up waiting for a neighbour */
+#define HM_MEMBER_REDO_STEP      32  /* (internal, never left set) the slab sweep let dry slabs sit a step out and water reached one: the step is redone with every slab */
 
 /* Device-resident form of the same path (what bench.py times; what ES-MDA/IES drivers chain). */
 int  hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,
@@ -138,11 +139,21 @@ int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
  * member whose elimination met a non-positive pivot, or whose fluxes missed the wells by more than 1e-4 of the largest rate (the
  * reference's sparse direct solve with partial pivoting, HistoryMatch.py:362, does not fail on such members either). */
 long long hm_fwd_nd_fallbacks(hm_fwd* f);
+/* Member-steps of the workgroup-team saturation sweeps that were redone by the single-workgroup tiled sweep since the plan was created: a team
+ * gave up waiting for a neighbouring workgroup (CUs held by someone else), or water reached a slab that sat the step out (sat32s).  Results
+ * are the same either way; a number other than 0 says the run was slower than it should be.  Synchronises the plan's stream. */
+long long hm_fwd_team_retries(hm_fwd* f);
+/* Member-steps the float32 slab sweep (sat32s) did twice: it lets slabs that are dry, with dry neighbours, sit a time step out; where the
+ * frontier of denormal saturations ahead of the front reached such a slab within the step, the member's step is redone with every slab
+ * (same launch form, bit-identical, ~the cost of one more member).  Synchronises the plan's stream. */
+long long hm_fwd_slab_redos(hm_fwd* f);
 /* Test and experiment knobs of a plan (not part of the reference's surface; nothing reads the environment).  Keys:
  *   "nd_force_fallback"  value = member index: on the larger grids that member is handed to the two-level CG at EVERY time step, whatever
  *                        its direct solve was like (exercises the hand-over deterministically); -1 (default) = off
  *   "nd_cap"             value = members per block of the larger grids' direct solver (0, the default: automatic -- the whole ensemble
  *                        where its buffers fit the device, else blocks within 64 GB); must be set before the plan's first run
+ *   "team_rounds"        value = 1: the slab teams of the float32 sweep (sat32s) are launched in rounds of as many teams as are resident at
+ *                        once (round 4's form) instead of one launch for the whole ensemble; 0 (default) = one launch
  * Returns nonzero for an unknown key. */
 int  hm_fwd_set_debug(hm_fwd* f, const char* key, long long value);
 int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member);     /* D2H */

@@ -756,6 +756,41 @@ def test_multi_tile_saturation_teams_bitexact_vs_tiled(nx, ny, N, wells, dtype):
     assert out[0][0][:, -1].max() > 0.5  # the front has left the injector
 
 
+def test_float32_slab_sweep_skips_dry_slabs_without_changing_a_bit():
+    """The float32 slab sweep launches the whole ensemble at once and lets the workgroups of slabs that are dry (with dry neighbours and no
+    injector) leave at once (sat32s.hip: ACTIVE slabs).  512 x 256 (Nx = 512: 16 slabs of 32 rows... here 8 slabs of 64 rows at Ny = 256), 20
+    members, 10 steps: saturation history, producer series and sub-step counts equal those of round 4's form -- every slab of every member
+    in rounds of co-resident teams, hm_fwd_set_debug "team_rounds" -- and of the single-workgroup tiled kernel; a run continued from a
+    state written by hand (the record of wet slabs is void: every slab takes part) as well."""
+    nx, ny, N, steps = 512, 256, 20, 10
+    _, gm = make_models(nx, ny, dtype=32)
+    x = perms(nx, ny, N, seed=91)
+    out = {}
+    for mode in ("single", "rounds", "tiled"):
+        plan = _plan(gm, N, nTime=steps + 2)
+        if mode == "rounds":
+            plan.set_debug("team_rounds", 1)
+        if mode == "tiled":
+            plan.set_variant(0, 3)
+        plan.set_inputs(x, transformed=False)
+        plan.run(0, steps)
+        S = plan.get_field("S")
+        S[:, 300:310, 17:40] = 0.3   # water far from the front, in slabs that sat the last steps out
+        plan.set_field("S", S)
+        plan.run(steps, 2)
+        st = plan.sync()
+        w, p, status = plan.outputs()
+        assert not status.any() and st["team_retries"] == 0  # nobody waited in vain, nothing went to the tiled sweep
+        out[mode] = (w, p, plan.get_field("nts"), st["slab_redos"])
+        plan.close()
+    assert out["single"][0][:, steps].max() > 0.5 and out["tiled"][3] == 0
+    dry_rows = (out["single"][0][:, steps].reshape(N, nx, ny) == 0).all(axis=(0, 2))
+    assert dry_rows[:64].all() and dry_rows[-64:].all()  # the outer slabs are indeed still dry after ten steps: they did sit out
+    for mode in ("rounds", "tiled"):
+        for a, b in zip(out["single"][:3], out[mode][:3]):
+            assert np.array_equal(a, b), (mode, np.abs(a.astype(float) - b.astype(float)).max())
+
+
 @pytest.mark.parametrize("n", [20, 128, 256])
 def test_anisotropic_permeability(n):
     """K = (Kx, Ky) with Kx != Ky (the simulator's K is (2, Nx, Ny), HistoryMatch.py:164; the reference itself stacks Kx = Ky):
