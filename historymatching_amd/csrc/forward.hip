@@ -421,7 +421,8 @@ __global__ void k_saturation_stream(FwdParams p, const T* __restrict__ Sin_base,
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T* __restrict__ Sin_base, T* __restrict__ Sout_base,
-                                                           long long S_stride, T* __restrict__ prods, int k, int only_timed_out, int* retried) {
+                                                           long long S_stride, T* __restrict__ prods, int k, int only_timed_out, int* retried,
+                                                           unsigned char* wet_mark, int wet_T) {
     constexpr int TH = 64, TW = 256, LW = TW + 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -436,6 +437,9 @@ __global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T*
             if (go) {
                 atomicAnd(&p.status[m], ~HM_MEMBER_SYNC_TIMEOUT);
                 if (retried) atomicAdd(retried, 1);  // hm_fwd_team_retries
+                // (sat32s.hip keeps a record of which slabs of a member hold water: what a team that gave up wrote there describes its
+                // broken run, not the state this retry produces -- every slab of this member counts as wet for the next step)
+                for (int t = 0; wet_mark && t < wet_T; ++t) wet_mark[(size_t)m * wet_T + t] = 1;
             }
         }
         __syncthreads();
@@ -996,12 +1000,15 @@ static int launch_saturation(hm_fwd* f, int k) {
             f->team_retries++;
         }
         const size_t lds = (size_t)1024 * 8 + (size_t)66 * 258 * f->esz;
+        // the float32 slab sweep's record of wet slabs (image written by this step's launch): marked all-wet for a member that is retried
+        const int wet_T = (f->dtype == 32 && f->slab_wet.p && (p.Ny == 128 || p.Ny == 256 || p.Ny == 512)) ? p.Nx / (16384 / p.Ny) : 0;
+        unsigned char* wet_mark = wet_T > 0 ? (unsigned char*)f->slab_wet.p + (size_t)((k + 1) & 1) * p.N * wet_T : nullptr;
         if (f->dtype == 64) {
             HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_saturation_tiled<double>, dim3(p.N), dim3(1024), lds, s, f->p, (const double*)Sin, (double*)Sout, stride, (double*)f->prods.p, k, 1, (int*)f->retried.p);
+            hipLaunchKernelGGL(k_saturation_tiled<double>, dim3(p.N), dim3(1024), lds, s, f->p, (const double*)Sin, (double*)Sout, stride, (double*)f->prods.p, k, 1, (int*)f->retried.p, (unsigned char*)nullptr, 0);
         } else {
             HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_saturation_tiled<float>, dim3(p.N), dim3(1024), lds, s, f->p, (const float*)Sin, (float*)Sout, stride, (float*)f->prods.p, k, 1, (int*)f->retried.p);
+            hipLaunchKernelGGL(k_saturation_tiled<float>, dim3(p.N), dim3(1024), lds, s, f->p, (const float*)Sin, (float*)Sout, stride, (float*)f->prods.p, k, 1, (int*)f->retried.p, wet_mark, wet_T);
         }
         HM_HIP(hipGetLastError());
     }
@@ -1017,8 +1024,8 @@ static int launch_saturation(hm_fwd* f, int k) {
         size_t lds = tiled ? (size_t)1024 * 8 + (size_t)66 * 258 * f->esz : (size_t)T * 8;
 #define SAT(KERN, TT, ...) hipLaunchKernelGGL(KERN<TT>, dim3(p.N), dim3(T), lds, s, f->p, (const TT*)Sin, (TT*)Sout, stride, (TT*)f->prods.p, k, ##__VA_ARGS__)
         if (tiled) {
-            if (f->dtype == 64) { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, double, 0, (int*)nullptr); }
-            else { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, float, 0, (int*)nullptr); }
+            if (f->dtype == 64) { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, double, 0, (int*)nullptr, (unsigned char*)nullptr, 0); }
+            else { HM_HIP(hipFuncSetAttribute((const void*)k_saturation_tiled<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); SAT(k_saturation_tiled, float, 0, (int*)nullptr, (unsigned char*)nullptr, 0); }
         } else if (stream) { if (f->dtype == 64) SAT(k_saturation_stream, double); else SAT(k_saturation_stream, float); }
         else { if (f->dtype == 64) SAT(k_saturation_generic, double); else SAT(k_saturation_generic, float); }
 #undef SAT
