@@ -17,8 +17,7 @@
 // 1e-191, 0), so values of the second kind sit along the whole front all the time: a form that branched to the compiler's division
 // for them was slower than no change at all.  Non-finite or absurd |S| >= 2^500 is outside the claim (such members are flagged).
 // The general fluid keeps the compiler's division (four quotients with arbitrary operand ranges).
-// fp32 sweeps (dtype = 32 plans): the same in single precision -- the compiler's sequence there is v_rcp_f32, ONE Newton step and
-// two residual corrections; scaling is an identity for S^2 >= 2^-103, and 1 - S, S^2 + 1 round to exactly 1.0f for |S| < 2^-25.
+// fp32 sweeps (dtype = 32 plans): single precision has 2^32 operands, so there the short form is CHECKED on every one of them (below).
 #pragma once
 #include "fwd.h"
 
@@ -82,14 +81,16 @@ __device__ __forceinline__ float frac_flow_ieee(const FwdParams& p, float s) {
     return mw / (mw + mo);
 }
 
+// Round 5: FOUR instructions.  fw is a function of one float, so a shorter sequence can be checked on every bit pattern of s: on gfx950
+// (its v_rcp_f32 seed included) rcp, q = n r and ONE residual correction give the IEEE quotient of n = s^2 by d = s^2 + (1 - s)^2 for all
+// 2^32 values of s except |s| >= 6.5e18 -- exactly the values on which the eight-instruction form it replaces (the compiler's sequence
+// without scaling and fix-up: v_rcp_f32, a Newton step, two residual corrections) differs from it as well
+// (profiles/diag/div32_exhaustive.hip, profiles/r05/div32_exhaustive.txt).  Only for THIS n and d: a quotient
+// in [0, 1] with d >= 0.5; not a general division.
 __device__ __forceinline__ float div_unscaled(float n, float d) {
-    float r = __builtin_amdgcn_rcpf(d);
-    float e = __builtin_fmaf(-d, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    float q = n * r;
-    e = __builtin_fmaf(-d, q, n);
-    q = __builtin_fmaf(e, r, q);
-    e = __builtin_fmaf(-d, q, n);
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = n * r;
+    const float e = __builtin_fmaf(-d, q, n);
     return __builtin_fmaf(e, r, q);
 }
 
