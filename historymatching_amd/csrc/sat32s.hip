@@ -557,6 +557,42 @@ int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, 
 extern "C" int hm_debug_sat32_prof(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hm_sat32_prof_buf), sizeof(long long) * 64); }
 #endif
 
+// Hardware self-test of the float32 fractional flow (fracflow.h): frac_flow<true> as the sweeps compute it -- v_rcp_f32, q = n r, one residual
+// correction -- against the compiler's IEEE division on EVERY float s (the function has one operand: 2^32 cases, a second of GPU time).
+// out[0]: cases with |s| < 2^62 whose bits differ (the claim is 0: that is the bit-for-bit equality with the NumPy float32 specification);
+// out[1]: cases that differ anywhere (operands beyond 6.5e18, where s^2 + (1 - s)^2 leaves the range the short form is exact on).
+namespace {
+__global__ __launch_bounds__(256) void k_fracflow32_check(FwdParams p, unsigned long long* out) {
+    const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0, bad_in = 0;
+    for (unsigned long long b = gid; b < (1ull << 32); b += stride) {
+        const float s = __uint_as_float((unsigned)b);
+        const float got = frac_flow<true>(p, s), want = frac_flow_ieee<true>(p, s);
+        if (__float_as_uint(got) != __float_as_uint(want) && !(got != got && want != want)) {
+            ++bad;
+            if (fabsf(s) < 4.611686e18f) ++bad_in;
+        }
+    }
+    if (bad_in) atomicAdd(out, bad_in);
+    if (bad) atomicAdd(out + 1, bad);
+}
+}  // namespace
+
+extern "C" int hm_debug_fracflow32_check(hm_ctx* ctx, unsigned long long* out) {
+    HM_REQUIRE(ctx && out, "hm_debug_fracflow32_check: NULL argument");
+    HM_HIP(hipSetDevice(ctx->device));
+    unsigned long long* d;
+    HM_HIP(hipMalloc(&d, 16));
+    HM_HIP(hipMemsetAsync(d, 0, 16, ctx->stream));
+    FwdParams p{};
+    hipLaunchKernelGGL(k_fracflow32_check, dim3(8 * ctx->num_cu), dim3(256), 0, ctx->stream, p, d);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipStreamSynchronize(ctx->stream));
+    HM_HIP(hipMemcpy(out, d, 16, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
+}
+
 // Returns 0 if launched, >0 on error, -1 if this specialisation does not apply.
 int launch_saturation_32s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
     const FwdParams& p = f->p;

@@ -208,6 +208,11 @@ void* hm_fwd_device_ptr(hm_fwd* f, const char* name);
 /* Hardware self-test: D(16x16) = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 with the lane maps the
  * pressure kernel assumes (host buffers, row-major). */
 int hm_debug_mfma_f64(hm_ctx* ctx, const double* A, const double* B, double* D);
+/* Hardware self-test of the float32 fractional flow fw(s) = s^2 / (s^2 + (1 - s)^2) of dtype = 32 plans (csrc/fracflow.h: reciprocal seed,
+ * quotient, ONE residual correction) against the IEEE division on all 2^32 operands s (oracle/ressim.py: frac_flow in float32; the
+ * reference's own is fp64, HistoryMatch.py:362 -> ResSim).  out[0] = operands with |s| < 2^62 whose result differs in any bit (claimed: 0),
+ * out[1] = operands that differ at all (|s| >= 6.5e18 only). */
+int hm_debug_fracflow32_check(hm_ctx* ctx, unsigned long long* out /* 2 */);
 /* Symbolic phase of the nested-dissection pressure solve (press_nd.hip; replaces the sparse direct solve inside
  * ResSim.sim, notebooks/HistoryMatch.py:362): the elimination tree of the Nx x Ny grid as the kernels use it.
  * Runs on the host, no device needed.  info[0..3] = fronts, cell entries, factor doubles and arena doubles per member;

@@ -59,6 +59,21 @@ def test_mfma_f64_layout():
     assert np.array_equal(D, A @ B)
 
 
+def test_float32_fractional_flow_is_the_ieee_quotient_for_every_operand():
+    """dtype = 32 plans compute fw(s) = s^2 / (s^2 + (1 - s)^2) with a four-instruction division (csrc/fracflow.h).  fw has ONE float operand:
+    the kernels' function is compared with the IEEE division on all 2^32 of them, on the GPU the tests run on (the reciprocal seed is the
+    hardware's).  This is what makes the fp32 sweeps equal to the NumPy float32 specification (oracle/ressim.py) bit for bit."""
+    import ctypes as C
+
+    from historymatching_amd import _lib
+
+    ctx = _lib.Context.get()
+    out = (C.c_ulonglong * 2)()
+    _lib.check(ctx.lib.hm_debug_fracflow32_check(ctx.handle, out), "hm_debug_fracflow32_check")
+    assert out[0] == 0, f"{out[0]} float32 operands below 2^62 give a fractional flow that is not the IEEE quotient"
+    assert out[1] < 2**25  # (operands beyond 6.5e18: s^2 near the top of the float32 range; no saturation is ever there)
+
+
 def test_perm_transform_on_device():
     om, gm = make_models(20, 20)
     x = perms(20, 20, 5)
