@@ -681,6 +681,12 @@ extern "C" int hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, doub
     p.dt = dt;
     int rc = build_q(f, nInj, inj_ind, inj_rates, inj_rate_cols, nPrd, prd_ind, prd_rates, prd_rate_cols);
     if (rc) { delete f; return rc; }
+    f->Lx = Lx; f->Ly = Ly;
+    f->inj_ind_host.assign(inj_ind, inj_ind + nInj);
+    f->prd_ind_host.assign(prd_ind, prd_ind + nPrd);
+    f->inj_rates_host.assign(inj_rates, inj_rates + (size_t)nInj * inj_rate_cols);
+    f->prd_rates_host.assign(prd_rates, prd_rates + (size_t)nPrd * prd_rate_cols);
+    f->inj_cols = inj_rate_cols; f->prd_cols = prd_rate_cols;
     const size_t Nxy = p.Nxy, n = N;
 #define ALLOC(buf, bytes) do { rc = hm_dev_alloc(f->buf, (bytes)); if (rc) { hm_fwd_destroy(f); return rc; } } while (0)
     ALLOC(K, n * Nxy * 8);
@@ -736,6 +742,8 @@ extern "C" void hm_fwd_destroy(hm_fwd* f) {
     if (!f) return;
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
+    if (f->inner) hm_fwd_destroy(f->inner);
+    if (f->is_inner) f->status = f->nts = f->n_cg = f->prods = DevBuf{};  // the outer plan's
     DevBuf* bufs[] = {&f->K, &f->por, &f->q, &f->prd_ind, &f->TX, &f->TY, &f->G, &f->yv, &f->P, &f->Vx,
                       &f->Vy, &f->coef, &f->fw, &f->status, &f->nts, &f->perm_in, &f->S, &f->prods, &f->well_cells, &f->cg_r, &f->cg_p, &f->n_cg,
                       &f->tl_TXc, &f->tl_TYc, &f->tl_pin, &f->tl_rc, &f->tl_yc, &f->tl_yv, &f->tl_G, &f->tl_cgs, &f->tl_done, &f->tl_ndone, &f->tl_z1, &f->tl_dinv, &f->tl_parts, &f->team_mem, &f->Ky, &f->comp, &f->slab_wet, &f->retried};
@@ -818,6 +826,7 @@ extern "C" int hm_fwd_set_inputs(hm_fwd* f, const void* perm, int perm_is_transf
     }
     HM_HIP(hipMemsetAsync(f->status.p, 0, (size_t)p.N * 4, s));
     f->cur = 0;
+    f->inner_S_step = -1;
     HM_HIP(hipStreamSynchronize(s));
     return 0;
 }
@@ -881,6 +890,7 @@ extern "C" int hm_fwd_set_inputs_device(hm_fwd* f, const void* perm_dev, int per
     else HM_HIP(hipMemsetAsync(S0, 0, (size_t)n * f->esz, s));
     HM_HIP(hipMemsetAsync(f->status.p, 0, (size_t)p.N * 4, s));
     f->cur = 0;
+    f->inner_S_step = -1;
     return 0;
 }
 
@@ -907,13 +917,165 @@ static int generic_threads(int Ny) {
     return Ny * (maxT / Ny);
 }
 
+// ------------------------------------------------------------------------------------------------
+// EMBEDDED GRIDS.  The fast kernels are written for 128 x 128 cells (press_nd.hip, sat128r.hip, sat32s.hip); every other grid of at
+// most 128 x 128 cells used to take the generic pair -- at 100 x 100 and 1000 members 68 + 29 ms a time step against the 5.6 + 8.3 ms
+// of the LARGER 128 x 128 grid.  Such a grid now runs inside a 128 x 128 plan of the same cell size: its cells in the corner at the
+// origin, the others with permeability ZERO.  A face next to such a cell has 1 / (mobility K) = inf on one side, so its harmonic-mean
+// transmissibility is c / inf = 0 exactly -- the no-flow boundary the grid has there anyway; the padding's own equations are 1 p = 0
+// (press_nd.hip gives an all-zero row a unit diagonal), its fluxes 0, its saturation stays 0 (the sweeps skip dry bands), its CFL
+// term pv / 0 = inf never is the minimum.  What the sweeps compute for the grid's own cells is the same arithmetic on the same
+// operands as on the grid alone (a zero coefficient times a zero fractional flow adds +0), so they stay bit-identical to the oracle
+// for given fluxes; the pressure solve is a different elimination order of the same system, as on every grid.
+// The OUTER plan (the one the caller holds) keeps every buffer in the caller's layout; permeability and the current saturation are
+// copied in when they changed, the new saturation is copied out after every sweep, P / Vx / Vy / TX / TY when somebody asks for them.
+// Applies with the default kernel variants only: hm_fwd_set_variant(1, 1) (or hm_fwd_set_debug "embed" 0) is the generic pair on the
+// grid as given, the in-library cross-check.
+// ------------------------------------------------------------------------------------------------
+constexpr int EMB = 128;
+
+template <typename T>
+__global__ void k_embed2d(const T* __restrict__ src, long long s_ms, int s_cols, T* __restrict__ dst, long long d_ms, int d_rows, int d_cols,
+                          int rows, int cols, T fill, int N) {
+    const long long per = (long long)d_rows * d_cols, n = per * N, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long long m = i / per, rc = i - m * per;
+        const int r = (int)(rc / d_cols), c = (int)(rc - (long long)r * d_cols);
+        dst[m * d_ms + rc] = (r < rows && c < cols) ? src[m * s_ms + (long long)r * s_cols + c] : fill;
+    }
+}
+template <typename T>
+__global__ void k_extract2d(const T* __restrict__ src, long long s_ms, int s_cols, T* __restrict__ dst, long long d_ms, int rows, int cols, int N) {
+    const long long per = (long long)rows * cols, n = per * N, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long long m = i / per, rc = i - m * per;
+        const int r = (int)(rc / cols), c = (int)(rc - (long long)r * cols);
+        dst[m * d_ms + rc] = src[m * s_ms + (long long)r * s_cols + c];
+    }
+}
+
+static int launch_pressure(hm_fwd* f, int k);
+static int launch_saturation(hm_fwd* f, int k);
+
+// The inner 128 x 128 plan of `f` if this launch is to run embedded (created on first use), else NULL.
+static hm_fwd* embedded_inner(hm_fwd* f, int* rc_out) {
+    *rc_out = 0;
+    const FwdParams& p = f->p;
+    if (f->is_inner || !f->dbg_embed) return nullptr;
+    if (p.Nx > EMB || p.Ny > EMB || (p.Nx == EMB && p.Ny == EMB)) return nullptr;
+    if (p.Ny <= 32 && p.Nxy <= 1024) return nullptr;                                   // the one-launch kernel of small grids (small.hip)
+    if (!(f->press_variant == 0 || f->press_variant == 12 || f->press_variant == 14) || f->sat_variant != 0) return nullptr;
+    if (p.q_mstride != 0 || p.por != nullptr || p.Ky != nullptr) return nullptr;       // per-member wells, porosity field, anisotropy: generic
+    if (!f->inner) {
+        auto remap = [&](int cell) { return (cell / p.Ny) * EMB + cell % p.Ny; };
+        std::vector<int> inj(f->inj_ind_host), prd(f->prd_ind_host);
+        for (int& c : inj) c = remap(c);
+        for (int& c : prd) c = remap(c);
+        hm_fwd* in = nullptr;
+        int rc = hm_fwd_create(f->ctx, p.N, EMB, EMB, p.hx * EMB, p.hy * EMB, p.nInj, inj.data(), f->inj_rates_host.data(), f->inj_cols, p.nPrd,
+                               prd.data(), f->prd_rates_host.data(), f->prd_cols, p.dt, p.nTime, p.vw, p.vo, p.swc, p.sor, nullptr, f->dtype, 0, &in);
+        if (rc) { *rc_out = rc; return nullptr; }
+        // per-member outputs are the outer plan's: the inner kernels write status, sub-step counts and producer series straight there
+        hm_dev_free(in->status); hm_dev_free(in->nts); hm_dev_free(in->n_cg); hm_dev_free(in->prods);
+        in->status = f->status; in->nts = f->nts; in->n_cg = f->n_cg; in->prods = f->prods;
+        in->p.status = (int*)f->status.p; in->p.nts = (int*)f->nts.p; in->p.n_cg = (int*)f->n_cg.p;
+        in->is_inner = true;
+        // exactly the cell size of the outer grid (Lx / Nx * 128 / 128 may round differently)
+        in->p.hx = p.hx; in->p.hy = p.hy; in->p.h2 = p.h2; in->p.cx = p.cx; in->p.cy = p.cy;
+        f->inner = in;
+        f->inner_K_gen = -1;
+        f->inner_S_step = -1;
+    }
+    f->inner->press_variant = f->press_variant;
+    return f->inner;
+}
+
+#define EMB_GRID dim3(2048), dim3(256), 0, s
+// permeability (when the outer plan's inputs changed) and the saturation of time index k (unless the inner plan's last sweep left it there)
+static int embed_inputs(hm_fwd* f, hm_fwd* in, int k) {
+    const FwdParams& p = f->p;
+    hipStream_t s = f->ctx->stream;
+    if (f->inner_K_gen != f->inputs_gen) {
+        hipLaunchKernelGGL(k_embed2d<double>, EMB_GRID, (const double*)f->K.p, (long long)p.Nxy, p.Ny, (double*)in->K.p, (long long)EMB * EMB, EMB, EMB,
+                           p.Nx, p.Ny, 0.0, p.N);
+        f->inner_K_gen = f->inputs_gen;
+        ++in->inputs_gen;
+    }
+    if (f->inner_S_step != k || f->raw_state_exposed) {
+        long long so, si;
+        const void* So = fwd_S_ptr(f, k, &so);
+        void* Si = fwd_S_ptr(in, k, &si);
+        if (f->dtype == 64) hipLaunchKernelGGL(k_embed2d<double>, EMB_GRID, (const double*)So, so, p.Ny, (double*)Si, si, EMB, EMB, p.Nx, p.Ny, 0.0, p.N);
+        else hipLaunchKernelGGL(k_embed2d<float>, EMB_GRID, (const float*)So, so, p.Ny, (float*)Si, si, EMB, EMB, p.Nx, p.Ny, 0.0f, p.N);
+        f->inner_S_step = k;
+        in->cur = k;
+    }
+    HM_HIP(hipGetLastError());
+    return 0;
+}
+// P, Vx, Vy, TX, TY of the outer plan from the inner plan's (when they are older)
+static int extract_fields(hm_fwd* f) {
+    if (!f->inner || !f->fields_stale) return 0;
+    const FwdParams& p = f->p;
+    hm_fwd* in = f->inner;
+    hipStream_t s = f->ctx->stream;
+    const long long e2 = (long long)EMB * EMB, ex = (long long)(EMB + 1) * EMB;
+    hipLaunchKernelGGL(k_extract2d<double>, EMB_GRID, (const double*)in->P.p, e2, EMB, (double*)f->P.p, (long long)p.Nxy, p.Nx, p.Ny, p.N);
+    hipLaunchKernelGGL(k_extract2d<double>, EMB_GRID, (const double*)in->Vx.p, ex, EMB, (double*)f->Vx.p, (long long)(p.Nx + 1) * p.Ny, p.Nx + 1, p.Ny, p.N);
+    hipLaunchKernelGGL(k_extract2d<double>, EMB_GRID, (const double*)in->TX.p, ex, EMB, (double*)f->TX.p, (long long)(p.Nx + 1) * p.Ny, p.Nx + 1, p.Ny, p.N);
+    hipLaunchKernelGGL(k_extract2d<double>, EMB_GRID, (const double*)in->Vy.p, ex, EMB + 1, (double*)f->Vy.p, (long long)p.Nx * (p.Ny + 1), p.Nx, p.Ny + 1, p.N);
+    hipLaunchKernelGGL(k_extract2d<double>, EMB_GRID, (const double*)in->TY.p, ex, EMB + 1, (double*)f->TY.p, (long long)p.Nx * (p.Ny + 1), p.Nx, p.Ny + 1, p.N);
+    HM_HIP(hipGetLastError());
+    f->fields_stale = false;
+    return 0;
+}
+static int embedded_pressure(hm_fwd* f, hm_fwd* in, int k) {
+    int rc = embed_inputs(f, in, k);
+    if (!rc) rc = launch_pressure(in, k);
+    f->fields_stale = true;
+    f->inner_V_dirty = false;
+    return rc;
+}
+static int embedded_saturation(hm_fwd* f, hm_fwd* in, int k) {
+    const FwdParams& p = f->p;
+    hipStream_t s = f->ctx->stream;
+    int rc = embed_inputs(f, in, k);
+    if (rc) return rc;
+    if (f->inner_V_dirty) {  // fluxes given by the caller (hm_fwd_set_field): zero on every face of the padding
+        const long long ex = (long long)(EMB + 1) * EMB;
+        hipLaunchKernelGGL(k_embed2d<double>, EMB_GRID, (const double*)f->Vx.p, (long long)(p.Nx + 1) * p.Ny, p.Ny, (double*)in->Vx.p, ex, EMB + 1, EMB, p.Nx + 1, p.Ny, 0.0, p.N);
+        hipLaunchKernelGGL(k_embed2d<double>, EMB_GRID, (const double*)f->Vy.p, (long long)p.Nx * (p.Ny + 1), p.Ny + 1, (double*)in->Vy.p, ex, EMB, EMB + 1, p.Nx, p.Ny + 1, 0.0, p.N);
+        f->inner_V_dirty = false;
+    }
+    if ((rc = launch_saturation(in, k))) return rc;
+    long long so, si;
+    void* So = fwd_S_ptr(f, k + 1, &so);
+    const void* Si = fwd_S_ptr(in, k + 1, &si);
+    if (f->dtype == 64) hipLaunchKernelGGL(k_extract2d<double>, EMB_GRID, (const double*)Si, si, EMB, (double*)So, so, p.Nx, p.Ny, p.N);
+    else hipLaunchKernelGGL(k_extract2d<float>, EMB_GRID, (const float*)Si, si, EMB, (float*)So, so, p.Nx, p.Ny, p.N);
+    HM_HIP(hipGetLastError());
+    f->inner_S_step = k + 1;
+    in->cur = k + 1;
+    return 0;
+}
+#undef EMB_GRID
+
 static int launch_pressure(hm_fwd* f, int k) {
     const FwdParams& p = f->p;
     hipStream_t s = f->ctx->stream;
     long long stride;
     void* S = fwd_S_ptr(f, k, &stride);
-    int rc = f->t_press.begin(s);
+    int rc = 0;
+    hm_fwd* in = embedded_inner(f, &rc);
     if (rc) return rc;
+    if ((rc = f->t_press.begin(s))) return rc;
+    if (in) {
+        if ((rc = embedded_pressure(f, in, k))) return rc;
+        rc = f->t_press.end(s);
+        f->n_press++;
+        return rc;
+    }
+    f->fields_stale = false;  // (this plan's own pressure step: its fields are the current ones)
     int done = -1;
     // press_variant: 0 the default (128 x 128: nested dissection, press_nd.hip; other grids with Ny = 128: press128s), 1 generic (the
     // in-library cross-check), 9 Jacobi-CG, 7 the 16-wave form of press128s, 12 nested dissection (14: every front eliminated every step), 13 press128s (block elimination,
@@ -970,8 +1132,18 @@ static int launch_saturation(hm_fwd* f, int k) {
     long long stride;
     void* Sin = fwd_S_ptr(f, k, &stride);
     void* Sout = fwd_S_ptr(f, k + 1, &stride);
-    int rc = f->t_sat.begin(s);
+    int rc = 0;
+    hm_fwd* in = embedded_inner(f, &rc);
     if (rc) return rc;
+    if ((rc = f->t_sat.begin(s))) return rc;
+    if (in) {
+        if ((rc = embedded_saturation(f, in, k))) return rc;
+        rc = f->t_sat.end(s);
+        f->n_sat++;
+        return rc;
+    }
+    if ((rc = extract_fields(f))) return rc;  // (a sweep of this plan's own kernels behind an embedded pressure step: the fluxes it reads)
+    f->inner_S_step = -1;
     int done = -1;
     if (f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
         // fp64, register/LDS resident: fw in registers, scaled fluxes (sat128r.hip); sat_variant 5: fw image in LDS (sat128.hip)
@@ -1056,6 +1228,9 @@ extern "C" int hm_fwd_run(hm_fwd* f, int first_step, int n_steps) {
         const int pv = f->press_variant;
         if (pv == 0 || pv == 12 || pv == 14)
             if ((rc = prepare_pressure_nd(f)) || (rc = prepare_pressure_nd256(f)) || (rc = prepare_pressure_nd512(f))) return rc;
+        hm_fwd* in = embedded_inner(f, &rc);
+        if (rc) return rc;
+        if (in && (rc = prepare_pressure_nd(in))) return rc;
     }
     if ((rc = f->t_total.begin(f->ctx->stream))) return rc;
     // small grids (the reference's default 20 x 20): the whole run as ONE launch, a wave per member (small.hip; bit-identical to the
@@ -1122,6 +1297,10 @@ extern "C" int hm_fwd_sync(hm_fwd* f, hm_stats* st) {
     }
     f->t_total.reset(); f->t_press.reset(); f->t_sat.reset();
     f->n_press = f->n_sat = 0;
+    if (f->inner) {
+        f->inner->t_total.reset(); f->inner->t_press.reset(); f->inner->t_sat.reset();
+        f->inner->n_press = f->inner->n_sat = 0;
+    }
     return 0;
 }
 
@@ -1169,9 +1348,11 @@ static int field_ref(hm_fwd* f, const char* name, FieldRef& r) {
 extern "C" int hm_fwd_get_field(hm_fwd* f, const char* name, void* out) {
     HM_REQUIRE(f && name && out, "hm_fwd_get_field: NULL argument");
     HM_HIP(hipSetDevice(f->ctx->device));
+    int rc = extract_fields(f);
+    if (rc) return rc;
     HM_HIP(hipStreamSynchronize(f->ctx->stream));
     FieldRef r;
-    int rc = field_ref(f, name, r);
+    rc = field_ref(f, name, r);
     if (rc) return rc;
     if (r.strided) {
         long long stride;
@@ -1188,9 +1369,13 @@ extern "C" int hm_fwd_set_field(hm_fwd* f, const char* name, const void* in) {
     HM_REQUIRE(f && name && in, "hm_fwd_set_field: NULL argument");
     ++f->inputs_gen;
     HM_HIP(hipSetDevice(f->ctx->device));
+    int rc = extract_fields(f);  // (what the caller does not set keeps the values of the last step)
+    if (rc) return rc;
     HM_HIP(hipStreamSynchronize(f->ctx->stream));
+    f->inner_S_step = -1;
+    f->inner_V_dirty = true;
     FieldRef r;
-    int rc = field_ref(f, name, r);
+    rc = field_ref(f, name, r);
     if (rc) return rc;
     if (r.strided) {
         long long stride;
@@ -1220,6 +1405,7 @@ extern "C" int hm_fwd_set_debug(hm_fwd* f, const char* key, long long value) {
     const std::string k(key);
     if (k == "nd_force_fallback") f->dbg_nd_force_fallback = (int)value;
     else if (k == "team_rounds") f->dbg_team_rounds = (int)value;
+    else if (k == "embed") f->dbg_embed = (int)value;
     else if (k == "nd_cap") {
         HM_REQUIRE(!f->nd, "hm_fwd_set_debug: \"nd_cap\" must be set before the plan's first run");
         f->dbg_nd_cap = (int)value;
@@ -1229,6 +1415,7 @@ extern "C" int hm_fwd_set_debug(hm_fwd* f, const char* key, long long value) {
 
 extern "C" void* hm_fwd_device_ptr(hm_fwd* f, const char* name) {
     if (!f || !name) return nullptr;
+    if (extract_fields(f)) return nullptr;  // (an embedded plan: a snapshot of the inner plan's fields as of the last step)
     std::string s(name);
     // (the saturation may be written through these pointers without the library seeing it: the float32 slab sweep then keeps no record of
     // which slabs are dry from one step to the next -- sat32s.hip)

@@ -86,6 +86,20 @@ struct hm_fwd {
     int dbg_nd_force_fallback = -1, dbg_nd_cap = 0;  // hm_fwd_set_debug: test / experiment knobs of the larger grids' direct solver (press_nd.hip)
     long long nd_fallbacks = 0;  // member-steps the direct solver of the larger grids handed to the two-level CG (press_nd.hip: nd_check_and_fall_back)
     long long team_retries = 0, team_retries_seen = 0;  // time steps redone by the tiled sweep after a team gave up waiting
+    // EMBEDDED GRIDS (forward.hip: embedded_inner).  A grid of at most 128 x 128 cells that no specialised kernel takes runs INSIDE a
+    // 128 x 128 plan (`inner`): its cells in the corner at the origin, the rest padded with cells of zero permeability.  This plan keeps
+    // every buffer in the caller's layout; the inner plan shares its outputs per member (status, sub-step counts, producer series).
+    hm_fwd* inner = nullptr;
+    bool is_inner = false;            // this plan IS the inner plan of another: status / nts / n_cg / prods belong to the outer plan
+    int dbg_embed = 1;                // hm_fwd_set_debug "embed": 0 = never (the generic kernels on the grid as given)
+    long long inner_K_gen = -1;       // inputs_gen the inner plan's permeability was embedded at
+    int inner_S_step = -1;            // time index whose saturation the inner plan holds (-1: none)
+    bool inner_V_dirty = false;       // face fluxes were set from the host (hm_fwd_set_field): the inner plan's are stale
+    bool fields_stale = false;        // P, Vx, Vy, TX, TY of this plan are older than the inner plan's (copied out when somebody asks)
+    double Lx = 0, Ly = 0;            // as given to hm_fwd_create, with the well lists and rates (what the inner plan is created from)
+    std::vector<int> inj_ind_host, prd_ind_host;
+    std::vector<double> inj_rates_host, prd_rates_host;
+    int inj_cols = 1, prd_cols = 1;
 };
 
 // Pointer to the saturation of (member 0, time index k) and the member stride in elements.

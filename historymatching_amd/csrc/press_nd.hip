@@ -356,6 +356,7 @@ __global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, con
             const double tx0 = ix == 0 ? 0.0 : p.cx / (L[c - NB] + L[c]), tx1 = ix == Nx - 1 ? 0.0 : p.cx / (L[c] + L[c + NB]);
             double d = ty0 + ty1 + tx0 + tx1;
             if (c == 0) d += Km[0] + Kym[0];
+            if (d == 0.0) d = 1.0;  // a cell of zero permeability (the padding of an embedded grid, forward.hip): every face closed, its equation is 1 p = 0
             cf[c] = d;
             cf[CF_OQ + c] = q[c];
         }

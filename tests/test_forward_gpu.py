@@ -297,7 +297,10 @@ def test_fp32_sweeps_equal_the_float32_specification_bit_for_bit(nx, ny, general
         _, _, status = plan.outputs(want_wsats=False)
         plan.close()
         assert not status.any()
-        if ref is None:  # the specification on the first kernel's state and fluxes; every kernel reaches the same state bit for bit
+        # the specification on the first kernel's state and fluxes; every kernel reaches the same state bit for bit -- except where the
+        # default variant runs embedded in a 128 x 128 plan (96 x 80: another pressure solver than the generic pair the other variants
+        # keep on such a grid, so another state at rounding level): there the specification is evaluated again on the new state
+        if ref is None or (max(nx, ny) < 128 and sat_variant == 1):
             ref = []
             for m in range(N):
                 set_perm(om, x[m])
@@ -880,6 +883,80 @@ def test_tile_team_timeout_is_retried_by_the_tiled_sweep(dtype):
         out[sat_variant] = (w, p, plan.get_field("nts"))
         plan.close()
     assert all(np.array_equal(a, b) for a, b in zip(out[0], out[4]))
+
+
+@pytest.mark.parametrize("nx,ny,dtype", [(100, 100, 64), (64, 96, 64), (40, 24, 64), (48, 128, 64), (100, 100, 32), (33, 57, 32)])
+def test_grids_below_128_run_embedded_in_the_128_kernels(nx, ny, dtype):
+    """A grid of at most 128 x 128 cells that is neither 128 x 128 nor small enough for the one-launch kernel runs inside a 128 x 128
+    plan, padded with cells of zero permeability (csrc/forward.hip: embedded grids).  Against the generic kernels on the grid as given
+    (hm_fwd_set_debug "embed" 0) and against the oracle:
+      * the sweep for given fluxes: the same bits as the oracle (fp64) / as the generic kernels (fp32), the same sub-step counts;
+      * transmissibilities out of the embedded plan: the same bits; pressure and fluxes: within the solvers' noise of the generic pair;
+      * a run of several steps: within the oracle's own solver noise (fp64), producer series = the history at the producers."""
+    from oracle.ressim import perm_transf, set_perm
+
+    N, steps = 3, 3
+    om, gm = make_models(nx, ny, dtype=dtype)
+    x = perms(nx, ny, N, seed=11)
+    plans = {}
+    for name in ("embedded", "generic"):
+        plan = _plan(gm, N, nTime=steps)
+        if name == "generic":
+            plan.set_debug("embed", 0)
+        plan.set_inputs(x, transformed=False)
+        plans[name] = plan
+    # --- one sweep from given fluxes (the oracle's, from a developed state)
+    S_in, Vxs, Vys, S_ref, nts_ref = [], [], [], [], []
+    for m in range(N):
+        S, q = _oracle_state(om, x[m], 2)
+        set_perm(om, x[m])
+        _, Vx, Vy = om.pressure_step(S, q)
+        S_in.append(S), Vxs.append(Vx), Vys.append(Vy)
+        S_ref.append(om.saturation_step_upwind(S, q, Vx, Vy, DT))
+        nts_ref.append(om.cfl_substeps(Vx, Vy, q, DT)[0])
+    ft = np.float64 if dtype == 64 else np.float32
+    out = {}
+    for name, plan in plans.items():
+        plan.set_field("S", np.array(S_in).astype(ft))
+        plan.set_field("Vx", np.array(Vxs))
+        plan.set_field("Vy", np.array(Vys))
+        plan.saturation_only(0)
+        out[name] = (plan.get_field("S").reshape(N, -1), plan.get_field("nts")[:, 0].copy())
+        assert out[name][1].tolist() == nts_ref
+    assert np.array_equal(out["embedded"][0], out["generic"][0])
+    if dtype == 64:
+        for m in range(N):
+            assert np.array_equal(out["embedded"][0][m], S_ref[m])
+    # --- one pressure step from that state
+    fields = {}
+    for name, plan in plans.items():
+        plan.set_field("S", np.array(S_in).astype(ft))
+        plan.pressure_only(0)
+        fields[name] = {k: plan.get_field(k) for k in ("TX", "TY", "P", "Vx", "Vy")}
+    assert np.array_equal(fields["embedded"]["TX"], fields["generic"]["TX"]) and np.array_equal(fields["embedded"]["TY"], fields["generic"]["TY"])
+    for k in ("Vx", "Vy"):
+        assert np.abs(fields["embedded"][k] - fields["generic"][k]).max() < 1e-8, k
+    pe, pg = fields["embedded"]["P"].reshape(N, -1), fields["generic"]["P"].reshape(N, -1)
+    assert np.abs(pe - pg).max() < 1e-7 * np.abs(pg).max()
+    # --- a run
+    res = {}
+    for name, plan in plans.items():
+        plan.set_inputs(x, transformed=False)
+        plan.run()
+        plan.sync()
+        w, pr, status = plan.outputs()
+        assert not status.any()
+        res[name] = (w, pr, plan.get_field("nts").copy())
+    assert np.array_equal(res["embedded"][2], res["generic"][2])
+    for m in range(N):
+        if dtype == 64:
+            ref, noise = oracle_sim_and_noise(om, x[m], DT, steps)
+            assert np.abs(res["embedded"][0][m] - ref).max() <= 10 * noise + 1e-9
+        else:
+            assert np.abs(res["embedded"][0][m].astype(np.float64) - res["generic"][0][m]).max() < 1e-4
+    assert np.abs(res["embedded"][1].astype(np.float64) - res["generic"][1]).max() < (1e-7 if dtype == 64 else 1e-4)
+    for plan in plans.values():
+        plan.close()
 
 
 @pytest.mark.parametrize("nx,ny", [(64, 128), (200, 128), (128, 64)])
