@@ -918,10 +918,10 @@ static int generic_threads(int Ny) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// EMBEDDED GRIDS.  The fast kernels are written for 128 x 128 cells (press_nd.hip, sat128r.hip, sat32s.hip); every other grid of at
-// most 128 x 128 cells used to take the generic pair -- at 100 x 100 and 1000 members 68 + 29 ms a time step against the 5.6 + 8.3 ms
-// of the LARGER 128 x 128 grid.  Such a grid now runs inside a 128 x 128 plan of the same cell size: its cells in the corner at the
-// origin, the others with permeability ZERO.  A face next to such a cell has 1 / (mobility K) = inf on one side, so its harmonic-mean
+// EMBEDDED GRIDS.  The fast kernels are written for 128 x 128, 256 x 256 and 512 x 512 cells (press_nd.hip, sat128r.hip, sat256s.hip,
+// sat32s.hip); every other grid used to take the generic pair -- at 100 x 100 and 1000 members 68 + 29 ms a time step against the
+// 5.6 + 8.3 ms of the LARGER 128 x 128 grid.  Such a grid now runs inside a plan of the next of those squares, with the same cell size:
+// its cells in the corner at the origin, the others with permeability ZERO.  A face next to such a cell has 1 / (mobility K) = inf on one side, so its harmonic-mean
 // transmissibility is c / inf = 0 exactly -- the no-flow boundary the grid has there anyway; the padding's own equations are 1 p = 0
 // (press_nd.hip gives an all-zero row a unit diagonal), its fluxes 0, its saturation stays 0 (the sweeps skip dry bands), its CFL
 // term pv / 0 = inf never is the minimum.  What the sweeps compute for the grid's own cells is the same arithmetic on the same
@@ -932,7 +932,6 @@ static int generic_threads(int Ny) {
 // Applies with the default kernel variants only: hm_fwd_set_variant(1, 1) (or hm_fwd_set_debug "embed" 0) is the generic pair on the
 // grid as given, the in-library cross-check.
 // ------------------------------------------------------------------------------------------------
-constexpr int EMB = 128;
 
 template <typename T>
 __global__ void k_embed2d(const T* __restrict__ src, long long s_ms, int s_cols, T* __restrict__ dst, long long d_ms, int d_rows, int d_cols,
@@ -962,8 +961,10 @@ static hm_fwd* embedded_inner(hm_fwd* f, int* rc_out) {
     *rc_out = 0;
     const FwdParams& p = f->p;
     if (f->is_inner || !f->dbg_embed) return nullptr;
-    if (p.Nx > EMB || p.Ny > EMB || (p.Nx == EMB && p.Ny == EMB)) return nullptr;
+    const int big = p.Nx > p.Ny ? p.Nx : p.Ny, EMB = big <= 128 ? 128 : big <= 256 ? 256 : 512;  // the square the fast kernels exist for
+    if (big > 512 || (p.Nx == EMB && p.Ny == EMB)) return nullptr;
     if (p.Ny <= 32 && p.Nxy <= 1024) return nullptr;                                   // the one-launch kernel of small grids (small.hip)
+    if (EMB > 128 && (p.Ny == 128 || (p.Nx % 128 == 0 && p.Ny % 128 == 0))) return nullptr;  // grids of 128-wide blocks / tiles keep their own kernels
     if (!(f->press_variant == 0 || f->press_variant == 12 || f->press_variant == 14) || f->sat_variant != 0) return nullptr;
     if (p.q_mstride != 0 || p.por != nullptr || p.Ky != nullptr) return nullptr;       // per-member wells, porosity field, anisotropy: generic
     if (!f->inner) {
@@ -983,6 +984,7 @@ static hm_fwd* embedded_inner(hm_fwd* f, int* rc_out) {
         // exactly the cell size of the outer grid (Lx / Nx * 128 / 128 may round differently)
         in->p.hx = p.hx; in->p.hy = p.hy; in->p.h2 = p.h2; in->p.cx = p.cx; in->p.cy = p.cy;
         f->inner = in;
+        f->emb = EMB;
         f->inner_K_gen = -1;
         f->inner_S_step = -1;
     }
@@ -994,6 +996,7 @@ static hm_fwd* embedded_inner(hm_fwd* f, int* rc_out) {
 // permeability (when the outer plan's inputs changed) and the saturation of time index k (unless the inner plan's last sweep left it there)
 static int embed_inputs(hm_fwd* f, hm_fwd* in, int k) {
     const FwdParams& p = f->p;
+    const int EMB = f->emb;
     hipStream_t s = f->ctx->stream;
     if (f->inner_K_gen != f->inputs_gen) {
         hipLaunchKernelGGL(k_embed2d<double>, EMB_GRID, (const double*)f->K.p, (long long)p.Nxy, p.Ny, (double*)in->K.p, (long long)EMB * EMB, EMB, EMB,
@@ -1019,6 +1022,7 @@ static int extract_fields(hm_fwd* f) {
     const FwdParams& p = f->p;
     hm_fwd* in = f->inner;
     hipStream_t s = f->ctx->stream;
+    const int EMB = f->emb;
     const long long e2 = (long long)EMB * EMB, ex = (long long)(EMB + 1) * EMB;
     hipLaunchKernelGGL(k_extract2d<double>, EMB_GRID, (const double*)in->P.p, e2, EMB, (double*)f->P.p, (long long)p.Nxy, p.Nx, p.Ny, p.N);
     hipLaunchKernelGGL(k_extract2d<double>, EMB_GRID, (const double*)in->Vx.p, ex, EMB, (double*)f->Vx.p, (long long)(p.Nx + 1) * p.Ny, p.Nx + 1, p.Ny, p.N);
@@ -1038,6 +1042,7 @@ static int embedded_pressure(hm_fwd* f, hm_fwd* in, int k) {
 }
 static int embedded_saturation(hm_fwd* f, hm_fwd* in, int k) {
     const FwdParams& p = f->p;
+    const int EMB = f->emb;
     hipStream_t s = f->ctx->stream;
     int rc = embed_inputs(f, in, k);
     if (rc) return rc;
@@ -1230,7 +1235,7 @@ extern "C" int hm_fwd_run(hm_fwd* f, int first_step, int n_steps) {
             if ((rc = prepare_pressure_nd(f)) || (rc = prepare_pressure_nd256(f)) || (rc = prepare_pressure_nd512(f))) return rc;
         hm_fwd* in = embedded_inner(f, &rc);
         if (rc) return rc;
-        if (in && (rc = prepare_pressure_nd(in))) return rc;
+        if (in && ((rc = prepare_pressure_nd(in)) || (rc = prepare_pressure_nd256(in)) || (rc = prepare_pressure_nd512(in)))) return rc;
     }
     if ((rc = f->t_total.begin(f->ctx->stream))) return rc;
     // small grids (the reference's default 20 x 20): the whole run as ONE launch, a wave per member (small.hip; bit-identical to the

@@ -86,10 +86,11 @@ struct hm_fwd {
     int dbg_nd_force_fallback = -1, dbg_nd_cap = 0;  // hm_fwd_set_debug: test / experiment knobs of the larger grids' direct solver (press_nd.hip)
     long long nd_fallbacks = 0;  // member-steps the direct solver of the larger grids handed to the two-level CG (press_nd.hip: nd_check_and_fall_back)
     long long team_retries = 0, team_retries_seen = 0;  // time steps redone by the tiled sweep after a team gave up waiting
-    // EMBEDDED GRIDS (forward.hip: embedded_inner).  A grid of at most 128 x 128 cells that no specialised kernel takes runs INSIDE a
-    // 128 x 128 plan (`inner`): its cells in the corner at the origin, the rest padded with cells of zero permeability.  This plan keeps
+    // EMBEDDED GRIDS (forward.hip: embedded_inner).  A grid of at most 512 x 512 cells that no specialised kernel takes runs INSIDE a
+    // 128 x 128, 256 x 256 or 512 x 512 plan (`inner`): its cells in the corner at the origin, the rest padded with cells of zero permeability.  This plan keeps
     // every buffer in the caller's layout; the inner plan shares its outputs per member (status, sub-step counts, producer series).
     hm_fwd* inner = nullptr;
+    int emb = 0;                      // side of the inner plan's square grid (128, 256 or 512)
     bool is_inner = false;            // this plan IS the inner plan of another: status / nts / n_cg / prods belong to the outer plan
     int dbg_embed = 1;                // hm_fwd_set_debug "embed": 0 = never (the generic kernels on the grid as given)
     long long inner_K_gen = -1;       // inputs_gen the inner plan's permeability was embedded at

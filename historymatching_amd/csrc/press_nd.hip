@@ -505,6 +505,7 @@ __global__ __launch_bounds__(NB) void k_ndl_assemble(FwdParams p, NdDev nd, cons
     if (iy == NB - 1) { TY[fy + 1] = 0.0; cf[CF_OY + fy + 1] = -0.0; }
     double d = ty0 + ty1 + tx0 + tx1;
     if (c == 0) d += Km[0] + Kym[0];  // SPD pin: A[0,0] += Kx[0,0] + Ky[0,0]
+    if (d == 0.0) d = 1.0;  // a cell of zero permeability (the padding of an embedded grid, forward.hip): its equation is 1 p = 0
     cf[c] = d;
     cf[CF_OQ + c] = q[c];
 }
@@ -2171,7 +2172,9 @@ static int nd_check_and_fall_back(hm_fwd* f, const void* S, long long S_stride, 
         pb.status = p.status + o;
         pb.n_cg = p.n_cg + o * p.nTime;
         f->p = pb;  // (launch_pressure_two_level reads the plan's parameter block)
-        rc = launch_pressure_two_level(f, (const char*)S + (size_t)(o * S_stride) * f->esz, S_stride, k);
+        // (the inner plan of an embedded grid, forward.hip: the padding's empty rows would make the two-level method's coarse matrix singular)
+        rc = f->is_inner ? launch_pressure_pcg(f, (const char*)S + (size_t)(o * S_stride) * f->esz, S_stride, k)
+                         : launch_pressure_two_level(f, (const char*)S + (size_t)(o * S_stride) * f->esz, S_stride, k);
         f->p = p;
         if (rc) return rc;
         f->nd_fallbacks++;

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(PT) void k_pressure_pcg(FwdParams p, const TS* __re
         const double x1 = TX[ix * Ny + iy], x2 = TX[(ix + 1) * Ny + iy];
         double dg = y1 + y2 + x1 + x2;
         if (j == 0) dg += pin;
-        return dg;
+        return dg == 0.0 ? 1.0 : dg;  // (a cell of zero permeability -- the padding of an embedded grid, forward.hip: residual 0, correction 0)
     };
     // y = A v at cell j
     auto row = [&](const double* __restrict__ v, int j, int ix, int iy) {

@@ -470,6 +470,7 @@ def test_large_grid_sim_cg_pressure(nx, ny, variant):
     x = perms(nx, ny, N, seed=23)
     plan = _plan(gm, N, nTime=steps)
     plan.set_variant(variant, 0)
+    plan.set_debug("embed", 0)  # (by default such a grid runs inside a 256 x 256 plan: test_grids_..._run_embedded...; here: the CG on the grid as given)
     plan.set_inputs(x, transformed=False)
     plan.run()
     st = plan.sync()
@@ -493,6 +494,7 @@ def test_cg_solver_reports_non_convergence():
     om, gm = make_models(n, n)
     plan = _plan(gm, N, nTime=1)
     plan.set_solver(rtol=1e-12, max_iter=5)
+    plan.set_debug("embed", 0)  # the CG on the grid as given (embedded in a 256 x 256 plan the solve is direct)
     plan.set_inputs(perms(n, n, N, seed=5), transformed=False)
     plan.run()
     plan.sync()
@@ -885,17 +887,19 @@ def test_tile_team_timeout_is_retried_by_the_tiled_sweep(dtype):
     assert all(np.array_equal(a, b) for a, b in zip(out[0], out[4]))
 
 
-@pytest.mark.parametrize("nx,ny,dtype", [(100, 100, 64), (64, 96, 64), (40, 24, 64), (48, 128, 64), (100, 100, 32), (33, 57, 32)])
-def test_grids_below_128_run_embedded_in_the_128_kernels(nx, ny, dtype):
-    """A grid of at most 128 x 128 cells that is neither 128 x 128 nor small enough for the one-launch kernel runs inside a 128 x 128
-    plan, padded with cells of zero permeability (csrc/forward.hip: embedded grids).  Against the generic kernels on the grid as given
+@pytest.mark.parametrize("nx,ny,dtype", [(100, 100, 64), (64, 96, 64), (40, 24, 64), (48, 128, 64), (100, 100, 32), (33, 57, 32),
+                                         (160, 160, 64), (96, 192, 64), (200, 150, 32), (300, 260, 64), (260, 300, 32)])
+def test_grids_run_embedded_in_the_next_square_the_fast_kernels_take(nx, ny, dtype):
+    """A grid that no specialised kernel takes (not 128 / 256 / 512 square, not made of 128-wide blocks, not small enough for the
+    one-launch kernel) runs inside a 128 x 128, 256 x 256 or 512 x 512 plan,
+    padded with cells of zero permeability (csrc/forward.hip: embedded grids).  Against the generic kernels on the grid as given
     (hm_fwd_set_debug "embed" 0) and against the oracle:
       * the sweep for given fluxes: the same bits as the oracle (fp64) / as the generic kernels (fp32), the same sub-step counts;
       * transmissibilities out of the embedded plan: the same bits; pressure and fluxes: within the solvers' noise of the generic pair;
       * a run of several steps: within the oracle's own solver noise (fp64), producer series = the history at the producers."""
     from oracle.ressim import perm_transf, set_perm
 
-    N, steps = 3, 3
+    N, steps = (3, 3) if max(nx, ny) <= 128 else (2, 2) if max(nx, ny) <= 256 else (2, 1)
     om, gm = make_models(nx, ny, dtype=dtype)
     x = perms(nx, ny, N, seed=11)
     plans = {}
@@ -908,7 +912,7 @@ def test_grids_below_128_run_embedded_in_the_128_kernels(nx, ny, dtype):
     # --- one sweep from given fluxes (the oracle's, from a developed state)
     S_in, Vxs, Vys, S_ref, nts_ref = [], [], [], [], []
     for m in range(N):
-        S, q = _oracle_state(om, x[m], 2)
+        S, q = _oracle_state(om, x[m], 2 if max(nx, ny) <= 128 else 1)
         set_perm(om, x[m])
         _, Vx, Vy = om.pressure_step(S, q)
         S_in.append(S), Vxs.append(Vx), Vys.append(Vy)
@@ -934,10 +938,11 @@ def test_grids_below_128_run_embedded_in_the_128_kernels(nx, ny, dtype):
         plan.pressure_only(0)
         fields[name] = {k: plan.get_field(k) for k in ("TX", "TY", "P", "Vx", "Vy")}
     assert np.array_equal(fields["embedded"]["TX"], fields["generic"]["TX"]) and np.array_equal(fields["embedded"]["TY"], fields["generic"]["TY"])
+    tol = 1e-8 if max(nx, ny) <= 128 else 1e-6  # (above 128 the generic pair solves by conjugate gradients to rtol 1e-12 of the residual)
     for k in ("Vx", "Vy"):
-        assert np.abs(fields["embedded"][k] - fields["generic"][k]).max() < 1e-8, k
+        assert np.abs(fields["embedded"][k] - fields["generic"][k]).max() < tol, k
     pe, pg = fields["embedded"]["P"].reshape(N, -1), fields["generic"]["P"].reshape(N, -1)
-    assert np.abs(pe - pg).max() < 1e-7 * np.abs(pg).max()
+    assert np.abs(pe - pg).max() < 10 * tol * np.abs(pg).max()
     # --- a run
     res = {}
     for name, plan in plans.items():

@@ -1,5 +1,5 @@
 """Timing of the large-grid path (CG pressure + generic saturation kernels) on shards of BASELINE configs 4 and 5.
-   python tests/tools/large_grid_timing.py [n members nTime [pressure_variant [dtype [saturation_variant]]]]   (saturation_variant 5: tile teams instead of slabs at 256 wide)"""
+   python tests/tools/large_grid_timing.py [n members nTime [pressure_variant [dtype [saturation_variant [embed]]]]]   (saturation_variant 5: tile teams instead of slabs at 256 wide)"""
 import sys
 import time
 from pathlib import Path
@@ -15,10 +15,12 @@ cases = [(256, 64, 2), (512, 16, 1)] if len(sys.argv) < 4 else [tuple(int(a) for
 pressure_variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # 9: Jacobi-CG instead of the two-level preconditioner
 dtype = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 sat_variant = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+embed = int(sys.argv[7]) if len(sys.argv) > 7 else 1           # 0: the generic kernels on the grid as given (no embedding in the next square)
 for n, N, nTime in cases:
     gm = wells_4corners(ResSim(n, n, 2, 1, dtype=dtype))
     plan = ForwardPlan(gm, N, 0.025, nTime + 1, keep_history=False, device=0)
     plan.set_variant(pressure_variant, sat_variant)
+    plan.set_debug("embed", embed)
     plan.set_inputs(perms(n, n, N, seed=3), None, transformed=False)
     plan.run(0, 1)  # first step: the lazily allocated solver buffers
     plan.sync()
