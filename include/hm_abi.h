@@ -112,7 +112,11 @@ int hm_forward_batched(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,
 #define HM_MEMBER_SYNC_TIMEOUT   16  /* a tile workgroup of the multi-tile saturation sweep gave up waiting for a neighbour */
 #define HM_MEMBER_REDO_STEP      32  /* (internal, never left set) the slab sweep let dry slabs sit a step out and water reached one: the step is redone with every slab */
 
-/* Device-resident form of the same path (what bench.py times; what ES-MDA/IES drivers chain). */
+/* Device-resident form of the same path (what bench.py times; what ES-MDA/IES drivers chain).
+ * Any grid up to 4096 cells a side.  The fast kernels exist for 128 x 128, 256 x 256 and 512 x 512 (and grids of 128-wide blocks); every
+ * other grid up to 512 x 512 -- unless it is small enough for the one-launch kernel (about 21 x 21), has per-member wells, a porosity
+ * field or anisotropic permeability -- runs EMBEDDED in the next of those squares, padded with cells of zero permeability (csrc/forward.hip):
+ * same results (sweeps bit-identical, pressure a direct solve of the same system), every buffer of this API in the caller's Nx x Ny layout. */
 int  hm_fwd_create(hm_ctx* ctx, int N, int Nx, int Ny, double Lx, double Ly,
                    int nInj, const int* inj_ind, const double* inj_rates, int inj_rate_cols,
                    int nPrd, const int* prd_ind, const double* prd_rates, int prd_rate_cols,
@@ -154,6 +158,8 @@ long long hm_fwd_slab_redos(hm_fwd* f);
  *                        where its buffers fit the device, else blocks within 64 GB); must be set before the plan's first run
  *   "team_rounds"        value = 1: the slab teams of the float32 sweep (sat32s) are launched in rounds of as many teams as are resident at
  *                        once (round 4's form) instead of one launch for the whole ensemble; 0 (default) = one launch
+ *   "embed"              value = 0: never run the grid embedded in the next square (hm_fwd_create): the generic kernels on the grid as
+ *                        given -- block elimination / conjugate gradients and the tiled sweep, the in-library cross-check; 1 (default)
  * Returns nonzero for an unknown key. */
 int  hm_fwd_set_debug(hm_fwd* f, const char* key, long long value);
 int  hm_fwd_get_outputs(hm_fwd* f, void* wsats_out, void* prods_out, int* status_per_member);     /* D2H */
