@@ -964,7 +964,7 @@ static hm_fwd* embedded_inner(hm_fwd* f, int* rc_out) {
     const int big = p.Nx > p.Ny ? p.Nx : p.Ny, EMB = big <= 128 ? 128 : big <= 256 ? 256 : 512;  // the square the fast kernels exist for
     if (big > 512 || (p.Nx == EMB && p.Ny == EMB)) return nullptr;
     if (p.Ny <= 32 && p.Nxy <= 1024) return nullptr;                                   // the one-launch kernel of small grids (small.hip)
-    if (EMB > 128 && (p.Ny == 128 || (p.Nx % 128 == 0 && p.Ny % 128 == 0))) return nullptr;  // grids of 128-wide blocks / tiles keep their own kernels
+    if (EMB > 128 && (p.Ny == 128 || (p.Nx % 128 == 0 && p.Ny % 128 == 0)) && f->dbg_embed != 2) return nullptr;  // grids of 128-wide blocks / tiles keep their own kernels ("embed" 2: they too)
     if (!(f->press_variant == 0 || f->press_variant == 12 || f->press_variant == 14) || f->sat_variant != 0) return nullptr;
     if (p.q_mstride != 0 || p.por != nullptr || p.Ky != nullptr) return nullptr;       // per-member wells, porosity field, anisotropy: generic
     if (!f->inner) {
