@@ -11,7 +11,10 @@
 // tile column out of global memory (press_nd.hip: k_big_*), their update matrices stored as whole 16 x 16 tiles.
 //
 // A front = s pivots (its separator / leaf cells) + b boundary cells (the part of the region's perimeter that is an
-// ancestor's separator) + ONE extra boundary row that carries the right-hand side.  In tiles of 16: st pivot tiles,
+// ancestor's separator) + ONE extra boundary row that carries the right-hand side.  The boundary cells of a front with children are
+// ORDERED BY CHILD (round 5): those on child 0's perimeter, those on neither's (next to the separator's ends only), those on child
+// 1's -- the assembled update matrix is then block diagonal over the children, and a tile that lies in one child's block (or in
+// neither's) skips the other child's gather altogether (NDF_KIDM; half of a front's tile gathers and more).  In tiles of 16: st pivot tiles,
 // bt = ceil((b + 1) / 16) boundary tiles.  Front position p: [0, 16 st) pivots (padded with identity rows),
 // [16 st, 16 st + b) boundary cells, 16 st + b the right-hand-side row, then padding.
 #pragma once
@@ -39,6 +42,10 @@
 #define NDF_PBOY 18    // y0 | y1 << 16 of the pivot box
 #define NDF_RBOY 19    // y0 | y1 << 16 of the region
 #define NDF_PIMG 20    // big fronts: offset (doubles) of the front's st inverse pivot tiles in a member's pivot-image scratch, else -1
+#define NDF_KIDM 21    // fronts of at most 16 tile rows: bit R = tile row R holds a position of child 0's update, bit 16 + R = of child 1's
+                       // (the pivot tiles and the right-hand-side row's tile: both); -1: no information, gather everything
+#define NDF_COFM 22    // same fronts: bit R = tile row R has a matrix coefficient against some pivot of the front (a pivot tile, the
+                       // right-hand-side row's tile, a tile with a cell next to the separator's ends); -1: no information
 
 #define ND_MAX_LEVELS 15       // 512 x 512
 // Level numbers below are those of the 128 x 128 tree; a larger grid's level is LO higher (NdInfo::lo).

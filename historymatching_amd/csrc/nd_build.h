@@ -95,6 +95,18 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
     B.dissect(root, 0, 0);
     const int nF = (1 << levels) - 1;
     if (!B.complete || (int)B.piv.size() != nF) { t.error = "grid does not dissect into the complete tree"; return false; }
+    {   // boundary cells of a front with children, ordered by child (nd.h): [child 0's | both (none on this grid) | neither's | child 1's]
+        std::vector<unsigned char> mark((size_t)Nx * Ny, 0);
+        for (int f = 0; f < nF; ++f) {
+            if (B.c0[f] < 0) continue;
+            for (int c : B.bnd[B.c0[f]]) mark[c] |= 1;
+            for (int c : B.bnd[B.c1[f]]) mark[c] |= 2;
+            static const int rank[4] = {2, 0, 3, 1};  // mark -> place
+            std::stable_sort(B.bnd[f].begin(), B.bnd[f].end(), [&](int a, int c) { return rank[mark[a]] < rank[mark[c]]; });
+            for (int c : B.bnd[B.c0[f]]) mark[c] = 0;
+            for (int c : B.bnd[B.c1[f]]) mark[c] = 0;
+        }
+    }
     for (int f = 0; f < nF; ++f)
         if (B.level[f] < 0) { t.error = "missing front"; return false; }
     {  // every cell is a pivot exactly once
@@ -180,6 +192,29 @@ inline bool nd_build_tables(int Nx, int Ny, NdTablesHost& t) {
             }
             for (size_t i = 0; i < cb.size(); ++i) where[cb[i]] = -1;
             if (found != cb.size()) { t.error = "a child's boundary does not lie inside its parent's front"; return false; }
+        }
+        // which tile rows hold anything of child 0 / child 1 / a matrix coefficient against a pivot (nd.h: NDF_KIDM, NDF_COFM)
+        F[NDF_KIDM] = F[NDF_COFM] = -1;
+        if (T <= 16 && F[NDF_C0] >= 0) {
+            const int st = F[NDF_ST], s = F[NDF_S];
+            const short* P0 = &t.cpos[(size_t)2 * F[NDF_CELLS]];
+            const short* P1 = P0 + 16 * T;
+            int km = 0, cm = 0;
+            for (int R = 0; R < T; ++R)
+                for (int i = 0; i < 16; ++i) {
+                    const int p = 16 * R + i;
+                    if (P0[p] >= 0) km |= 1 << R;
+                    if (P1[p] >= 0) km |= 0x10000 << R;
+                    bool co = R < st || C[p] == -2;
+                    if (C[p] >= 0)
+                        for (int k = 0; k < s && !co; ++k) {
+                            const int d = C[p] - C[k];
+                            co = d == 0 || d == Ny || d == -Ny || (d == 1 && C[k] % Ny != Ny - 1) || (d == -1 && C[k] % Ny != 0);
+                        }
+                    if (co) cm |= 1 << R;
+                }
+            F[NDF_KIDM] = km;
+            F[NDF_COFM] = cm;
         }
     }
     // ---- assembly recipes (nd.h)

@@ -34,6 +34,9 @@
 #ifdef HM_ND_PROF
 // cycle stamps: block 0, wave 0, lane 0.  [0..15] k_nd_top phases, [16..31] k_nd_sub (wave-front phases by level), [32..47] counts
 __device__ long long hm_nd_prof_buf[64];
+#ifndef HM_ND_PROF_TOP_WAVE
+#define HM_ND_PROF_TOP_WAVE 0  // the wave of k_nd_top's block 0 whose stamps are kept
+#endif
 #ifndef HM_ND_PROF_SUB_BLOCK
 #define HM_ND_PROF_SUB_BLOCK 0
 #endif
@@ -212,24 +215,28 @@ template <int MAXBT, bool KIDS>
 struct NdPanelRec {
     s4 rc[MAXBT + 1], r0[MAXBT + 1], r1[MAXBT + 1];
 };
+// kidm / cofm: the front's NDF_KIDM / NDF_COFM (nd.h): tile rows that hold anything of child 0 / child 1 / a coefficient against a pivot.
+// Recipes of what a tile does not have are neither loaded nor followed (they would point at the zero cell: one ds_read and one add each).
 template <int MAXBT, bool KIDS>
-__device__ __forceinline__ void nd_panel_rec_load(NdPanelRec<MAXBT, KIDS>& pr, const short* __restrict__ rec, int bt, int lane) {
+__device__ __forceinline__ void nd_panel_rec_load(NdPanelRec<MAXBT, KIDS>& pr, const short* __restrict__ rec, int bt, int lane, int kidm, int cofm) {
     constexpr int NK = KIDS ? 3 : 1;
 #pragma unroll
     for (int R = 0; R <= MAXBT; ++R) {
         const int Rc = R <= bt ? R : bt;
-        pr.rc[R] = rec_load(rec, NK * Rc, lane);
+        if ((cofm >> Rc) & 1) pr.rc[R] = rec_load(rec, NK * Rc, lane);
         if (KIDS) {
-            pr.r0[R] = rec_load(rec, NK * Rc + 1, lane);
-            pr.r1[R] = rec_load(rec, NK * Rc + 2, lane);
+            if ((kidm >> Rc) & 1) pr.r0[R] = rec_load(rec, NK * Rc + 1, lane);
+            if ((kidm >> (16 + Rc)) & 1) pr.r1[R] = rec_load(rec, NK * Rc + 2, lane);
         }
     }
 }
 
 template <int MAXBT, bool KIDS>
 __device__ __forceinline__ void nd_wave_front(int bt, int kreg, const NdPanelRec<MAXBT, KIDS>& pr, const short* __restrict__ rec, const double* blk,
-                                              double* out, double* __restrict__ fa, const NdGeo& g, int& bad) {
+                                              double* out, double* __restrict__ fa, const NdGeo& g, int& bad, int kidm, int cofm) {
     constexpr int NK = KIDS ? 3 : 1;
+    // a trailing tile (R, C) takes child c's update where both its rows and its columns hold something of it
+    const int both0 = kidm & 0xffff, both1 = (kidm >> 16) & 0xffff;
     // ---- recipes of the trailing tiles, one tile row at a time: row 1 requested now (used after the sweep), row R + 1 while row R
     // is computed (all rows at once would be 126 registers for a level-5 front)
     const short* rect = rec + (long long)NK * (bt + 1) * 256;
@@ -241,8 +248,8 @@ __device__ __forceinline__ void nd_wave_front(int bt, int kreg, const NdPanelRec
             const int t = R * (R - 1) / 2 + C - 1;
             const int tc = R <= bt ? t : 0;
             if (KIDS) {
-                t0[buf][C - 1] = rec_load(rect, NK * tc, g.lane);
-                t1[buf][C - 1] = rec_load(rect, NK * tc + 1, g.lane);
+                if ((both0 >> R) & (both0 >> C) & 1) t0[buf][C - 1] = rec_load(rect, NK * tc, g.lane);
+                if ((both1 >> R) & (both1 >> C) & 1) t1[buf][C - 1] = rec_load(rect, NK * tc + 1, g.lane);
             }
             to[buf][C - 1] = rec_load(rect, NK * tc + NK - 1, g.lane);
         }
@@ -253,10 +260,13 @@ __device__ __forceinline__ void nd_wave_front(int bt, int kreg, const NdPanelRec
 #pragma unroll
     for (int R = 0; R <= MAXBT; ++R) {
         if (R > bt) break;  // (tile rows beyond bt are never used below)
+        const bool hc = (cofm >> R) & 1, h0 = KIDS && ((both0 >> R) & 1), h1 = KIDS && ((both1 >> R) & 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double v = rec_val(blk, pr.rc[R][r]);
-            if (KIDS) v += rec_val(blk, pr.r0[R][r]) + rec_val(blk, pr.r1[R][r]);
+            double v = hc ? rec_val(blk, pr.rc[R][r]) : 0.0;
+            if (h0 && h1) v += rec_val(blk, pr.r0[R][r]) + rec_val(blk, pr.r1[R][r]);
+            else if (h0) v += rec_val(blk, pr.r0[R][r]);
+            else if (h1) v += rec_val(blk, pr.r1[R][r]);
             V[R][r] = v;
         }
     }
@@ -287,8 +297,17 @@ __device__ __forceinline__ void nd_wave_front(int bt, int kreg, const NdPanelRec
         for (int C = 1; C <= R; ++C) {
             d4 acc = {0.0, 0.0, 0.0, 0.0};
             if (KIDS) {
+                const bool a0 = (both0 >> R) & (both0 >> C) & 1, a1 = (both1 >> R) & (both1 >> C) & 1;
+                if (a0 && a1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = rec_val(blk, t0[R & 1][C - 1][r]) + rec_val(blk, t1[R & 1][C - 1][r]);
+                    for (int r = 0; r < 4; ++r) acc[r] = rec_val(blk, t0[R & 1][C - 1][r]) + rec_val(blk, t1[R & 1][C - 1][r]);
+                } else if (a0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = rec_val(blk, t0[R & 1][C - 1][r]);
+                } else if (a1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = rec_val(blk, t1[R & 1][C - 1][r]);
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -797,6 +816,8 @@ __global__ __launch_bounds__(64 * SUB_WPB) void k_nd_sub(FwdParams p, NdDev nd, 
     auto recp = [&](const int* F) { return nd.rec + (long long)__builtin_amdgcn_readfirstlane(F[NDF_REC]) * 256; };
     auto btof = [&](const int* F) { return __builtin_amdgcn_readfirstlane(F[NDF_BT]); };
     auto krof = [&](const int* F) { return __builtin_amdgcn_readfirstlane(F[NDF_KREG]); };
+    auto kidof = [&](const int* F) { return __builtin_amdgcn_readfirstlane(F[NDF_KIDM]); };
+    auto cofof = [&](const int* F) { return __builtin_amdgcn_readfirstlane(F[NDF_COFM]); };
     const int* F10[4];
     const int* F9[2];
 #pragma unroll
@@ -814,7 +835,7 @@ __global__ __launch_bounds__(64 * SUB_WPB) void k_nd_sub(FwdParams p, NdDev nd, 
     };
     static_assert(true, "slot10 <= 128 doubles is checked on the host (nd_setup)");
     double2 lf0 = leaf_d2(0), lf1 = leaf_d2(1), lf2 = leaf_d2(2), lf3 = leaf_d2(3);
-    nd_panel_rec_load(pp, recp(F9[0]), btof(F9[0]), g.lane);
+    nd_panel_rec_load(pp, recp(F9[0]), btof(F9[0]), g.lane, kidof(F9[0]), cofof(F9[0]));
     NdCfl L;
     nd_stage_cf(cf, cfl, SUB_CF_PLANE, nd_box(F8, NDF_RBOX), g.lane, L);
     {
@@ -824,8 +845,8 @@ __global__ __launch_bounds__(64 * SUB_WPB) void k_nd_sub(FwdParams p, NdDev nd, 
     }
     nd_wave_fence();
     NPROF(0);
-    nd_wave_front<2, true>(btof(F9[0]), krof(F9[0]), pp, recp(F9[0]), blk, s9, fact + F9[0][NDF_FACT], g, bad);
-    nd_panel_rec_load(pp, recp(F9[1]), btof(F9[1]), g.lane);
+    nd_wave_front<2, true>(btof(F9[0]), krof(F9[0]), pp, recp(F9[0]), blk, s9, fact + F9[0][NDF_FACT], g, bad, kidof(F9[0]), cofof(F9[0]));
+    nd_panel_rec_load(pp, recp(F9[1]), btof(F9[1]), g.lane, kidof(F9[1]), cofof(F9[1]));
     nd_wave_fence();
     {
         double2* a2 = reinterpret_cast<double2*>(s10);
@@ -834,11 +855,11 @@ __global__ __launch_bounds__(64 * SUB_WPB) void k_nd_sub(FwdParams p, NdDev nd, 
     }
     nd_wave_fence();
     NPROF(1);
-    nd_wave_front<2, true>(btof(F9[1]), krof(F9[1]), pp, recp(F9[1]), blk, s9 + nd.slot9, fact + F9[1][NDF_FACT], g, bad);
-    nd_panel_rec_load(pp, recp(F8), btof(F8), g.lane);
+    nd_wave_front<2, true>(btof(F9[1]), krof(F9[1]), pp, recp(F9[1]), blk, s9 + nd.slot9, fact + F9[1][NDF_FACT], g, bad, kidof(F9[1]), cofof(F9[1]));
+    nd_panel_rec_load(pp, recp(F8), btof(F8), g.lane, kidof(F8), cofof(F8));
     nd_wave_fence();
     NPROF(2);
-    nd_wave_front<2, true>(btof(F8), krof(F8), pp, recp(F8), blk, arena + F8[NDF_UPD], fact + F8[NDF_FACT], g, bad);
+    nd_wave_front<2, true>(btof(F8), krof(F8), pp, recp(F8), blk, arena + F8[NDF_UPD], fact + F8[NDF_FACT], g, bad, kidof(F8), cofof(F8));
     NPROF(3);
 #ifdef HM_ND_PROF
     if (blockIdx.x == HM_ND_PROF_SUB_BLOCK && tid == 0)
@@ -882,8 +903,9 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     const int n0 = (((bc0 + 1) * (bc0 + 2) >> 1) + 1) & ~1, n1 = (((bc1 + 1) * (bc1 + 2) >> 1) + 1) & ~1;
     const int bt = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
     const short* rec = nd.rec + (long long)__builtin_amdgcn_readfirstlane(F[NDF_REC]) * 256;
+    const int kidm = __builtin_amdgcn_readfirstlane(F[NDF_KIDM]), cofm = __builtin_amdgcn_readfirstlane(F[NDF_COFM]);
     NdPanelRec<MAXBT, true> pr;
-    nd_panel_rec_load(pr, rec, bt, g.lane);  // in flight beside the bulk copies below
+    nd_panel_rec_load(pr, rec, bt, g.lane, kidm, cofm);  // in flight beside the bulk copies below
     nd_wave_copy(c0l, arena + F[NDF_UC0], n0, g.lane);
     nd_wave_copy(c1l, arena + F[NDF_UC1], n1, g.lane);
     NdCfl L;
@@ -891,7 +913,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA pieces have landed
     nd_wave_fence();
     int bad = 0;
-    nd_wave_front<MAXBT, true>(bt, __builtin_amdgcn_readfirstlane(F[NDF_KREG]), pr, rec, blk, arena + F[NDF_UPD], fact + F[NDF_FACT], g, bad);
+    nd_wave_front<MAXBT, true>(bt, __builtin_amdgcn_readfirstlane(F[NDF_KREG]), pr, rec, blk, arena + F[NDF_UPD], fact + F[NDF_FACT], g, bad, kidm, cofm);
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
@@ -994,7 +1016,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
         for (int idx = 0; idx < nt; ++idx) {
             const int f = __builtin_amdgcn_readfirstlane(tlist[1 + idx]);
 #ifdef HM_ND_PROF
-            if (blockIdx.x == 0 && tid == 0)
+            if (blockIdx.x == 0 && tid == 64 * HM_ND_PROF_TOP_WAVE)
                 for (int lv = 4; lv >= 0; --lv)
                     if (f == (1 << lv) - 1 || (idx == 0 && f >= (1 << lv) - 1 && f < (2 << lv) - 1)) hm_nd_prof_buf[48 + lv] = clock64();
 #endif
@@ -1058,24 +1080,35 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
             __syncthreads();
             NPROF(1);
-            // ---- coefficients + child 0
+            // ---- coefficients + child 0.  The boundary rows of a front are ordered by child (nd.h): a tile whose rows or columns hold
+            // nothing of a child skips that child's gather, a panel tile with no cell next to a pivot its coefficient loads (round 5:
+            // 114 -> 56 tile gathers for a level-4 front)
+            const int kidm = __builtin_amdgcn_readfirstlane(F[NDF_KIDM]), cofm = __builtin_amdgcn_readfirstlane(F[NDF_COFM]);
+            auto has = [&](int c, int R) { return ((kidm >> (16 * c + R)) & 1) != 0; };  // (tile row R < 16 whenever kidm != -1)
 #pragma unroll
             for (int s = 0; s < TOP_NVS; ++s) {
                 vt[s] = d4{0.0, 0.0, 0.0, 0.0};
                 if (vq[s] >= 0) {
                     const int pm = 16 * vR[s] + g.lc;
-                    const int cm = cl_s[pm], pm0 = cp_s0[pm];
+                    if ((cofm >> vR[s]) & 1) {
+                        const int cm = cl_s[pm];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int pk = 16 * vq[s] + 4 * r + g.lq;
-                        vt[s][r] = nd_coef_global(cf, cm, cl_s[pk], pk == pm) + nd_gather(chl, cp_s0[pk], pm0);
+                        for (int r = 0; r < 4; ++r) {
+                            const int pk = 16 * vq[s] + 4 * r + g.lq;
+                            vt[s][r] = nd_coef_global(cf, cm, cl_s[pk], pk == pm);
+                        }
+                    }
+                    if (has(0, vR[s])) {
+                        const int pm0 = cp_s0[pm];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vt[s][r] += nd_gather(chl, cp_s0[16 * vq[s] + 4 * r + g.lq], pm0);
                     }
                 }
             }
 #pragma unroll
             for (int s = 0; s < TOP_NTS; ++s) {
                 tr[s] = d4{0.0, 0.0, 0.0, 0.0};
-                if (tR[s] >= 0) {
+                if (tR[s] >= 0 && has(0, tR[s]) && has(0, tC[s])) {
                     const int pc0 = cp_s0[16 * tC[s] + g.lc];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) tr[s][r] = nd_gather(chl, cp_s0[16 * tR[s] + 4 * r + g.lq], pc0);
@@ -1093,7 +1126,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             // ---- child 1
 #pragma unroll
             for (int s = 0; s < TOP_NVS; ++s) {
-                if (vq[s] >= 0) {
+                if (vq[s] >= 0 && has(1, vR[s])) {
                     const int pm1 = cp_s1[16 * vR[s] + g.lc];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vt[s][r] += nd_gather(ch1, cp_s1[16 * vq[s] + 4 * r + g.lq], pm1);
@@ -1101,7 +1134,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             }
 #pragma unroll
             for (int s = 0; s < TOP_NTS; ++s) {
-                if (tR[s] >= 0) {
+                if (tR[s] >= 0 && has(1, tR[s]) && has(1, tC[s])) {
                     const int pc1 = cp_s1[16 * tC[s] + g.lc];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) tr[s][r] += nd_gather(ch1, cp_s1[16 * tR[s] + 4 * r + g.lq], pc1);
@@ -1216,7 +1249,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
         }
     }
 #ifdef HM_ND_PROF
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blockIdx.x == 0 && tid == 64 * HM_ND_PROF_TOP_WAVE) {
         for (int i = 0; i < 16; ++i) hm_nd_prof_buf[i] = prof_acc[i];
         hm_nd_prof_buf[53] = clock64();
     }
