@@ -422,7 +422,8 @@ def main():
     ap.add_argument("--no-esmda", action="store_true", help="skip the 4-pass ES-MDA leg (config 3)")
     ap.add_argument("--no-host-call", action="store_true", help="skip the PCIe-inclusive leg (the drop-in call with host arrays in and out)")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (N_e=4096 at 256x256 over the ranks)")
-    ap.add_argument("--no-two-streams", action="store_true", help="skip the two-stream leg (profiling runs: one kernel shape per name)")
+    ap.add_argument("--no-two-streams", action="store_true", help="the timed region as ONE member block on one stream (profiling runs: one kernel shape per name, no overlapping launches); same as --blocks 1")
+    ap.add_argument("--blocks", type=int, default=0, help="member blocks (HIP streams) of the timed region; 0 = the library's default for the ensemble (forward.default_blocks)")
     ap.add_argument("--config5", action="store_true", help="run the WHOLE config-5 leg (N_e=1000 at 512x512, localised) also below 4 ranks (default there: one GPU's shard of 125 members)")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -441,7 +442,7 @@ def main():
 
     from historymatching_amd import _lib
     from historymatching_amd.dist import Comm
-    from historymatching_amd.forward import ForwardPlan
+    from historymatching_amd.forward import BlockedForwardPlan, ForwardPlan, default_blocks
     from historymatching_amd.geostat import gaussian_fields_kron
 
     comm = Comm.from_env()
@@ -471,7 +472,15 @@ def main():
     model = build_model(64, device=local_rank)
     n_e = args.members
     perms = gaussian_fields_kron(NX, NY, 2, 1, n_e, r=0.8, seed=1 + rank)  # synthetic prior, SURVEY.md 8d
-    plan = ForwardPlan(model, n_e, DT, NTIME, keep_history=True, device=local_rank)
+    # The timed region runs the ensemble the way the library's forward_model runs it (forward.make_forward_model): as
+    # default_blocks(model, N) member blocks, each on a HIP stream of its own, launches interleaved time step by time step -- at
+    # N_e = 1000 three blocks: the pressure solve of one block (latency at modest occupancy) runs beside the sweeps of the others
+    # and fills the partial last rounds of their launches.  Members are independent; the results are bit-identical to one block's
+    # (checked below).  Per-kernel launch times, which the roofline needs, are taken from a ONE-block pass of the same workload
+    # right behind the timed region (kernels of different streams overlap in the blocked run: their event times are not
+    # durations of one kernel on an otherwise idle device).
+    n_blocks = 1 if (args.no_two_streams or args.variant != 0) else (args.blocks or default_blocks(model, n_e))
+    plan = BlockedForwardPlan(model, n_e, DT, NTIME, keep_history=True, device=local_rank, blocks=n_blocks)
     plan.set_variant(args.variant, args.variant)
     plan.set_inputs(perms, None, transformed=False)  # inputs resident in HBM before the timed region
 
@@ -479,17 +488,40 @@ def main():
         plan.run(0, NTIME)
     plan.sync()
 
-    comm.barrier()           # all ranks' devices are idle here: plan.sync() above is a stream synchronisation
+    comm.barrier()           # all ranks' devices are idle here: plan.sync() above is a stream synchronisation per block
     t0 = time.perf_counter()
     for _ in range(args.steps):
         plan.run(0, NTIME)
-    stats = plan.sync()      # hipStreamSynchronize on the launch stream + event read-out
+    stats = plan.sync()      # hipStreamSynchronize on every block's launch stream + event read-out
     comm.barrier()
     elapsed = comm.all_reduce_max(time.perf_counter() - t0)
 
     _, prods, status = plan.outputs(want_wsats=False)
     ok = not status.any() and np.isfinite(prods).all()
     plan.close()
+
+    blocks_info = {"n": n_blocks, "bounds": plan.bounds, "device_ms_longest_block": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
+                   "how": "member blocks on HIP streams of their own, launches interleaved time step by time step from one host thread (forward.BlockedForwardPlan; "
+                          "forward_model runs every large ensemble on the 128 x 128 kernels this way)"}
+    if n_blocks > 1:
+        # the same workload as ONE block on one stream: the per-kernel statistics below (and the roofline) come from here
+        one = ForwardPlan(model, n_e, DT, NTIME, keep_history=True, device=local_rank)
+        one.set_variant(args.variant, args.variant)
+        one.set_inputs(perms, None, transformed=False)
+        one.run(0, NTIME)
+        one.sync()
+        passes1 = max(1, min(args.steps, 3))
+        t1 = time.perf_counter()
+        for _ in range(passes1):
+            one.run(0, NTIME)
+        stats = one.sync()
+        wall1 = (time.perf_counter() - t1) / passes1
+        p1 = one.outputs(want_wsats=False)[1]
+        one.close()
+        blocks_info["one_block"] = {"value": n_e * NTIME / wall1, "unit": "ensemble-steps/s", "ms_per_pass": 1e3 * wall1, "passes": passes1,
+                                    "producer_series_identical_to_the_blocked_run": bool(np.array_equal(p1, prods)),
+                                    "note": "this rank's ensemble as one member block on one stream; `roofline`, `device_ms` and avg_launch_ms are this pass's"}
+        ok = ok and blocks_info["one_block"]["producer_series_identical_to_the_blocked_run"]
 
     def guarded(leg):
         """Run a leg every rank takes part in; if it fails on any rank, every rank reports the error instead of a result
@@ -502,40 +534,6 @@ def main():
         msgs = comm.host.all_gather(err) if world > 1 else [err]
         bad = [m for m in msgs if m]
         return {"error": "; ".join(bad)} if bad else res
-
-    # The same workload as two member blocks on two HIP streams (members are independent; the partial last round of one kernel --
-    # 1000 members are 3.9 rounds of 256 CUs -- is filled by the other block's kernels).  Reported beside `value`, which stays the
-    # one-stream figure its per-kernel roofline refers to.
-    two_streams = None
-    if world == 1 and args.variant == 0 and not args.no_two_streams:
-        try:
-            ctx2 = _lib.Context.secondary(local_rank)
-            halves = []
-            for c, lo, hi in ((ctx, 0, n_e // 2), (ctx2, n_e // 2, n_e)):
-                hp = ForwardPlan(model, hi - lo, DT, NTIME, keep_history=True, ctx=c)
-                hp.set_inputs(perms[lo:hi], None, transformed=False)
-                halves.append(hp)
-
-            def both(reps):
-                for _ in range(reps):
-                    for k in range(NTIME):
-                        for hp in halves:
-                            hp.run(k, 1)
-                for hp in halves:
-                    hp.sync()
-
-            both(1)
-            t1 = time.perf_counter()
-            both(2)
-            wall2 = (time.perf_counter() - t1) / 2
-            p2 = np.concatenate([hp.outputs(want_wsats=False)[1] for hp in halves])
-            two_streams = {"value": n_e * NTIME / wall2, "unit": "ensemble-steps/s", "ms_per_pass": 1e3 * wall2,
-                           "producer_series_identical_to_one_stream": bool(np.array_equal(p2, prods)),
-                           "how": "two plans of N_e/2 members on two streams of one GPU, launches interleaved step by step"}
-            for hp in halves:
-                hp.close()
-        except Exception as e:
-            two_streams = {"error": str(e)}
 
     # The same workload through the drop-in call itself -- forward_model(perms) -> [wsats (N, 41, Nxy), prods] with host arrays in
     # and the whole 5.4 GB saturation history out (HistoryMatch.py:383-387).  PCIe-inclusive; reported beside `value`, never as it.
@@ -554,8 +552,8 @@ def main():
                          "bytes_in": int(perms.nbytes), "bytes_out": int(w_h.nbytes + p_h.nbytes),
                          "producer_series_identical_to_device_resident_run": bool(np.array_equal(p_h, prods)),
                          "how": "forward_model(perms) of the host mirror: host arrays in, saturation history of every member and step out "
-                                "(copied out time index by time index while the run goes on: hm_fwd_run_to_host); as forward_model runs every ensemble of 512 members "
-                                "or more on these kernels: two member blocks on two streams, a host thread each"}
+                                "(copied out time index by time index while the run goes on: hm_fwd_run_to_host); as forward_model runs every large ensemble "
+                                "on these kernels: member blocks on streams of their own (forward.default_blocks), a host thread each"}
             fm.release()
             del w_h, p_h, fm
         except Exception as e:
@@ -621,6 +619,9 @@ def main():
             # (`stale_inputs`), `frac` is a number priced with another build's counts -- kept, but flagged.  The executed / algorithmic
             # ratio is a committed measurement (profiles/rNN/fp64_roofline.json), not re-measured in this run.
             "frac_valid": not stale, "executed_ratio_measured_in_this_run": False,
+            "launch_times_measured_in": ("the timed region" if n_blocks == 1 else
+                                         f"a one-block pass of the same workload right behind the timed region ({blocks_info['one_block']['passes']} passes, HIP events on the "
+                                         "launch stream): the timed region runs the ensemble as member blocks on several streams, whose kernels overlap"),
             "stale_inputs": bool(stale), "stale_inputs_detail": stale or None,
             "inputs_taken_from_objects": recorded, "objects_run": {k: built.get(k) for k in ("sat128r.o", "press_nd.o")},
             "unit_note": "for bound fp64_valu `achieved` is an issue-slot rate: DP lane-instructions/s x 2 (every DP VALU instruction priced as one FMA "
@@ -707,7 +708,7 @@ def main():
                        "ranks": "one process per GPU, host channel for barriers/timing, RCCL from the library for the update's reductions (no PyTorch)"},
             "ranks": {"world": world, "rccl_communicator_ranks": (world if all(r["rccl"] for r in rank_info) else 0), "rccl_error": comm.rccl_error,
                       "per_rank": rank_info, "self_launched": os.environ.get("HM_BENCH_SELF_LAUNCHED") == "1"},
-            "roofline": roofline, "cpu_baseline": cpu, "two_streams": two_streams, "host_call": host_call, "es_update": upd, "config4": c4, "config5": c5,
+            "roofline": roofline, "cpu_baseline": cpu, "blocks": blocks_info, "host_call": host_call, "es_update": upd, "config4": c4, "config5": c5,
             "device_ms": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
         }
         print(json.dumps(out), flush=True)

@@ -165,6 +165,80 @@ class ForwardPlan:
         return self.lib.hm_fwd_device_ptr(self.h, name.encode())
 
 
+def default_blocks(model, N):
+    """Member blocks a forward run of ``N`` members is split into (each on its own HIP stream): three (two below 768 members) for a
+    large ensemble on the 128 x 128 kernels -- the pressure solve of one block (latency at modest occupancy, matrix pipes) runs beside
+    the saturation sweeps (vector pipe) of the others and fills the partial last round of their launches (1000 workgroups are 3.9 rounds
+    of 256 CUs) -- one otherwise.  Config 2 on one MI355X (profiles/diag/blocks_time.py, round 5): 565 / 549 / 535-540 / 552-564 / 556 ms
+    per pass with 1 / 2 / 3 / 4 / 5 equal blocks.  Members are independent (HistoryMatch.py:376-380): the results are bit-identical
+    to the one-block run."""
+    if model.Nx != 128 or model.Ny != 128:
+        return 1
+    return 3 if N >= 768 else 2 if N >= 512 else 1
+
+
+class BlockedForwardPlan:
+    """A device-resident ensemble as ``default_blocks`` member blocks, each a ``ForwardPlan`` on a stream of its own; ``run`` queues
+    the blocks' launches interleaved time step by time step from the calling thread (nothing waits for the device).  The same
+    arrangement ``make_forward_model`` uses for its host-array calls (there with a host thread per block, for the copies)."""
+
+    def __init__(self, model: ResSim, N, dt, nTime, keep_history=True, device=None, blocks=None, bounds=None):
+        device = model.device if device is None else device
+        if bounds is None:
+            blocks = default_blocks(model, N) if blocks is None else int(blocks)
+            bounds = np.linspace(0, N, blocks + 1).astype(int)
+        self.bounds = [int(b) for b in bounds]
+        assert self.bounds[0] == 0 and self.bounds[-1] == N and all(a < b for a, b in zip(self.bounds[:-1], self.bounds[1:]))
+        self.N, self.nTime, self.model, self.keep_history = int(N), int(nTime), model, bool(keep_history)
+        ctxs = [_lib.Context.get(device)] + [_lib.Context.secondary(device, i) for i in range(len(self.bounds) - 2)]
+        self.plans = [ForwardPlan(model, hi - lo, dt, nTime, keep_history=keep_history, ctx=c)
+                      for c, lo, hi in zip(ctxs, self.bounds[:-1], self.bounds[1:])]
+        self.ft = self.plans[0].ft
+
+    def close(self):
+        for pl in self.plans:
+            pl.close()
+
+    def set_variant(self, pressure=0, saturation=0):
+        for pl in self.plans:
+            pl.set_variant(pressure, saturation)
+
+    def set_inputs(self, perms, wsat0s=None, transformed=False):
+        perms = _lib.as_c(perms, np.float64)
+        if perms.shape != (self.N, self.model.Nxy):
+            raise ValueError(f"perms must have shape {(self.N, self.model.Nxy)}, got {perms.shape}")
+        for pl, lo, hi in zip(self.plans, self.bounds[:-1], self.bounds[1:]):
+            pl.set_inputs(perms[lo:hi], None if wsat0s is None else wsat0s[lo:hi], transformed=transformed)
+
+    def run(self, first_step=0, n_steps=None):
+        n = self.nTime - first_step if n_steps is None else n_steps
+        if len(self.plans) == 1:
+            return self.plans[0].run(first_step, n)
+        for k in range(first_step, first_step + n):
+            for pl in self.plans:
+                pl.run(k, 1)
+
+    def sync(self):
+        """Waits for every block; device times are the longest block's, counts add up."""
+        sts = [pl.sync() for pl in self.plans]
+        st = dict(sts[0])
+        for r in sts[1:]:
+            for key, v in r.items():
+                if key.startswith("ms_"):
+                    st[key] = max(st[key], v)
+                elif key.startswith("mean_"):
+                    st[key] = (st[key] + v) / 2
+                elif isinstance(v, (int, float)):
+                    st[key] = st[key] + v
+        st["blocks"] = len(self.plans)
+        return st
+
+    def outputs(self, want_wsats=True):
+        outs = [pl.outputs(want_wsats) for pl in self.plans]
+        return (np.concatenate([o[0] for o in outs]) if want_wsats else None, np.concatenate([o[1] for o in outs]),
+                np.concatenate([o[2] for o in outs]))
+
+
 def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True):
     """Build the notebook's ``forward_model`` for a given base ``model`` (HistoryMatch.py:358-387).
 
@@ -195,13 +269,10 @@ def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True
         # The device plans (22 GB of buffers at N_e = 1000, 128 x 128) are kept between calls: creating and freeing them costs
         # 0.25 s per call, a fifth of the run itself.  They are rebuilt when the ensemble size or the model's wells / rates /
         # fluid / porosity change.
-        # A large ensemble on the 128 x 128 kernels runs as TWO member blocks on two streams, each driven by its own host
-        # thread: the pressure solve (matrix pipes, three SIMDs) of one block runs beside the saturation sweep (vector pipe) of
-        # the other and fills the partial last round of its launches -- 41.0 k against 39.3 k ensemble-steps/s at config 2
-        # (tests/tools/multi_stream_timing.py; three or more blocks are slower).  Members are independent: results are
-        # bit-identical to the one-block run.
+        # A large ensemble on the 128 x 128 kernels runs as member blocks on streams of their own (default_blocks), each driven by
+        # its own host thread (the copies of a block's history go out beside the other blocks' kernels); bit-identical to one block.
         N = len(perms)
-        blocks = 2 if (N >= 512 and model.Nx == 128 and model.Ny == 128) else 1
+        blocks = default_blocks(model, N)
         inj_ind, inj, prd_ind, prd = model._wells(nTime)
         sig = (N, blocks, model.dtype, inj_ind.tobytes(), inj.tobytes(), prd_ind.tobytes(), prd.tobytes(), model.vw, model.vo, model.swc,
                model.sor, None if model.por is None else np.asarray(model.por, dtype=float).tobytes())

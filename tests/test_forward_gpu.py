@@ -394,6 +394,36 @@ def test_large_ensemble_runs_as_two_member_blocks_with_identical_results():
     fm.release()
 
 
+def test_device_resident_ensemble_in_member_blocks_is_bit_identical():
+    """forward.BlockedForwardPlan (what bench.py times, and the arrangement forward_model uses): an ensemble of 768 members or more on the
+    128 x 128 kernels is three member blocks on three streams, launches interleaved step by step; uneven bounds work as well; outputs and
+    member order equal the one-block plan's bit for bit, the statistics cover all blocks."""
+    from historymatching_amd.forward import BlockedForwardPlan, default_blocks
+
+    n, N, nT = 128, 770, 3
+    _, gm = make_models(n, n)
+    assert (default_blocks(gm, 1000), default_blocks(gm, 767), default_blocks(gm, 511)) == (3, 2, 1)
+    x = perms(n, n, N, seed=31)
+    plan = _plan(gm, N, nTime=nT)
+    plan.set_inputs(x, None, transformed=False)
+    plan.run()
+    st_ref = plan.sync()
+    w_ref, p_ref, status = plan.outputs()
+    plan.close()
+    assert not status.any()
+    for kw in (dict(), dict(bounds=[0, 100, 770])):
+        bp = BlockedForwardPlan(gm, N, DT, nT, keep_history=True, **kw)
+        assert len(bp.plans) == (3 if not kw else 2)
+        bp.set_inputs(x, None, transformed=False)
+        bp.run(0, 2)
+        bp.run(2, 1)
+        st = bp.sync()
+        w, p, status = bp.outputs()
+        bp.close()
+        assert not status.any() and np.array_equal(w, w_ref) and np.array_equal(p, p_ref)
+        assert st["member_steps"] == st_ref["member_steps"] == N * nT and st["n_saturation_launches"] == len(bp.plans) * nT
+
+
 def test_restart_from_member_states_and_order():
     """forward_model(perms, wsat0s): two zipped ensembles, member order preserved (HistoryMatch.py:1224-1227)."""
     from oracle.ressim import forward_model as oracle_forward
