@@ -305,7 +305,7 @@ def test_config5_grid_properties_over_steps(dtype):
     tol = 1e-9 if dtype == 64 else 1e-6
     assert not status.any() and np.abs(prods).max() == 0
     S_end = S_end.astype(float)
-    assert S_end.min() >= -tol and S_end.max() <= 1 + (tol if dtype == 64 else 1e-4)  # fp32: the injector's cell holds fw = 1 to a float32 ulp
+    assert S_end.min() >= -tol and S_end.max() <= 1 + (tol if dtype == 64 else 1e-3)  # fp32: the injector's cell creeps above 1 (see test_config5_shard_whole_run_properties)
     water = S_end.sum(1) * (gm.Lx / n) * (gm.Ly / n)
     assert np.abs(water - steps * DT).max() < (1e-9 if dtype == 64 else 1e-6)  # fp32: the compensated pair of csrc/sat32.h (1e-4 before it)
     plan = ForwardPlan(gm, 2, DT, steps, keep_history=False)
@@ -349,7 +349,12 @@ def test_config5_shard_whole_run_properties():
     assert worst < 3e-5, worst
     S64, p64 = S_end.astype(float), prods.astype(float)
     tol = 1e-6
-    assert S64.min() >= -tol and S64.max() <= 1 + 1e-4 and np.isfinite(p64).all()  # (the injector's cell holds fw = 1 to a float32 ulp)
+    # The injector's cell sits at S = 1 (fw = 1): it is stationary when the float32-rounded scaled inflow equals the sum of the four
+    # float32-rounded scaled outflows, which holds to a few float32 ulps of d q only -- a bias that is the same in every sub-step of a
+    # time step, so the cell creeps above 1 by up to 9 831 x that residual per time step.  How far depends on the last bits of the
+    # fluxes: 8.4e-5 with round 4's boundary order in the pressure solve, 1.7e-4 (one member of the 125) with round 5's
+    # (profiles/diag/c5_smax.py).  The bar is the fp32 mode's stated 1e-3 on S, not the value of one build.
+    assert S64.min() >= -tol and S64.max() <= 1 + 1e-3 and np.isfinite(p64).all()
     assert (np.diff(p64, axis=1) >= -tol).all()
     fw = lambda s: s * s / (s * s + (1 - s) * (1 - s))  # noqa: E731
     water = S64.sum(1) * (gm.Lx / n) * (gm.Ly / n)
