@@ -935,12 +935,12 @@ constexpr int TOP_MAXT = LG == 7 ? 13 : (LG == 8 ? 25 : 49);  // tile rows of th
 
 // A child's packed update matrix (n2 double2), arena -> LDS, by the whole workgroup through LDS-DMA (global_load_lds_dwordx4: no
 // registers, every piece in flight at once, retired by the issuing wave's vmcnt): pieces of 64 double2 = 1 KB, wave w takes pieces
-// w, w + 16, ...; the lanes of the last piece past n2 re-read the last element (the destination is padded to whole pieces).
+// w, w + nw, ...; the lanes of the last piece past n2 re-read the last element (the destination is padded to whole pieces).
 __device__ __host__ __forceinline__ int top_pad(int doubles) { return (doubles + 127) & ~127; }
-__device__ __forceinline__ void top_dma(double* dst, const double* __restrict__ src, int n2, int w, int lane) {
+__device__ __forceinline__ void top_dma(double* dst, const double* __restrict__ src, int n2, int w, int lane, int nw) {
     const double2* s2 = reinterpret_cast<const double2*>(src);
     double2* d2 = reinterpret_cast<double2*>(dst);
-    for (int pc = w; pc * 64 < n2; pc += 16) {
+    for (int pc = w; pc * 64 < n2; pc += nw) {
         const int i = pc * 64 + lane;
         __builtin_amdgcn_global_load_lds((nd_glb_ptr)(s2 + (i < n2 ? i : n2 - 1)), (nd_lds_ptr)(d2 + pc * 64), 16, 0, 0);
     }
@@ -966,21 +966,26 @@ __device__ __forceinline__ void img_store(double* img, int lane, const d4& v) {
 // tiles, up to 13 boundary tiles), ONE FRONT PER WORKGROUP (grid: members x fronts of the level); the levels above are the big fronts
 // (k_big_*).  As big fronts the 64 / 256 fronts of level LO + 4 cost 3.0 ms per 512 members at 256 x 256 (one wave per tile row or 2 x 2
 // tiles, every operand through L2); here 1.4.
-template <int TOP_NVS, int TOP_NTS, int TOPK_MAXT, int TOPK_LEVEL>
-__global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, int k, int top_child_doubles) {
+// NW: waves per workgroup.  ONE: one front per workgroup -- front blockIdx.x / N of level TOPK_LEVEL of member blockIdx.x % N -- instead of
+// a member's fronts in turn.  Round 5: the 16 (x 4^h) fronts of level LO + 4, two pivot tiles and at most 8 boundary tiles each, run as
+// workgroups of EIGHT waves with 75 KB of LDS (children staged one after the other), TWO of them to a CU: a front is a sequence of phases
+// that each load a different unit of the CU (LDS issue in the gathers, one wave's dependent chain in the pivot-tile inverse, the matrix
+// pipe in the updates) with barriers in between -- inside one workgroup nothing overlaps them (profiles/r05/nd_top_ablation.txt), a
+// second workgroup on the CU does.  128 x 128: that launch first, then levels 3..0 of a member in one workgroup of 16 waves as before.
+constexpr __host__ __device__ int top_lds_doubles(int maxt, int child_doubles) { return 256 * (2 * maxt - 1) + 256 + ((child_doubles + 127) & ~127); }
+template <int TOP_NVS, int TOP_NTS, int TOPK_MAXT, int TOPK_LEVEL, int NW = TOP_NW, bool ONE = (ND_LG > 7)>
+__global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams p, NdDev nd, int k, int top_child_doubles) {
     extern __shared__ double nd_lds[];
+    // images: P, then W(R) and V(R) for tile rows R = 1 .. TOPK_MAXT - 1 (row 0 is never published: a panel's images are those of the
+    // rows BELOW its pivot tile), addressed as Wimg + 256 R / Vimg + 256 R
     double* Pimg = nd_lds;                       // 256
-    double* Wimg = Pimg + 256;                   // TOPK_MAXT x 256
-    double* Vimg = Wimg + TOPK_MAXT * 256;       // TOPK_MAXT x 256
+    double* Wimg = Pimg;                         // rows 1 .. TOPK_MAXT - 1 behind P
+    double* Vimg = Wimg + (TOPK_MAXT - 1) * 256;
     int* cl_s = reinterpret_cast<int*>(Vimg + TOPK_MAXT * 256);  // 16 T ints (<= 832 B) in one DMA piece of 1 KB
     short* cp_s0 = reinterpret_cast<short*>(cl_s + 256);        // 16 T shorts for child 0, then 16 T for child 1, as in memory: one piece
     double* chl = reinterpret_cast<double*>(cp_s0 + 512);       // the children's packed updates
     const int tid = threadIdx.x;
-#if ND_LG == 7
-    const int m = blockIdx.x;
-#else
-    const int m = blockIdx.x % p.N;
-#endif
+    const int m = ONE ? blockIdx.x % p.N : blockIdx.x;
     NdGeo g;
     g.lane = tid & 63;
     g.lc = g.lane & 15;
@@ -995,30 +1000,41 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
     // cost two dependent round trips to memory (the front's record, then its children's) before anything else can start
     const int chl_cap = top_pad(top_child_doubles);  // doubles: whole DMA pieces
     int* frec = reinterpret_cast<int*>(chl + chl_cap);  // 31 records behind the child buffer
+    // 128 x 128: the fronts of levels 4..0 that are eliminated this step, in order (k_nd_plan: those whose subtree is still dry keep the
+    // results they have); larger grids: a `todo` byte per front (k_ndl_plan)
+    const int* wlist = nd.work + (long long)m * ND_WORK_INTS + ND_WT;
+    const int f0 = (1 << TOPK_LEVEL) - 1 + (ONE ? blockIdx.x / p.N : 0);
+    int first = 0;  // (not ONE) the list entries in front of `first` belong to the levels a launch of their own has eliminated
+    if (ONE) {
+        // one front: its record at frec[0] (the code below indexes the records by front id: `frec - f0 * ND_FRONT_INTS` makes that this one)
 #if ND_LG == 7
-    for (int i = tid; i < 31 * ND_FRONT_INTS; i += 64 * TOP_NW) frec[i] = nd.fronts[i];
-    __syncthreads();
-    // the fronts of levels 4..0 that are eliminated this step, in order (k_nd_plan: those whose subtree is still dry keep the results they have)
-    const int* tlist = nd.work + (long long)m * ND_WORK_INTS + ND_WT;
-    const int nt = __builtin_amdgcn_readfirstlane(tlist[0]);
+        bool listed = false;
+        const int nl = __builtin_amdgcn_readfirstlane(wlist[0]);
+        for (int i = 0; i < nl && i < (1 << TOPK_LEVEL); ++i) listed = listed || __builtin_amdgcn_readfirstlane(wlist[1 + i]) == f0;  // (the level's fronts come first)
+        if (!listed) return;
 #else
-    // one front: its record at frec[0] (the code below indexes the records by front id: `frec - f0 * ND_FRONT_INTS` makes that this one)
-    const int f0 = (1 << TOPK_LEVEL) - 1 + blockIdx.x / p.N;
-    if (!nd.todo[(long long)m * NTODO + f0]) return;  // (k_ndl_plan: the front keeps the results it has; the whole workgroup leaves)
-    if (tid < ND_FRONT_INTS) frec[tid] = nd.fronts[f0 * ND_FRONT_INTS + tid];
-    __syncthreads();
-    frec -= f0 * ND_FRONT_INTS;
-    const int tlist[3] = {1, f0, 0};
-    const int nt = 1;
+        if (!nd.todo[(long long)m * NTODO + f0]) return;  // (the front keeps the results it has; the whole workgroup leaves)
 #endif
+        if (tid < ND_FRONT_INTS) frec[tid] = nd.fronts[f0 * ND_FRONT_INTS + tid];
+        __syncthreads();
+        frec -= f0 * ND_FRONT_INTS;
+    } else {
+        for (int i = tid; i < ((2 << TOPK_LEVEL) - 1) * ND_FRONT_INTS; i += 64 * NW) frec[i] = nd.fronts[i];
+        __syncthreads();
+        const int nl = __builtin_amdgcn_readfirstlane(wlist[0]);
+        while (first < nl && __builtin_amdgcn_readfirstlane(wlist[1 + first]) >= (2 << TOPK_LEVEL) - 1) ++first;
+    }
+    const int one_list[3] = {1, f0, 0};
+    const int* tlist = ONE ? one_list : wlist;
+    const int nt = ONE ? 1 : __builtin_amdgcn_readfirstlane(wlist[0]);
     bool prefetched = false;  // (wave-uniform) this front's tables and children were issued during the previous front's panels
     {
-        for (int idx = 0; idx < nt; ++idx) {
+        for (int idx = first; idx < nt; ++idx) {
             const int f = __builtin_amdgcn_readfirstlane(tlist[1 + idx]);
 #ifdef HM_ND_PROF
             if (blockIdx.x == 0 && tid == 64 * HM_ND_PROF_TOP_WAVE)
                 for (int lv = 4; lv >= 0; --lv)
-                    if (f == (1 << lv) - 1 || (idx == 0 && f >= (1 << lv) - 1 && f < (2 << lv) - 1)) hm_nd_prof_buf[48 + lv] = clock64();
+                    if (f == (1 << lv) - 1 || (idx == first && f >= (1 << lv) - 1 && f < (2 << lv) - 1)) hm_nd_prof_buf[48 + lv] = clock64();
 #endif
             const int* F = frec + f * ND_FRONT_INTS;
             const int b = __builtin_amdgcn_readfirstlane(F[NDF_B]);
@@ -1042,9 +1058,9 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
                 const int m0 = (((b0 + 1) * (b0 + 2) >> 1) + 1) >> 1, m1 = (((b1 + 1) * (b1 + 2) >> 1) + 1) >> 1;
                 if (w == 0) __builtin_amdgcn_global_load_lds((nd_glb_ptr)(nd.cells + con + 4 * g.lane), (nd_lds_ptr)cl_s, 16, 0, 0);
                 if (w == 1) __builtin_amdgcn_global_load_lds((nd_glb_ptr)(nd.cpos + 2 * con + 8 * g.lane), (nd_lds_ptr)cp_s0, 16, 0, 0);
-                top_dma(chl, arena + __builtin_amdgcn_readfirstlane(Fn[NDF_UC0]), m0, w, g.lane);
+                top_dma(chl, arena + __builtin_amdgcn_readfirstlane(Fn[NDF_UC0]), m0, w, g.lane, NW);
                 const int o1 = top_pad(2 * m0);
-                if (o1 + top_pad(2 * m1) <= chl_cap) top_dma(chl + o1, arena + __builtin_amdgcn_readfirstlane(Fn[NDF_UC1]), m1, w, g.lane);
+                if (o1 + top_pad(2 * m1) <= chl_cap) top_dma(chl + o1, arena + __builtin_amdgcn_readfirstlane(Fn[NDF_UC1]), m1, w, g.lane, NW);
             };
             if (!prefetched) stage_front(F);
             prefetched = false;
@@ -1054,7 +1070,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             int vq[TOP_NVS], vR[TOP_NVS], tR[TOP_NTS], tC[TOP_NTS];
 #pragma unroll
             for (int s = 0; s < TOP_NVS; ++s) {
-                const int idx = s * TOP_NW + w;
+                const int idx = s * NW + w;
                 int q = -1, R = -1;
                 if (idx < nV) {
                     int rem = idx;
@@ -1066,7 +1082,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             }
 #pragma unroll
             for (int s = 0; s < TOP_NTS; ++s) {
-                const int idx = s * TOP_NW + w;
+                const int idx = s * NW + w;
                 int R = -1, C = -1;
                 if (idx < nT) {
                     int rem = idx;
@@ -1117,7 +1133,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             NPROF(2);
             if (!both) {
                 __syncthreads();
-                top_dma(chl, arena + __builtin_amdgcn_readfirstlane(F[NDF_UC1]), n2c[1], w, g.lane);
+                top_dma(chl, arena + __builtin_amdgcn_readfirstlane(F[NDF_UC1]), n2c[1], w, g.lane, NW);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
@@ -1145,8 +1161,8 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
             // the in-wave sweep then runs beside the other waves' updates instead of in front of a barrier.
             auto sweep_diag = [&](int pp, int kreg) {
                 const int ipp = pp * T - ((pp * (pp - 1)) >> 1);  // index of V(pp, pp)
-                if (w == ipp % TOP_NW) {
-                    const int sl = ipp / TOP_NW;
+                if (w == ipp % NW) {
+                    const int sl = ipp / NW;
 #pragma unroll
                     for (int s = 0; s < TOP_NVS; ++s)
                         if (s == sl) {
@@ -1202,8 +1218,8 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
                 }
                 if (pp + 1 < st) {
                     const int inx = (pp + 1) * T - (((pp + 1) * pp) >> 1);
-                    if (w == inx % TOP_NW) {
-                        const int sl = inx / TOP_NW;
+                    if (w == inx % NW) {
+                        const int sl = inx / NW;
 #pragma unroll
                         for (int s = 0; s < TOP_NVS; ++s)
                             if (s == sl) update_v(s, kreg);
@@ -1212,7 +1228,7 @@ __global__ __launch_bounds__(64 * TOP_NW) void k_nd_top(FwdParams p, NdDev nd, i
                     NPROF(12);
 #pragma unroll
                     for (int s = 0; s < TOP_NVS; ++s) {
-                        const int idx = s * TOP_NW + w;
+                        const int idx = s * NW + w;
                         if (vq[s] > pp && idx != inx) update_v(s, kreg);
                     }
                 }
@@ -1985,11 +2001,13 @@ static int nd_setup(hm_fwd* f) {
         if (F[NDF_LEVEL] > LO + 4) continue;
         if (LO > 0) HM_REQUIRE(F[NDF_KREG] == 4, "nested-dissection tables: front %d of the top levels has a partial last pivot tile", fI);
         if (LO > 0 && F[NDF_LEVEL] <= LO + 2) continue;
-        const int top_nts = LO > 0 && F[NDF_LEVEL] == LO + 3 ? 6 : 4, top_nvs = LO > 0 && F[NDF_LEVEL] == LO + 3 ? 2 : 3, top_maxt = LO > 0 && F[NDF_LEVEL] == LO + 3 ? 15 : 13;
+        // the three instances of k_nd_top: level LO + 4 <3, 5, 10, ., 8 waves>, level LO + 3 of the larger grids <2, 6, 15, ., 16>, levels 3..0 at 128 x 128 <3, 4, 13, ., 16>
+        const bool l4 = F[NDF_LEVEL] == LO + 4, l3big = LO > 0 && F[NDF_LEVEL] == LO + 3;
+        const int top_nts = l4 ? 5 : l3big ? 6 : 4, top_nvs = l3big ? 2 : 3, top_maxt = l4 ? 10 : l3big ? 15 : 13, top_nw = l4 ? 8 : TOP_NW;
         HM_REQUIRE(F[NDF_ST] + F[NDF_BT] <= top_maxt, "nested-dissection tables: front %d has %d tile rows (k_nd_top takes %d)", fI, F[NDF_ST] + F[NDF_BT], top_maxt);
         const int st = F[NDF_ST], bt = F[NDF_BT], T = st + bt;
         const int nV = st * T - st * (st - 1) / 2, nT = F[NDF_B] > 0 ? bt * (bt + 1) / 2 : 0;
-        HM_REQUIRE(nV <= top_nvs * TOP_NW && nT <= top_nts * TOP_NW, "nested-dissection tables: front %d has %d + %d tiles", fI, nV, nT);
+        HM_REQUIRE(nV <= top_nvs * top_nw && nT <= top_nts * top_nw, "nested-dissection tables: front %d has %d + %d tiles", fI, nV, nT);
     }
     // the LDS-DMA copies move 16-byte pieces: every update matrix starts on an even double of an even-strided, 16-byte aligned arena
     HM_REQUIRE(t.info.arena_doubles % 2 == 0, "nested dissection: odd arena stride %lld", (long long)t.info.arena_doubles);
@@ -2076,11 +2094,16 @@ static int nd_setup(hm_fwd* f) {
     // dynamic LDS beyond 64 KB must be requested per kernel
     for (int f = LO == 0 ? 0 : (1 << (LO + 3)) - 1; f < (2 << (LO + 4)) - 1; ++f)  // (k_nd_top's fronts: their 1 KB table pieces)
         HM_REQUIRE(t.fronts[f * ND_FRONT_INTS + NDF_CELLS] + 256 <= (int)t.cells.size(), "nested dissection: the table piece of front %d runs past the tables", f);
-    d.top_child_doubles = 0;
-    for (int lv = LO == 0 ? 1 : LO + 5; lv <= LO + 5; ++lv) d.top_child_doubles = std::max(d.top_child_doubles, t.info.upd_doubles[lv]);
-    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<3, 4, 13, LO + 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    d.top_child_doubles = 0;  // (128 x 128: the largest child of a front of levels 3..0)
+    for (int lv = 1; lv <= 4 && LO == 0; ++lv) d.top_child_doubles = std::max(d.top_child_doubles, t.info.upd_doubles[lv]);
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<3, 5, 10, LO + 4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef ND_EXP_TOP4_16
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<3, 4, 10, LO + 4, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
 #if ND_LG > 7
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<2, 6, 15, LO + 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#else
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<3, 4, 13, 3, TOP_NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
 #if ND_LG == 7
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_assemble<double>, hipFuncAttributeMaxDynamicSharedMemorySize, NB * NB * 8));
@@ -2119,14 +2142,25 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
     hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * (NF7 / 4)), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * (NF6 / 4)), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<5, 6, 2>), dim3(p.N * (NF5 / 2)), dim3(128), (size_t)2 * (ND_LDS_DATA + 2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
-    const size_t lds_top = (size_t)(256 + 2 * 13 * 256 + 256 + top_pad(nd.top_child_doubles)) * 8 + 31 * ND_FRONT_INTS * 4;  // images, 2 KB of tables, children, records
-    hipLaunchKernelGGL((k_nd_top<3, 4, 13, LO + 4>), dim3(LO == 0 ? p.N : p.N << (LO + 4)), dim3(64 * TOP_NW), lds_top, s, p, nd, k, nd.top_child_doubles);  // (larger grids: one front of level LO + 4 per workgroup)
+    // level LO + 4: one front per workgroup of 8 waves, two workgroups a CU (images, 2 KB of tables, ONE child, records)
+    const int chd4 = f->nd->info.upd_doubles[LO + 5];
+    const size_t lds_top4 = (size_t)top_lds_doubles(10, chd4) * 8 + 31 * ND_FRONT_INTS * 4;
+#ifdef ND_EXP_TOP4_16  // (A/B: the level as workgroups of 16 waves, one to a CU -- round 4's form)
+    hipLaunchKernelGGL((k_nd_top<3, 4, 10, LO + 4, 16, true>), dim3(p.N << (LO + 4)), dim3(64 * 16), lds_top4 + 70000, s, p, nd, k, chd4);
+#else
+    hipLaunchKernelGGL((k_nd_top<3, 5, 10, LO + 4, 8, true>), dim3(p.N << (LO + 4)), dim3(64 * 8), lds_top4, s, p, nd, k, chd4);
+#endif
+    if (hipError_t e_ = hipGetLastError()) { hm_set_error("k_nd_top<level LO + 4> launch with %zu bytes of LDS: %s", lds_top4, hipGetErrorString(e_)); return 1; }
+#if ND_LG == 7
+    const size_t lds_top = (size_t)top_lds_doubles(13, nd.top_child_doubles) * 8 + 31 * ND_FRONT_INTS * 4;
+    hipLaunchKernelGGL((k_nd_top<3, 4, 13, 3, TOP_NW, false>), dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k, nd.top_child_doubles);  // levels 3..0 of a member
     if (hipError_t e_ = hipGetLastError()) { hm_set_error("k_nd_top launch with %zu bytes of LDS: %s", lds_top, hipGetErrorString(e_)); return 1; }
+#endif
 #if ND_LG > 7
     const NdInfo& I = f->nd->info;
     {   // level LO + 3: one front per workgroup as well, six trailing tiles a wave; its children (level LO + 4) staged one after the other
         const int chd = I.upd_doubles[LO + 4];
-        const size_t lds3 = (size_t)(256 + 2 * 15 * 256 + 256 + top_pad(chd)) * 8 + 31 * ND_FRONT_INTS * 4;
+        const size_t lds3 = (size_t)top_lds_doubles(15, chd) * 8 + 31 * ND_FRONT_INTS * 4;
         hipLaunchKernelGGL((k_nd_top<2, 6, 15, LO + 3>), dim3(p.N << (LO + 3)), dim3(64 * TOP_NW), lds3, s, p, nd, k, chd);
         if (hipError_t e_ = hipGetLastError()) { hm_set_error("k_nd_top<level LO + 3> launch with %zu bytes of LDS: %s", lds3, hipGetErrorString(e_)); return 1; }
     }

@@ -1,0 +1,34 @@
+"""Pressure, fluxes and saturation after a few time steps at 128 x 128, saved for a bitwise comparison between two builds:
+     HM_AMD_LIB=build_ab/libhm_<a>.so python profiles/diag/nd_bits.py a ; python profiles/diag/nd_bits.py b ; python profiles/diag/nd_bits.py a b"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "tests"))
+if len(sys.argv) == 3:
+    a, b = (np.load(f"gpurun_out/nd_bits_{t}.npz") for t in sys.argv[1:])
+    for k in a.files:
+        print(f"{k}: identical {np.array_equal(a[k], b[k])}  max |diff| {np.abs(a[k].astype(float) - b[k].astype(float)).max():.3e}")
+    sys.exit(0)
+from helpers import make_models, perms  # noqa: E402
+from historymatching_amd.forward import ForwardPlan  # noqa: E402
+
+N = 300
+_, gm = make_models(128, 128)
+out = {}
+for variant in (0, 14):
+    plan = ForwardPlan(gm, N, 0.025, 6, keep_history=False, device=0)
+    plan.set_variant(variant, 0)
+    plan.set_inputs(perms(128, 128, N, seed=3), None, transformed=False)
+    plan.run(0, 6)
+    plan.sync()
+    S, prods, status = plan.outputs()
+    assert not status.any()
+    out[f"P_v{variant}"] = plan.get_field("P")
+    out[f"Vx_v{variant}"] = plan.get_field("Vx")
+    out[f"S_v{variant}"] = S
+    plan.close()
+print("variant 0 == variant 14:", all(np.array_equal(out[f"{k}_v0"], out[f"{k}_v14"]) for k in ("P", "Vx", "S")))
+np.savez(f"gpurun_out/nd_bits_{sys.argv[1]}.npz", **out)
