@@ -30,7 +30,9 @@ print(f"k_nd_top, block 0 wave 0: {sum(v)} cycles")
 for n, x in zip(top, v):
     print(f"   {n:28s} {x:10d}  {100 * x / max(sum(v), 1):5.1f} %")
 lv = list(buf[48:54])
-print("   by level (4, 3, 2, 1, 0): " + ", ".join(f"{lv[i - 1] - lv[i]}" for i in (4, 3, 2, 1)) + f", {lv[5] - lv[0]} cycles")
+# (round 5: level 4 is a launch of its own -- one front per workgroup of 8 waves, two workgroups a CU; the stamps are those of the kernel that
+# ran last, the member-per-workgroup kernel of levels 3..0)
+print("   by level (3, 2, 1, 0): " + ", ".join(f"{lv[i - 1] - lv[i]}" for i in (3, 2, 1)) + f", {lv[5] - lv[0]} cycles")
 sub = ["staging (leaf updates, recipes, coefficients)", "level 9, first front", "level 9, second front", "level 8 front"]
 v = list(buf[16:32])
 print(f"k_nd_sub, one workgroup (block 0, or -DHM_ND_PROF_SUB_BLOCK=n: one that starts on a busy GPU), wave 0: {sum(v)} cycles")

@@ -22,7 +22,7 @@ from collections import defaultdict
 
 def short(name):
     """k_sat128, k_nd_sub, k_nd_wave<7, 3, 4> ...: the kernel's name with its template arguments where several instantiations run."""
-    m = re.search(r"(k_nd_wave<[^>]*>)", name)
+    m = re.search(r"(k_nd_(?:wave|top)<[^>]*>)", name)
     if m:
         return m.group(1)
     m = re.search(r"(k_\w+)", name)
@@ -92,7 +92,8 @@ for name, cs in sorted(agg.items()):
 nd = {k: v for k, v in out.items() if k.startswith("k_nd_")}
 pressure_nd = None
 if nd:
-    members = max(v["members_per_launch"] for k, v in nd.items() if k in ("k_nd_top", "k_nd_assemble", "k_nd_flux")) if any(k in nd for k in ("k_nd_top",)) else None
+    # (a member per workgroup in k_nd_assemble and k_nd_flux; k_nd_top: round 5 runs level 4 as a launch of its own, a front per workgroup)
+    members = max((v["members_per_launch"] for k, v in nd.items() if k in ("k_nd_assemble", "k_nd_flux")), default=None) if any(k.startswith("k_nd_top") for k in nd) else None
     flops = sum(v.get("fp64_mfma_flops_per_launch", 0.0) for v in nd.values())
     us = sum(v["avg_us"] for v in nd.values())
     if members:

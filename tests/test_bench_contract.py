@@ -39,3 +39,13 @@ def test_committed_bench_line_has_the_contract_keys():
     # value = members x time steps x steps / wall, with the wall the line itself reports
     members, n_time = d["config"]["members_per_gpu"], d["config"]["nTime"]
     assert abs(d["value"] - members * n_time / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    if "blocks" in d:  # (lines from round 5's second half on) the timed region runs the ensemble as member blocks on streams of their own
+        b = d["blocks"]
+        assert b["n"] >= 1 and b["bounds"][0] == 0 and b["bounds"][-1] == members and len(b["bounds"]) == b["n"] + 1
+        if b["n"] > 1:
+            one = b["one_block"]
+            assert one["producer_series_identical_to_the_blocked_run"] is True and one["value"] > 0
+            assert "one-block pass" in r["launch_times_measured_in"]
+            # the blocked run is the faster one (that is why it is the default), but not by a margin that would point at skipped work
+            assert one["value"] <= d["value"] <= 1.15 * one["value"]
+
