@@ -96,3 +96,14 @@ def test_host_model_mirrors_the_surface_the_notebook_uses():
         assert np.array_equal(clone.K, gm.K) and np.array_equal(clone.prd_xy, gm.prd_xy) and clone.nPrd == gm.nPrd
         clone.K = clone.K * 2
         assert not np.array_equal(clone.K, gm.K)  # isolated state
+
+
+def test_member_block_rule_is_host_logic():
+    """forward.default_blocks: how many member blocks (HIP streams) a device-resident ensemble is split into -- three from 768 members, two
+    from 512 on the 128 x 128 kernels, one everywhere else (profiles/r05/blocks_time.txt: the larger grids gain nothing)."""
+    from historymatching_amd.forward import default_blocks
+    from historymatching_amd.ressim import ResSim
+
+    m128, m256, m20 = ResSim(128, 128, 2, 1), ResSim(256, 256, 2, 1), ResSim(20, 20, 2, 1)
+    assert [default_blocks(m128, n) for n in (1, 511, 512, 767, 768, 1000, 4096)] == [1, 1, 2, 2, 3, 3, 3]
+    assert default_blocks(m256, 4096) == 1 and default_blocks(m20, 1000) == 1 and default_blocks(ResSim(128, 256, 2, 1), 1000) == 1
