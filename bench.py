@@ -277,6 +277,7 @@ def es_mda_c3(device, perms, n_iter=4):
     wall = time.perf_counter() - t0
     # the assimilation must have pulled the ensemble's simulated production towards the observations
     return {"iterations": n_iter, "wall_s": wall, "device_ms_forward": st["ms_forward"], "device_ms_update": st["ms_update"],
+            "fallbacks": {k: int(st.get(k, 0)) for k in FALLBACK_KEYS},
             "ensemble_steps_per_s_incl_updates": len(perms) * NTIME * n_iter / wall,
             "posterior_finite": bool(np.isfinite(post).all()),
             "rms_change_of_log_perm": float(np.sqrt(np.mean((post - perms) ** 2))),
@@ -311,6 +312,7 @@ def config4_sharded(device, comm, n_total=4096, n_grid=256):
     return {"members_total": n_total, "members_per_rank": hi - lo, "grid": [n_grid, n_grid], "n_ranks": comm.world_size, "scaling": "strong",
             "passes": 1, "wall_s": wall, "device_ms_forward_max": fwd_ms, "device_ms_update_max": upd_ms,
             "member_steps_handed_to_the_cg": int(comm.all_reduce_max(float(st.get("nd_fallbacks", 0)))),  # (direct solver's a-posteriori check; max over ranks)
+            "fallbacks": fallbacks_over_ranks(comm, st),
             "ensemble_steps_per_s_forward": n_total * NTIME / (fwd_ms * 1e-3), "ensemble_steps_per_s_incl_update_and_setup": n_total * NTIME / wall,
             "posterior_finite": bool(ok),
             "collective": "RCCL (hm_upd_run_comm)" if comm.rccl is not None else ("none (one rank)" if comm.world_size == 1 else f"host channel ({comm.rccl_error})")}
@@ -350,9 +352,22 @@ def config5_sharded(device, comm, n_total=1000, n_grid=512, bounded=False):
                        if bounded else "the whole configuration"),
             "passes": 1, "wall_s": wall, "device_ms_forward_max": fwd_ms, "device_ms_localised_update_max": upd_ms,
             "member_steps_handed_to_the_cg": int(comm.all_reduce_max(float(st.get("nd_fallbacks", 0)))),
+            "fallbacks": fallbacks_over_ranks(comm, st),
             "ensemble_steps_per_s_forward": n_total * NTIME / (fwd_ms * 1e-3), "posterior_finite": bool(ok), "dtype": "f32 saturation sweep + fp64 pressure, fp32 matrix-core analysis",
             "collective": "RCCL (hm_upd_run_comm: 2 all-reduces + all-gather of the column-sharded weights)" if comm.rccl is not None
                           else ("none (one rank)" if comm.world_size == 1 else f"host channel ({comm.rccl_error})")}
+
+
+# Silent fall-backs of the forward kernels, reported with every leg that runs them (a run that took one is slower than it should be and
+# says nothing else): member-steps handed to the CG by the direct pressure solver's a-posteriori check (256 x 256 / 512 x 512), member-steps
+# of a workgroup-team sweep redone by the single-workgroup tiled sweep (a team gave up waiting for a neighbour), member-steps the float32
+# slab sweep did twice because water reached a slab that sat the step out.
+FALLBACK_KEYS = ("nd_fallbacks", "team_retries", "slab_redos")
+
+
+def fallbacks_over_ranks(comm, st):
+    """The counters of `st` (forward statistics of this rank), largest over the ranks."""
+    return {k: int(comm.all_reduce_max(float(st.get(k, 0)))) for k in FALLBACK_KEYS}
 
 
 def load_profile_json(name):
@@ -499,8 +514,10 @@ def main():
     _, prods, status = plan.outputs(want_wsats=False)
     ok = not status.any() and np.isfinite(prods).all()
     plan.close()
+    timed_fallbacks = {k: int(stats.get(k, 0)) for k in FALLBACK_KEYS}  # (plans created for this run: the counters cover warm-up + timed region)
+    ok = ok and timed_fallbacks["team_retries"] == 0  # a team sweep that fell back to the tiled sweep inside the timed region: not the number to report
 
-    blocks_info = {"n": n_blocks, "bounds": plan.bounds, "device_ms_longest_block": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
+    blocks_info = {"n": n_blocks, "bounds": plan.bounds, "fallbacks": timed_fallbacks, "device_ms_longest_block": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
                    "how": "member blocks on HIP streams of their own, launches interleaved time step by time step from one host thread (forward.BlockedForwardPlan; "
                           "forward_model runs every large ensemble on the 128 x 128 kernels this way)"}
     if n_blocks > 1:
@@ -702,6 +719,9 @@ def main():
             "metric": "ensemble-steps/sec", "value": value, "unit": "ensemble-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # (near the front so that a truncated tail of the line keeps them: the analysis step where it is used, and the silent fall-backs)
+            "es_update_headline": None if not upd else {k: upd.get(k) for k in ("in_situ_ms", "mfma_frac_in_situ", "wall_ms", "mfma_frac_of_fp32_peak")},
+            "fallbacks_in_timed_region": timed_fallbacks,
             "config": {"workload": f"N_e={n_e} per GPU, {NX}x{NY} grid, forward model only (nTime={NTIME}, dt={DT}), fp64",
                        "members_per_gpu": n_e, "grid": [NX, NY], "nTime": NTIME, "device": ctx.name(),
                        "kernel_variant": args.variant, "results_finite_and_status_ok": bool(ok),

@@ -22,10 +22,12 @@
 // {tag, float} words, write-through stores, polled until the tag matches); the last row polls right before its row 3, behind three
 // rows of work.  Wells: a producer's rate is part of c_C; the injector's lane adds fi d in a scalar branch inside asm (sat128r.hip).
 // Dry waves (every base and dS of the wave zero, no injector) publish zeros and skip the sweep until something non-zero arrives.
-// Arithmetic per cell and sub-step: 23 VALU instructions (s, fw: 12, 5 products, 4 + 1 sums) + 0.25 DPP moves.
+// Arithmetic per cell and sub-step: 19 VALU instructions (s, fw: 8 -- the division in four, fracflow.h --, 5 products, 4 + 1 sums) + 0.25
+// DPP moves.
 // Bit-identical to k_saturation_generic<float> / _stream / _tiled and to oracle/ressim.py:saturation_step_stencil_f32c.
-// Spins are bounded: on a timeout the member is flagged HM_MEMBER_SYNC_TIMEOUT and the host redoes the step with the single-workgroup
-// tiled sweep (forward.hip).  Compiled with -ffp-contract=off.
+// Spins are bounded: on a timeout the member is flagged HM_MEMBER_SYNC_TIMEOUT, and the device-gated launch of the single-workgroup tiled
+// sweep that follows every team launch (forward.hip: launch_saturation) redoes the member's step -- nothing waits for the host.
+// Compiled with -ffp-contract=off (and without the SLP vectoriser: Makefile).
 #include "sat_team.h"
 #include "fracflow.h"
 #include "sat32.h"

@@ -370,7 +370,7 @@ def es_mda_sharded(model, prior_local, obs, R12, dt, nTime, n_iter=4, seed=0, co
         device = comm.ctx.device
     fwd = upd = None
     ms_fwd = ms_upd = ms_comm = 0.0
-    nd_fallbacks = 0
+    nd_fallbacks = team_retries = slab_redos = 0
     alpha = float(n_iter)
     try:
         err = None
@@ -391,7 +391,7 @@ def es_mda_sharded(model, prior_local, obs, R12, dt, nTime, n_iter=4, seed=0, co
                 upd.set_inputs_device(obs_ens_ptr=fwd.device_ptr("prods"), obs_dtype=model.dtype)
                 st_f = fwd.sync()
                 ms_fwd += st_f["ms_total"]
-                nd_fallbacks = st_f["nd_fallbacks"]  # (cumulative over the plan's life)
+                nd_fallbacks, team_retries, slab_redos = st_f["nd_fallbacks"], st_f["team_retries"], st_f["slab_redos"]  # (cumulative over the plan's life)
                 _, _, status = fwd.outputs(want_wsats=False)
                 if status.any():
                     raise _lib.HmError(f"forward model failed for members {(lo + np.flatnonzero(status))[:8].tolist()} "
@@ -412,5 +412,5 @@ def es_mda_sharded(model, prior_local, obs, R12, dt, nTime, n_iter=4, seed=0, co
         if upd is not None:
             upd.close()
     if stats is not None:
-        stats.update(ms_forward=ms_fwd, ms_update=ms_upd, ms_comm=ms_comm, nd_fallbacks=nd_fallbacks)
+        stats.update(ms_forward=ms_fwd, ms_update=ms_upd, ms_comm=ms_comm, nd_fallbacks=nd_fallbacks, team_retries=team_retries, slab_redos=slab_redos)
     return out.astype(float)

@@ -177,6 +177,22 @@ def default_blocks(model, N):
     return 3 if N >= 768 else 2 if N >= 512 else 1
 
 
+def merge_block_stats(sts, sizes):
+    """Statistics of member blocks that ran side by side as one record: device times are the longest block's, counts add up, the
+    ``mean_*`` entries are member-weighted means over the blocks (one division, whatever the number and sizes of the blocks)."""
+    st = dict(sts[0])
+    total = float(sum(sizes))
+    for key, v in sts[0].items():
+        if key.startswith("ms_"):
+            st[key] = max(r[key] for r in sts)
+        elif key.startswith("mean_"):
+            st[key] = sum(r[key] * n for r, n in zip(sts, sizes)) / total
+        elif isinstance(v, (int, float)):
+            st[key] = sum(r[key] for r in sts)
+    st["blocks"] = len(sts)
+    return st
+
+
 class BlockedForwardPlan:
     """A device-resident ensemble as ``default_blocks`` member blocks, each a ``ForwardPlan`` on a stream of its own; ``run`` queues
     the blocks' launches interleaved time step by time step from the calling thread (nothing waits for the device).  The same
@@ -221,17 +237,7 @@ class BlockedForwardPlan:
     def sync(self):
         """Waits for every block; device times are the longest block's, counts add up."""
         sts = [pl.sync() for pl in self.plans]
-        st = dict(sts[0])
-        for r in sts[1:]:
-            for key, v in r.items():
-                if key.startswith("ms_"):
-                    st[key] = max(st[key], v)
-                elif key.startswith("mean_"):
-                    st[key] = (st[key] + v) / 2
-                elif isinstance(v, (int, float)):
-                    st[key] = st[key] + v
-        st["blocks"] = len(self.plans)
-        return st
+        return merge_block_stats(sts, [pl.N for pl in self.plans])
 
     def outputs(self, want_wsats=True):
         outs = [pl.outputs(want_wsats) for pl in self.plans]
@@ -307,17 +313,8 @@ def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True
         for r in results:
             if isinstance(r, BaseException):
                 raise r
-        # the blocks run side by side: device times are the longest block's, counts add up
-        st = dict(results[0])
-        for r in results[1:]:
-            for key, v in r.items():
-                if key.startswith("ms_"):
-                    st[key] = max(st[key], v)
-                elif key.startswith("mean_"):
-                    st[key] = (st[key] + v) / 2
-                elif isinstance(v, (int, float)):
-                    st[key] = st[key] + v
-        model.last_stats = st
+        # the blocks run side by side: device times are the longest block's, counts add up, means are member-weighted
+        model.last_stats = merge_block_stats(results, [hi - lo for _, lo, hi in cache["plans"][:blocks]])
         if status.any():
             bad = np.flatnonzero(status)
             raise _lib.HmError(f"forward model failed for members {bad[:8].tolist()} (status {status[bad[:8]].tolist()}): "

@@ -214,6 +214,7 @@ def es_mda_device(model, prior_ens, obs, R12, dt, nTime, n_iter=4, rng=None, dty
     decorr = sla.inv(R12.T) / np.sqrt(alpha)
     upd.set_inputs(E=E0, obs=obs, decorr=decorr)
     ms_fwd = ms_upd = 0.0
+    counters = {}
     try:
         for _ in range(n_iter):
             # the perturbations do not wait for the forward pass: they go up first, and the analysis step is QUEUED behind the pass on the
@@ -226,6 +227,7 @@ def es_mda_device(model, prior_ens, obs, R12, dt, nTime, n_iter=4, rng=None, dty
             _lib.check(upd.lib.hm_upd_run(upd.h), "hm_upd_run")
             st = fwd.sync()
             ms_fwd += st["ms_total"]
+            counters = {k: st[k] for k in ("nd_fallbacks", "team_retries", "slab_redos")}  # (cumulative over the plan's life)
             _, _, status = fwd.outputs(want_wsats=False)
             if status.any():
                 raise _lib.HmError(f"forward model failed for members {np.flatnonzero(status)[:8].tolist()}")
@@ -238,7 +240,7 @@ def es_mda_device(model, prior_ens, obs, R12, dt, nTime, n_iter=4, rng=None, dty
         fwd.close()
         upd.close()
     if stats is not None:
-        stats.update(ms_forward=ms_fwd, ms_update=ms_upd)
+        stats.update(ms_forward=ms_fwd, ms_update=ms_upd, **counters)
     return out.astype(float)
 
 

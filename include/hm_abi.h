@@ -144,8 +144,9 @@ int  hm_fwd_sync(hm_fwd* f, hm_stats* stats);
  * reference's sparse direct solve with partial pivoting, HistoryMatch.py:362, does not fail on such members either). */
 long long hm_fwd_nd_fallbacks(hm_fwd* f);
 /* Member-steps of the workgroup-team saturation sweeps that were redone by the single-workgroup tiled sweep since the plan was created: a team
- * gave up waiting for a neighbouring workgroup (CUs held by someone else), or water reached a slab that sat the step out (sat32s).  Results
- * are the same either way; a number other than 0 says the run was slower than it should be.  Synchronises the plan's stream. */
+ * gave up waiting for a neighbouring workgroup (CUs held by someone else).  Results are the same either way; a number other than 0 says the
+ * run was slower than it should be.  (Slabs that sat a step out and were reached by water are counted by hm_fwd_slab_redos, not here.)
+ * Synchronises the plan's stream. */
 long long hm_fwd_team_retries(hm_fwd* f);
 /* Member-steps the float32 slab sweep (sat32s) did twice: it lets slabs that are dry, with dry neighbours, sit a time step out; where the
  * frontier of denormal saturations ahead of the front reached such a slab within the step, the member's step is redone with every slab

@@ -49,3 +49,26 @@ def test_committed_bench_line_has_the_contract_keys():
             # the blocked run is the faster one (that is why it is the default), but not by a margin that would point at skipped work
             assert one["value"] <= d["value"] <= 1.15 * one["value"]
 
+    # (lines from round 6 on) silent fall-backs of the forward kernels are part of the line: the timed region's counters near the front,
+    # and one record per leg that runs a forward model; a team retry inside the timed region makes the line's `ok` false
+    if int(path.parent.name[1:]) >= 6:
+        keys = {"nd_fallbacks", "team_retries", "slab_redos"}
+        assert set(d["fallbacks_in_timed_region"]) == keys and d["fallbacks_in_timed_region"]["team_retries"] == 0
+        assert set(d["blocks"]["fallbacks"]) == keys
+        for leg in (d["config4"], d["config5"], d["es_update"]["es_mda_config3"]):
+            assert set(leg["fallbacks"]) == keys and leg["fallbacks"]["team_retries"] == 0, leg
+        head = d["es_update_headline"]
+        assert head["in_situ_ms"] == d["es_update"]["in_situ_ms"] and head["mfma_frac_in_situ"] == d["es_update"]["mfma_frac_in_situ"]
+        assert list(d).index("es_update_headline") < list(d).index("roofline")  # in front of the long records: a truncated tail keeps it
+
+
+def test_block_statistics_are_member_weighted():
+    """forward.merge_block_stats: times are the longest block's, counts add up, means are weighted by the blocks' sizes (three blocks of
+    333 / 333 / 334 members: the pairwise (a + b) / 2 fold of round 5 weighted the last block by a half)."""
+    from historymatching_amd.forward import merge_block_stats
+
+    sts = [dict(ms_total=3.0, mean_nts=600.0, member_steps=10, team_retries=0), dict(ms_total=5.0, mean_nts=630.0, member_steps=20, team_retries=1),
+           dict(ms_total=4.0, mean_nts=615.0, member_steps=30, team_retries=0)]
+    st = merge_block_stats(sts, [100, 100, 200])
+    assert st["ms_total"] == 5.0 and st["member_steps"] == 60 and st["team_retries"] == 1 and st["blocks"] == 3
+    assert abs(st["mean_nts"] - (600.0 * 100 + 630.0 * 100 + 615.0 * 200) / 400) < 1e-12
