@@ -249,12 +249,16 @@ __global__ void k_saturation_generic(FwdParams p, const T* __restrict__ Sin_base
         double vys = Vy[ix * (Ny + 1) + iy], vyn = Vy[ix * (Ny + 1) + iy + 1];
         double fp = fmin(q[j], 0.0), fi = fmax(q[j], 0.0);
         double x1 = fmin(vxw, 0.0), x2 = fmax(vxe, 0.0), y1 = fmin(vys, 0.0), y2 = fmax(vyn, 0.0);
-        cC[j] = (T)(d * (fp + x1 - x2 + y1 - y2));
+        const double cC64 = d * (fp + x1 - x2 + y1 - y2);
+        cC[j] = (T)cC64;
         cW[j] = (T)(d * fmax(vxw, 0.0));
         cE[j] = (T)(d * (-fmin(vxe, 0.0)));
         cS[j] = (T)(d * fmax(vys, 0.0));
         cN[j] = (T)(d * (-fmin(vyn, 0.0)));
-        fid[j] = (T)(fi * d);
+        if constexpr (F32) {
+            fid[j] = source32(cC64, cC[j], fi, d);  // (sat32.h: rounded jointly with c_C)
+            cC[j] = diag32(cC[j], cE[j], cN[j], cS[j], cW[j], fid[j], Sin[j]);  // (sat32.h: a saturated neighbourhood gains nothing)
+        } else fid[j] = (T)(fi * d);
         S[j] = Sin[j];
         if constexpr (F32) dSa[j] = 0.0f;
     }
@@ -379,12 +383,17 @@ __global__ void k_saturation_stream(FwdParams p, const T* __restrict__ Sin_base,
             const double qj = q[j];
             const double fp = fmin(qj, 0.0), fi = fmax(qj, 0.0);
             const double x1 = fmin(vxw, 0.0), x2 = fmax(vxe, 0.0), y1 = fmin(vys, 0.0), y2 = fmax(vyn, 0.0);
-            const T cC = (T)(d * (fp + x1 - x2 + y1 - y2));
+            const double cC64 = d * (fp + x1 - x2 + y1 - y2);
+            T cC = (T)cC64;
             const T cW = (T)(d * fmax(vxw, 0.0));
             const T cE = (T)(d * (-fmin(vxe, 0.0)));
             const T cS = (T)(d * fmax(vys, 0.0));
             const T cN = (T)(d * (-fmin(vyn, 0.0)));
-            const T fid = (T)(fi * d);
+            T fid;
+            if constexpr (F32) {
+                fid = source32(cC64, cC, fi, d);           // (sat32.h: rounded jointly with c_C)
+                cC = diag32(cC, cE, cN, cS, cW, fid, Sin[j]);      // (sat32.h: a saturated neighbourhood gains nothing)
+            } else fid = (T)(fi * d);
             const T sc = src[j];
             T acc = (ix + 1 < Nx) ? cE * fwf(src[j + Ny]) : T(0);
             if (iy + 1 < Ny) acc = acc + cN * fwf(src[j + 1]);
@@ -533,12 +542,17 @@ __global__ __launch_bounds__(1024) void k_saturation_tiled(FwdParams p, const T*
                     const double d = p.por ? (p.dt / (double)Nts) / (p.h2 * p.por[j]) : d_uniform;
                     const double fp = fmin(qj, 0.0), fi = fmax(qj, 0.0);
                     const double x1 = fmin(vxw, 0.0), x2 = fmax(vxe, 0.0), y1 = fmin(vys, 0.0), y2 = fmax(vyn, 0.0);
-                    const T cC = (T)(d * (fp + x1 - x2 + y1 - y2));
+                    const double cC64 = d * (fp + x1 - x2 + y1 - y2);
+                    T cC = (T)cC64;
                     const T cW = (T)(d * fmax(vxw, 0.0));
                     const T cE = (T)(d * (-fmin(vxe, 0.0)));
                     const T cS = (T)(d * fmax(vys, 0.0));
                     const T cN = (T)(d * (-fmin(vyn, 0.0)));
-                    const T fid = (T)(fi * d);
+                    T fid;
+                    if constexpr (F32) {
+                        fid = source32(cC64, cC, fi, d);           // (sat32.h: rounded jointly with c_C)
+                        cC = diag32(cC, cE, cN, cS, cW, fid, Sin[j]);      // (sat32.h: a saturated neighbourhood gains nothing)
+                    } else fid = (T)(fi * d);
                     const T* f = fwt + (li + 1) * LW + lj + 1;
                     T acc = (ix + 1 < Nx) ? cE * f[LW] : T(0);
                     if (iy + 1 < Ny) acc = acc + cN * f[1];
@@ -963,10 +977,11 @@ static hm_fwd* embedded_inner(hm_fwd* f, int* rc_out) {
     if (f->is_inner || !f->dbg_embed) return nullptr;
     const int big = p.Nx > p.Ny ? p.Nx : p.Ny, EMB = big <= 128 ? 128 : big <= 256 ? 256 : 512;  // the square the fast kernels exist for
     if (big > 512 || (p.Nx == EMB && p.Ny == EMB)) return nullptr;
-    if (p.Ny <= 32 && p.Nxy <= 1024) return nullptr;                                   // the one-launch kernel of small grids (small.hip)
+    if (small_forward_applies(f)) return nullptr;                                      // the one-launch kernel of small grids takes it (small.hip: the same predicate)
     if (EMB > 128 && (p.Ny == 128 || (p.Nx % 128 == 0 && p.Ny % 128 == 0)) && f->dbg_embed != 2) return nullptr;  // grids of 128-wide blocks / tiles keep their own kernels ("embed" 2: they too)
     if (!(f->press_variant == 0 || f->press_variant == 12 || f->press_variant == 14) || f->sat_variant != 0) return nullptr;
     if (p.q_mstride != 0 || p.por != nullptr || p.Ky != nullptr) return nullptr;       // per-member wells, porosity field, anisotropy: generic
+    if (f->raw_q_exposed) return nullptr;  // the caller holds a pointer to the OUTER source field: writes through it would never reach the inner plan's
     if (!f->inner) {
         auto remap = [&](int cell) { return (cell / p.Ny) * EMB + cell % p.Ny; };
         std::vector<int> inj(f->inj_ind_host), prd(f->prd_ind_host);
@@ -988,7 +1003,15 @@ static hm_fwd* embedded_inner(hm_fwd* f, int* rc_out) {
         f->inner_K_gen = -1;
         f->inner_S_step = -1;
     }
+    // everything of the outer plan that steers the inner kernels: solver choice and tolerances, and what the caller may have written
+    // behind the library's back (hm_fwd_device_ptr) -- the inner plan then keeps nothing from step to step either (sat32s.hip's wet-slab
+    // record, press_nd.hip's dry fronts)
     f->inner->press_variant = f->press_variant;
+    f->inner->p.cg_rtol = p.cg_rtol;
+    f->inner->p.cg_max_iter = p.cg_max_iter;
+    f->inner->raw_state_exposed = f->raw_state_exposed;
+    f->inner->raw_field_exposed = f->raw_field_exposed;
+    f->inner->dbg_slab_margin = f->dbg_slab_margin;
     return f->inner;
 }
 
@@ -998,7 +1021,7 @@ static int embed_inputs(hm_fwd* f, hm_fwd* in, int k) {
     const FwdParams& p = f->p;
     const int EMB = f->emb;
     hipStream_t s = f->ctx->stream;
-    if (f->inner_K_gen != f->inputs_gen) {
+    if (f->inner_K_gen != f->inputs_gen || f->raw_field_exposed) {  // (a raw pointer to K is out: it may have been written since the last step)
         hipLaunchKernelGGL(k_embed2d<double>, EMB_GRID, (const double*)f->K.p, (long long)p.Nxy, p.Ny, (double*)in->K.p, (long long)EMB * EMB, EMB, EMB,
                            p.Nx, p.Ny, 0.0, p.N);
         f->inner_K_gen = f->inputs_gen;
@@ -1411,6 +1434,10 @@ extern "C" int hm_fwd_set_debug(hm_fwd* f, const char* key, long long value) {
     if (k == "nd_force_fallback") f->dbg_nd_force_fallback = (int)value;
     else if (k == "team_rounds") f->dbg_team_rounds = (int)value;
     else if (k == "embed") f->dbg_embed = (int)value;
+    else if (k == "slab_margin") {
+        f->dbg_slab_margin = (int)value;
+        if (f->inner) f->inner->dbg_slab_margin = (int)value;
+    }
     else if (k == "nd_cap") {
         HM_REQUIRE(!f->nd, "hm_fwd_set_debug: \"nd_cap\" must be set before the plan's first run");
         f->dbg_nd_cap = (int)value;
@@ -1436,6 +1463,7 @@ extern "C" void* hm_fwd_device_ptr(hm_fwd* f, const char* name) {
     if (s == "K" || s == "Ky" || s == "TX" || s == "TY" || s == "q" || s == "por") {
         ++f->inputs_gen;
         f->raw_field_exposed = true;
+        if (s == "q") f->raw_q_exposed = true;
     }
     return r.p;
 }

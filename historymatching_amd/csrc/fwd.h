@@ -56,6 +56,7 @@ struct hm_fwd {
     int keep_history = 0;
     int press_variant = 0, sat_variant = 0;
     bool raw_state_exposed = false;  // a device pointer to the saturation was handed out: nothing about it is remembered from step to step
+    bool raw_q_exposed = false;      // a device pointer to the source field was handed out: the plan no longer runs embedded (the inner plan has a source field of its own)
     bool raw_field_exposed = false;  // a device pointer to K / TX / ... was handed out (hm_fwd_device_ptr): no caching across time steps
     long long inputs_gen = 0;  // bumped by every call that can change K, wells, rates or kernel selection: results cached across time steps (press_nd.hip) die with it
     bool cg_lazy = true;  // CG work vectors not allocated yet
@@ -81,6 +82,7 @@ struct hm_fwd {
     DevBuf slab_wet;  // sat32s.hip: which slabs of which member hold water, two images in turn (written by the launch of step k, read by that of k + 1)
     int slab_wet_step = -1;       // time index whose launch may read the record
     long long slab_wet_gen = -1;  // inputs_gen the record belongs to
+    int dbg_slab_margin = 1;      // hm_fwd_set_debug "slab_margin": 0 = the float32 slab sweep lets the neighbours of wet slabs sit out too (exercises its REDO launch)
     int dbg_team_rounds = 0;      // hm_fwd_set_debug "team_rounds": 1 = the slab teams in rounds of co-resident teams (round 4's form)
     DevBuf team_mem;  // synchronisation blocks of the multi-tile saturation sweep (sat128t.hip), allocated on first use
     int dbg_nd_force_fallback = -1, dbg_nd_cap = 0;  // hm_fwd_set_debug: test / experiment knobs of the larger grids' direct solver (press_nd.hip)
@@ -134,5 +136,6 @@ int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_
 int launch_saturation_128r(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // fw in registers, scaled fluxes (sat128r.hip)
 int launch_saturation_32s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // dtype = 32 plans, grids 128 / 256 / 512 wide (sat32s.hip)
 int launch_saturation_128t(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // grids of 128 x 128 tiles, fp64
+bool small_forward_applies(const hm_fwd* f);                        // ... takes this plan (grid, LDS image, kernel variants)
 int launch_small_forward(hm_fwd* f, int first_step, int n_steps);  // small grids: the whole run as one launch, a wave per member (small.hip)
 int launch_saturation_256s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // grids 256 cells wide, fp64: slabs of 64 rows, fw in registers (sat256s.hip)

@@ -12,6 +12,12 @@ struct NdDev {
     const int* cells;
     const short* cpos;
     const short* rec;  // assembly recipes (nd.h), blocks of 256 int16
+    // Flat per-leaf and per-subtree tables (round 6, press_nd.hip: nd_build_flat_tables): everything a lane of the leaf kernels / a wave of
+    // k_nd_solve_sub derives today from front record -> position table -> cell through two or three DEPENDENT trips to memory, as one
+    // coalesced read.  leaft: [ND_LEAF_INTS][leaves] ints, entry-major (a lane per leaf reads consecutive ints);  ssub: per level-8 subtree
+    // [ND_SSUB_HDR] wave-uniform ints, then [ND_SSUB_LANE][64] per-lane ints.
+    const int* leaft;
+    const int* ssub;
     double* fact;
     double* arena;
     double* cf;  // per member: [dg | -TX | -TY | q], CF_STRIDE doubles
@@ -36,7 +42,7 @@ struct NdDev {
 
 struct hm_nd {
     NdInfo info{};
-    DevBuf fronts, cells, cpos, rec, fact, arena, dg, work, cached, wells, vfac, pimg, wet, todo;
+    DevBuf fronts, cells, cpos, rec, fact, arena, dg, work, cached, wells, vfac, pimg, wet, todo, leaft, ssub;
     NdDev dev{};
     int cap = 0;                // members the per-member buffers hold: larger ensembles are solved in blocks of `cap` members (larger grids)
     long long cached_gen = -1;  // hm_fwd::inputs_gen the cached results belong to

@@ -69,6 +69,15 @@ constexpr int NCACHE = 512 << LO;              // >= fronts of levels 0 .. LO + 
 constexpr int NTODO = 32 << LO;                // >= fronts of levels 0 .. LO + 4
 constexpr int WETW = NB / 64;                  // 64-bit words of a grid row's wet-cell bitmap
 __device__ __forceinline__ const int* nd_work(const NdDev& nd, int m) { return nd.work + (long long)m * ND_WORK_INTS; }
+// Flat tables (nd_plan.h: NdDev::leaft, ssub; built by nd_build_flat_tables below).  A leaf: [0] x0, [1] y0, [2] w, [3] h of its box, [4] b,
+// [5] offset of its update matrix in the arena, then for boundary entry j < 12: [6 + 3 j] the local cell 4 lx + ly it touches, [7 + 3 j] the
+// index of the face between them in the coefficient block (-1: no such entry), [8 + 3 j] the boundary cell (-1).  A level-8 subtree (fronts
+// i = 0: the level-8 front, 1, 2: its level-9 children): header [i] boundary tiles, [3 + i] pivot register rows, [6 + i] factor offset,
+// [9] x0, [10] y0 of its region, [11] the LDS plane's row length; per lane [2 i + R] the cell of boundary position 16 R + lc (tile R < 2; a
+// tile beyond bt repeats tile 0), [6], [7] the level-8 front's pivot cells 4 r + lq (r < 2), [8], [9] those of the level-9 fronts (r = 0).
+constexpr int NLEAF = 1024 << LO;
+constexpr int ND_LEAF_INTS = 44;
+constexpr int ND_SSUB_HDR = 16, ND_SSUB_LANE = 10, ND_SSUB_INTS = ND_SSUB_HDR + ND_SSUB_LANE * 64;
 
 struct NdGeo {
     int lane, lc, lq;
@@ -616,10 +625,8 @@ struct NdLeaf {
     int cell[16];      // global cell of local cell i = 4 lx + ly, -1: padding
 };
 
-// band + factorisation of leaf front `f` (per lane); returns false for a non-positive pivot
-__device__ __forceinline__ bool nd_leaf_factor(NdLeaf& Lf, const NdDev& nd, const double* __restrict__ cf, int f) {
-    const NdBox box = nd_box(nd.fronts + f * ND_FRONT_INTS, NDF_RBOX);
-    const int x0 = box.x0, y0 = box.y0, w = box.x1 - x0, h = box.y1 - y0;
+// band + factorisation of the leaf whose cells are the box [x0, x0 + w) x [y0, y0 + h) (per lane); returns false for a non-positive pivot
+__device__ __forceinline__ bool nd_leaf_factor(NdLeaf& Lf, const double* __restrict__ cf, int x0, int y0, int w, int h) {
     double d[16], e1[16], e4[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -674,25 +681,14 @@ __device__ __forceinline__ void nd_leaf_solve(const NdLeaf& Lf, double (&v)[16])
         for (int k = 0; k < 4; ++k)
             if (i + 1 + k < 16) v[i] -= Lf.l[i + 1 + k][k] * v[i + 1 + k];
 }
-// boundary entry j of the leaf: the local cell it touches and the coefficient A[boundary cell, that cell] (0: no such entry)
-__device__ __forceinline__ void nd_leaf_boundary(const NdDev& nd, const double* __restrict__ cf, int f, int j, int& il, double& t, int& bcell) {
-    const int* F = nd.fronts + f * ND_FRONT_INTS;
-    const NdBox box = nd_box(F, NDF_RBOX);
-    const int b = F[NDF_B];
-    const int x0 = box.x0, y0 = box.y0, x1 = box.x1, y1 = box.y1;
-    const bool on = j < b;
-    const int c = on ? nd.cells[F[NDF_CELLS] + 16 + j] : 0;
-    const int bx = c >> LG, by = c & (NB - 1);
-    // the one region cell next to it, and the face between them
-    int ix = bx, iy = by, fidx;
-    if (bx < x0) { ix = x0; fidx = CF_OX + ix * NB + iy; }                 // west side: the cell's west face
-    else if (bx >= x1) { ix = x1 - 1; fidx = CF_OX + bx * NB + by; }      // east side: the boundary cell's west face
-    else if (by < y0) { iy = y0; fidx = CF_OY + ix * (NB + 1) + iy; }      // south side: the cell's south face
-    else { iy = y1 - 1; fidx = CF_OY + bx * (NB + 1) + by; }              // north side: the boundary cell's south face
-    const double tv = cf[on ? fidx : 0];
-    il = on ? (ix - x0) * 4 + (iy - y0) : 0;
-    t = on ? tv : 0.0;
-    bcell = on ? c : -1;
+// boundary entry j of a leaf from the leaf table (one lane per leaf; entry k of leaf l at leaft[k * NLEAF + l]): the local cell it touches
+// and the coefficient A[boundary cell, that cell] (0: no such entry)
+__device__ __forceinline__ void nd_leaf_boundary(const int* __restrict__ LT, const double* __restrict__ cf, int j, int& il, double& t, int& bcell) {
+    il = LT[(6 + 3 * j) * NLEAF];
+    const int fidx = LT[(7 + 3 * j) * NLEAF];
+    bcell = LT[(8 + 3 * j) * NLEAF];
+    const double tv = cf[fidx >= 0 ? fidx : 0];  // (unconditional load, then the mask: see nd_coef_global)
+    t = fidx >= 0 ? tv : 0.0;
 }
 
 __global__ __launch_bounds__(256, 2) void k_nd_leaf(FwdParams p, NdDev nd, int k) {
@@ -703,18 +699,20 @@ __global__ __launch_bounds__(256, 2) void k_nd_leaf(FwdParams p, NdDev nd, int k
     const int* work = nd_work(nd, m);
     const int e = (bidx * 256 + tid) >> 2;
     if (e >= work[0]) return;  // (no workgroup barrier below)
-    const int f = FID(10) + 4 * work[ND_W8 + e] + (tid & 3);
+    // (round 6: box, boundary cells and faces of the leaf come from the flat leaf table -- one coalesced read instead of the chain front
+    // record -> position table -> cell, two dependent trips to memory less per wave)
+    const int* LT = nd.leaft + 4 * work[ND_W8 + e] + (tid & 3);
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
-    double* out = nd.arena + (long long)m * nd.arena_stride + nd.fronts[f * ND_FRONT_INTS + NDF_UPD];
-    const int b = nd.fronts[f * ND_FRONT_INTS + NDF_B];
+    double* out = nd.arena + (long long)m * nd.arena_stride + LT[5 * NLEAF];
+    const int b = LT[4 * NLEAF];
     NdLeaf Lf;
-    const bool ok = nd_leaf_factor(Lf, nd, cf, f);
+    const bool ok = nd_leaf_factor(Lf, cf, LT[0], LT[NLEAF], LT[2 * NLEAF], LT[3 * NLEAF]);
     int il[12];
     double t[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         int bc;
-        nd_leaf_boundary(nd, cf, f, j, il[j], t[j], bc);
+        nd_leaf_boundary(LT, cf, j, il[j], t[j], bc);
     }
     double (*gl)[64] = gsh[w];
     // right-hand-side row: z = A_II^-1 q_I
@@ -749,23 +747,31 @@ __global__ __launch_bounds__(256, 2) void k_nd_leaf(FwdParams p, NdDev nd, int k
 // The last step of the back substitution: the leaves' own cells, with every separator pressure known.
 __global__ __launch_bounds__(256) void k_nd_leaf_solve(FwdParams p, NdDev nd, int k) {
     const int m = blockIdx.x % p.N, bidx = blockIdx.x / p.N;
-    const int f = FID(10) + bidx * 256 + threadIdx.x;
+    const int* LT = nd.leaft + bidx * 256 + threadIdx.x;  // the leaf's row of the flat leaf table (see k_nd_leaf)
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
     double* P = p.P + (long long)m * p.Nxy;
-    NdLeaf Lf;
-    nd_leaf_factor(Lf, nd, cf, f);
+    // box, boundary cells and faces arrive with ONE (coalesced) table read; the leaf's coefficients, its right-hand side, the faces towards
+    // the separators and the separator pressures are all requested behind it -- the lane waits for two trips to memory, not four
+    const int x0 = LT[0], y0 = LT[NLEAF], w = LT[2 * NLEAF], h = LT[3 * NLEAF];
     double v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = Lf.cell[i] >= 0 ? cf[CF_OQ + Lf.cell[i]] : 0.0;
+    for (int i = 0; i < 16; ++i) {
+        const int lx = i >> 2, ly = i & 3;
+        const bool alive = lx < w && ly < h;
+        const double qv = cf[CF_OQ + (alive ? (x0 + lx) * NB + y0 + ly : 0)];
+        v[i] = alive ? qv : 0.0;
+    }
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         int il, bc;
         double t;
-        nd_leaf_boundary(nd, cf, f, j, il, t, bc);
+        nd_leaf_boundary(LT, cf, j, il, t, bc);
         const double s = t * P[bc >= 0 ? bc : 0];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] -= (i == il) ? s : 0.0;
     }
+    NdLeaf Lf;
+    nd_leaf_factor(Lf, cf, x0, y0, w, h);
     nd_leaf_solve(Lf, v);
 #pragma unroll
     for (int i = 0; i < 16; ++i)
@@ -904,6 +910,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     const int bt = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
     const short* rec = nd.rec + (long long)__builtin_amdgcn_readfirstlane(F[NDF_REC]) * 256;
     const int kidm = __builtin_amdgcn_readfirstlane(F[NDF_KIDM]), cofm = __builtin_amdgcn_readfirstlane(F[NDF_COFM]);
+    NPROF_DECL;
     NdPanelRec<MAXBT, true> pr;
     nd_panel_rec_load(pr, rec, bt, g.lane, kidm, cofm);  // in flight beside the bulk copies below
     nd_wave_copy(c0l, arena + F[NDF_UC0], n0, g.lane);
@@ -912,8 +919,13 @@ __global__ __launch_bounds__(64 * WPB) void k_nd_wave(FwdParams p, NdDev nd, int
     nd_stage_cf(cf, cfl, WAVE_CF_PLANE, nd_box(F, NDF_PBOX), g.lane, L);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA pieces have landed
     nd_wave_fence();
+    NPROF(0);
     int bad = 0;
     nd_wave_front<MAXBT, true>(bt, __builtin_amdgcn_readfirstlane(F[NDF_KREG]), pr, rec, blk, arena + F[NDF_UPD], fact + F[NDF_FACT], g, bad, kidm, cofm);
+    NPROF(1);
+#ifdef HM_ND_PROF
+    if (blockIdx.x == HM_ND_PROF_SUB_BLOCK && tid == 0) { hm_nd_prof_buf[54 + 2 * (7 - LEVEL)] = prof_acc[0]; hm_nd_prof_buf[55 + 2 * (7 - LEVEL)] = prof_acc[1]; }
+#endif
     if (bad && g.lane == 0) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
 
@@ -1851,27 +1863,28 @@ __global__ __launch_bounds__(256, 4) void k_nd_solve_sub(FwdParams p, NdDev nd, 
     const double* fact = nd.fact + (long long)m * nd.fact_stride;
     const int i8 = 4 * bidx + w;
     constexpr int NFR = 3;  // the level-8 front and its two level-9 children (the leaves: k_nd_leaf_solve)
-    const int fid[NFR] = {FID(8) + i8, FID(9) + 2 * i8, FID(9) + 1 + 2 * i8};
     constexpr int MB[NFR] = {2, 2, 2}, MK[NFR] = {2, 1, 1};  // most boundary tiles / pivot register rows per front
+    // (round 6) the subtree's flat record: shapes and factor offsets of the three fronts as wave-uniform ints, boundary and pivot cells per
+    // lane -- one read, and the factor tiles and the ring's pressures are requested right behind it (two dependent trips to memory per
+    // wave instead of front record -> position table -> cell -> pressure: four)
+    const int* H = nd.ssub + (long long)i8 * ND_SSUB_INTS;
+    const int* TL = H + ND_SSUB_HDR + g.lane;
     int bt[NFR], kreg[NFR], cb[NFR][2], cpv[NFR][4];
     double t[NFR][2][4];
-    const NdBox box = nd_box(nd.fronts + fid[0] * ND_FRONT_INTS, NDF_RBOX);
-    const int x0 = box.x0, y0 = box.y0, x1 = box.x1, y1 = box.y1, ld = y1 - y0 + 2;
+    const int x0 = __builtin_amdgcn_readfirstlane(H[9]), y0 = __builtin_amdgcn_readfirstlane(H[10]), ld = __builtin_amdgcn_readfirstlane(H[11]);
 #pragma unroll
     for (int i = 0; i < NFR; ++i) {
-        const int* F = nd.fronts + fid[i] * ND_FRONT_INTS;
-        bt[i] = __builtin_amdgcn_readfirstlane(F[NDF_BT]);
-        kreg[i] = __builtin_amdgcn_readfirstlane(F[NDF_KREG]);
-        const int* cl = nd.cells + __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
-        const double* fa = fact + F[NDF_FACT];
+        bt[i] = __builtin_amdgcn_readfirstlane(H[i]);
+        kreg[i] = __builtin_amdgcn_readfirstlane(H[3 + i]);
+        const double* fa = fact + __builtin_amdgcn_readfirstlane(H[6 + i]);
 #pragma unroll
         for (int R = 0; R < MB[i]; ++R) {
-            cb[i][R] = cl[16 * (1 + (R < bt[i] ? R : 0)) + g.lc];
+            cb[i][R] = TL[(2 * i + R) * 64];
 #pragma unroll
             for (int r = 0; r < MK[i]; ++r) t[i][R][r] = fa[((R < bt[i] ? R : 0) * kreg[i] + (r < kreg[i] ? r : 0)) * 64 + g.lane];
         }
 #pragma unroll
-        for (int r = 0; r < MK[i]; ++r) cpv[i][r] = cl[4 * r + g.lq];
+        for (int r = 0; r < MK[i]; ++r) cpv[i][r] = TL[(i == 0 ? 6 + r : 7 + i) * 64];
     }
     auto li = [&](int c) { return ((c >> LG) - x0 + 1) * ld + ((c & (NB - 1)) - y0 + 1); };
     // the ring: the level-8 front's boundary cells, solved by the levels above
@@ -1905,7 +1918,6 @@ __global__ __launch_bounds__(256, 4) void k_nd_solve_sub(FwdParams p, NdDev nd, 
         }
         if (i == 0) nd_wave_fence();  // level boundary 8 | 9
     }
-    (void)x1;
 }
 
 // Face fluxes from the pressures (fwd_dev.h), one workgroup per member.
@@ -1976,11 +1988,52 @@ bool ND_ENTRY(pressure_nd_applies)(const FwdParams& p) { return p.Nx == NB && p.
 #if ND_LG == 7
 void hm_nd_free(hm_nd* n) {
     if (!n) return;
-    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->rec, &n->fact, &n->arena, &n->dg, &n->work, &n->cached, &n->wells, &n->vfac, &n->pimg, &n->wet, &n->todo};
+    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->rec, &n->fact, &n->arena, &n->dg, &n->work, &n->cached, &n->wells, &n->vfac, &n->pimg, &n->wet, &n->todo, &n->leaft, &n->ssub};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     delete n;
 }
 #endif
+
+// The flat per-leaf and per-subtree tables of the leaf kernels and k_nd_solve_sub (layout: the constants at the top of this file), from the
+// symbolic tables: what the kernels of rounds 3-5 derived per lane from front record -> position table -> cell.
+static void nd_build_flat_tables(const NdTablesHost& t, std::vector<int>& leaft, std::vector<int>& ssub) {
+    leaft.assign((size_t)ND_LEAF_INTS * NLEAF, -1);
+    for (int l = 0; l < NLEAF; ++l) {
+        const int* F = &t.fronts[(size_t)(FID(10) + l) * ND_FRONT_INTS];
+        const NdBox box = nd_box(F, NDF_RBOX);
+        const int x0 = box.x0, y0 = box.y0, x1 = box.x1, y1 = box.y1, b = F[NDF_B];
+        auto put = [&](int k, int v) { leaft[(size_t)k * NLEAF + l] = v; };
+        put(0, x0); put(1, y0); put(2, x1 - x0); put(3, y1 - y0); put(4, b); put(5, F[NDF_UPD]);
+        for (int j = 0; j < 12; ++j) {
+            if (j >= b) { put(6 + 3 * j, 0); put(7 + 3 * j, -1); put(8 + 3 * j, -1); continue; }
+            const int c = t.cells[F[NDF_CELLS] + 16 + j], bx = c >> LG, by = c & (NB - 1);
+            int ix = bx, iy = by, fidx;  // the one region cell next to the boundary cell, and the face between them
+            if (bx < x0) { ix = x0; fidx = CF_OX + ix * NB + iy; }                 // west side: the cell's west face
+            else if (bx >= x1) { ix = x1 - 1; fidx = CF_OX + bx * NB + by; }      // east side: the boundary cell's west face
+            else if (by < y0) { iy = y0; fidx = CF_OY + ix * (NB + 1) + iy; }      // south side: the cell's south face
+            else { iy = y1 - 1; fidx = CF_OY + bx * (NB + 1) + by; }              // north side: the boundary cell's south face
+            put(6 + 3 * j, (ix - x0) * 4 + (iy - y0)); put(7 + 3 * j, fidx); put(8 + 3 * j, c);
+        }
+    }
+    ssub.assign((size_t)ND_SSUB_INTS * NF8, 0);
+    for (int i8 = 0; i8 < NF8; ++i8) {
+        int* H = &ssub[(size_t)i8 * ND_SSUB_INTS];
+        const int fid[3] = {FID(8) + i8, FID(9) + 2 * i8, FID(9) + 1 + 2 * i8};
+        const NdBox box = nd_box(&t.fronts[(size_t)fid[0] * ND_FRONT_INTS], NDF_RBOX);
+        H[9] = box.x0; H[10] = box.y0; H[11] = box.y1 - box.y0 + 2;
+        for (int i = 0; i < 3; ++i) {
+            const int* F = &t.fronts[(size_t)fid[i] * ND_FRONT_INTS];
+            const int* cl = &t.cells[F[NDF_CELLS]];
+            const int bt = F[NDF_BT];
+            H[i] = bt; H[3 + i] = F[NDF_KREG]; H[6 + i] = F[NDF_FACT];
+            for (int lane = 0; lane < 64; ++lane) {
+                const int lc = lane & 15, lq = lane >> 4;
+                for (int R = 0; R < 2; ++R) H[ND_SSUB_HDR + (2 * i + R) * 64 + lane] = cl[16 * (1 + (R < bt ? R : 0)) + lc];
+                for (int r = 0; r < (i == 0 ? 2 : 1); ++r) H[ND_SSUB_HDR + (i == 0 ? 6 + r : 7 + i) * 64 + lane] = cl[4 * r + lq];
+            }
+        }
+    }
+}
 
 static int nd_setup(hm_fwd* f) {
     const FwdParams& p = f->p;
@@ -2049,7 +2102,19 @@ static int nd_setup(hm_fwd* f) {
     HM_HIP(hipMemcpy(n->cells.p, t.cells.data(), t.cells.size() * 4, hipMemcpyHostToDevice));
     HM_HIP(hipMemcpy(n->cpos.p, t.cpos.data(), t.cpos.size() * 2, hipMemcpyHostToDevice));
     HM_HIP(hipMemcpy(n->rec.p, t.rec.data(), t.rec.size() * 2, hipMemcpyHostToDevice));
+    {
+        std::vector<int> leaft, ssub;
+        nd_build_flat_tables(t, leaft, ssub);
+        if ((rc = hm_dev_alloc(n->leaft, leaft.size() * 4)) || (rc = hm_dev_alloc(n->ssub, ssub.size() * 4))) {
+            hm_nd_free(n);
+            return rc;
+        }
+        HM_HIP(hipMemcpy(n->leaft.p, leaft.data(), leaft.size() * 4, hipMemcpyHostToDevice));
+        HM_HIP(hipMemcpy(n->ssub.p, ssub.data(), ssub.size() * 4, hipMemcpyHostToDevice));
+    }
     NdDev& d = n->dev;
+    d.leaft = (const int*)n->leaft.p;
+    d.ssub = (const int*)n->ssub.p;
     d.fronts = (const int*)n->fronts.p;
     d.cells = (const int*)n->cells.p;
     d.cpos = (const short*)n->cpos.p;

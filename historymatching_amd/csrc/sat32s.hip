@@ -148,10 +148,11 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
         }
         return any;
     };
+    const bool narrow = all_active == 3;  // (hm_fwd_set_debug "slab_margin" 0: the neighbours of a wet slab sit out as well -- tests of the REDO launch)
     auto slab_active = [&](int sl) {
         if (sl < 0 || sl >= T) return false;
-        if (all_active || T == 1) return true;  // (1: record void; 2: the redo launch)
-        return wet[sl] != 0 || (sl > 0 && wet[sl - 1] != 0) || (sl + 1 < T && wet[sl + 1] != 0) || slab_has_injector(sl);
+        if (all_active == 1 || all_active == 2 || T == 1) return true;  // (1: record void; 2: the redo launch)
+        return wet[sl] != 0 || (!narrow && ((sl > 0 && wet[sl - 1] != 0) || (sl + 1 < T && wet[sl + 1] != 0))) || slab_has_injector(sl);
     };
     const bool active = slab_active(slab);
     const bool hasPrev = slab_active(slab - 1), hasNext = slab_active(slab + 1);  // (an active neighbour: the one this slab trades rows with)
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
 
     // ---------------- the state and its coefficients: fp64 arithmetic on the fp64 fluxes, rounded to float32 once (= the generic kernel)
     float base[PX][PY], dS[PX][PY], fx[PX][PY], fy[PX][PY], cC[PX][PY];
+    float fidw = 0.0f;  // fi d of this patch's well (an injector), float32
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
         const long long ix = gx0 + i;
@@ -273,9 +275,15 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
             const double vxw = gVx[ix * NY + iy], vxe = gVx[(ix + 1) * NY + iy];
             const double vys = gVy[ix * (NY + 1) + iy], vyn = gVy[ix * (NY + 1) + iy + 1];
             const double x1 = fmin(vxw, 0.0), x2 = fmax(vxe, 0.0), y1 = fmin(vys, 0.0), y2 = fmax(vyn, 0.0);
-            cC[i][j] = (float)(d * (((wrow == i && wcol == j) ? fpq : 0.0) + x1 - x2 + y1 - y2));
+            const double cC64 = d * (((wrow == i && wcol == j) ? fpq : 0.0) + x1 - x2 + y1 - y2);
+            cC[i][j] = (float)cC64;
+            float fidc = 0.0f;
+            if (wrow == i && wcol == j) fidc = fidw = source32(cC64, cC[i][j], fiq, d);  // (sat32.h: the well's source, rounded jointly with its c_C)
             fx[i][j] = (float)(d * vxw);
             fy[i][j] = (float)(d * vys);
+            // (sat32.h: a saturated neighbourhood gains nothing; the four off-diagonal coefficients as the sweep forms them from the rounded
+            // scaled fluxes: max(fx, 0), max(fy, 0), max(-fx_east, 0), max(-fy_north, 0))
+            cC[i][j] = diag32(cC[i][j], fmaxf(-(float)(d * vxe), 0.0f), fmaxf(-(float)(d * vyn), 0.0f), fmaxf(fy[i][j], 0.0f), fmaxf(fx[i][j], 0.0f), fidc, base[i][j]);
             dS[i][j] = 0.0f;
         }
     }
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(NT) void k_sat32s(FwdParams p, const float* __restr
     const unsigned long long injb = __ballot(inj);
     const int injl = injb ? __ffsll((long long)injb) - 1 : 0;
     const int irow = injb ? __builtin_amdgcn_readlane(wrow, injl) : -1, icol = __builtin_amdgcn_readlane(wcol, injl);
-    const float fid = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)(fiq * d)), injl));
+    const float fid = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fidw), injl));
     float fi[PY];
 #pragma unroll
     for (int j = 0; j < PY; ++j) fi[j] = icol == j ? fid : 0.0f;
@@ -520,7 +528,10 @@ int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, 
         f->slab_wet_step = -1;
     }
     // the record of wet slabs written by the launch of time index k - 1 is good for this one if nothing touched the plan's inputs or state since
-    const int all_active = !(f->slab_wet_step == k && f->slab_wet_gen == f->inputs_gen) || p.swc != 0.0 || f->raw_state_exposed;  // (swc > 0: fw(0) != 0, no slab is inert)
+    const bool record_void = !(f->slab_wet_step == k && f->slab_wet_gen == f->inputs_gen) || p.swc != 0.0 || f->raw_state_exposed;  // (swc > 0: fw(0) != 0, no slab is inert)
+    // 0: slabs sit out by the record; 1: everybody takes part; 3: by the record WITHOUT the margin of one slab around the wet ones (a test knob:
+    // the front then crosses into a sitting-out slab within a few steps, which the border check flags and the REDO launch below repairs)
+    const int all_active = record_void ? 1 : (f->dbg_slab_margin == 0 ? 3 : 0);
     const unsigned char* wet_in = (const unsigned char*)f->slab_wet.p + (size_t)(k & 1) * nflags;
     unsigned char* wet_out = (unsigned char*)f->slab_wet.p + (size_t)((k + 1) & 1) * nflags;
     hipStream_t s = f->ctx->stream;
@@ -538,7 +549,7 @@ int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, 
         hipLaunchKernelGGL(kern, dim3(8 * used_per_xcd * T), dim3(NT), LDS_BYTES, s, f->p, (const float*)S_in, (float*)S_out, S_stride,
                            (float*)f->prods.p, k, (char*)f->team_mem.p, T, first, wet_in, wet_out, all_active, (int*)f->retried.p);
     }
-    if (T > 1 && !all_active) {  // slabs may have sat out: the gated redo launch (only flagged members do anything)
+    if (T > 1 && all_active != 1) {  // slabs may have sat out: the gated redo launch (only flagged members do anything)
         for (int first = 0; first < p.N; first += per_launch) {
             const int nteams = std::min(per_launch, p.N - first);
             const int used_per_xcd = (nteams + 7) / 8;

@@ -159,6 +159,9 @@ long long hm_fwd_slab_redos(hm_fwd* f);
  *                        where its buffers fit the device, else blocks within 64 GB); must be set before the plan's first run
  *   "team_rounds"        value = 1: the slab teams of the float32 sweep (sat32s) are launched in rounds of as many teams as are resident at
  *                        once (round 4's form) instead of one launch for the whole ensemble; 0 (default) = one launch
+ *   "slab_margin"        value = 0: the float32 slab sweep (sat32s) lets a slab sit a time step out as soon as IT is dry -- by default its
+ *                        neighbours must be dry as well -- so the front reaches a sitting-out slab within a few steps; the border check flags
+ *                        the member and the gated REDO launch repeats its step with every slab (hm_fwd_slab_redos counts): results unchanged
  *   "embed"              value = 0: never run the grid embedded in the next square (hm_fwd_create): the generic kernels on the grid as
  *                        given -- block elimination / conjugate gradients and the tiled sweep, the in-library cross-check; 1 (default)
  * Returns nonzero for an unknown key. */

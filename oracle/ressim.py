@@ -280,6 +280,7 @@ class ResSim:
 
     # ---- the build's fp32 forward mode (NOT in the reference, which is fp64 end to end: HistoryMatch.py:362) ----
     F32_FOLD = 64
+    F32_HOT = 0.9997  # sat32.h: cells entering a time step at S >= this get the saturated-neighbourhood rule (diag32)
 
     def saturation_step_stencil_f32c(self, S32, q, Vx, Vy, T, compensated=True):
         """Specification of the saturation step of ``dtype=32`` plans (historymatching_amd/csrc/sat32.h), operation for
@@ -302,12 +303,29 @@ class ResSim:
         XN, XP = Vx.clip(max=0), Vx.clip(min=0)
         YN, YP = Vy.clip(max=0), Vy.clip(min=0)
         x1, x2, y1, y2 = XN[:-1, :], XP[1:, :], YN[:, :-1], YP[:, 1:]
-        cC = (d * (fp + x1 - x2 + y1 - y2)).astype(f32)
+        cC64 = d * (fp + x1 - x2 + y1 - y2)
+        cC = cC64.astype(f32)
         cW = (d * XP[:-1, :]).astype(f32)
         cE = (d * (-XN[1:, :])).astype(f32)
         cS = (d * YP[:, :-1]).astype(f32)
         cN = (d * (-YN[:, 1:])).astype(f32)
-        fid = (fi * dtx).reshape(Nx, Ny).astype(f32)
+        # the source term of an injector's cell is rounded JOINTLY with its diagonal coefficient (sat32.h: source32): fid = fl32((c_C + fi d)
+        # - cC32), so that cC32 + fid is the fp64 sum to one rounding -- zero for a pure source cell, which then fills up to S = 1 and stays
+        # (0 <= S <= 1); rounded independently the two differ by an ulp that the cell gains every sub-step at fw = 1
+        fid64 = (fi * dtx).reshape(Nx, Ny)
+        fid = np.where(fi.reshape(Nx, Ny) > 0, (cC64 + fid64) - cC.astype(np.float64), fid64).astype(f32)
+        # ... and for the cells that enter the step at S >= F32_HOT c_C is lowered by whole ulps until the increment of a SATURATED
+        # neighbourhood (every fw = 1), evaluated in float32 in the sweeps' order of additions, is not positive (sat32.h: diag32): in exact
+        # arithmetic that sum is d (q - div V) = 0, rounded one by one it is an ulp-sized residue, the same in all Nts sub-steps of a
+        # step, on which cells around the injector creep above 1
+        hot = np.asarray(S32, dtype=f32).reshape(Nx, Ny) >= f32(self.F32_HOT)
+        for _ in range(4):
+            r = ((((cE + cN) + cC) + cS) + cW) + fid
+            pos = hot & (r > 0)
+            if not pos.any():
+                break
+            cC = np.where(pos, np.nextafter(cC, f32(-np.inf)), cC)
+        assert cC.dtype == f32
         base = np.asarray(S32, dtype=f32).reshape(Nx, Ny).copy()
         dS = np.zeros((Nx, Ny), dtype=f32)
         one = f32(1)

@@ -40,3 +40,6 @@ for n, x in zip(sub, v):
     print(f"   {n:28s} {x:10d}  {100 * x / max(sum(v), 1):5.1f} %")
 v = list(buf[32:48])
 print(f"k_nd_solve, block 0 wave 0: {sum(v)} cycles; slots (level 5..10 compute at 5..10, barrier waits at 0..5, levels 0-4 at 12): {v}")
+v = list(buf[54:60])
+print("k_nd_wave<7>, <6>, <5>, one wave (workgroup HM_ND_PROF_SUB_BLOCK, wave 0): staging (recipes, children by LDS-DMA, coefficient planes) / the front, cycles: "
+      + ", ".join(f"{v[2 * i]} / {v[2 * i + 1]}" for i in range(3)))

@@ -1497,3 +1497,72 @@ def test_nested_dissection_in_member_blocks_is_bit_identical():
         plan.close()
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_float32_slab_sweep_redo_launch_repairs_a_slab_that_sat_out():
+    """The gated REDO launch of the float32 slab sweep (sat32s.hip: all_active = 2, HM_MEMBER_REDO_STEP) is what keeps slab skipping exact
+    when water reaches a slab that sat the step out.  With the default rule (a slab sits out only if its neighbours are dry too) that
+    happens to 1 member in 125 of config 5's prior; hm_fwd_set_debug "slab_margin" 0 lets a slab sit out as soon as it is dry itself, so the
+    front crosses into a sitting-out slab within a few steps on EVERY member: slab_redos > 0, the status words clean (the REDO bit cleared),
+    saturation history, producer series and sub-step counts bit-identical to the single-workgroup tiled sweep (sat_variant 3)."""
+    nx, ny, N, steps = 512, 256, 6, 12
+    _, gm = make_models(nx, ny, dtype=32)
+    x = perms(nx, ny, N, seed=92)
+    out = {}
+    for mode in ("narrow", "tiled"):
+        plan = _plan(gm, N, nTime=steps)
+        if mode == "narrow":
+            plan.set_debug("slab_margin", 0)
+        else:
+            plan.set_variant(0, 3)
+        plan.set_inputs(x, transformed=False)
+        plan.run(0, steps)
+        st = plan.sync()
+        w, p, status = plan.outputs()
+        assert not status.any(), status  # (HM_MEMBER_REDO_STEP = 32 cleared by every redo)
+        assert st["team_retries"] == 0
+        out[mode] = (w, p, plan.get_field("nts").copy(), st["slab_redos"])
+        plan.close()
+    assert out["narrow"][3] > 0 and out["tiled"][3] == 0, out["narrow"][3]
+    # the front did cross slab borders during the run: slabs 2 and 5 (rows 128..191, 320..383) were dry after the first step and are wet at the end
+    S1, Send = out["narrow"][0][:, 1].reshape(N, nx, ny), out["narrow"][0][:, steps].reshape(N, nx, ny)
+    assert (S1[:, 128:192] == 0).all() and (Send[:, 128:192] != 0).any() and (Send[:, 320:384] != 0).any()
+    for a, b in zip(out["narrow"][:3], out["tiled"][:3]):
+        assert np.array_equal(a, b), np.abs(a.astype(float) - b.astype(float)).max()
+
+
+@pytest.mark.gpu
+def test_embedded_fp32_plan_sees_a_state_written_through_the_raw_pointer():
+    """hm_fwd_device_ptr("S") hands out the OUTER plan's saturation; an embedded grid (200 x 150 inside 256 x 256, dtype = 32) must then
+    keep no record of wet slabs in its INNER plan either (forward.hip: embedded_inner passes raw_state_exposed on): water written through the
+    pointer into a slab that sat the previous steps out is swept, not zeroed.  Against the generic kernels on the grid as given ("embed" 0):
+    within the float32 bar, the written water still there."""
+    import ctypes as C
+
+    from historymatching_amd import _lib
+
+    nx, ny, N, steps = 200, 150, 3, 3
+    _, gm = make_models(nx, ny, dtype=32)
+    x = perms(nx, ny, N, seed=93)
+    res = {}
+    for name in ("embedded", "generic"):
+        plan = _plan(gm, N, nTime=steps + 2, keep_history=False)
+        if name == "generic":
+            plan.set_debug("embed", 0)
+        plan.set_inputs(x, transformed=False)
+        plan.run(0, steps)
+        plan.sync()
+        S = np.ascontiguousarray(plan.get_field("S").reshape(N, nx, ny))
+        assert (S[:, 192:] == 0).all()  # rows 192.. (the inner plan's last slab of 64 rows) are dry: that slab sat out
+        S[:, 193:199, 20:60] = np.float32(0.3)
+        ptr = plan.device_ptr("S")
+        _lib.check(plan.lib.hm_copy_to_device(plan.ctx.handle, C.c_void_p(ptr), S.ctypes.data_as(C.c_void_p), S.nbytes), "copy S")
+        plan.run(steps, 2)
+        plan.sync()
+        _, _, status = plan.outputs(want_wsats=False)
+        assert not status.any()
+        res[name] = plan.get_field("S").reshape(N, nx, ny).astype(np.float64)
+        plan.close()
+    assert res["embedded"][:, 193:199, 20:60].min() > 0.05  # the water written by hand was swept, not zeroed
+    assert np.abs(res["embedded"] - res["generic"]).max() < 1e-4

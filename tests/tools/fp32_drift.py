@@ -25,10 +25,11 @@ t0 = time.time()
 
 
 def report(r):
-    print(f"{r['step']:5d}  {r['max']:.3e}  {r['p999']:.3e}  {r['mean']:.3e}  {r['prod']:.3e}   {r['wip_max']:+.3e} / {r['wip_min']:+.3e}   {r['same_nts']}  "
+    print(f"{r['step']:5d}  {r['max']:.3e}  {r['p999']:.3e}  {r['mean']:.3e}  {r['prod']:.3e}   {r['wip_max']:+.3e} / {r['wip_min']:+.3e}   {r['same_nts']}  smax-1 {r['s_max'] - 1:+.2e}  "
           f"{time.time() - t0:.0f}{'' if not r['status'] else '   STATUS ' + str(r['status'])}", flush=True)
 
 
 rows = fp32_vs_fp64_drift(grid, N, steps, seed=seed, sat_variant32=sv32, report=report)
 print(f"# whole run: max|S32 - S64| = {max(r['max'] for r in rows):.3e}, p99.9 = {max(r['p999'] for r in rows):.3e}, max producer difference = "
-      f"{max(r['prod'] for r in rows):.3e}, max |water-in-place difference| = {max(max(abs(r['wip_max']), abs(r['wip_min'])) for r in rows):.3e}")
+      f"{max(r['prod'] for r in rows):.3e}, max |water-in-place difference| = {max(max(abs(r['wip_max']), abs(r['wip_min'])) for r in rows):.3e}, "
+      f"max S32 - 1 = {max(r['s_max'] for r in rows) - 1:+.3e}")
