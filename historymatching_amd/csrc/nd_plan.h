@@ -18,6 +18,12 @@ struct NdDev {
     // [ND_SSUB_HDR] wave-uniform ints, then [ND_SSUB_LANE][64] per-lane ints.
     const int* leaft;
     const int* ssub;
+    // the leaves' update matrices (k_nd_leaf -> k_nd_sub), per member and level-8 subtree one block of 4 * slot10 doubles, the four leaves
+    // INTERLEAVED: entry e of leaf l at [4 e + l].  k_nd_leaf's lanes (one leaf each, four consecutive lanes = the leaves of one subtree)
+    // then write 32 contiguous bytes per subtree and entry instead of 8 bytes into four packed arrays 700 bytes apart, and k_nd_sub reads
+    // its subtree's block as one contiguous piece (round 6; the arena's per-leaf slots are no longer used)
+    double* leafu;
+    long long leafu_stride;
     double* fact;
     double* arena;
     double* cf;  // per member: [dg | -TX | -TY | q], CF_STRIDE doubles
@@ -42,7 +48,7 @@ struct NdDev {
 
 struct hm_nd {
     NdInfo info{};
-    DevBuf fronts, cells, cpos, rec, fact, arena, dg, work, cached, wells, vfac, pimg, wet, todo, leaft, ssub;
+    DevBuf fronts, cells, cpos, rec, fact, arena, dg, work, cached, wells, vfac, pimg, wet, todo, leaft, ssub, leafu;
     NdDev dev{};
     int cap = 0;                // members the per-member buffers hold: larger ensembles are solved in blocks of `cap` members (larger grids)
     long long cached_gen = -1;  // hm_fwd::inputs_gen the cached results belong to

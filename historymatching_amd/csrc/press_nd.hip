@@ -701,9 +701,11 @@ __global__ __launch_bounds__(256, 2) void k_nd_leaf(FwdParams p, NdDev nd, int k
     if (e >= work[0]) return;  // (no workgroup barrier below)
     // (round 6: box, boundary cells and faces of the leaf come from the flat leaf table -- one coalesced read instead of the chain front
     // record -> position table -> cell, two dependent trips to memory less per wave)
-    const int* LT = nd.leaft + 4 * work[ND_W8 + e] + (tid & 3);
+    const int i8 = work[ND_W8 + e];
+    const int* LT = nd.leaft + 4 * i8 + (tid & 3);
     const double* cf = nd.cf + (long long)m * CF_STRIDE;
-    double* out = nd.arena + (long long)m * nd.arena_stride + LT[5 * NLEAF];
+    // the subtree's block of interleaved leaf updates (nd_plan.h: leafu): entry e of this leaf at out[4 e]
+    double* out = nd.leafu + (long long)m * nd.leafu_stride + (long long)i8 * (4 * nd.slot10) + (tid & 3);
     const int b = LT[4 * NLEAF];
     NdLeaf Lf;
     const bool ok = nd_leaf_factor(Lf, cf, LT[0], LT[NLEAF], LT[2 * NLEAF], LT[3 * NLEAF]);
@@ -725,8 +727,8 @@ __global__ __launch_bounds__(256, 2) void k_nd_leaf(FwdParams p, NdDev nd, int k
         for (int i = 0; i < 16; ++i) gl[i][lane] = v[i];
 #pragma unroll
         for (int l = 0; l < 12; ++l)
-            if (l < b) out[((b * (b + 1)) >> 1) + l] = -t[l] * gl[il[l]][lane];
-        out[((b * (b + 1)) >> 1) + b] = 0.0;
+            if (l < b) out[4 * (((b * (b + 1)) >> 1) + l)] = -t[l] * gl[il[l]][lane];
+        out[4 * (((b * (b + 1)) >> 1) + b)] = 0.0;
     }
     // boundary rows: g = A_II^-1 e_{il[j]}
 #pragma unroll
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void k_nd_leaf(FwdParams p, NdDev nd, int k
         for (int i = 0; i < 16; ++i) gl[i][lane] = v[i];
 #pragma unroll
         for (int l = 0; l <= j; ++l)
-            if (j < b) out[((j * (j + 1)) >> 1) + l] = -(t[j] * t[l]) * gl[il[l]][lane];
+            if (j < b) out[4 * (((j * (j + 1)) >> 1) + l)] = -(t[j] * t[l]) * gl[il[l]][lane];
     }
     if (!ok) atomicOr(&p.status[m], HM_MEMBER_BAD_PIVOT);
 }
@@ -831,34 +833,39 @@ __global__ __launch_bounds__(64 * SUB_WPB) void k_nd_sub(FwdParams p, NdDev nd, 
 #pragma unroll
     for (int i = 0; i < 2; ++i) F9[i] = nd.fronts + (f9 + i) * ND_FRONT_INTS;
     NdPanelRec<2, true> pp;
-    // the four leaves' update matrices (k_nd_leaf wrote them to the arena; <= 92 doubles each: one double2 per lane): the first pair
-    // straight into the level-10 slots, the second pair into registers until the first level-9 front has read the slots
-    auto leaf_d2 = [&](int i) {
-        const int bl = __builtin_amdgcn_readfirstlane(F10[i][NDF_B]);
-        const int n2 = ((((bl + 1) * (bl + 2)) >> 1) + 1) >> 1;
-        const double2* src = reinterpret_cast<const double2*>(arena + __builtin_amdgcn_readfirstlane(F10[i][NDF_UPD]));
-        return src[g.lane < n2 ? g.lane : n2 - 1];
-    };
+    // the four leaves' update matrices: the subtree's block of 4 * slot10 doubles, interleaved by leaf (nd_plan.h: leafu), as one contiguous
+    // read of 2 * slot10 double2 (three per lane).  double2 k holds entry k / 2 of leaves 0, 1 (k even) or 2, 3 (k odd): even lanes fill the
+    // level-10 slots now, odd lanes keep theirs in registers until the first level-9 front has read the slots
     static_assert(true, "slot10 <= 128 doubles is checked on the host (nd_setup)");
-    double2 lf0 = leaf_d2(0), lf1 = leaf_d2(1), lf2 = leaf_d2(2), lf3 = leaf_d2(3);
+    const int lu_n2 = 2 * nd.slot10;
+    double2 lu[3];
+    {
+        const double2* src = reinterpret_cast<const double2*>(nd.leafu + (long long)m * nd.leafu_stride + (long long)i8 * (4 * nd.slot10));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int kq = g.lane + 64 * q;
+            lu[q] = src[kq < lu_n2 ? kq : lu_n2 - 1];
+        }
+    }
+    auto leaf_slots = [&](int odd) {  // the kept double2 of the even (leaves 0, 1) or odd (leaves 2, 3) lanes -> level-10 slots A, B
+        if ((g.lane & 1) == odd) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int kq = g.lane + 64 * q;
+                if (kq < lu_n2) { s10[kq >> 1] = lu[q].x; s10[nd.slot10 + (kq >> 1)] = lu[q].y; }
+            }
+        }
+    };
     nd_panel_rec_load(pp, recp(F9[0]), btof(F9[0]), g.lane, kidof(F9[0]), cofof(F9[0]));
     NdCfl L;
     nd_stage_cf(cf, cfl, SUB_CF_PLANE, nd_box(F8, NDF_RBOX), g.lane, L);
-    {
-        double2* a2 = reinterpret_cast<double2*>(s10);
-        double2* b2 = reinterpret_cast<double2*>(s10 + nd.slot10);
-        if (2 * g.lane < nd.slot10) { a2[g.lane] = lf0; b2[g.lane] = lf1; }
-    }
+    leaf_slots(0);
     nd_wave_fence();
     NPROF(0);
     nd_wave_front<2, true>(btof(F9[0]), krof(F9[0]), pp, recp(F9[0]), blk, s9, fact + F9[0][NDF_FACT], g, bad, kidof(F9[0]), cofof(F9[0]));
     nd_panel_rec_load(pp, recp(F9[1]), btof(F9[1]), g.lane, kidof(F9[1]), cofof(F9[1]));
     nd_wave_fence();
-    {
-        double2* a2 = reinterpret_cast<double2*>(s10);
-        double2* b2 = reinterpret_cast<double2*>(s10 + nd.slot10);
-        if (2 * g.lane < nd.slot10) { a2[g.lane] = lf2; b2[g.lane] = lf3; }
-    }
+    leaf_slots(1);
     nd_wave_fence();
     NPROF(1);
     nd_wave_front<2, true>(btof(F9[1]), krof(F9[1]), pp, recp(F9[1]), blk, s9 + nd.slot9, fact + F9[1][NDF_FACT], g, bad, kidof(F9[1]), cofof(F9[1]));
@@ -1988,7 +1995,7 @@ bool ND_ENTRY(pressure_nd_applies)(const FwdParams& p) { return p.Nx == NB && p.
 #if ND_LG == 7
 void hm_nd_free(hm_nd* n) {
     if (!n) return;
-    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->rec, &n->fact, &n->arena, &n->dg, &n->work, &n->cached, &n->wells, &n->vfac, &n->pimg, &n->wet, &n->todo, &n->leaft, &n->ssub};
+    DevBuf* bufs[] = {&n->fronts, &n->cells, &n->cpos, &n->rec, &n->fact, &n->arena, &n->dg, &n->work, &n->cached, &n->wells, &n->vfac, &n->pimg, &n->wet, &n->todo, &n->leaft, &n->ssub, &n->leafu};
     for (DevBuf* b : bufs) hm_dev_free(*b);
     delete n;
 }
@@ -2072,7 +2079,8 @@ static int nd_setup(hm_fwd* f) {
     int rc = 0;
     // members per block: the whole ensemble where its factor, update matrices and panels fit the budget below (always at 128 x 128:
     // 9.6 MB a member), else blocks of that many members, one after the other through the same buffers
-    const size_t per_member = (size_t)(t.info.fact_doubles + t.info.arena_doubles + t.info.big_fact_doubles + t.info.pimg_doubles + CF_STRIDE) * 8;
+    const size_t leafu_doubles = (size_t)NF8 * 4 * t.info.upd_doubles[LO + 10];  // interleaved leaf updates (nd_plan.h: leafu)
+    const size_t per_member = (size_t)(t.info.fact_doubles + t.info.arena_doubles + t.info.big_fact_doubles + t.info.pimg_doubles + CF_STRIDE + leafu_doubles) * 8;
     size_t cap = p.N;
     if (LO > 0) {
         size_t free_b = 0, total_b = 0;
@@ -2092,7 +2100,7 @@ static int nd_setup(hm_fwd* f) {
     if ((rc = hm_dev_alloc(n->fronts, t.fronts.size() * 4)) || (rc = hm_dev_alloc(n->cells, t.cells.size() * 4)) ||
         (rc = hm_dev_alloc(n->cpos, t.cpos.size() * 2)) || (rc = hm_dev_alloc(n->rec, t.rec.size() * 2)) || (rc = hm_dev_alloc(n->fact, N * t.info.fact_doubles * 8)) ||
         (rc = hm_dev_alloc(n->arena, N * t.info.arena_doubles * 8)) || (rc = hm_dev_alloc(n->dg, N * (size_t)CF_STRIDE * 8)) ||
-        (rc = hm_dev_alloc(n->work, N * (size_t)ND_WORK_INTS * 4)) || (rc = hm_dev_alloc(n->cached, N * n_cached)) || (rc = hm_dev_alloc(n->wells, n_cached)) ||
+        (rc = hm_dev_alloc(n->leafu, N * leafu_doubles * 8)) || (rc = hm_dev_alloc(n->work, N * (size_t)ND_WORK_INTS * 4)) || (rc = hm_dev_alloc(n->cached, N * n_cached)) || (rc = hm_dev_alloc(n->wells, n_cached)) ||
         (LO > 0 && ((rc = hm_dev_alloc(n->vfac, N * (size_t)t.info.big_fact_doubles * 8)) || (rc = hm_dev_alloc(n->pimg, N * (size_t)t.info.pimg_doubles * 8)) ||
                     (rc = hm_dev_alloc(n->wet, N * (size_t)NB * WETW * 8)) || (rc = hm_dev_alloc(n->todo, N * (size_t)NTODO))))) {
         hm_nd_free(n);
@@ -2113,6 +2121,8 @@ static int nd_setup(hm_fwd* f) {
         HM_HIP(hipMemcpy(n->ssub.p, ssub.data(), ssub.size() * 4, hipMemcpyHostToDevice));
     }
     NdDev& d = n->dev;
+    d.leafu = (double*)n->leafu.p;
+    d.leafu_stride = (long long)leafu_doubles;
     d.leaft = (const int*)n->leaft.p;
     d.ssub = (const int*)n->ssub.p;
     d.fronts = (const int*)n->fronts.p;
