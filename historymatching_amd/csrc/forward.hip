@@ -1173,16 +1173,21 @@ static int launch_saturation(hm_fwd* f, int k) {
     if ((rc = extract_fields(f))) return rc;  // (a sweep of this plan's own kernels behind an embedded pressure step: the fluxes it reads)
     f->inner_S_step = -1;
     int done = -1;
+    bool teams128 = false;
     if (f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
         // fp64, register/LDS resident: fw in registers, scaled fluxes (sat128r.hip); sat_variant 5: fw image in LDS (sat128.hip)
-        if (f->sat_variant != 5) done = launch_saturation_128r(f, Sin, Sout, stride, k);
+        // small member shards at 128 x 128 (members x slabs <= CUs: one rank's share of a strong-scaled ensemble): a member as a team of
+        // two or four workgroups on CUs of their own (sat128s.hip) -- sat128r's one workgroup per member would leave the other CUs idle
+        if (f->sat_variant == 0 || f->sat_variant == 4) done = launch_saturation_128s(f, Sin, Sout, stride, k);
+        teams128 = done == 0;
+        if (done < 0 && f->sat_variant != 5) done = launch_saturation_128r(f, Sin, Sout, stride, k);
         if (done < 0) done = launch_saturation_128(f, Sin, Sout, stride, k);
         if (done < 0) done = launch_saturation_32s(f, Sin, Sout, stride, k);  // dtype = 32 plans, grids 128 / 256 / 512 wide: slabs (workgroup teams), fw in registers
         if (done < 0 && f->sat_variant != 5) done = launch_saturation_256s(f, Sin, Sout, stride, k);  // fp64, grids 256 wide: slabs of 64 rows (workgroup teams), fw in registers
         if (done < 0) done = launch_saturation_128t(f, Sin, Sout, stride, k);  // fp64, grids of 128 x 128 tiles (workgroup teams)
     }
     if (done > 0) return done;
-    if (done == 0 && p.Nxy > 128 * 128 && f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
+    if (done == 0 && (p.Nxy > 128 * 128 || teams128) && f->sat_variant != 1 && f->sat_variant != 2 && f->sat_variant != 3) {
         // The team sweeps spin on their neighbours' rows, which needs every workgroup of a team resident at once; the launch is sized for
         // an otherwise idle GPU (one workgroup per CU).  If something else held CUs (another process, a masked device), a team can be
         // partly resident: its workgroups give up after a bounded spin and flag the member HM_MEMBER_SYNC_TIMEOUT.  The single-workgroup
@@ -1434,6 +1439,8 @@ extern "C" int hm_fwd_set_debug(hm_fwd* f, const char* key, long long value) {
     if (k == "nd_force_fallback") f->dbg_nd_force_fallback = (int)value;
     else if (k == "team_rounds") f->dbg_team_rounds = (int)value;
     else if (k == "embed") f->dbg_embed = (int)value;
+    else if (k == "sat_teams") f->dbg_sat_teams = (int)value;
+    else if (k == "top_per_level") f->dbg_top_per_level = (int)value;
     else if (k == "slab_margin") {
         f->dbg_slab_margin = (int)value;
         if (f->inner) f->inner->dbg_slab_margin = (int)value;

@@ -82,6 +82,8 @@ struct hm_fwd {
     DevBuf slab_wet;  // sat32s.hip: which slabs of which member hold water, two images in turn (written by the launch of step k, read by that of k + 1)
     int slab_wet_step = -1;       // time index whose launch may read the record
     long long slab_wet_gen = -1;  // inputs_gen the record belongs to
+    int dbg_top_per_level = 1;    // hm_fwd_set_debug "top_per_level": 0 = levels 3 .. 0 of the 128 x 128 nested dissection always as one workgroup per member (default: a launch per level, a front per workgroup, for shards of fewer members than CUs)
+    int dbg_sat_teams = -1;       // hm_fwd_set_debug "sat_teams": workgroups per member of the 128 x 128 fp64 sweep -- -1 automatic (2 / 4 where members x slabs <= CUs), 0 never, 2, 4
     int dbg_slab_margin = 1;      // hm_fwd_set_debug "slab_margin": 0 = the float32 slab sweep lets the neighbours of wet slabs sit out too (exercises its REDO launch)
     int dbg_team_rounds = 0;      // hm_fwd_set_debug "team_rounds": 1 = the slab teams in rounds of co-resident teams (round 4's form)
     DevBuf team_mem;  // synchronisation blocks of the multi-tile saturation sweep (sat128t.hip), allocated on first use
@@ -133,6 +135,7 @@ int launch_pressure_pcg(hm_fwd* f, const void* S, long long S_stride, int k);   
 bool pressure_two_level_applies(const FwdParams& p);
 int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int k);  // two-level CG, Ny = 128 c
 int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);
+int launch_saturation_128s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // 128 x 128 fp64, small member shards: teams of 2 / 4 slab workgroups (sat128s.hip)
 int launch_saturation_128r(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // fw in registers, scaled fluxes (sat128r.hip)
 int launch_saturation_32s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // dtype = 32 plans, grids 128 / 256 / 512 wide (sat32s.hip)
 int launch_saturation_128t(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // grids of 128 x 128 tiles, fp64

@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams
 #if ND_LG == 7
         bool listed = false;
         const int nl = __builtin_amdgcn_readfirstlane(wlist[0]);
-        for (int i = 0; i < nl && i < (1 << TOPK_LEVEL); ++i) listed = listed || __builtin_amdgcn_readfirstlane(wlist[1 + i]) == f0;  // (the level's fronts come first)
+        for (int i = 0; i < nl; ++i) listed = listed || __builtin_amdgcn_readfirstlane(wlist[1 + i]) == f0;  // (at most 31 entries: levels 4 .. 0 in order)
         if (!listed) return;
 #else
         if (!nd.todo[(long long)m * NTODO + f0]) return;  // (the front keeps the results it has; the whole workgroup leaves)
@@ -1650,8 +1650,12 @@ __device__ __forceinline__ void nd_solve_single(const NdDev& nd, const double* _
     }
 }
 
+#ifndef SOL_DEPTH
+#define SOL_DEPTH 8  // factor tiles a wave keeps in flight in the fronts of levels 0 .. 4 (64 of its 128 registers)
+#endif
 __global__ __launch_bounds__(64 * SOL_NW, SOL_OCC) void k_nd_solve(FwdParams p, NdDev nd, int k) {
     __shared__ double xe_all[SOL_NW][16 * TOP_MAXT];
+    __shared__ int pcell_all[SOL_NW][16 * TOP_MAXT];  // the current front's pivot cells
     const int m = blockIdx.x, tid = threadIdx.x;
     NdGeo g;
     g.lane = tid & 63;
@@ -1685,7 +1689,10 @@ __global__ __launch_bounds__(64 * SOL_NW, SOL_OCC) void k_nd_solve(FwdParams p, 
             const int kreg_last = __builtin_amdgcn_readfirstlane(F[NDF_KREG]);
             const int* cl = nd.cells + __builtin_amdgcn_readfirstlane(F[NDF_CELLS]);
             const double* fa = fact + F[NDF_FACT];
-            // boundary values (ancestors' pivots, already known), -1 on the right-hand-side row
+            // boundary values (ancestors' pivots, already known), -1 on the right-hand-side row; the front's own pivot cells to LDS in the same
+            // trip to memory (round 6: every panel used to fetch its 16 from the position table when it was done -- a trip per panel)
+            int* pcell = pcell_all[w];
+            for (int pos = g.lane; pos < 16 * st; pos += 64) pcell[pos] = cl[pos];
             for (int pos = 16 * st + g.lane; pos < 16 * T; pos += 64) {
                 const int c = cl[pos];
                 xe[pos] = c >= 0 ? P[c] : (c == -2 ? -1.0 : 0.0);
@@ -1693,6 +1700,74 @@ __global__ __launch_bounds__(64 * SOL_NW, SOL_OCC) void k_nd_solve(FwdParams p, 
             nd_wave_fence();
             int fo = 0;
             for (int pp = 0; pp < st - 1; ++pp) fo += (T - pp - 1) * 4;
+            if (kreg_last == 4) {
+                // Round 6: the front's factor as ONE stream.  The tiles are consumed in a fixed order -- panels st - 1 .. 0, within a panel the
+                // tile rows pp + 1 .. T - 1 -- at addresses that do not depend on the solution, so SOL_DEPTH tiles are kept in flight in
+                // registers across panel boundaries: the chain of dependent trips to memory (one per four tiles, two per panel: 95 for levels
+                // 0 .. 4 of a member) becomes one trip per front plus the stream.  With a whole ensemble resident the phase is bound by HBM
+                // bandwidth either way (1.28 MB of factor per member at 4.9 TB/s: profiles/r06/nd_cycle_stamps_mid_grid.txt); a SMALL member
+                // shard -- 125 members: one rank's share of config 2 over 8 GPUs -- does not fill the memory system, and there the chain was
+                // the kernel's time (0.27 of the shard's 1.13 ms pressure step).  Same products, same order of additions per pivot (tile rows
+                // ascending): the same bits.
+                const int ntot = st * T - ((st * (st + 1)) >> 1);
+                d4 buf[SOL_DEPTH];
+                int ppf = st - 1, Rf = st, fof = fo;  // the prefetch stream's panel, tile row, factor offset
+                auto fetch = [&](d4& b, bool real) {  // (`real`: wave-uniform; a slot past the end re-reads the front's first tile: the load
+                                                      // count per iteration stays static, which is what lets the compiler wait by count)
+                    const double* tl = fa + (real ? (long long)(fof + (Rf - ppf - 1) * 4) * 64 : 0LL) + g.lane;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[r] = tl[r * 64];
+                    if (real && ++Rf == T) {
+                        --ppf;
+                        fof -= (T - ppf - 1) * 4;
+                        Rf = ppf + 1;
+                    }
+                };
+#pragma unroll
+                for (int j = 0; j < SOL_DEPTH; ++j) fetch(buf[j], j < ntot);
+                int pp = st - 1, R = st;
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int base = 0; base < ntot; base += SOL_DEPTH) {
+#pragma unroll
+                    for (int j = 0; j < SOL_DEPTH; ++j) {
+                        const int i = base + j;
+                        const bool live = i < ntot;  // (wave-uniform)
+                        const double xv = xe[16 * (live ? R : 0) + g.lc];
+                        if (live) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[r] = fma(buf[j][r], xv, acc[r]);
+                        }
+                        fetch(buf[j], i + SOL_DEPTH < ntot);
+                        if (live && ++R == T) {  // the panel is complete: its 16 pivots
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                double v = acc[r];
+                                v += __shfl_xor(v, 8);
+                                v += __shfl_xor(v, 4);
+                                v += __shfl_xor(v, 2);
+                                v += __shfl_xor(v, 1);
+                                acc[r] = -v;
+                            }
+                            if (g.lc == 0) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int pos = 16 * pp + 4 * r + g.lq;
+                                    const int c = pcell[pos];
+                                    const double v = c >= 0 ? acc[r] : 0.0;
+                                    xe[pos] = v;
+                                    if (c >= 0) P[c] = v;
+                                }
+                            }
+                            nd_wave_fence();
+                            --pp;
+                            R = pp + 1;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[r] = 0.0;
+                        }
+                    }
+                }
+                continue;
+            }
             for (int pp = st - 1; pp >= 0; --pp) {
                 const int kreg = pp == st - 1 ? kreg_last : 4;
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -2179,6 +2254,10 @@ static int nd_setup(hm_fwd* f) {
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<2, 6, 15, LO + 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #else
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<3, 4, 13, 3, TOP_NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<3, 4, 13, 3, TOP_NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<3, 4, 13, 2, TOP_NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<3, 4, 13, 1, TOP_NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_top<3, 4, 13, 0, TOP_NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
 #if ND_LG == 7
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_assemble<double>, hipFuncAttributeMaxDynamicSharedMemorySize, NB * NB * 8));
@@ -2228,7 +2307,19 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
     if (hipError_t e_ = hipGetLastError()) { hm_set_error("k_nd_top<level LO + 4> launch with %zu bytes of LDS: %s", lds_top4, hipGetErrorString(e_)); return 1; }
 #if ND_LG == 7
     const size_t lds_top = (size_t)top_lds_doubles(13, nd.top_child_doubles) * 8 + 31 * ND_FRONT_INTS * 4;
-    hipLaunchKernelGGL((k_nd_top<3, 4, 13, 3, TOP_NW, false>), dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k, nd.top_child_doubles);  // levels 3..0 of a member
+    if (4 * p.N <= 3 * f->ctx->num_cu && f->dbg_top_per_level != 0) {
+        // A SMALL member shard (at most three quarters as many members as CUs -- one rank's share of a strong-scaled ensemble; measured: 64
+        // members 0.90 -> 0.77 ms a pressure step, 125 members 1.11 -> 1.03, 250 members no gain): a workgroup per member would leave CUs
+        // idle while each member's 15 fronts of levels 3 .. 0 run one after the other (0.29 of the 1.13 ms pressure step at 125 members).  So a
+        // launch per level, ONE FRONT PER WORKGROUP -- the larger grids' form of this kernel: 8, 4, 2, 1 fronts a member side by side.  Same
+        // tiles, same products, same order of additions: the same bits (hm_fwd_set_debug "top_per_level" 0: the member-per-workgroup form).
+        hipLaunchKernelGGL((k_nd_top<3, 4, 13, 3, TOP_NW, true>), dim3(p.N << 3), dim3(64 * TOP_NW), lds_top, s, p, nd, k, nd.top_child_doubles);
+        hipLaunchKernelGGL((k_nd_top<3, 4, 13, 2, TOP_NW, true>), dim3(p.N << 2), dim3(64 * TOP_NW), lds_top, s, p, nd, k, nd.top_child_doubles);
+        hipLaunchKernelGGL((k_nd_top<3, 4, 13, 1, TOP_NW, true>), dim3(p.N << 1), dim3(64 * TOP_NW), lds_top, s, p, nd, k, nd.top_child_doubles);
+        hipLaunchKernelGGL((k_nd_top<3, 4, 13, 0, TOP_NW, true>), dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k, nd.top_child_doubles);
+    } else {
+        hipLaunchKernelGGL((k_nd_top<3, 4, 13, 3, TOP_NW, false>), dim3(p.N), dim3(64 * TOP_NW), lds_top, s, p, nd, k, nd.top_child_doubles);  // levels 3..0 of a member
+    }
     if (hipError_t e_ = hipGetLastError()) { hm_set_error("k_nd_top launch with %zu bytes of LDS: %s", lds_top, hipGetErrorString(e_)); return 1; }
 #endif
 #if ND_LG > 7

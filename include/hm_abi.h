@@ -159,6 +159,11 @@ long long hm_fwd_slab_redos(hm_fwd* f);
  *                        where its buffers fit the device, else blocks within 64 GB); must be set before the plan's first run
  *   "team_rounds"        value = 1: the slab teams of the float32 sweep (sat32s) are launched in rounds of as many teams as are resident at
  *                        once (round 4's form) instead of one launch for the whole ensemble; 0 (default) = one launch
+ *   "sat_teams"          value = workgroups per member of the 128 x 128 fp64 saturation sweep: -1 (default) automatic -- a member is a team of
+ *                        two or four slab workgroups (sat128s) where members x slabs <= CUs (small shards of a strong-scaled ensemble), else
+ *                        one workgroup (sat128r); 0 = never teams; 2, 4 = that many, provided the teams fit the CUs
+ *   "top_per_level"      value = 0: levels 3 .. 0 of the 128 x 128 nested dissection as one workgroup per member whatever the shard size; 1
+ *                        (default): for shards of fewer members than CUs a launch per level, one front per workgroup (bit-identical)
  *   "slab_margin"        value = 0: the float32 slab sweep (sat32s) lets a slab sit a time step out as soon as IT is dry -- by default its
  *                        neighbours must be dry as well -- so the front reaches a sitting-out slab within a few steps; the border check flags
  *                        the member and the gated REDO launch repeats its step with every slab (hm_fwd_slab_redos counts): results unchanged

@@ -45,4 +45,4 @@ for dt_ in dts:
             if 1000 % N == 0 and N != 1000:
                 G = 1000 // N
                 print(f"dtype {dt_}  implied strong scaling of N_e = 1000 over {G} GPUs (no communication in the forward model): "
-                      f"{rates[N] * G / rates[1000]:.2f}x  (per-member rate at N = {N}: {rates[N] / N / (rates[1000] / 1000):.2f} of N = 1000's)", flush=True)
+                      f"{rates[N] * G / rates[1000]:.2f}x of the ideal {G}x  (throughput of a {N}-member shard: {rates[N] / rates[1000]:.2f} of the 1000-member one's)", flush=True)

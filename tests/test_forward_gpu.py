@@ -1566,3 +1566,70 @@ def test_embedded_fp32_plan_sees_a_state_written_through_the_raw_pointer():
         plan.close()
     assert res["embedded"][:, 193:199, 20:60].min() > 0.05  # the water written by hand was swept, not zeroed
     assert np.abs(res["embedded"] - res["generic"]).max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("teams", [2, 4])
+def test_small_shard_team_sweep_128_is_bit_identical_to_the_one_workgroup_sweep(teams):
+    """Small member shards at 128 x 128 (one rank's share of a strong-scaled ensemble: members x slabs <= CUs) run the fp64 sweep as TEAMS
+    of two or four slab workgroups per member (sat128s.hip), each on a CU of its own, instead of sat128r's one workgroup per member.  Same
+    arithmetic per cell: saturation history, producer series and sub-step counts of a 12-step run equal the one-workgroup sweep's
+    (hm_fwd_set_debug "sat_teams" 0) bit for bit -- with the default automatic choice as well (24 members: teams of four; 100: of two) --
+    and nobody waited in vain (team_retries 0).  Also from a state with water in every band (late-run: every slab border is crossed)."""
+    n, steps = 128, 12
+    _, gm = make_models(n, n)
+    for N, auto in ((24, 4), (100, 2)):
+        if teams * ((N + 7) // 8) * 8 > 256:  # (teams of four need 4 x 104 CUs for 100 members: not on this chip)
+            continue
+        x = perms(n, n, N, seed=95 + N)
+        out = {}
+        for mode in ("one", "teams", "auto"):
+            if mode == "auto" and auto != teams:
+                continue
+            plan = _plan(gm, N, nTime=steps + 2)
+            plan.set_debug("sat_teams", {"one": 0, "teams": teams, "auto": -1}[mode])
+            plan.set_inputs(x, transformed=False)
+            plan.run(0, steps)
+            S = plan.get_field("S")
+            S[:, ::7, 3::11] = 0.25  # water in every band of 16 rows
+            plan.set_field("S", S)
+            plan.run(steps, 2)
+            st = plan.sync()
+            w, p, status = plan.outputs()
+            assert not status.any() and st["team_retries"] == 0
+            out[mode] = (w, p, plan.get_field("nts").copy(), st["ms_saturation"] / st["n_saturation_launches"])
+            plan.close()
+        assert len(out) >= 2
+        for mode in out:
+            if mode == "one":
+                continue
+            for a, b in zip(out["one"][:3], out[mode][:3]):
+                assert np.array_equal(a, b), (N, mode, np.abs(a - b).max())
+            assert out[mode][3] < out["one"][3], (N, mode, out[mode][3], out["one"][3])  # and it is the faster one at this shard size
+
+
+@pytest.mark.gpu
+def test_small_shard_pressure_levels_one_front_per_workgroup_is_bit_identical():
+    """A shard of fewer members than CUs eliminates levels 3 .. 0 of the 128 x 128 nested dissection as a launch per level, one front per
+    workgroup (press_nd.hip: the larger grids' form of k_nd_top), instead of one workgroup per member taking the 15 fronts in turn.  Same
+    tiles, same products: pressures, fluxes and the saturation after four steps equal the member-per-workgroup form's
+    (hm_fwd_set_debug "top_per_level" 0) bit for bit, with and without the reuse of dry fronts."""
+    n, N, steps = 128, 20, 4
+    _, gm = make_models(n, n)
+    x = perms(n, n, N, seed=97)
+    out = {}
+    for per_level in (0, 1):
+        for variant in (0, 14):
+            plan = _plan(gm, N, nTime=steps, keep_history=False)
+            plan.set_variant(variant, 0)
+            plan.set_debug("top_per_level", per_level)
+            plan.set_inputs(x, transformed=False)
+            plan.run(0, steps)
+            plan.sync()
+            S, _, status = plan.outputs()
+            assert not status.any()
+            out[per_level, variant] = (plan.get_field("P").copy(), plan.get_field("Vx").copy(), plan.get_field("Vy").copy(), S)
+            plan.close()
+    for key in ((1, 0), (0, 14), (1, 14)):
+        for a, b in zip(out[0, 0], out[key]):
+            assert np.array_equal(a, b), key
