@@ -103,8 +103,11 @@ __device__ __forceinline__ void get4(const u64* slot, int lane, double (&v)[PY],
 }
 
 
+// (launch bound 512 threads although 256 / 128 are launched: with a bound of 256 the compiler may give a thread 512 registers and parks what
+// does not fit the 256 architectural ones in accumulator registers -- 330 v_accvgpr moves inside the sub-step loop, a third more vector
+// instructions; bounded like sat128r.hip it keeps the loop in 256 registers with its spills outside)
 template <int NPR, bool FD>
-__global__ __launch_bounds__(Geo<NPR>::NT) void k_sat128s(FwdParams p, const double* __restrict__ Sin_base, double* __restrict__ Sout_base,
+__global__ __launch_bounds__(512) void k_sat128s(FwdParams p, const double* __restrict__ Sin_base, double* __restrict__ Sout_base,
                                                 long long S_stride, double* __restrict__ prods, int k, char* team_mem, int T, int first_member) {
     constexpr int SLAB = Geo<NPR>::SLAB, NT = Geo<NPR>::NT, CHUNK = Geo<NPR>::CHUNK, HW_BASE = Geo<NPR>::HW_BASE, HE_BASE = Geo<NPR>::HE_BASE;
     extern __shared__ __attribute__((aligned(16))) char lds[];

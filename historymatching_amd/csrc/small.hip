@@ -27,8 +27,12 @@
 
 namespace {
 
-constexpr int WV = 256;  // threads per member
-constexpr int MAXR = 4;   // rows of the Schur block a thread holds (Ny <= 32 with eight row groups)
+// Threads per member WV (a template parameter since round 6) and the rows of the Schur block a thread holds, MAXR >= ceil(Ny / (WV / Ny)).
+// Round 5 ran 256 threads (four waves: a workgroup barrier per pivot).  The pivot chain is what bounds the kernel -- 400 dependent pivots a
+// pressure step -- and with ONE wave per member a workgroup barrier is no instruction at all: the pivot row goes through LDS behind an
+// s_waitcnt.  hm_fwd_set_debug "small_wv" chooses 64 / 128 / 256 (0 = the default below).
+constexpr int SMALL_WV_DEFAULT = 256;
+template <int WV> struct SmallShape { static constexpr int MAXR = WV >= 256 ? 4 : WV >= 128 ? 8 : 16; };
 
 struct SmallGeo {
     int gw;       // row groups of the workgroup: threads [g Ny, (g + 1) Ny) hold rows g, g + gw, ...
@@ -42,11 +46,12 @@ __host__ __device__ inline size_t small_lds_doubles(int Nx, int Ny, int groupsG)
     return (size_t)Nx * Ny * Ny + 2 * nxy + 2 * ((size_t)(Nx + 1) * Ny + (size_t)Nx * (Ny + 1)) + (size_t)groupsG * Ny + 4 * Ny + 3 * nxy + 6 * nxy;
 }
 
-template <typename TS>
+template <typename TS, int WV>
 __global__ __launch_bounds__(WV) void k_small_forward(FwdParams p, SmallGeo geo, TS* __restrict__ S_all, int keep_history, TS* __restrict__ prods,
                                                       int first_step, int n_steps) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr bool F32 = std::is_same<TS, float>::value;
+    constexpr int MAXR = SmallShape<WV>::MAXR;
     const int m = blockIdx.x, tid = threadIdx.x;
     const int Nx = p.Nx, Ny = p.Ny, Nxy = p.Nxy;
     const int gw = geo.gw, groupsG = geo.groupsG, npl = groupsG / gw;  // npl: partial sums a lane carries
@@ -251,7 +256,9 @@ __global__ __launch_bounds__(WV) void k_small_forward(FwdParams p, SmallGeo geo,
         for (int off = 32; off > 0; off >>= 1) lmin = fmin(lmin, __shfl_xor(lmin, off));  // (a minimum: any order)
         if ((tid & 63) == 0) red[tid >> 6] = lmin;
         __syncthreads();
-        const double pm = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+        double pm = red[0];
+#pragma unroll
+        for (int wv = 1; wv < WV / 64; ++wv) pm = fmin(pm, red[wv]);  // (a minimum: any order)
         __syncthreads();
         const double sat = p.swc + p.sor;
         const double cfl = ((1.0 - sat) / 3.0) * pm;
@@ -344,14 +351,20 @@ int generic_threads_of(int Ny) {  // forward.hip: generic_threads
 
 // The whole run [first_step, first_step + n_steps) of a small grid as one launch.  Returns 0 if launched, >0 on error, -1 if this path does
 // not apply (grid too large for the LDS image, kernel variants chosen by hand).
+static int small_wv_of(const hm_fwd* f) {
+    const int v = f->dbg_small_wv;
+    return (v == 64 || v == 128 || v == 256) ? v : SMALL_WV_DEFAULT;
+}
 static bool small_geometry(const hm_fwd* f, SmallGeo& geo, size_t& bytes) {
     const FwdParams& p = f->p;
     if (f->press_variant != 0 || f->sat_variant != 0) return false;
     if (p.Ny > 32 || p.Ny < 2 || p.Nxy > 1024) return false;
+    const int wv = small_wv_of(f), maxr = wv >= 256 ? 4 : wv >= 128 ? 8 : 16;
     geo.groupsG = generic_threads_of(p.Ny) / p.Ny;
-    geo.gw = WV / p.Ny;
+    geo.gw = wv / p.Ny;
+    if (geo.gw < 1) return false;
     while (geo.gw > 1 && geo.groupsG % geo.gw) --geo.gw;  // the generic kernel's partial sums must split evenly over the wave's row groups
-    if ((p.Ny + geo.gw - 1) / geo.gw > MAXR) return false;
+    if ((p.Ny + geo.gw - 1) / geo.gw > maxr) return false;
     bytes = small_lds_doubles(p.Nx, p.Ny, geo.groupsG) * 8;
     return bytes <= 160 * 1024;
 }
@@ -369,13 +382,16 @@ int launch_small_forward(hm_fwd* f, int first_step, int n_steps) {
     size_t bytes = 0;
     if (!small_geometry(f, geo, bytes)) return -1;
     hipStream_t s = f->ctx->stream;
+#define SMALL_LAUNCH(TT, W) do { \
+        HM_HIP(hipFuncSetAttribute((const void*)k_small_forward<TT, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); \
+        hipLaunchKernelGGL((k_small_forward<TT, W>), dim3(p.N), dim3(W), bytes, s, p, geo, (TT*)f->S.p, f->keep_history, (TT*)f->prods.p, first_step, n_steps); } while (0)
+    const int wv = small_wv_of(f);
     if (f->dtype == 64) {
-        HM_HIP(hipFuncSetAttribute((const void*)k_small_forward<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        hipLaunchKernelGGL(k_small_forward<double>, dim3(p.N), dim3(WV), bytes, s, p, geo, (double*)f->S.p, f->keep_history, (double*)f->prods.p, first_step, n_steps);
+        if (wv == 64) SMALL_LAUNCH(double, 64); else if (wv == 128) SMALL_LAUNCH(double, 128); else SMALL_LAUNCH(double, 256);
     } else {
-        HM_HIP(hipFuncSetAttribute((const void*)k_small_forward<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        hipLaunchKernelGGL(k_small_forward<float>, dim3(p.N), dim3(WV), bytes, s, p, geo, (float*)f->S.p, f->keep_history, (float*)f->prods.p, first_step, n_steps);
+        if (wv == 64) SMALL_LAUNCH(float, 64); else if (wv == 128) SMALL_LAUNCH(float, 128); else SMALL_LAUNCH(float, 256);
     }
+#undef SMALL_LAUNCH
     HM_HIP(hipGetLastError());
     return 0;
 }
