@@ -370,6 +370,34 @@ def fallbacks_over_ranks(comm, st):
     return {k: int(comm.all_reduce_max(float(st.get(k, 0)))) for k in FALLBACK_KEYS}
 
 
+def config2_strong_shard(device, n_shard=125, passes=3):
+    """One rank's share of BASELINE config 2 split over 8 GPUs (STRONG scaling: N_e = 1000 / 8 = 125 members at 128 x 128, fp64): a 40-step
+    forward pass of the shard, timed like the headline (inputs resident, best of `passes`).  A shard of fewer members than CUs runs the sweep as
+    teams of two slab workgroups per member (sat128s) and levels 3..0 of the pressure solve one front per workgroup.  Reported BESIDE `value`,
+    never as it; `implied_speedup_8_gpus` = 8 x this rate / the 1000-member rate of this run: no multi-GPU run stands behind it (the
+    forward model has no communication between members, HistoryMatch.py:376-380)."""
+    from historymatching_amd.forward import ForwardPlan
+    from historymatching_amd.geostat import gaussian_fields_kron
+
+    model = build_model(64, device=device)
+    perms = gaussian_fields_kron(NX, NY, 2, 1, n_shard, r=0.8, seed=1)
+    plan = ForwardPlan(model, n_shard, DT, NTIME, keep_history=True, device=device)
+    best, st = 1e9, None
+    for _ in range(passes + 1):
+        plan.set_inputs(perms, None, transformed=False)
+        plan.sync()
+        t0 = time.perf_counter()
+        plan.run(0, NTIME)
+        st = plan.sync()
+        best = min(best, time.perf_counter() - t0)
+    _, prods, status = plan.outputs(want_wsats=False)
+    plan.close()
+    return {"members": n_shard, "value": n_shard * NTIME / best, "unit": "ensemble-steps/s", "ms_per_pass": 1e3 * best,
+            "avg_launch_ms": {"pressure": st["ms_pressure"] / max(1, st["n_pressure_launches"]), "saturation": st["ms_saturation"] / max(1, st["n_saturation_launches"])},
+            "fallbacks": {k: int(st.get(k, 0)) for k in FALLBACK_KEYS}, "status_ok": bool(not status.any() and np.isfinite(prods).all()),
+            "what": "one rank's shard of config 2 over 8 GPUs (strong scaling), one GPU, one member block; not part of `value`"}
+
+
 def load_profile_json(name):
     """Newest committed profiles/rNN/<name> (measured separately under rocprofv3 / from the built object), or None."""
     try:
@@ -441,6 +469,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="member blocks (HIP streams) of the timed region; 0 = the library's default for the ensemble (forward.default_blocks)")
     ap.add_argument("--config5", action="store_true", help="run the WHOLE config-5 leg (N_e=1000 at 512x512, localised) also below 4 ranks (default there: one GPU's shard of 125 members)")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg")
+    ap.add_argument("--no-strong-shard", action="store_true", help="skip the 125-member shard of config 2 (one rank's share of a strong-scaled run over 8 GPUs)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0, help="0 = fastest kernels, 1 = generic kernels")
     ap.add_argument("--dry-run", action="store_true", help="no device work: the ranks rendezvous, agree on a time and rank 0 prints a line (tests of the N-rank launch path)")
@@ -715,6 +744,15 @@ def main():
                 cpu["config1"] = config1_reference_run(local_rank, nproc)
             except Exception as e:
                 cpu["config1"] = {"error": f"{type(e).__name__}: {e}"}
+        strong = None
+        if world == 1 and args.members == N_E and args.variant == 0 and not args.no_strong_shard:
+            try:
+                strong = config2_strong_shard(local_rank)
+                strong["implied_speedup_8_gpus"] = 8.0 * strong["value"] / value
+                strong["implied_speedup_note"] = ("8 x the 125-member shard's rate / this run's 1000-member rate: what splitting config 2's N_e = 1000 over 8 GPUs "
+                                                  "would give with no communication; a projection from one GPU, not a measured scaling curve")
+            except Exception as e:
+                strong = {"error": f"{type(e).__name__}: {e}"}
         out = {
             "metric": "ensemble-steps/sec", "value": value, "unit": "ensemble-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -729,6 +767,7 @@ def main():
             "ranks": {"world": world, "rccl_communicator_ranks": (world if all(r["rccl"] for r in rank_info) else 0), "rccl_error": comm.rccl_error,
                       "per_rank": rank_info, "self_launched": os.environ.get("HM_BENCH_SELF_LAUNCHED") == "1"},
             "roofline": roofline, "cpu_baseline": cpu, "blocks": blocks_info, "host_call": host_call, "es_update": upd, "config4": c4, "config5": c5,
+            "config2_strong_shard": strong,
             "device_ms": {"total": stats["ms_total"], "pressure": stats["ms_pressure"], "saturation": stats["ms_saturation"]},
         }
         print(json.dumps(out), flush=True)

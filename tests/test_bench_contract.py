@@ -57,6 +57,9 @@ def test_committed_bench_line_has_the_contract_keys():
         assert set(d["blocks"]["fallbacks"]) == keys
         for leg in (d["config4"], d["config5"], d["es_update"]["es_mda_config3"]):
             assert set(leg["fallbacks"]) == keys and leg["fallbacks"]["team_retries"] == 0, leg
+        sh = d["config2_strong_shard"]
+        assert sh["members"] == 125 and sh["value"] > 0 and sh["status_ok"] is True and sh["fallbacks"]["team_retries"] == 0
+        assert sh["value"] < d["value"] and abs(sh["implied_speedup_8_gpus"] - 8.0 * sh["value"] / d["value"]) < 1e-9  # beside `value`, never as it
         head = d["es_update_headline"]
         assert head["in_situ_ms"] == d["es_update"]["in_situ_ms"] and head["mfma_frac_in_situ"] == d["es_update"]["mfma_frac_in_situ"]
         assert list(d).index("es_update_headline") < list(d).index("roofline")  # in front of the long records: a truncated tail keeps it
