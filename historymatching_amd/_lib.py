@@ -92,6 +92,7 @@ SIGNATURES = {
     "hm_fwd_device_ptr": (_vp, [_vp, C.c_char_p]),
     "hm_debug_mfma_f64": (C.c_int, [_vp, _dp, _dp, _dp]),
     "hm_debug_fracflow32_check": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
+    "hm_debug_fracflow64_check": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
     "hm_debug_nd_tables": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_longlong), _ip, _ip, C.POINTER(C.c_short), C.POINTER(C.c_short)]),
     "hm_es_update": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp,
                                C.POINTER(hm_stats)]),

@@ -591,6 +591,63 @@ __global__ __launch_bounds__(256) void k_fracflow32_check(FwdParams p, unsigned 
 }
 }  // namespace
 
+// The same for the fp64 fractional flow (fracflow.h: v_rcp_f64, ONE cubic refinement of the reciprocal, the quotient and one residual correction --
+// seven instructions against the compiler's eleven).  A double has 2^64 bit patterns: not all of them can be tried, so the claim "the IEEE quotient,
+// bit for bit" is pinned on the operands a saturation can take, densely: (i) 2^33 values spread over [0, 1 + 2^-9) by a 64-bit hash, every one with
+// a full 52-bit mantissa; (ii) the same count next to 0, 1/2 and 1 (|s - c| = 2^-k u, k = 0..63: where 1 - s, s^2 and the denominator cancel or
+// lose bits); (iii) every binade from 2^-1074 up to 2^-1 with 2^18 mantissas each (the doubly exponentially small values ahead of the front,
+// denormals included: fracflow.h's |S| < 2^-480 case).  out[0] = operands whose result differs from the compiler's IEEE division in any bit
+// (claimed: 0), out[1] = operands tried.
+namespace {
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {  // splitmix64 finaliser
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_fracflow64_check(FwdParams p, unsigned long long* out, unsigned long long per_class) {
+    const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0, tried = 0;
+    auto check = [&](double s) {
+        const double got = frac_flow<true>(p, s), want = frac_flow_ieee<true>(p, s);
+        if (__double_as_longlong(got) != __double_as_longlong(want) && !(got != got && want != want)) ++bad;
+        ++tried;
+    };
+    for (unsigned long long i = gid; i < per_class; i += stride) {
+        const unsigned long long h = mix64(i), h2 = mix64(h);
+        const double u = (double)(h >> 11) * 0x1.0p-53;  // [0, 1), 53 random bits
+        check(u * (1.0 + 0x1.0p-9));                                                        // (i)
+        const int k = (int)(h2 & 63), which = (int)((h2 >> 6) % 3);                         // (ii)
+        const double c = which == 0 ? 0.0 : which == 1 ? 0.5 : 1.0;
+        const double dlt = ldexp(u, -k);
+        check(which == 0 ? dlt : ((h2 >> 8) & 1) ? c + dlt * 0x1.0p-10 : c - dlt * 0x1.0p-1);
+    }
+    for (unsigned long long i = gid; i < (1075ull << 18); i += stride) {                     // (iii)
+        const int e = (int)(i >> 18);  // binade: value in [2^(e - 1075), 2^(e - 1074)); e = 0: the denormals
+        const unsigned long long man = mix64(i) & ((1ull << 52) - 1);
+        const unsigned long long bits = e == 0 ? man : (((unsigned long long)e) << 52) | man;
+        check(__longlong_as_double((long long)bits));
+    }
+    if (bad) atomicAdd(out, bad);
+    atomicAdd(out + 1, tried);
+}
+}  // namespace
+
+extern "C" int hm_debug_fracflow64_check(hm_ctx* ctx, unsigned long long* out) {
+    HM_REQUIRE(ctx && out, "hm_debug_fracflow64_check: NULL argument");
+    HM_HIP(hipSetDevice(ctx->device));
+    unsigned long long* d;
+    HM_HIP(hipMalloc(&d, 16));
+    HM_HIP(hipMemsetAsync(d, 0, 16, ctx->stream));
+    FwdParams p{};
+    hipLaunchKernelGGL(k_fracflow64_check, dim3(8 * ctx->num_cu), dim3(256), 0, ctx->stream, p, d, 1ull << 33);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipStreamSynchronize(ctx->stream));
+    HM_HIP(hipMemcpy(out, d, 16, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
+}
+
 extern "C" int hm_debug_fracflow32_check(hm_ctx* ctx, unsigned long long* out) {
     HM_REQUIRE(ctx && out, "hm_debug_fracflow32_check: NULL argument");
     HM_HIP(hipSetDevice(ctx->device));

@@ -228,6 +228,11 @@ int hm_debug_mfma_f64(hm_ctx* ctx, const double* A, const double* B, double* D);
  * reference's own is fp64, HistoryMatch.py:362 -> ResSim).  out[0] = operands with |s| < 2^62 whose result differs in any bit (claimed: 0),
  * out[1] = operands that differ at all (|s| >= 6.5e18 only). */
 int hm_debug_fracflow32_check(hm_ctx* ctx, unsigned long long* out /* 2 */);
+/* The same for the fp64 fractional flow of the saturation sweeps (csrc/fracflow.h: seven instructions -- reciprocal seed, one cubic refinement,
+ * quotient, one residual correction; what ResSim.sim's fw = mw / (mw + mo) is in NumPy, HistoryMatch.py:362), against the compiler's IEEE division
+ * on 2^34 + 2.8e8 operands: dense over [0, 1 + 2^-9), clustered next to 0, 1/2 and 1, and every binade down to the denormals.  out[0] = operands
+ * whose result differs in any bit (claimed: 0), out[1] = operands tried. */
+int hm_debug_fracflow64_check(hm_ctx* ctx, unsigned long long* out /* 2 */);
 /* Symbolic phase of the nested-dissection pressure solve (press_nd.hip; replaces the sparse direct solve inside
  * ResSim.sim, notebooks/HistoryMatch.py:362): the elimination tree of the Nx x Ny grid as the kernels use it.
  * Runs on the host, no device needed.  info[0..3] = fronts, cell entries, factor doubles and arena doubles per member;

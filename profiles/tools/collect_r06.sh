@@ -15,7 +15,7 @@ OUT=gpurun_out/profiles/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 W=/tmp/hmprof; rm -rf $W; mkdir -p $W
-LEGS="--no-cpu-baseline --no-esmda --no-config4 --no-config5 --no-two-streams --no-host-call"
+LEGS="--no-cpu-baseline --no-esmda --no-config4 --no-config5 --no-two-streams --no-host-call --no-strong-shard"
 rocprofv3 --kernel-trace --stats --output-format csv -d $W/ks -o ks -- python3 bench.py --steps 2 --warmup 1 $LEGS > $OUT/bench_under_rocprof.json 2> $W/ks.err
 cp "$(find $W/ks -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_bench.csv
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $W/f64 -o f64 -- python3 bench.py --steps 1 --warmup 0 $LEGS > /dev/null 2> $W/f64.err
@@ -54,7 +54,7 @@ done
 python3 profiles/tools/pmc_nd_large_to_json.py $OUT 128 > $OUT/pmc_hbm_traffic_nd256.json
 python3 tests/tools/nd_residual_stats.py 256 1024 1000 > $OUT/nd_residual_stats.txt 2>&1
 # 6. the analysis step
-rm -rf $W/upd; rocprofv3 --kernel-trace --stats --output-format csv -d $W/upd -o upd -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-config4 --no-config5 --no-two-streams --no-host-call > $OUT/bench_update_legs.json 2> $W/upd.err
+rm -rf $W/upd; rocprofv3 --kernel-trace --stats --output-format csv -d $W/upd -o upd -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-config4 --no-config5 --no-two-streams --no-host-call --no-strong-shard > $OUT/bench_update_legs.json 2> $W/upd.err
 cp "$(find $W/upd -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_update.csv
 python3 profiles/tools/upd_in_situ.py $W/upd > $OUT/upd_in_situ.txt
 # 6b. round 6: small member shards (one rank's share of a strong-scaled config 2), config 1, the fp32 mode's timing, the fp32 shards' kernel statistics

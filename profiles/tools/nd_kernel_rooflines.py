@@ -9,7 +9,7 @@ import sys
 pmc = json.load(open(sys.argv[1]))["kernels"]
 members = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 NAMES = {"nd_assemble": "k_nd_assemble", "nd_leaf": "k_nd_leaf(", "nd_sub": "k_nd_sub(", "nd_wave7": "k_nd_wave<7", "nd_wave6": "k_nd_wave<6", "nd_wave5": "k_nd_wave<5",
-         "nd_top4": "k_nd_top<3, 5", "nd_top": "k_nd_top<3, 4", "nd_solve": "k_nd_solve(", "nd_solve_sub": "k_nd_solve_sub", "nd_leaf_solve": "k_nd_leaf_solve", "nd_flux": "k_nd_flux"}
+         "nd_top4": "k_nd_top<3, 5", "nd_top": "k_nd_top<3, 4, 13, 3, 16, false>", "nd_solve": "k_nd_solve(", "nd_solve_sub": "k_nd_solve_sub", "nd_leaf_solve": "k_nd_leaf_solve", "nd_flux": "k_nd_flux"}
 avg = {}
 for r in csv.DictReader(open(sys.argv[2])):
     for key, pat in NAMES.items():
