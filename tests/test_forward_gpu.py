@@ -74,6 +74,21 @@ def test_float32_fractional_flow_is_the_ieee_quotient_for_every_operand():
     assert out[1] < 2**25  # (operands beyond 6.5e18: s^2 near the top of the float32 range; no saturation is ever there)
 
 
+def test_fp64_fractional_flow_is_the_ieee_quotient_on_a_dense_operand_set():
+    """The fp64 sweeps divide in seven instructions (csrc/fracflow.h: div_unscaled -- one cubic refinement of the reciprocal instead of two
+    quadratic ones).  A double has too many bit patterns to try them all as the float32 form is; the claim "the IEEE quotient bit for bit" is pinned
+    on 1.7e10 operands where saturations live: dense over [0, 1 + 2^-9), clustered next to 0, 1/2 and 1, every binade down to the denormals
+    (hm_debug_fracflow64_check).  Zero differences from the compiler's IEEE division."""
+    import ctypes as C
+
+    from historymatching_amd import _lib
+
+    ctx = _lib.Context.get()
+    out = (C.c_ulonglong * 2)()
+    _lib.check(ctx.lib.hm_debug_fracflow64_check(ctx.handle, out), "hm_debug_fracflow64_check")
+    assert out[1] >= 2**34 and out[0] == 0, f"{out[0]} of {out[1]} fp64 operands give a fractional flow that is not the IEEE quotient"
+
+
 def test_perm_transform_on_device():
     om, gm = make_models(20, 20)
     x = perms(20, 20, 5)
