@@ -1012,6 +1012,7 @@ static hm_fwd* embedded_inner(hm_fwd* f, int* rc_out) {
     f->inner->raw_state_exposed = f->raw_state_exposed;
     f->inner->raw_field_exposed = f->raw_field_exposed;
     f->inner->dbg_slab_margin = f->dbg_slab_margin;
+    f->inner->dbg_lazy_flux = f->dbg_lazy_flux;
     return f->inner;
 }
 
@@ -1040,7 +1041,14 @@ static int embed_inputs(hm_fwd* f, hm_fwd* in, int k) {
     return 0;
 }
 // P, Vx, Vy, TX, TY of the outer plan from the inner plan's (when they are older)
-static int extract_fields(hm_fwd* f) {
+static int extract_fields(hm_fwd* f, bool fluxes = true) {
+    if (fluxes) {  // (lazy face fluxes, fwd.h: whoever is about to read or hand out Vx / Vy comes through here; the sweep dispatch decides for itself)
+        if (int rc = nd128_materialize_fluxes(f)) return rc;
+        if (f->inner)
+            if (int rc = nd128_materialize_fluxes(f->inner)) return rc;
+    } else if (f->inner && f->fields_stale) {
+        if (int rc = nd128_materialize_fluxes(f->inner)) return rc;  // (the copy-out below reads the inner plan's fluxes)
+    }
     if (!f->inner || !f->fields_stale) return 0;
     const FwdParams& p = f->p;
     hm_fwd* in = f->inner;
@@ -1074,6 +1082,7 @@ static int embedded_saturation(hm_fwd* f, hm_fwd* in, int k) {
         hipLaunchKernelGGL(k_embed2d<double>, EMB_GRID, (const double*)f->Vx.p, (long long)(p.Nx + 1) * p.Ny, p.Ny, (double*)in->Vx.p, ex, EMB + 1, EMB, p.Nx + 1, p.Ny, 0.0, p.N);
         hipLaunchKernelGGL(k_embed2d<double>, EMB_GRID, (const double*)f->Vy.p, (long long)p.Nx * (p.Ny + 1), p.Ny + 1, (double*)in->Vy.p, ex, EMB, EMB + 1, p.Nx, p.Ny + 1, 0.0, p.N);
         f->inner_V_dirty = false;
+        in->flux_pending = false;  // (the caller's fluxes, not the ones of the inner plan's last pressure step)
     }
     if ((rc = launch_saturation(in, k))) return rc;
     long long so, si;
@@ -1104,6 +1113,7 @@ static int launch_pressure(hm_fwd* f, int k) {
         return rc;
     }
     f->fields_stale = false;  // (this plan's own pressure step: its fields are the current ones)
+    f->flux_pending = false;  // (set again by the 128 x 128 nested dissection, which leaves the fluxes to their readers)
     int done = -1;
     // press_variant: 0 the default (128 x 128: nested dissection, press_nd.hip; other grids with Ny = 128: press128s), 1 generic (the
     // in-library cross-check), 9 Jacobi-CG, 7 the 16-wave form of press128s, 12 nested dissection (14: every front eliminated every step), 13 press128s (block elimination,
@@ -1170,7 +1180,7 @@ static int launch_saturation(hm_fwd* f, int k) {
         f->n_sat++;
         return rc;
     }
-    if ((rc = extract_fields(f))) return rc;  // (a sweep of this plan's own kernels behind an embedded pressure step: the fluxes it reads)
+    if ((rc = extract_fields(f, false))) return rc;  // (a sweep of this plan's own kernels behind an embedded pressure step: the fluxes it reads)
     f->inner_S_step = -1;
     int done = -1;
     bool teams128 = false;
@@ -1178,9 +1188,13 @@ static int launch_saturation(hm_fwd* f, int k) {
         // fp64, register/LDS resident: fw in registers, scaled fluxes (sat128r.hip); sat_variant 5: fw image in LDS (sat128.hip)
         // small member shards at 128 x 128 (members x slabs <= CUs: one rank's share of a strong-scaled ensemble): a member as a team of
         // two or four workgroups on CUs of their own (sat128s.hip) -- sat128r's one workgroup per member would leave the other CUs idle
-        if (f->sat_variant == 0 || f->sat_variant == 4) done = launch_saturation_128s(f, Sin, Sout, stride, k);
+        if (f->sat_variant == 0 || f->sat_variant == 4) {
+            if (sat128s_applies(f, k) && (rc = nd128_materialize_fluxes(f))) return rc;
+            done = launch_saturation_128s(f, Sin, Sout, stride, k);
+        }
         teams128 = done == 0;
-        if (done < 0 && f->sat_variant != 5) done = launch_saturation_128r(f, Sin, Sout, stride, k);
+        if (done < 0 && f->sat_variant != 5) done = launch_saturation_128r(f, Sin, Sout, stride, k);  // (forms pending fluxes itself: fwd.h)
+        if (done < 0 && (rc = nd128_materialize_fluxes(f))) return rc;  // every other sweep reads Vx, Vy
         if (done < 0) done = launch_saturation_128(f, Sin, Sout, stride, k);
         if (done < 0) done = launch_saturation_32s(f, Sin, Sout, stride, k);  // dtype = 32 plans, grids 128 / 256 / 512 wide: slabs (workgroup teams), fw in registers
         if (done < 0 && f->sat_variant != 5) done = launch_saturation_256s(f, Sin, Sout, stride, k);  // fp64, grids 256 wide: slabs of 64 rows (workgroup teams), fw in registers
@@ -1218,6 +1232,7 @@ static int launch_saturation(hm_fwd* f, int k) {
         HM_HIP(hipGetLastError());
     }
     if (done < 0) {
+        if ((rc = nd128_materialize_fluxes(f))) return rc;  // (these sweeps read Vx, Vy: fwd.h, lazy face fluxes)
         // sat_variant 1: generic (coefficient arrays + fw image); 2: streaming; 3: tiled; otherwise (no 128 x 128 specialisation
         // applies: other sizes, porosity field, two wells in one patch) tiled from 64 x 64 cells up (67.9 vs 124 ms per launch at
         // 128 x 128, N = 1000), generic below
@@ -1442,6 +1457,10 @@ extern "C" int hm_fwd_set_debug(hm_fwd* f, const char* key, long long value) {
     else if (k == "sat_teams") f->dbg_sat_teams = (int)value;
     else if (k == "top_per_level") f->dbg_top_per_level = (int)value;
     else if (k == "small_wv") f->dbg_small_wv = (int)value;
+    else if (k == "lazy_flux") {
+        f->dbg_lazy_flux = (int)value;
+        if (f->inner) f->inner->dbg_lazy_flux = (int)value;
+    }
     else if (k == "slab_margin") {
         f->dbg_slab_margin = (int)value;
         if (f->inner) f->inner->dbg_slab_margin = (int)value;
@@ -1464,6 +1483,10 @@ extern "C" void* hm_fwd_device_ptr(hm_fwd* f, const char* name) {
     if (s == "S_all") { f->raw_state_exposed = true; return f->S.p; }
     FieldRef r;
     if (field_ref(f, name, r)) return nullptr;
+    if (s == "Vx" || s == "Vy") {  // a raw pointer to the fluxes may be read at any later time: from now on every pressure step writes them (fwd.h: lazy fluxes)
+        f->dbg_lazy_flux = 0;
+        if (f->inner) f->inner->dbg_lazy_flux = 0;
+    }
     // the caller may write an INPUT of the pressure step (K, the transmissibilities it may overwrite, the source field) through this
     // pointer at any later time without the library seeing it: results cached across time steps (press_nd.hip) are not kept for this
     // plan any more.  Pure outputs (P, Vx, Vy, nts, status ...) are rewritten by every step before anything reads them: handing

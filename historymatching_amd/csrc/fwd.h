@@ -101,6 +101,12 @@ struct hm_fwd {
     long long inner_K_gen = -1;       // inputs_gen the inner plan's permeability was embedded at
     int inner_S_step = -1;            // time index whose saturation the inner plan holds (-1: none)
     bool inner_V_dirty = false;       // face fluxes were set from the host (hm_fwd_set_field): the inner plan's are stale
+    // LAZY FACE FLUXES (round 6, 128 x 128 nested dissection): the pressure step leaves P, TX, TY and does NOT launch k_nd_flux; the default
+    // sweep (sat128r.hip) forms the scaled fluxes of its patch from them itself -- the same expression, the same bits -- and Vx / Vy are
+    // materialised (nd128_materialize_fluxes: the k_nd_flux launch) only for whoever else reads them: another sweep kernel, hm_fwd_get_field
+    // / set_field / device_ptr, the copy-out of an embedded grid.  Saves the write and the read of 0.53 MB per member and step.
+    bool flux_pending = false;        // Vx, Vy of this plan are older than its P, TX, TY
+    int dbg_lazy_flux = 1;            // hm_fwd_set_debug "lazy_flux": 0 = k_nd_flux behind every pressure step (round 5's form)
     bool fields_stale = false;        // P, Vx, Vy, TX, TY of this plan are older than the inner plan's (copied out when somebody asks)
     double Lx = 0, Ly = 0;            // as given to hm_fwd_create, with the well lists and rates (what the inner plan is created from)
     std::vector<int> inj_ind_host, prd_ind_host;
@@ -136,7 +142,9 @@ int launch_pressure_pcg(hm_fwd* f, const void* S, long long S_stride, int k);   
 bool pressure_two_level_applies(const FwdParams& p);
 int launch_pressure_two_level(hm_fwd* f, const void* S, long long S_stride, int k);  // two-level CG, Ny = 128 c
 int launch_saturation_128(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);
+bool sat128s_applies(const hm_fwd* f, int k);  // ... it takes step k of this plan
 int launch_saturation_128s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // 128 x 128 fp64, small member shards: teams of 2 / 4 slab workgroups (sat128s.hip)
+int nd128_materialize_fluxes(hm_fwd* f);  // Vx, Vy from P, TX, TY if they are pending (press_nd.hip)
 int launch_saturation_128r(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);  // fw in registers, scaled fluxes (sat128r.hip)
 int launch_saturation_32s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // dtype = 32 plans, grids 128 / 256 / 512 wide (sat32s.hip)
 int launch_saturation_128t(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k);   // grids of 128 x 128 tiles, fp64

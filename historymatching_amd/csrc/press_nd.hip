@@ -2356,10 +2356,27 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
 #endif
     hipLaunchKernelGGL(k_nd_solve_sub, dim3(p.N * (64 << LO)), dim3(256), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_leaf_solve, dim3(p.N * (4 << LO)), dim3(256), 0, s, p, nd, k);
+#if ND_LG == 7
+    if (f->dbg_lazy_flux && p.N == f->p.N) {  // (the whole ensemble in one block: always at 128 x 128)
+        f->flux_pending = true;               // fwd.h: the fluxes are formed by whoever needs them
+        HM_HIP(hipGetLastError());
+        return 0;
+    }
+#endif
     hipLaunchKernelGGL(k_nd_flux, dim3(p.N), dim3(1024), 0, s, p, k);
     HM_HIP(hipGetLastError());
     return 0;
 }
+
+#if ND_LG == 7
+int nd128_materialize_fluxes(hm_fwd* f) {
+    if (!f->flux_pending) return 0;
+    hipLaunchKernelGGL(k_nd_flux, dim3(f->p.N), dim3(1024), 0, f->ctx->stream, f->p, 0);
+    HM_HIP(hipGetLastError());
+    f->flux_pending = false;
+    return 0;
+}
+#endif
 
 #if ND_LG > 7
 // The direct solver's safety net on the larger grids.  A member the elimination could not solve -- a non-positive pivot, or fluxes that

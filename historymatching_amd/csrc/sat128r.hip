@@ -76,7 +76,10 @@ __device__ __forceinline__ double nmulc(double v, double f) {
     return r;
 }
 
-template <bool FD>
+// FROMP (round 6, lazy face fluxes: fwd.h): the pressure step left P, TX, TY and no Vx, Vy -- the thread forms the fluxes of its patch's faces
+// itself, V = (P_upwind-side - P_this) T with zero on the domain boundary: face_fluxes' expression (fwd_dev.h), the same bits; k_nd_flux's
+// launch, its 0.26 MB of writes per member and this kernel's read of them are gone.
+template <bool FD, bool FROMP>
 __global__ __launch_bounds__(NT) void k_sat128r(FwdParams p, const double* __restrict__ Sin_base, double* __restrict__ Sout_base,
                                                 long long S_stride, double* __restrict__ prods, int k) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -100,18 +103,65 @@ __global__ __launch_bounds__(NT) void k_sat128r(FwdParams p, const double* __res
             S[i][j] = v.x;
             S[i][j + 1] = v.y;
         }
+    if constexpr (!FROMP) {
 #pragma unroll
-    for (int i = 0; i <= PX; ++i)
+        for (int i = 0; i <= PX; ++i)
 #pragma unroll
-        for (int j = 0; j < PY; j += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(gVx + (ix0 + i) * N128 + iy0 + j);
-            if (i < PX) { Vx[i < PX ? i : 0][j] = v.x; Vx[i < PX ? i : 0][j + 1] = v.y; }
-            else { Vx8[j] = v.x; Vx8[j + 1] = v.y; }  // the east faces of the last row: for the CFL bound and c_C only
+            for (int j = 0; j < PY; j += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(gVx + (ix0 + i) * N128 + iy0 + j);
+                if (i < PX) { Vx[i < PX ? i : 0][j] = v.x; Vx[i < PX ? i : 0][j + 1] = v.y; }
+                else { Vx8[j] = v.x; Vx8[j + 1] = v.y; }  // the east faces of the last row: for the CFL bound and c_C only
+            }
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+#pragma unroll
+            for (int j = 0; j < PY; ++j) Vy[i][j] = gVy[(ix0 + i) * (N128 + 1) + iy0 + j];
+    } else {
+        const double* gP = p.P + (long long)m * p.Nxy;
+        const double* gTX = p.TX + (long long)m * (N128 + 1) * N128;
+        const double* gTY = p.TY + (long long)m * N128 * (N128 + 1);
+        // pressures of rows ix0 - 1 .. ix0 + 8 (clamped into the grid: a clamped row only meets a boundary face, whose flux is set to zero)
+        double Pm[PY], Pc[PY];
+        {
+            const int r = ix0 > 0 ? ix0 - 1 : 0;
+#pragma unroll
+            for (int j = 0; j < PY; j += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(gP + r * N128 + iy0 + j);
+                Pm[j] = v.x; Pm[j + 1] = v.y;
+            }
         }
 #pragma unroll
-    for (int i = 0; i < PX; ++i)
+        for (int i = 0; i <= PX; ++i) {
+            const int ix = ix0 + i, r = ix < N128 ? ix : N128 - 1;
+            double tx[PY];
 #pragma unroll
-        for (int j = 0; j < PY; ++j) Vy[i][j] = gVy[(ix0 + i) * (N128 + 1) + iy0 + j];
+            for (int j = 0; j < PY; j += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(gP + r * N128 + iy0 + j);
+                Pc[j] = v.x; Pc[j + 1] = v.y;
+                const double2 t = *reinterpret_cast<const double2*>(gTX + ix * N128 + iy0 + j);
+                tx[j] = t.x; tx[j + 1] = t.y;
+            }
+            const bool edge = ix == 0 || ix == N128;
+#pragma unroll
+            for (int j = 0; j < PY; ++j) {
+                const double v = edge ? 0.0 : (Pm[j] - Pc[j]) * tx[j];  // face_fluxes (fwd_dev.h)
+                if (i < PX) Vx[i < PX ? i : 0][j] = v;
+                else Vx8[j] = v;
+            }
+            if (i < PX) {  // the south faces of row ix: its own pressures and the one of the cell south of the patch
+                const double ps = gP[r * N128 + (iy0 > 0 ? iy0 - 1 : 0)];
+#pragma unroll
+                for (int j = 0; j < PY; ++j) {
+                    const int iy = iy0 + j;
+                    const double pl = j > 0 ? Pc[j > 0 ? j - 1 : 0] : ps;
+                    const double ty = gTY[ix * (N128 + 1) + iy];
+                    Vy[i][j] = iy == 0 ? 0.0 : (pl - Pc[j]) * ty;  // (iy = 128 is no cell's south face)
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PY; ++j) Pm[j] = Pc[j];
+        }
+    }
 #define VXE(i, j) ((i) + 1 < PX ? Vx[(i) + 1 < PX ? (i) + 1 : 0][j] : Vx8[j])
 
     // ---------------- the (at most one) well of this patch
@@ -342,9 +392,9 @@ __global__ __launch_bounds__(NT) void k_sat128r(FwdParams p, const double* __res
     if (tid < p.nPrd) prods[((long long)m * p.nTime + k) * p.nPrd + tid] = Sout[p.prd_ind[tid]];
 }
 
-template <bool FD>
+template <bool FD, bool FROMP>
 int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
-    auto kern = k_sat128r<FD>;
+    auto kern = k_sat128r<FD, FROMP>;
     HM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(f->p.N), dim3(NT), LDS_BYTES, f->ctx->stream, f->p, (const double*)S_in, (double*)S_out, S_stride,
                        (double*)f->prods.p, k);
@@ -380,5 +430,7 @@ int launch_saturation_128r(hm_fwd* f, const void* S_in, void* S_out, long long S
             if (inj_waves & bit) return -1;
             inj_waves |= bit;
         }
-    return p.fluid_default ? launch<true>(f, S_in, S_out, S_stride, k) : launch<false>(f, S_in, S_out, S_stride, k);
+    if (f->flux_pending)  // (lazy face fluxes, fwd.h: P, TX, TY are current, Vx / Vy are not -- and stay so: they are materialised on demand)
+        return p.fluid_default ? launch<true, true>(f, S_in, S_out, S_stride, k) : launch<false, true>(f, S_in, S_out, S_stride, k);
+    return p.fluid_default ? launch<true, false>(f, S_in, S_out, S_stride, k) : launch<false, false>(f, S_in, S_out, S_stride, k);
 }

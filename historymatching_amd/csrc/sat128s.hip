@@ -422,16 +422,17 @@ int launch(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k, 
 
 // Returns 0 if launched, >0 on error, -1 if this specialisation does not apply: the 128 x 128 fp64 sweep as workgroup teams, for member shards
 // whose teams all find a CU of their own at once (hm_fwd_set_debug "sat_teams": 0 = never, 2 / 4 = that many slabs whatever the shard).
-int launch_saturation_128s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
+// slabs per member the team sweep would run this plan's step k with: 2, 4, or 0 (it does not apply)
+static int sat128s_teams(const hm_fwd* f, int k) {
     const FwdParams& p = f->p;
-    if (p.q_mstride != 0) return -1;  // per-member wells: the well cells come from one shared well list
-    if (p.Nx != NY || p.Ny != NY || f->dtype != 64 || p.por != nullptr) return -1;
+    if (p.q_mstride != 0) return 0;  // per-member wells: the well cells come from one shared well list
+    if (p.Nx != NY || p.Ny != NY || f->dtype != 64 || p.por != nullptr) return 0;
     const int cus = f->ctx->num_cu;
     int T = f->dbg_sat_teams;
     if (T < 0) T = 4 * p.N <= cus ? 4 : 2 * p.N <= cus ? 2 : 0;  // automatic: the most slabs whose teams all fit the CUs
-    if (T != 2 && T != 4) return -1;
-    if (T * ((p.N + 7) / 8) * 8 > cus) return -1;                // (teams are placed by XCD: sat_team.h team_of_block)
-    if (!sat_team::wells_fit_patches(f, MAX_WELLS)) return -1;
+    if (T != 2 && T != 4) return 0;
+    if (T * ((p.N + 7) / 8) * 8 > cus) return 0;                 // (teams are placed by XCD: sat_team.h team_of_block)
+    if (!sat_team::wells_fit_patches(f, MAX_WELLS)) return 0;
     // at most one injector (a well with q > 0 in this time column) per wave = per band of 16 grid rows
     const double* qk = f->q_host.data() + (size_t)(p.q_cols > 1 ? k : 0) * p.Nxy;
     std::vector<int> bands;
@@ -439,9 +440,17 @@ int launch_saturation_128s(hm_fwd* f, const void* S_in, void* S_out, long long S
         if (qk[cell] > 0.0) {
             const int band = (cell / NY) / (2 * PX);
             for (int b : bands)
-                if (b == band) return -1;
+                if (b == band) return 0;
             bands.push_back(band);
         }
+    return T;
+}
+bool sat128s_applies(const hm_fwd* f, int k) { return sat128s_teams(f, k) != 0; }
+
+int launch_saturation_128s(hm_fwd* f, const void* S_in, void* S_out, long long S_stride, int k) {
+    const FwdParams& p = f->p;
+    const int T = sat128s_teams(f, k);
+    if (!T) return -1;
     if (T == 2) return p.fluid_default ? launch<8, true>(f, S_in, S_out, S_stride, k, T) : launch<8, false>(f, S_in, S_out, S_stride, k, T);
     return p.fluid_default ? launch<4, true>(f, S_in, S_out, S_stride, k, T) : launch<4, false>(f, S_in, S_out, S_stride, k, T);
 }

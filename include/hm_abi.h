@@ -164,6 +164,9 @@ long long hm_fwd_slab_redos(hm_fwd* f);
  *                        one workgroup (sat128r); 0 = never teams; 2, 4 = that many, provided the teams fit the CUs
  *   "top_per_level"      value = 0: levels 3 .. 0 of the 128 x 128 nested dissection as one workgroup per member whatever the shard size; 1
  *                        (default): for shards of fewer members than CUs a launch per level, one front per workgroup (bit-identical)
+ *   "lazy_flux"          value = 0: the 128 x 128 nested dissection writes the face fluxes Vx, Vy behind every pressure step (k_nd_flux); 1
+ *                        (default): it leaves P, TX, TY, the default sweep forms its fluxes from them, and Vx / Vy are materialised when
+ *                        somebody else reads them (hm_fwd_get_field, another sweep kernel ...): bit-identical
  *   "slab_margin"        value = 0: the float32 slab sweep (sat32s) lets a slab sit a time step out as soon as IT is dry -- by default its
  *                        neighbours must be dry as well -- so the front reaches a sitting-out slab within a few steps; the border check flags
  *                        the member and the gated REDO launch repeats its step with every slab (hm_fwd_slab_redos counts): results unchanged

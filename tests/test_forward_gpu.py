@@ -1648,3 +1648,38 @@ def test_small_shard_pressure_levels_one_front_per_workgroup_is_bit_identical():
     for key in ((1, 0), (0, 14), (1, 14)):
         for a, b in zip(out[0, 0], out[key]):
             assert np.array_equal(a, b), key
+
+
+@pytest.mark.gpu
+def test_lazy_face_fluxes_are_bit_identical_and_materialised_on_demand():
+    """Round 6: at 128 x 128 the pressure step leaves P, TX, TY and launches no flux kernel; the default sweep forms the fluxes of its patch
+    from them (the same expression), and Vx / Vy appear when somebody asks (hm_fwd_get_field).  Against hm_fwd_set_debug "lazy_flux" 0 over a
+    run with fields read at several steps, a pressure-only / saturation-only sequence and fluxes GIVEN by the caller: bit-identical."""
+    n, N, steps = 128, 12, 6
+    _, gm = make_models(n, n)
+    x = perms(n, n, N, seed=101)
+    out = {}
+    for lazy in (0, 1):
+        plan = _plan(gm, N, nTime=steps + 2, keep_history=False)
+        plan.set_debug("lazy_flux", lazy)
+        plan.set_inputs(x, transformed=False)
+        res = []
+        plan.run(0, 3)
+        res += [plan.get_field("Vx").copy(), plan.get_field("Vy").copy(), plan.get_field("S").copy()]  # fluxes of step 2, asked for after its sweep
+        plan.run(3, 3)
+        plan.pressure_only(6)
+        res += [plan.get_field("P").copy(), plan.get_field("Vx").copy()]
+        plan.saturation_only(6)
+        res += [plan.get_field("S").copy(), plan.get_field("nts").copy()]
+        Vx = plan.get_field("Vx")
+        plan.set_field("Vx", 0.5 * Vx)          # the caller's fluxes: the sweep must take these, not recompute from P
+        plan.set_field("Vy", 0.5 * plan.get_field("Vy"))
+        plan.saturation_only(7)
+        res += [plan.get_field("S").copy(), plan.get_field("nts").copy()]
+        _, _, status = plan.outputs()
+        assert not status.any()
+        out[lazy] = res
+        plan.close()
+    assert not np.array_equal(out[1][-2], out[1][-4])  # (the halved fluxes did change the step)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
