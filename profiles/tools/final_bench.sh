@@ -13,4 +13,4 @@ for n in ("bench_default", "bench_driver", "bench_2ranks_one_gpu"):
     except Exception as e:
         print(n, "unreadable:", e)
 PY
-tail -2 gpurun_out/final/*.err
+for e in gpurun_out/final/*.err; do tail -n 2 "$e"; done
