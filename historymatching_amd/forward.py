@@ -177,6 +177,23 @@ def default_blocks(model, N):
     return 3 if N >= 768 else 2 if N >= 512 else 1
 
 
+def block_bounds(N, blocks):
+    """Member ranges of ``blocks`` member blocks: equal sizes rounded to a MULTIPLE OF 32 members, the last block takes the rest.  Workgroups
+    are dealt round-robin to the 8 XCDs (each with an L2 of its own); the per-member launches of the 128 x 128 kernels index members fastest,
+    and ``k_nd_sub`` groups four consecutive members into a workgroup -- with a multiple of 32 members per block every launch of a time step
+    puts a member's workgroups on the same XCD, so what one launch writes (coefficient block, update matrices, factor) the next finds in that
+    L2.  Measured at config 2 on one MI355X (profiles/r06/blocks_time.txt): three blocks of 320 / 320 / 360 members 77.0-77.4 k
+    ensemble-steps/s, 288 / 288 / 424 77.2-77.5 k, equal thirds (333 / 333 / 334) 75.6-75.9 k, 304 / 304 / 392 75.9 k.  Results do not depend on
+    the partition (members are independent)."""
+    N, blocks = int(N), int(blocks)
+    if blocks <= 1:
+        return [0, N]
+    size = max(32, int(round(N / blocks / 32.0)) * 32)
+    if size * (blocks - 1) >= N:
+        return [int(b) for b in np.linspace(0, N, blocks + 1).astype(int)]
+    return [i * size for i in range(blocks)] + [N]
+
+
 def merge_block_stats(sts, sizes):
     """Statistics of member blocks that ran side by side as one record: device times are the longest block's, counts add up, the
     ``mean_*`` entries are member-weighted means over the blocks (one division, whatever the number and sizes of the blocks)."""
@@ -202,7 +219,7 @@ class BlockedForwardPlan:
         device = model.device if device is None else device
         if bounds is None:
             blocks = default_blocks(model, N) if blocks is None else int(blocks)
-            bounds = np.linspace(0, N, blocks + 1).astype(int)
+            bounds = block_bounds(N, blocks)
         self.bounds = [int(b) for b in bounds]
         assert self.bounds[0] == 0 and self.bounds[-1] == N and all(a < b for a, b in zip(self.bounds[:-1], self.bounds[1:]))
         self.N, self.nTime, self.model, self.keep_history = int(N), int(nTime), model, bool(keep_history)
@@ -284,7 +301,7 @@ def make_forward_model(model: ResSim, dt, nTime, wsat0=None, return_history=True
                model.sor, None if model.por is None else np.asarray(model.por, dtype=float).tobytes())
         if cache.get("sig") != sig:
             release()
-            bounds = np.linspace(0, N, blocks + 1).astype(int)
+            bounds = block_bounds(N, blocks)
             # the further blocks' own streams: one secondary context per device and block index, shared process-wide
             ctxs = [None] + [_lib.Context.secondary(model.device, i) for i in range(blocks - 1)]
             cache["plans"] = [(ForwardPlan(model, hi - lo, dt, nTime, keep_history=return_history, ctx=c), lo, hi)

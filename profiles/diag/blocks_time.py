@@ -17,6 +17,8 @@ model = bench.build_model(DT_, device=0)
 perms = gaussian_fields_kron(128, 128, 2, 1, N, r=0.8, seed=1)
 ref = None
 SPLITS = ([0, 1000], [0, 500, 1000], [0, 334, 667, 1000], [0, 250, 500, 750, 1000]) if DT_ == 32 else ([0, 1000], [0, 500, 1000], [0, 334, 667, 1000], [0, 256, 512, 1000], [0, 400, 700, 1000], [0, 250, 500, 750, 1000], [0, 200, 400, 600, 800, 1000], [0, 167, 334, 500, 667, 834, 1000])
+if len(sys.argv) > 2:  # custom partitions: "0,256,512,1000;0,500,1000"
+    SPLITS = [[int(v) for v in part.split(",")] for part in sys.argv[2].split(";")]
 for bounds in SPLITS:
     plan = BlockedForwardPlan(model, N, bench.DT, bench.NTIME, keep_history=False, bounds=bounds)
     best = 1e9

@@ -75,3 +75,17 @@ def test_block_statistics_are_member_weighted():
     st = merge_block_stats(sts, [100, 100, 200])
     assert st["ms_total"] == 5.0 and st["member_steps"] == 60 and st["team_retries"] == 1 and st["blocks"] == 3
     assert abs(st["mean_nts"] - (600.0 * 100 + 630.0 * 100 + 615.0 * 200) / 400) < 1e-12
+
+
+def test_member_blocks_are_multiples_of_32_members():
+    """forward.block_bounds: the blocks a large ensemble is split into have a multiple of 32 members each (the last takes the rest), so that a
+    member's workgroups meet the same XCD's L2 launch after launch; they cover the ensemble, in order, without gaps."""
+    from historymatching_amd.forward import block_bounds
+
+    assert block_bounds(1000, 3) == [0, 320, 640, 1000] and block_bounds(1000, 1) == [0, 1000] and block_bounds(512, 2) == [0, 256, 512]
+    for N in (40, 100, 333, 768, 1000, 1024, 2000, 4096):
+        for blocks in (1, 2, 3, 4):
+            b = block_bounds(N, blocks)
+            assert b[0] == 0 and b[-1] == N and len(b) == blocks + 1 and all(x < y for x, y in zip(b[:-1], b[1:])), (N, blocks, b)
+            if blocks > 1 and N >= 64 * blocks:
+                assert all((y - x) % 32 == 0 for x, y in zip(b[:-2], b[1:-1])), (N, blocks, b)
