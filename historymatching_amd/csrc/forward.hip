@@ -1456,6 +1456,7 @@ extern "C" int hm_fwd_set_debug(hm_fwd* f, const char* key, long long value) {
     else if (k == "embed") f->dbg_embed = (int)value;
     else if (k == "sat_teams") f->dbg_sat_teams = (int)value;
     else if (k == "top_per_level") f->dbg_top_per_level = (int)value;
+    else if (k == "top_deal") f->dbg_top_deal = (int)value;
     else if (k == "small_wv") f->dbg_small_wv = (int)value;
     else if (k == "lazy_flux") {
         f->dbg_lazy_flux = (int)value;

@@ -83,6 +83,7 @@ struct hm_fwd {
     int slab_wet_step = -1;       // time index whose launch may read the record
     long long slab_wet_gen = -1;  // inputs_gen the record belongs to
     int dbg_top_per_level = 1;    // hm_fwd_set_debug "top_per_level": 0 = levels 3 .. 0 of the 128 x 128 nested dissection always as one workgroup per member (default: a launch per level, a front per workgroup, for shards of fewer members than CUs)
+    int dbg_top_deal = 1;         // hm_fwd_set_debug "top_deal": 0 = k_nd_top deals its trailing tiles round-robin over all waves (rounds 3-5)
     int dbg_small_wv = 0;         // hm_fwd_set_debug "small_wv": threads per member of the one-launch kernel of small grids (small.hip): 64 / 128 / 256, 0 = its default
     int dbg_sat_teams = -1;       // hm_fwd_set_debug "sat_teams": workgroups per member of the 128 x 128 fp64 sweep -- -1 automatic (2 / 4 where members x slabs <= CUs), 0 never, 2, 4
     int dbg_slab_margin = 1;      // hm_fwd_set_debug "slab_margin": 0 = the float32 slab sweep lets the neighbours of wet slabs sit out too (exercises its REDO launch)

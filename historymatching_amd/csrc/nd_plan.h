@@ -38,6 +38,7 @@ struct NdDev {
     const unsigned char* wells;  // NCACHE: a well somewhere in the front's subtree (its right-hand side rows carry the rates)
     int wells_ok;                // the rates of this time step are those the cached results of such fronts were computed with
     int reuse;                   // 0: every front is eliminated every step
+    int top_deal;                // k_nd_top: 1 = trailing tiles in row-major runs on the waves that own no pivot tile (round 6), 0 = round-robin as before
     // larger grids: the plan's inputs / outputs, and the big fronts' (levels 0 .. LO + 2) panel images
     unsigned long long* wet;     // per member: wet-cell bitmap, NB rows x NB / 64 words (k_ndl_assemble -> k_ndl_plan)
     unsigned char* todo;         // per member: NTODO bytes, front f of levels 0 .. LO + 4 is eliminated this step (k_ndl_plan)

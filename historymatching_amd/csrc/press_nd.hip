@@ -108,6 +108,24 @@ __device__ __forceinline__ double nd_coef_global(const double* __restrict__ cf, 
     return l * (off >= 0 ? 1.0 : 0.0) + ((ck < 0 && same_pos) ? 1.0 : 0.0);  // padded pivot: identity
 }
 
+// nd_coef_global in two halves: the load alone (flags: bit 0 = the entry is a coefficient, bit 1 = identity entry of a padded pivot), and
+// the arithmetic on the loaded value later -- k_nd_top issues the loads of all its panel tiles, gathers its trailing tiles out of LDS and
+// only then touches the values (one trip to memory for all of them, and the stores of the front before have drained meanwhile)
+__device__ __forceinline__ double nd_coef_issue(const double* __restrict__ cf, int cm, int ck, bool same_pos, int& flags) {
+    const int d = cm - ck;
+    const bool cell = ck >= 0 && cm >= 0;
+    int off = -1;
+    off = (cell && d == 0) ? ck : off;
+    off = (cell && d == NB) ? CF_OX + ck + NB : off;
+    off = (cell && d == -NB) ? CF_OX + ck : off;
+    off = (cell && d == 1) ? CF_OY + ck + (ck >> LG) + 1 : off;
+    off = (cell && d == -1) ? CF_OY + ck + (ck >> LG) : off;
+    off = (ck >= 0 && cm == -2) ? CF_OQ + ck : off;
+    flags = (off >= 0 ? 1 : 0) | ((ck < 0 && same_pos) ? 2 : 0);
+    return cf[off >= 0 ? off : 0];
+}
+__device__ __forceinline__ double nd_coef_finish(double l, int flags) { return l * ((flags & 1) ? 1.0 : 0.0) + ((flags & 2) ? 1.0 : 0.0); }
+
 // The same from an LDS copy of the coefficients around a box of cells [x0, x1) x [y0, y1): four planes (dg, -TX of the cell's
 // west face, -TY of its south face, q) over the box plus a ring of one cell, local index (ix - x0 + 1) * ld + (iy - y0 + 1),
 // ld = y1 - y0 + 2.  Every pivot of the fronts that use the copy lies inside the box.
@@ -961,7 +979,11 @@ __device__ __forceinline__ void top_dma(double* dst, const double* __restrict__ 
     double2* d2 = reinterpret_cast<double2*>(dst);
     for (int pc = w; pc * 64 < n2; pc += nw) {
         const int i = pc * 64 + lane;
+#if defined(HM_EXP_TOP) && (HM_EXP_TOP & 2)
+        __builtin_amdgcn_global_load_lds((nd_glb_ptr)(s2 + lane), (nd_lds_ptr)(d2 + pc * 64), 16, 0, 0);
+#else
         __builtin_amdgcn_global_load_lds((nd_glb_ptr)(s2 + (i < n2 ? i : n2 - 1)), (nd_lds_ptr)(d2 + pc * 64), 16, 0, 0);
+#endif
     }
 }
 
@@ -1022,15 +1044,19 @@ __global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams
     // 128 x 128: the fronts of levels 4..0 that are eliminated this step, in order (k_nd_plan: those whose subtree is still dry keep the
     // results they have); larger grids: a `todo` byte per front (k_ndl_plan)
     const int* wlist = nd.work + (long long)m * ND_WORK_INTS + ND_WT;
+    // ... kept in a REGISTER, lane i = entry i (count + at most 31 fronts; the block has 64 ints): read from memory per front, the entry came
+    // back behind every store the wave had in flight (vmcnt retires in order: the factor rows of the panel before, the update matrix of the
+    // front before) -- 3 k cycles between two fronts and 6 k in the first panel of each, where the next front's DMA is issued (round 6,
+    // profiles/r06/nd_top_deal.txt)
+    const int wl = ND_LG == 7 ? wlist[g.lane] : 0;  // (larger grids: a `todo` byte per front instead)
+    auto wl_at = [&](int i) { return __builtin_amdgcn_readlane(wl, i); };  // (i wave-uniform)
     const int f0 = (1 << TOPK_LEVEL) - 1 + (ONE ? blockIdx.x / p.N : 0);
     int first = 0;  // (not ONE) the list entries in front of `first` belong to the levels a launch of their own has eliminated
     if (ONE) {
         // one front: its record at frec[0] (the code below indexes the records by front id: `frec - f0 * ND_FRONT_INTS` makes that this one)
 #if ND_LG == 7
-        bool listed = false;
-        const int nl = __builtin_amdgcn_readfirstlane(wlist[0]);
-        for (int i = 0; i < nl; ++i) listed = listed || __builtin_amdgcn_readfirstlane(wlist[1 + i]) == f0;  // (at most 31 entries: levels 4 .. 0 in order)
-        if (!listed) return;
+        const int nl = wl_at(0);  // (at most 31 entries: levels 4 .. 0 in order)
+        if (__ballot(g.lane >= 1 && g.lane <= nl && wl == f0) == 0) return;
 #else
         if (!nd.todo[(long long)m * NTODO + f0]) return;  // (the front keeps the results it has; the whole workgroup leaves)
 #endif
@@ -1040,16 +1066,14 @@ __global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams
     } else {
         for (int i = tid; i < ((2 << TOPK_LEVEL) - 1) * ND_FRONT_INTS; i += 64 * NW) frec[i] = nd.fronts[i];
         __syncthreads();
-        const int nl = __builtin_amdgcn_readfirstlane(wlist[0]);
-        while (first < nl && __builtin_amdgcn_readfirstlane(wlist[1 + first]) >= (2 << TOPK_LEVEL) - 1) ++first;
+        const int nl = wl_at(0);
+        while (first < nl && wl_at(1 + first) >= (2 << TOPK_LEVEL) - 1) ++first;
     }
-    const int one_list[3] = {1, f0, 0};
-    const int* tlist = ONE ? one_list : wlist;
-    const int nt = ONE ? 1 : __builtin_amdgcn_readfirstlane(wlist[0]);
+    const int nt = ONE ? 1 : wl_at(0);
     bool prefetched = false;  // (wave-uniform) this front's tables and children were issued during the previous front's panels
     {
         for (int idx = first; idx < nt; ++idx) {
-            const int f = __builtin_amdgcn_readfirstlane(tlist[1 + idx]);
+            const int f = ONE ? f0 : wl_at(1 + idx);
 #ifdef HM_ND_PROF
             if (blockIdx.x == 0 && tid == 64 * HM_ND_PROF_TOP_WAVE)
                 for (int lv = 4; lv >= 0; --lv)
@@ -1081,6 +1105,46 @@ __global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams
                 const int o1 = top_pad(2 * m0);
                 if (o1 + top_pad(2 * m1) <= chl_cap) top_dma(chl + o1, arena + __builtin_amdgcn_readfirstlane(Fn[NDF_UC1]), m1, w, g.lane, NW);
             };
+            // The NEXT front's pieces, TRICKLED (round 6): a CU takes in the 100 KB of a front's children at about 15 bytes a cycle, and a
+            // wave's vector-memory instructions issue in order -- issued in one go behind the first panel's barrier, the prefetch held every
+            // wave in its issue loop for 7 k cycles, the owner of the next pivot tile among them (13 % of the kernel; wave 0 alone issuing
+            // them all only moved the wait to the next barrier: profiles/r06/nd_top_deal.txt).  So a wave issues ONE piece behind each tile
+            // update of the panels -- pieces w, w + NW, ... of [cells | positions | child 0 | child 1] -- and what is left after the last panel.
+            int nx_gi = 0, nx_tot = 0, nx_con = 0, nx_m0 = 0, nx_m1 = 0, nx_np0 = 0, nx_o1 = 0, nx_u0 = 0, nx_u1 = 0;
+            auto dma_setup = [&](const int* Fn) {
+                nx_con = __builtin_amdgcn_readfirstlane(Fn[NDF_CELLS]);
+                const int b0 = __builtin_amdgcn_readfirstlane(Fn[NDF_BC0]), b1 = __builtin_amdgcn_readfirstlane(Fn[NDF_BC1]);
+                nx_m0 = (((b0 + 1) * (b0 + 2) >> 1) + 1) >> 1;
+                nx_m1 = (((b1 + 1) * (b1 + 2) >> 1) + 1) >> 1;
+                nx_u0 = __builtin_amdgcn_readfirstlane(Fn[NDF_UC0]);
+                nx_u1 = __builtin_amdgcn_readfirstlane(Fn[NDF_UC1]);
+                nx_o1 = top_pad(2 * nx_m0);
+                nx_np0 = (nx_m0 + 63) >> 6;
+                nx_tot = 2 + nx_np0 + (nx_o1 + top_pad(2 * nx_m1) <= chl_cap ? (nx_m1 + 63) >> 6 : 0);
+                nx_gi = w;
+            };
+            auto dma_one = [&]() {
+                if (nx_gi >= nx_tot) return;
+                const int gi = nx_gi;
+                nx_gi += NW;
+                if (gi == 0) {
+                    __builtin_amdgcn_global_load_lds((nd_glb_ptr)(nd.cells + nx_con + 4 * g.lane), (nd_lds_ptr)cl_s, 16, 0, 0);
+                } else if (gi == 1) {
+                    __builtin_amdgcn_global_load_lds((nd_glb_ptr)(nd.cpos + 2 * nx_con + 8 * g.lane), (nd_lds_ptr)cp_s0, 16, 0, 0);
+                } else {
+                    int pc = gi - 2, n2 = nx_m0, uo = nx_u0, lo = 0;
+                    if (pc >= nx_np0) { pc -= nx_np0; n2 = nx_m1; uo = nx_u1; lo = nx_o1; }
+                    const double2* s2 = reinterpret_cast<const double2*>(arena + uo);
+                    double2* d2 = reinterpret_cast<double2*>(chl + lo);
+                    const int i = pc * 64 + g.lane;
+#if defined(HM_EXP_TOP) && (HM_EXP_TOP & 2)
+                    __builtin_amdgcn_global_load_lds((nd_glb_ptr)(s2 + g.lane), (nd_lds_ptr)(d2 + pc * 64), 16, 0, 0);
+#else
+                    __builtin_amdgcn_global_load_lds((nd_glb_ptr)(s2 + (i < n2 ? i : n2 - 1)), (nd_lds_ptr)(d2 + pc * 64), 16, 0, 0);
+#endif
+                }
+            };
+            const bool staged_now = !prefetched;
             if (!prefetched) stage_front(F);
             prefetched = false;
             const short* cp_s1 = cp_s0 + 16 * T;
@@ -1099,11 +1163,24 @@ __global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams
                 }
                 vq[s] = q; vR[s] = R;
             }
+            // trailing tiles (round 6): ROW-MAJOR RUNS -- a wave's tiles are neighbours in a tile row, so one W image serves the run -- dealt to
+            // the waves that own NO pivot tile V(q, q) where those can hold them all: the owner of the next pivot tile has that tile's update
+            // and its 16 dependent pivots between the two barriers of a panel, and with four trailing updates behind them it was the wave
+            // every other one waited for (profiles/r06/nd_top_deal.txt).  Which wave holds a tile changes nothing in its arithmetic.
+            unsigned ownmask = 0;
+            for (int q = 0; q < st; ++q) ownmask |= 1u << ((q * T - ((q * (q - 1)) >> 1)) % NW);
+            int tper = (nT + (NW - __builtin_popcount(ownmask)) - 1) / (NW - __builtin_popcount(ownmask));
+            if (tper > TOP_NTS || !nd.top_deal) {
+                ownmask = 0;
+                tper = (nT + NW - 1) / NW;
+            }
+            const bool ttake = !((ownmask >> w) & 1);
+            const int tbase = __builtin_popcount(~ownmask & ((1u << w) - 1)) * tper;
 #pragma unroll
             for (int s = 0; s < TOP_NTS; ++s) {
-                const int idx = s * NW + w;
+                const int idx = nd.top_deal ? tbase + s : s * NW + w;
                 int R = -1, C = -1;
-                if (idx < nT) {
+                if (idx < nT && (!nd.top_deal || (ttake && s < tper))) {
                     int rem = idx;
                     R = 0;
                     while (rem > R) { rem -= R + 1; ++R; }
@@ -1112,34 +1189,35 @@ __global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams
                 }
                 tR[s] = R; tC[s] = C;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
-            __syncthreads();
+            // (a prefetched front: every wave has waited for its own pieces in front of the barrier that ended the front before -- below)
+            if (staged_now || !nd.top_deal) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+                __syncthreads();
+            }
             NPROF(1);
             // ---- coefficients + child 0.  The boundary rows of a front are ordered by child (nd.h): a tile whose rows or columns hold
             // nothing of a child skips that child's gather, a panel tile with no cell next to a pivot its coefficient loads (round 5:
             // 114 -> 56 tile gathers for a level-4 front)
             const int kidm = __builtin_amdgcn_readfirstlane(F[NDF_KIDM]), cofm = __builtin_amdgcn_readfirstlane(F[NDF_COFM]);
             auto has = [&](int c, int R) { return ((kidm >> (16 * c + R)) & 1) != 0; };  // (tile row R < 16 whenever kidm != -1)
+            // (the panel tiles' coefficient loads: all of them issued here, used behind the trailing tiles' gather)
+            int cflags = 0;  // two flag bits per entry (4 s + r)
 #pragma unroll
             for (int s = 0; s < TOP_NVS; ++s) {
                 vt[s] = d4{0.0, 0.0, 0.0, 0.0};
-                if (vq[s] >= 0) {
+                if (vq[s] >= 0 && ((cofm >> vR[s]) & 1)) {
                     const int pm = 16 * vR[s] + g.lc;
-                    if ((cofm >> vR[s]) & 1) {
-                        const int cm = cl_s[pm];
+                    const int cm = cl_s[pm];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int pk = 16 * vq[s] + 4 * r + g.lq;
-                            vt[s][r] = nd_coef_global(cf, cm, cl_s[pk], pk == pm);
-                        }
-                    }
-                    if (has(0, vR[s])) {
-                        const int pm0 = cp_s0[pm];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) vt[s][r] += nd_gather(chl, cp_s0[16 * vq[s] + 4 * r + g.lq], pm0);
+                    for (int r = 0; r < 4; ++r) {
+                        const int pk = 16 * vq[s] + 4 * r + g.lq;
+                        int fl;
+                        vt[s][r] = nd_coef_issue(cf, cm, cl_s[pk], pk == pm, fl);
+                        cflags |= fl << (2 * (4 * s + r));
                     }
                 }
             }
+            // (trailing tiles first: no loads from memory in them -- the stores of the front before drain meanwhile)
 #pragma unroll
             for (int s = 0; s < TOP_NTS; ++s) {
                 tr[s] = d4{0.0, 0.0, 0.0, 0.0};
@@ -1147,6 +1225,18 @@ __global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams
                     const int pc0 = cp_s0[16 * tC[s] + g.lc];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) tr[s][r] = nd_gather(chl, cp_s0[16 * tR[s] + 4 * r + g.lq], pc0);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < TOP_NVS; ++s) {
+                if (vq[s] >= 0 && ((cofm >> vR[s]) & 1)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vt[s][r] = nd_coef_finish(vt[s][r], (cflags >> (2 * (4 * s + r))) & 3);
+                }
+                if (vq[s] >= 0 && has(0, vR[s])) {
+                    const int pm0 = cp_s0[16 * vR[s] + g.lc];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vt[s][r] += nd_gather(chl, cp_s0[16 * vq[s] + 4 * r + g.lq], pm0);
                 }
             }
             NPROF(2);
@@ -1203,6 +1293,7 @@ __global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams
             NPROF(5);
             for (int pp = 0; pp < st; ++pp) {
                 const int kreg = pp == st - 1 ? kreg_last : 4;
+                if (pp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (my stores of the front before are out: see the end of the front)
                 lds_barrier();  // P(pp) published; every read of the previous panel's images is done
                 NPROF(6);
                 {
@@ -1219,7 +1310,11 @@ __global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams
                             img_store(Vimg + 256 * R, g.lane, vt[s]);
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (r < kreg) fa[(fo + (R - pp - 1) * kreg + r) * 64 + g.lane] = -wv[r];
+#if !(defined(HM_EXP_TOP) && (HM_EXP_TOP & 1))
+                                if (r < kreg) __builtin_nontemporal_store(-wv[r], &fa[(fo + (R - pp - 1) * kreg + r) * 64 + g.lane]);
+#else
+                                ;
+#endif
                         }
                     }
                 }
@@ -1229,40 +1324,75 @@ __global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams
                 if (pp == 0 && idx + 1 < nt) {
                     // every wave is past its gathers: the tables and the child buffer are free -- the NEXT front's go in now, beside the
                     // panels, unless this front is one of its children (possible since fronts are skipped: its update is not written yet)
-                    const int fnext = __builtin_amdgcn_readfirstlane(tlist[2 + idx]);
+                    const int fnext = wl_at(2 + idx);  // (not ONE: nt = 1 there)
                     if (f != 2 * fnext + 1 && f != 2 * fnext + 2) {
-                        stage_front(frec + fnext * ND_FRONT_INTS);
+                        if (nd.top_deal) dma_setup(frec + fnext * ND_FRONT_INTS);
+                        else stage_front(frec + fnext * ND_FRONT_INTS);
                         prefetched = true;
                     }
                 }
+                NPROF(13);
                 if (pp + 1 < st) {
                     const int inx = (pp + 1) * T - (((pp + 1) * pp) >> 1);
+#ifdef HM_ND_PROF
+                    if (w == inx % NW) prof_acc[14] += 1;
+#endif
+                    // (the owner of the next pivot tile is the wave every other one will wait for: its 16 dependent pivots share the SIMD's
+                    // double-precision pipe with three waves of matrix instructions -- it goes first whenever it has an instruction ready)
                     if (w == inx % NW) {
+                        __builtin_amdgcn_s_setprio(3);
                         const int sl = inx / NW;
 #pragma unroll
                         for (int s = 0; s < TOP_NVS; ++s)
                             if (s == sl) update_v(s, kreg);
                     }
                     sweep_diag(pp + 1, pp + 1 == st - 1 ? kreg_last : 4);
+                    if (w == inx % NW) __builtin_amdgcn_s_setprio(0);
                     NPROF(12);
 #pragma unroll
                     for (int s = 0; s < TOP_NVS; ++s) {
                         const int idx = s * NW + w;
-                        if (vq[s] > pp && idx != inx) update_v(s, kreg);
+                        if (vq[s] > pp && idx != inx) {
+                            update_v(s, kreg);
+                            dma_one();
+                        }
                     }
                 }
+                d4 Y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int s = 0; s < TOP_NTS; ++s) {
                     if (tR[s] >= 0) {  // F22(R, C) -= W(pp, R) V(pp, C)^T
-                        const d4 Y = img_load(Wimg + 256 * tR[s], g.lane), Z = img_load(Vimg + 256 * tC[s], g.lane);
+#if defined(HM_EXP_S3) && HM_EXP_S3 == 2  // (timing experiment, wrong results: no image loads in the trailing updates)
+                        Y = tr[s];
+                        const d4 Z = tr[s];
+#else
+                        if (s == 0 || tR[s] != tR[s > 0 ? s - 1 : 0]) Y = img_load(Wimg + 256 * tR[s], g.lane);  // (a run in one tile row: one W image)
+                        const d4 Z = img_load(Vimg + 256 * tC[s], g.lane);
+#endif
+#if defined(HM_EXP_S3) && HM_EXP_S3 == 1  // (timing experiment, wrong results: no matrix instructions in the trailing updates)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(Y[kk]), "v"(Z[kk]));
+#else
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk)
                             if (kk < kreg) tr[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kk], Z[kk], tr[s], 0, 0, 0);
+#endif
+                        dma_one();
                     }
                 }
+                if (pp == 0)
+                    while (nx_gi < nx_tot) dma_one();  // (a wave with few tiles has pieces left: all out in the first panel, a panel ahead of the wait)
                 fo += (T - pp - 1) * kreg;
                 NPROF(9);
             }
+            while (nx_gi < nx_tot) dma_one();  // (the pieces the panels did not get to)
+            // A wave's vector-memory operations retire IN ORDER: whatever waits for a load behind the update's stores waits for the stores to
+            // drain at the CU's share of the memory bandwidth (13 bytes a cycle: 100 KB = 8 k cycles; without the stores of this kernel a
+            // member takes 592 k cycles instead of 819 k, profiles/r06/nd_top_deal.txt).  So the wait for the next front's pieces comes IN
+            // FRONT of the stores, the barrier behind them orders LDS only, and the stores drain beside the next front's gathers out of LDS
+            // (its trailing tiles first: the panel tiles' coefficient loads are the first thing that queues behind the stores).
+            const bool drain_aside = prefetched && nd.top_deal;
+            if (drain_aside) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ---- the update matrix to the arena
             if (nT > 0) {
                 double* out = arena + F[NDF_UPD];
@@ -1273,13 +1403,20 @@ __global__ __launch_bounds__(64 * NW, (NW <= 8 ? 2 : 1)) void k_nd_top(FwdParams
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int i = 16 * (tR[s] - st) + 4 * r + g.lq;
+#if !(defined(HM_EXP_TOP) && (HM_EXP_TOP & 1))
                             if (j <= i && i <= b) out[((i * (i + 1)) >> 1) + j] = tr[s][r];
+#else
+                            ;
+#endif
                         }
                     }
                 }
             }
             NPROF(10);
-            __syncthreads();  // children before parents; the images are free again
+            // children before parents; the images are free again.  drain_aside: the next front is no parent of this one, and every wave
+            // waits for its stores (vmcnt(0) in front of the first panel's barrier) before a later front's children are fetched
+            if (drain_aside) lds_barrier();
+            else __syncthreads();
             NPROF(11);
         }
     }
@@ -2453,6 +2590,7 @@ int ND_ENTRY(launch_pressure_nd)(hm_fwd* f, const void* S, long long S_stride, i
     // results kept from earlier time steps are only good for the inputs they were computed from; press_variant 14: no reuse at all; per-member
     // wells: none either (the well flags are per plan); an ensemble solved in several member blocks through the same buffers keeps nothing
     nd.reuse = f->press_variant != 14 && p.q_mstride == 0 && !f->raw_field_exposed && p.N <= f->nd->cap;
+    nd.top_deal = f->dbg_top_deal;
     if (f->nd->cached_gen != f->inputs_gen) {
         HM_HIP(hipMemsetAsync(f->nd->cached.p, 0, (size_t)std::min(p.N, f->nd->cap) * NCACHE, s));
         f->nd->cached_gen = f->inputs_gen;

@@ -164,6 +164,10 @@ long long hm_fwd_slab_redos(hm_fwd* f);
  *                        one workgroup (sat128r); 0 = never teams; 2, 4 = that many, provided the teams fit the CUs
  *   "top_per_level"      value = 0: levels 3 .. 0 of the 128 x 128 nested dissection as one workgroup per member whatever the shard size; 1
  *                        (default): for shards of fewer members than CUs a launch per level, one front per workgroup (bit-identical)
+ *   "top_deal"           value = 0: k_nd_top (levels <= LO + 4 of the nested dissection) as in rounds 3-5 -- trailing tiles round-robin over
+ *                        all waves, the next front's children fetched in one go, a full wait for memory at the end of a front; 1 (default):
+ *                        trailing tiles in row-major runs on the waves that own no pivot tile, the fetch trickled behind the tile
+ *                        updates, the update's stores draining beside the next front's gathers (bit-identical)
  *   "lazy_flux"          value = 0: the 128 x 128 nested dissection writes the face fluxes Vx, Vy behind every pressure step (k_nd_flux); 1
  *                        (default): it leaves P, TX, TY, the default sweep forms its fluxes from them, and Vx / Vy are materialised when
  *                        somebody else reads them (hm_fwd_get_field, another sweep kernel ...): bit-identical

@@ -13,6 +13,9 @@ from historymatching_amd.forward import ForwardPlan  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 _, gm = make_models(128, 128)
 plan = ForwardPlan(gm, N, 0.025, 4, keep_history=False, device=0)
+import os  # noqa: E402
+if os.environ.get("HM_TOP_DEAL"):
+    plan.set_debug("top_deal", int(os.environ["HM_TOP_DEAL"]))
 plan.set_variant(14, 0)  # every front eliminated (12 would skip the dry ones: on the initial state nearly all)
 plan.set_inputs(perms(128, 128, N, seed=1), None, transformed=False)
 for _ in range(4):
@@ -24,7 +27,7 @@ buf = (C.c_longlong * 64)()
 lib.hm_debug_nd_prof.argtypes = [C.POINTER(C.c_longlong)]
 assert lib.hm_debug_nd_prof(buf) == 0
 top = ["between fronts", "tables + child 0 -> LDS, tile decode, barrier", "coefficients + child 0 gather", "child 1 -> LDS (2 barriers)", "child 1 gather", "S1 sweep", "barrier 1", "S2 W = P V, publish",
-       "barrier 2", "S3 updates", "store update", "end barrier"]
+       "barrier 2", "S3 updates", "store update", "end barrier", "next pivot tile: update + sweep (its owner)", "next front's tables + children: DMA issue", "(count) panels whose next pivot tile this wave owns"]
 v = list(buf[:16])
 print(f"k_nd_top, block 0 wave 0: {sum(v)} cycles")
 for n, x in zip(top, v):

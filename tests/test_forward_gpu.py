@@ -1651,6 +1651,36 @@ def test_small_shard_pressure_levels_one_front_per_workgroup_is_bit_identical():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,N", [(128, 300), (128, 20), (256, 12)])
+def test_top_front_tile_dealing_and_trickled_prefetch_are_bit_identical(n, N):
+    """Round 6, k_nd_top: the trailing tiles of a front are dealt in row-major runs to the waves that own no pivot tile, the next front's tables
+    and children arrive piece by piece behind the tile updates, and the update's stores drain beside the next front's gathers
+    (hm_fwd_set_debug "top_deal" 1, the default).  Which wave holds a tile and when a copy is issued change no arithmetic: pressures, fluxes
+    and the saturation after four steps equal those of rounds 3-5's form ("top_deal" 0) bit for bit -- a member per workgroup (300 members),
+    a front per workgroup (20 members: a launch per level) and the larger grids' instances of the kernel (256 x 256), with and without the
+    reuse of dry fronts."""
+    steps = 4
+    _, gm = make_models(n, n)
+    x = perms(n, n, N, seed=131)
+    out = {}
+    for deal in (0, 1):
+        for variant in (0, 14):
+            plan = _plan(gm, N, nTime=steps, keep_history=False)
+            plan.set_variant(variant, 0)
+            plan.set_debug("top_deal", deal)
+            plan.set_inputs(x, transformed=False)
+            plan.run(0, steps)
+            plan.sync()
+            S, _, status = plan.outputs()
+            assert not status.any()
+            out[deal, variant] = (plan.get_field("P").copy(), plan.get_field("Vx").copy(), plan.get_field("Vy").copy(), S)
+            plan.close()
+    for key in ((1, 0), (0, 14), (1, 14)):
+        for a, b in zip(out[0, 0], out[key]):
+            assert np.array_equal(a, b), key
+
+
+@pytest.mark.gpu
 def test_lazy_face_fluxes_are_bit_identical_and_materialised_on_demand():
     """Round 6: at 128 x 128 the pressure step leaves P, TX, TY and launches no flux kernel; the default sweep forms the fluxes of its patch
     from them (the same expression), and Vx / Vy appear when somebody asks (hm_fwd_get_field).  Against hm_fwd_set_debug "lazy_flux" 0 over a
