@@ -359,7 +359,7 @@ __device__ __forceinline__ void nd_wave_front(int bt, int kreg, const NdPanelRec
 __device__ __forceinline__ void nd_plan_body(const NdDev& nd, int m, int t, const unsigned long long (*wet)[2], unsigned char* dry, int* wcount);  // below
 
 template <typename TS>
-__global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, const TS* __restrict__ S_base, long long S_stride, int k) {
+__global__ __launch_bounds__(1024, 2) void k_nd_assemble(FwdParams p, NdDev nd, const TS* __restrict__ S_base, long long S_stride, int k) {
     const int m = blockIdx.x, tid = threadIdx.x;
     const int Nx = p.Nx, Nxy = p.Nxy;
     const TS* S = S_base + (long long)m * S_stride;
@@ -374,37 +374,47 @@ __global__ __launch_bounds__(1024) void k_nd_assemble(FwdParams p, NdDev nd, con
         __shared__ unsigned char dry[512];
         __shared__ unsigned long long wet[NB][2];
         __shared__ int wcount[4];
+        // (round 6) in TWO passes of 64 grid rows, 1 / (mobility K) of rows ix0 - 1 .. ix0 + 64 in 66 KB of LDS instead of the whole member in
+        // 128 KB: two workgroups fit a CU, and one's loads run beside the other's stores (the kernel is nothing but 1 MB of memory traffic
+        // a member: 0.29 -> 0.24 ms per 1000 members, profiles/r06/nd_assemble_two_pass.txt).  The same expressions on the same operands.
         double* L = nd_lds;
-        for (int j = tid; j < Nxy; j += 1024) {  // (a wave = 64 consecutive cells of one grid row: its ballot is a word of the wet-cell bitmap)
-            const double sj = (double)S[j];
-            double mw, mo;
-            rel_perm<double>(p, sj, mw, mo);
-            L[j] = 1.0 / ((mw + mo) * Km[j]);
-            const unsigned long long bits = __ballot(S[j] != (TS)0);
-            if ((tid & 63) == 0) wet[j >> 7][(j >> 6) & 1] = bits;
-        }
-        __syncthreads();
-        for (int f = tid; f < (Nx + 1) * NB; f += 1024) {
-            const int ix = f >> 7;
-            const double tx = (ix == 0 || ix == Nx) ? 0.0 : p.cx / (L[f - NB] + L[f]);
-            TX[f] = tx;
-            cf[CF_OX + f] = -tx;
-        }
-        for (int f = tid; f < Nx * (NB + 1); f += 1024) {
-            const int ix = f / (NB + 1), iy = f - ix * (NB + 1), c = ix * NB + iy;
-            const double ty = (iy == 0 || iy == NB) ? 0.0 : p.cy / (L[c - 1] + L[c]);
-            TY[f] = ty;
-            cf[CF_OY + f] = -ty;
-        }
-        for (int c = tid; c < Nxy; c += 1024) {  // the diagonal: the four faces again, the same expressions (the same bits)
-            const int ix = c >> 7, iy = c & (NB - 1);
-            const double ty0 = iy == 0 ? 0.0 : p.cy / (L[c - 1] + L[c]), ty1 = iy == NB - 1 ? 0.0 : p.cy / (L[c] + L[c + 1]);
-            const double tx0 = ix == 0 ? 0.0 : p.cx / (L[c - NB] + L[c]), tx1 = ix == Nx - 1 ? 0.0 : p.cx / (L[c] + L[c + NB]);
-            double d = ty0 + ty1 + tx0 + tx1;
-            if (c == 0) d += Km[0] + Kym[0];
-            if (d == 0.0) d = 1.0;  // a cell of zero permeability (the padding of an embedded grid, forward.hip): every face closed, its equation is 1 p = 0
-            cf[c] = d;
-            cf[CF_OQ + c] = q[c];
+        constexpr int HALF = NB / 2;
+        for (int h = 0; h < 2; ++h) {
+            const int ix0 = h * HALF, lo = ix0 > 0 ? ix0 - 1 : 0, hi = ix0 + HALF < Nx ? ix0 + HALF : Nx - 1;  // rows held: lo .. hi
+            const double* Lr = L - lo * NB;  // Lr[cell] for the cells of rows lo .. hi
+            if (h) __syncthreads();  // (the first pass's reads are done)
+            for (int j = lo * NB + tid; j < (hi + 1) * NB; j += 1024) {  // (a wave = 64 consecutive cells of one grid row: its ballot is a word of the wet-cell bitmap)
+                const double sj = (double)S[j];
+                double mw, mo;
+                rel_perm<double>(p, sj, mw, mo);
+                L[j - lo * NB] = 1.0 / ((mw + mo) * Km[j]);
+                const unsigned long long bits = __ballot(S[j] != (TS)0);
+                if ((tid & 63) == 0) wet[j >> 7][(j >> 6) & 1] = bits;
+            }
+            __syncthreads();
+            const int fx1 = h ? (Nx + 1) * NB : (ix0 + HALF) * NB;  // x faces ix0 .. ix0 + 63 (the last pass: the boundary face Nx as well)
+            for (int f = ix0 * NB + tid; f < fx1; f += 1024) {
+                const int ix = f >> 7;
+                const double tx = (ix == 0 || ix == Nx) ? 0.0 : p.cx / (Lr[f - NB] + Lr[f]);
+                TX[f] = tx;
+                cf[CF_OX + f] = -tx;
+            }
+            for (int f = ix0 * (NB + 1) + tid; f < (ix0 + HALF) * (NB + 1); f += 1024) {
+                const int ix = f / (NB + 1), iy = f - ix * (NB + 1), c = ix * NB + iy;
+                const double ty = (iy == 0 || iy == NB) ? 0.0 : p.cy / (Lr[c - 1] + Lr[c]);
+                TY[f] = ty;
+                cf[CF_OY + f] = -ty;
+            }
+            for (int c = ix0 * NB + tid; c < (ix0 + HALF) * NB; c += 1024) {  // the diagonal: the four faces again, the same expressions (the same bits)
+                const int ix = c >> 7, iy = c & (NB - 1);
+                const double ty0 = iy == 0 ? 0.0 : p.cy / (Lr[c - 1] + Lr[c]), ty1 = iy == NB - 1 ? 0.0 : p.cy / (Lr[c] + Lr[c + 1]);
+                const double tx0 = ix == 0 ? 0.0 : p.cx / (Lr[c - NB] + Lr[c]), tx1 = ix == Nx - 1 ? 0.0 : p.cx / (Lr[c] + Lr[c + NB]);
+                double d = ty0 + ty1 + tx0 + tx1;
+                if (c == 0) d += Km[0] + Kym[0];
+                if (d == 0.0) d = 1.0;  // a cell of zero permeability (the padding of an embedded grid, forward.hip): every face closed, its equation is 1 p = 0
+                cf[c] = d;
+                cf[CF_OQ + c] = q[c];
+            }
         }
         nd_plan_body(nd, m, tid, wet, dry, wcount);  // what has to be eliminated this time step
         return;
@@ -2415,7 +2425,7 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
     const size_t lds_sub = (size_t)SUB_WPB * nd_sub_lds_doubles(nd) * 8;
 #if ND_LG == 7
     const bool iso = p.Ky == nullptr;  // isotropic: assembly from an LDS copy of 1 / (mobility K), the plan in the same launch
-    const size_t lds_asm = iso ? (size_t)NB * NB * 8 : 0;
+    const size_t lds_asm = iso ? (size_t)(NB / 2 + 2) * NB * 8 : 0;  // (two passes of 64 rows + a row either side)
     if (f->dtype == 64) {
         hipLaunchKernelGGL(k_nd_assemble<double>, dim3(p.N), dim3(1024), lds_asm, s, p, nd, (const double*)S, S_stride, k);
         if (!iso) hipLaunchKernelGGL(k_nd_plan<double>, dim3(p.N), dim3(256), 0, s, p, nd, (const double*)S, S_stride);
