@@ -2411,7 +2411,7 @@ static int nd_setup(hm_fwd* f) {
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_assemble<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NB * NB * 8));
 #endif
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<5, 6, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<6, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<6, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_wave<7, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HM_HIP(hipFuncSetAttribute((const void*)k_nd_sub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     f->nd = n;
@@ -2440,10 +2440,11 @@ static int nd_launch_block(hm_fwd* f, const FwdParams& p, const void* S, long lo
 #endif
     hipLaunchKernelGGL(k_nd_leaf, dim3(p.N * (4 << LO)), dim3(256), 0, s, p, nd, k);
     hipLaunchKernelGGL(k_nd_sub, dim3(((p.N + SUB_WPB - 1) / SUB_WPB) * NF8), dim3(64 * SUB_WPB), lds_sub, s, p, nd, k);
+    // (levels LO + 5, LO + 6 as workgroups of ONE wave: a level-5 wave's LDS block is 31.5 KB -- five fit a CU, workgroups of two put four there --
+    // and a wave that is done frees its block at once instead of when its workgroup's slowest is: 0.55 -> 0.52 and 0.43 -> 0.41 ms per 1000 members
+    // at 128 x 128 (round 6); level 7 is faster as workgroups of four, 0.38 against 0.39: its waves share a front's records and recipes in L1)
     hipLaunchKernelGGL((k_nd_wave<7, 3, 4>), dim3(p.N * (NF7 / 4)), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[0] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
-    hipLaunchKernelGGL((k_nd_wave<6, 4, 4>), dim3(p.N * (NF6 / 4)), dim3(256), (size_t)4 * (ND_LDS_DATA + 2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
-    // (level LO + 5: a wave's LDS block is 31.5 KB -- workgroups of ONE wave put five of them on a CU, workgroups of two only four: 0.55 -> 0.52 ms
-    // per 1000 members at 128 x 128, round 6)
+    hipLaunchKernelGGL((k_nd_wave<6, 4, 1>), dim3(p.N * NF6), dim3(64), (size_t)1 * (ND_LDS_DATA + 2 * nd.child_doubles[1] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     hipLaunchKernelGGL((k_nd_wave<5, 6, 1>), dim3(p.N * NF5), dim3(64), (size_t)1 * (ND_LDS_DATA + 2 * nd.child_doubles[2] + 4 * WAVE_CF_PLANE) * 8, s, p, nd, k);
     // level LO + 4: one front per workgroup of 8 waves, two workgroups a CU (images, 2 KB of tables, ONE child, records)
     const int chd4 = f->nd->info.upd_doubles[LO + 5];
